@@ -1,0 +1,458 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures tests/golden/*.npz FROM THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    python3 tests/golden/make_golden.py
+
+Everything numerical below is computed by the reference's own code
+(`odil.core`, `odil.optimizer`, `odil.linsolver`, `examples/poisson/poisson.py`,
+`tests/test_newton.py`) running unchanged on the torch-CPU `mod` shim of
+ref_shim.py; `torch.autograd` replaces `jax.value_and_grad` / `tf.GradientTape`
+exactly where the reference calls them (core.py:1100, :1062, :1346-1349).
+The fixtures are data only: inputs and expected outputs.
+"""
+
+import argparse
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_shim import T, import_reference  # noqa: E402
+
+odil = import_reference()
+mod = odil.runtime.mod
+torch.set_num_threads(1)
+
+
+def load_module(name, path):
+    import matplotlib
+
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location(name, path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module
+
+
+def npy(x):
+    return x.detach().numpy().copy() if isinstance(x, torch.Tensor) else np.array(x)
+
+
+def save(name, **data):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **data)
+    print("{:<28} {:>8.1f} kB  {} arrays".format(name + ".npz", os.path.getsize(path) / 1024, len(data)))
+
+
+# ---------------------------------------------------------------- interp (A3, A3^T)
+def gen_interp():
+    rng = np.random.default_rng(101)
+    data = dict()
+    cases = []
+    locs = ["c", "n", "cc", "nn", "cn", "nc", "c.", ".n", "ccc", "nnn", "cnn", "ncc", "c.n", "cccc", "nnnn", "cnnn", "nccc"]
+    for loc in locs:
+        ndim = len(loc)
+        shape = tuple(int(3 + i + (1 if l == "n" else 0)) for i, l in enumerate(loc))
+        u = rng.standard_normal(shape)
+        ut = T(u).requires_grad_(True)
+        fine = odil.core.interp_to_finer(ut, loc=loc, method="stack", mod=mod)
+        gf = rng.standard_normal(tuple(fine.shape))
+        (gu,) = torch.autograd.grad(fine, ut, T(gf))
+        cases.append(loc)
+        data[f"{loc}/u"] = u
+        data[f"{loc}/fine"] = npy(fine)
+        data[f"{loc}/gfine"] = gf
+        data[f"{loc}/gu"] = npy(gu)
+        if ndim <= 2:  # depth 2
+            fine2 = odil.core.interp_to_finer(T(u), loc=loc, method="stack", mod=mod, depth=2)
+            data[f"{loc}/fine2"] = npy(fine2)
+    data["cases"] = np.array(cases)
+    save("interp", **data)
+
+
+# ---------------------------------------------------------------- multigrid synthesis (A2) + adjoint
+def gen_mg():
+    rng = np.random.default_rng(202)
+    data = dict()
+    cases = []
+    for name, cshape, loc, axes, factors in [
+        ("1d_c", (16,), "c", None, None),
+        ("1d_n", (16,), "n", None, None),
+        ("2d_cc", (8, 16), "cc", None, None),
+        ("2d_nc", (8, 16), "nc", None, None),
+        ("2d_cn_axes", (8, 16), "cn", [True, False], None),
+        ("3d_ccc", (8, 8, 8), "ccc", None, [1.0, 2.0, 0.5]),
+        ("3d_ncc", (4, 8, 8), "ncc", None, None),
+    ]:
+        domain = odil.Domain(
+            cshape=cshape, dimnames=["x", "y", "z"][: len(cshape)], multigrid=True, dtype=np.float64, mod=mod,
+            mg_axes=axes, mg_factors=factors,
+        )
+        terms = []
+        for cs in domain.mg_cshapes:
+            shape = domain._get_field_shape(cs, loc)
+            terms.append(odil.Field(T(rng.standard_normal(shape)).requires_grad_(True), loc=loc, cshape=cs))
+        mgf = odil.MultigridField(terms=terms, loc=loc, factors=factors or [1] * len(terms), axes=axes, method="stack")
+        u = domain.multigrid_to_regular(mgf).array
+        gu = rng.standard_normal(tuple(u.shape))
+        grads = torch.autograd.grad(u, [t.array for t in terms], T(gu))
+        cases.append(name)
+        data[f"{name}/cshape"] = np.array(cshape)
+        data[f"{name}/loc"] = np.array(loc)
+        data[f"{name}/axes"] = np.array(axes if axes else [True] * len(cshape))
+        data[f"{name}/factors"] = np.array(factors or [1.0] * len(terms))
+        data[f"{name}/nlvl"] = np.array(len(terms))
+        for i, t in enumerate(terms):
+            data[f"{name}/w{i}"] = npy(t.array)
+            data[f"{name}/g{i}"] = npy(grads[i])
+        data[f"{name}/u"] = npy(u)
+        data[f"{name}/gu"] = gu
+    data["cases"] = np.array(cases)
+    save("mg", **data)
+
+
+# ---------------------------------------------------------------- ctx.field access (A4)
+def gen_field_access():
+    rng = np.random.default_rng(303)
+    data = dict()
+    cases = []
+    domain = odil.Domain(cshape=(4, 5), dimnames=["x", "y"], dtype=np.float64, mod=mod)
+    specs = [
+        ("cc", (0, 0), None),
+        ("cc", (1, 0), None),
+        ("cc", (-1, 2), None),
+        ("nc", (0, 0), "cc"),
+        ("nc", (1, 0), "cc"),
+        ("cc", (0, 0), "nc"),
+        ("cc", (-1, 0), "nc"),
+        ("nn", (1, -1), "cc"),
+        ("cn", (0, 1), "nc"),
+    ]
+    for k, (floc, shift, loc) in enumerate(specs):
+        shape = domain.get_field_shape(floc)
+        a = T(rng.standard_normal(shape)).requires_grad_(True)
+        state = odil.State(fields={"f": odil.Field(a, loc=floc, cshape=domain.cshape)}, initialized=True)
+        ctx = odil.core.Context(domain, state)
+        out = ctx.field("f", *shift, loc=loc)
+        g = rng.standard_normal(tuple(out.shape))
+        (ga,) = torch.autograd.grad(out, a, T(g))
+        name = f"case{k}"
+        cases.append(name)
+        data[f"{name}/field_loc"] = np.array(floc)
+        data[f"{name}/shift"] = np.array(shift)
+        data[f"{name}/loc"] = np.array(loc or floc)
+        data[f"{name}/a"] = npy(a)
+        data[f"{name}/out"] = npy(out)
+        data[f"{name}/g"] = g
+        data[f"{name}/ga"] = npy(ga)
+    data["cases"] = np.array(cases)
+    save("field_access", **data)
+
+
+# ---------------------------------------------------------------- Poisson (A1, A6, A7, A10, A11)
+poisson = load_module("ref_poisson", "/root/reference/examples/poisson/poisson.py")
+
+
+def make_poisson(ndim, N, multigrid=1, dtype=np.float64):
+    args = argparse.Namespace(
+        ndim=ndim, N=N, multigrid=multigrid, double=1, cellbased=1, ref="hat", rhs="discrete", plot=0, mgloss=0
+    )
+    domain = odil.Domain(
+        cshape=[N] * ndim, dimnames=["x", "y", "z"][:ndim], multigrid=multigrid, dtype=dtype, mod=mod
+    )
+    ref_u = poisson.get_ref_u("hat", args, domain)
+    rhs = poisson.get_discrete_rhs(ref_u, domain, mod)
+    state = odil.State()
+    state.fields["u"] = None
+    state = domain.init_state(state)
+    extra = argparse.Namespace(ref_u=ref_u, rhs=rhs, args=args)
+    return domain, state, extra
+
+
+def ref_loss_grad(domain, state, extra, operator, arrays):
+    """core.py:1082-1104 with torch.autograd in place of jax.value_and_grad."""
+    arrays = [T(a).detach().clone().requires_grad_(True) for a in arrays]
+    domain.arrays_to_state(arrays, state)
+    ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+    ff = operator(ctx)
+    values = [f[1] if isinstance(f, tuple) else f for f in ff]
+    terms = [mod.mean(mod.square(f)) for f in values]
+    loss = sum(terms)
+    grads = torch.autograd.grad(loss, arrays, allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(a) for g, a in zip(grads, arrays)]
+    return loss.detach(), [g.detach() for g in grads], [t.detach() for t in terms], values
+
+
+def gen_poisson():
+    rng = np.random.default_rng(404)
+    for ndim, N, epochs in [(1, 256, 20), (2, 32, 10), (3, 16, 10), (2, 8, 5), (3, 8, 5)]:
+        domain, state, extra = make_poisson(ndim, N)
+        data = dict(ndim=np.array(ndim), N=np.array(N), lr=np.array(0.005))
+        data["ref_u"] = npy(extra.ref_u)
+        data["rhs"] = npy(extra.rhs)
+        data["nlvl"] = np.array(domain.mg_nlvl)
+        # loss + grads at a random multigrid state.
+        arrays = [T(rng.standard_normal(tuple(a.shape)) * 0.1) for a in domain.arrays_from_state(state)]
+        loss, grads, terms, values = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+        for i, (a, g) in enumerate(zip(arrays, grads)):
+            data[f"rand/w{i}"] = npy(a)
+            data[f"rand/g{i}"] = npy(g)
+        data["rand/loss"] = npy(loss)
+        data["rand/fu"] = npy(values[0])
+        # Adam trajectory from the zero state with the reference optimizer.
+        domain, state, extra = make_poisson(ndim, N)
+        losses = []
+
+        def loss_grad(arrays):
+            loss, grads, terms, _ = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+            losses.append(float(loss))
+            return loss, grads, None
+
+        opt = odil.optimizer.AdamNativeOptimizer(dtype=np.float64, mod=mod)
+        arrays = domain.arrays_from_state(state)
+        x, _ = opt.run(arrays, loss_grad, epochs=epochs, lr=0.005, jit=False)
+        data["adam/losses"] = np.array(losses)
+        for i, a in enumerate(x):
+            data[f"adam/w{i}"] = npy(a)
+        save(f"poisson_{ndim}d_N{N}", **data)
+
+    # float32, no multigrid (exercise dtype + plain Field path), GD
+    domain, state, extra = make_poisson(2, 16, multigrid=0, dtype=np.float32)
+    data = dict(rhs=npy(extra.rhs), ref_u=npy(extra.ref_u))
+    arrays = [T(rng.standard_normal((16, 16)).astype(np.float32))]
+    loss, grads, terms, values = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+    data["rand/w0"] = npy(arrays[0])
+    data["rand/g0"] = npy(grads[0])
+    data["rand/loss"] = npy(loss)
+    data["rand/fu"] = npy(values[0])
+    save("poisson_2d_N16_f32_nomg", **data)
+
+
+def gen_lbfgsb():
+    import scipy
+
+    domain, state, extra = make_poisson(2, 32)
+    evals = []
+    iters = []
+    xs = []
+
+    def loss_grad(arrays):
+        loss, grads, terms, _ = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+        evals.append(float(loss))
+        return loss, grads, None
+
+    def callback(arrays, epoch, pinfo):
+        iters.append(evals[-1])
+        xs.append(np.concatenate([npy(a).ravel() for a in arrays]))
+
+    opt = odil.optimizer.LbfgsbOptimizer(dtype=np.float64, mod=mod, m=50, maxls=50)
+    arrays = domain.arrays_from_state(state)
+    epochs = 25
+    try:
+        x, optinfo = opt.run(arrays, loss_grad, epochs=epochs, callback=callback)
+    except odil.EarlyStopError as e:
+        print("early stop", e)
+    data = dict(
+        rhs=npy(extra.rhs), eval_losses=np.array(evals), iter_losses=np.array(iters), x_iters=np.array(xs),
+        scipy_version=np.array(scipy.__version__), epochs=np.array(epochs), m=np.array(50), maxls=np.array(50),
+    )
+    save("lbfgsb_poisson_2d_N32", **data)
+
+
+# ---------------------------------------------------------------- Newton (A13-A16)
+def make_ref_problem(operator, domain, extra):
+    """A reference `Problem` whose TF-only `_eval_operator_grad` (core.py:1313-1361) is
+    re-expressed with torch.autograd; `Problem.linearize` (core.py:1113-1217) itself
+    then runs unchanged."""
+    problem = object.__new__(odil.Problem)
+    problem.domain = domain
+    problem.operator = operator
+    problem.extra = extra
+    problem.tracers = {"epoch": 0}
+
+    def eval_operator_grad(state):
+        watched = []
+
+        def watch(x):
+            for a in x if isinstance(x, (list, tuple)) else [x]:
+                if not a.requires_grad:
+                    a.requires_grad_(True)
+                watched.append(a)
+
+        # Leaves must be detached copies so that watched shifted copies are independent symbols.
+        for field in state.fields.values():
+            for a in domain.arrays_from_field(field):
+                a.requires_grad_(True)
+        ctx = odil.core.Context(domain, state, watch_func=watch, extra=extra, tracers=problem.tracers, distinct_shift=True)
+        ff = operator(ctx)
+        names = [f[0] if isinstance(f, tuple) else "" for f in ff]
+        values = [f[1] if isinstance(f, tuple) else f for f in ff]
+        grads = []
+        for v in values:
+            s = v.sum()
+            descs = list(ctx.desc_to_array.keys())
+            arrs = [ctx.desc_to_array[d] for d in descs]
+            gg = torch.autograd.grad(s, arrs, retain_graph=True, allow_unused=True)
+            g = dict(zip(descs, gg))
+            for key, arr in ctx.key_to_array_jac.items():
+                # tape.jacobian(v, arr): shape v.shape + arr.shape (core.py:1347-1349)
+                def jac_of(a):
+                    rows = []
+                    for e in v.reshape(-1):
+                        (ge,) = torch.autograd.grad(e, a, retain_graph=True, allow_unused=True)
+                        rows.append(ge if ge is not None else torch.zeros_like(a))
+                    return torch.stack(rows).reshape(tuple(v.shape) + tuple(a.shape))
+
+                if isinstance(arr, list):
+                    jac = [jac_of(a) for a in arr]
+                    if all(float(j.abs().max()) == 0 for j in jac):
+                        jac = [None for _ in jac]
+                    g[key] = jac
+                else:
+                    j = jac_of(arr)
+                    g[key] = j if float(j.abs().max()) != 0 else None
+            grads.append(g)
+        values = [v.detach() for v in values]
+        return values, grads, names
+
+    problem.eval_operator_grad = eval_operator_grad
+    return problem
+
+
+def linsolver_args():
+    return argparse.Namespace(
+        linsolver="direct", linsolver_maxiter=None, linsolver_damp=0, linsolver_dampdiag=0, linsolver_tol=1e-10
+    )
+
+
+def gen_newton():
+    rng = np.random.default_rng(505)
+    # --- Poisson 2-D and 3-D, plain Field (multigrid is rejected by linearize, core.py:1208-1209)
+    for ndim, N in [(1, 8), (2, 6), (3, 4)]:
+        domain, state, extra = make_poisson(ndim, N, multigrid=0)
+        u0 = rng.standard_normal((N,) * ndim) * 0.1
+        state.fields["u"].array = T(u0).clone()
+        problem = make_ref_problem(poisson.operator, domain, extra)
+        values, grads, names = problem.eval_operator_grad(state)
+        data = dict(u0=u0, rhs=npy(extra.rhs), ref_u=npy(extra.ref_u), fu=npy(values[0]))
+        shifts = []
+        for (key, shift, loc), g in grads[0].items():
+            sname = ",".join(str(s) for s in shift)
+            shifts.append(sname)
+            data[f"coeff/{sname}"] = npy(g)
+        data["shifts"] = np.array(shifts)
+        vector, matrix = problem.linearize(state)
+        data["vector"] = npy(vector)
+        data["matrix"] = matrix.toarray()
+        delta = odil.linsolver.solve(matrix, -npy(vector), linsolver_args(), dict(), "direct")
+        data["delta"] = delta
+        packed = npy(domain.pack_state(state))
+        data["u1"] = (packed + delta).reshape(u0.shape)
+        save(f"newton_poisson_{ndim}d_N{N}", **data)
+
+
+def gen_test_newton():
+    """tests/test_newton.py:60-148 re-run with the shim (Problem constructed by hand
+    because Problem.__init__ rejects non-TF/JAX mods, core.py:1035-1036)."""
+    tn = load_module("ref_test_newton", "/root/reference/tests/test_newton.py")
+    args = argparse.Namespace(Nx=3, Ny=2, Na=5, Nnet=5, multigrid=0, mg_interp="stack", nlvl=None)
+    np.random.seed(1000)
+    domain = odil.Domain(
+        cshape=(args.Nx, args.Ny), dimnames=["x", "y"], lower=(0, 0), dtype=np.float64, upper=(args.Nx, args.Ny),
+        multigrid=0, mod=mod,
+    )
+    dtype = domain.dtype
+    net = domain.make_neural_net([args.Nnet, args.Nnet], activation="none")
+    state = odil.State(
+        fields={
+            "uc": odil.Field(np.ones(domain.size(loc="cc")), loc="cc"),
+            "ufx": odil.Field(np.ones(domain.size(loc="nc")), loc="nc"),
+            "a": odil.Array(np.zeros(args.Na, dtype=dtype)),
+            "net": net,
+        }
+    )
+    state = domain.init_state(state)
+    xc, yc = [npy(x) for x in domain.points(loc="cc")]
+    xfx, yfx = [npy(x) for x in domain.points(loc="nc")]
+    extra = argparse.Namespace()
+    extra.ref = {
+        "uc": 0.25 * xc * yc,
+        "ufx": 0.25 * xfx * yfx,
+        "dudx": 0.25 * yc,
+        "a": np.linspace(0, 1, args.Na, dtype=dtype),
+    }
+    extra.ref["net_in"] = np.random.rand(args.Nnet, args.Nnet + 1)
+    extra.ref["net_out"] = np.random.rand(args.Nnet, args.Nnet + 1)
+    extra.args = args
+    data = dict()
+    for k, a in enumerate(domain.arrays_from_state(state)):
+        data[f"x0/{k}"] = npy(a)
+    for k, v in extra.ref.items():
+        data[f"ref/{k}"] = np.array(v)
+    # The operator mixes torch tensors with NumPy reference arrays; give it tensors.
+    extra_t = argparse.Namespace(args=args, ref={k: T(v) for k, v in extra.ref.items()})
+    problem = make_ref_problem(tn.operator, domain, extra_t)
+    vector, matrix = problem.linearize(state)
+    data["vector"] = npy(vector)
+    data["matrix"] = matrix.toarray()
+    import scipy.sparse as sp
+
+    vector = npy(vector)
+    delta = sp.linalg.spsolve((matrix.T @ matrix).tocsc(), -matrix.T @ vector)
+    data["delta"] = delta
+    packed = npy(domain.pack_state(state))
+    with torch.no_grad():
+        domain.unpack_state(T(packed + delta), state)
+    for k, a in enumerate(domain.arrays_from_state(state)):
+        data[f"x1/{k}"] = npy(a)
+    errors = []
+    for key in ["ufx", "uc", "a", "net_out"]:
+        if key == "net_out":
+            value = torch.stack(domain.neural_net(state, "net")(*T(extra.ref["net_in"])))
+        else:
+            value = domain.field(state, key)
+        error = npy(value) - extra.ref[key]
+        errors.append(np.sqrt(np.mean(np.square(error))))
+    data["errors"] = np.array(errors)
+    print("test_newton errors (must be < 1e-6):", errors)
+    assert max(errors) < 1e-6
+    save("test_newton", **data)
+
+
+# ---------------------------------------------------------------- reference tests as known-answer checks
+def check_reference_tests():
+    """tests/test_mg_interp.py:11-32 on the shim: exact on linear functions."""
+    for ndim in [1, 2, 3, 4]:
+        for loc in {s[:ndim] for s in ["cccc", "nnnn", "cnnn", "nccc"]}:
+            cshapeh = 3 + np.array(range(ndim))
+            cshape = cshapeh * 2
+            dimnames = ["x", "y", "z", "w"][:ndim]
+            domain = odil.Domain(cshape=cshape, dimnames=dimnames, dtype=np.float64, mod=mod)
+            domainh = odil.Domain(cshape=cshapeh, dimnames=dimnames, dtype=np.float64, mod=mod)
+
+            def func(xx):
+                return sum(x * np.sqrt(i + 1) for i, x in enumerate(xx))
+
+            u = func(domain.points(loc=loc))
+            uh = func(domainh.points(loc=loc))
+            ui = odil.core.interp_to_finer(uh, loc=loc, mod=mod, method="stack")
+            error = float(mod.max(abs(ui - u)))
+            assert error <= np.finfo(np.float64).eps * 100, (ndim, loc, error)
+    print("reference test_mg_interp (stack) on shim: PASS")
+
+
+if __name__ == "__main__":
+    check_reference_tests()
+    gen_interp()
+    gen_mg()
+    gen_field_access()
+    gen_poisson()
+    gen_lbfgsb()
+    gen_newton()
+    gen_test_newton()
