@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-point-updates/s of the ODIL hot path on MI355X.
+
+Workload (BASELINE.json metric): 3-D Poisson 512^3, multigrid decomposition (9 levels),
+f64, Adam -- one "step" is one optimizer epoch of the reference's hot loop
+(reference src/odil/optimizer.py:331-336): multigrid synthesis -> residual + loss ->
+adjoint -> P^T chain -> Adam update.  Metric = prod(cshape) * steps / wall
+(reference src/odil/util.py:408-419), inputs resident in HBM, synthetic (`hat`
+reference solution, discrete rhs, zero initial state; poisson.py:21-24,71-86,264-266).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--N 512] [--ndim 3]
+
+For N > 1 it is launched by torch.distributed.run, one rank per GPU (RCCL).
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--N", type=int, default=512)
+    p.add_argument("--ndim", type=int, default=3)
+    p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_N", type=int, default=128, help="grid size of the CPU-baseline sample")
+    return p.parse_args()
+
+
+def algorithmic_bytes_per_update(ndim, nlvl, wordsize):
+    """(10 S + 5) words per fine cell per epoch, S = sum_l 2^(-d l)."""
+    S = sum(2.0 ** (-ndim * l) for l in range(nlvl))
+    return (10 * S + 5) * wordsize, S
+
+
+def cpu_baseline(ndim, N, budget_s=20.0):
+    """The oracle (NumPy port of the reference op sequence) timed on this host, 1 thread."""
+    from oracle import odil_np as onp
+
+    cshape = (N,) * ndim
+    dw = onp.step(cshape)
+    rhs = onp.poisson_discrete_rhs(onp.poisson_ref_u(cshape), dw)
+    x = [np.zeros(s) for s in onp.mg_cshapes(cshape)]
+    m = [np.zeros_like(a) for a in x]
+    v = [np.zeros_like(a) for a in x]
+
+    def epoch(k):
+        nonlocal x, m, v
+        loss, grads, _ = onp.poisson_loss_grad(x, rhs, dw)
+        x, m, v = onp.adam_step(x, m, v, grads, k, 0.005)
+
+    epoch(1)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        epoch(k + 2)
+        k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or k >= 50:
+            break
+    return {
+        "value": N**ndim * k / el,
+        "unit": "grid-point-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "oracle/odil_np.py, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s".format(
+            ndim, N, ndim, k, el
+        ),
+    }
+
+
+class Timers:
+    """HIP-event pairs per kernel family, recorded on the stream the kernels run on."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def section(self, name):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        self.pairs.setdefault(name, []).append((a, b))
+        return a, b
+
+    def summary(self):
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    dev = torch.device("cuda", local_rank)
+
+    from odil_amd.poisson_path import PoissonMultigridAdam
+
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    ndim, N = args.ndim, args.N
+    run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev, world=world, rank=rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.epoch()
+    barrier()
+    timers = Timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.epoch(timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = run.last_loss()
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        cells_total = run.global_cells
+        value = cells_total * args.steps / elapsed
+        wordsize = 8 if dtype == torch.float64 else 4
+        abytes, S = algorithmic_bytes_per_update(ndim, run.nlvl, wordsize)
+        kt = timers.summary()
+        # Dominant kernel: Adam over the packed multigrid state (7 words per unknown).
+        n_unknowns = run.n_unknowns_local
+        adam_bytes = 7.0 * n_unknowns * wordsize
+        adam_ms = kt["adam"]
+        achieved = adam_bytes / (adam_ms * 1e-3) / 1e9
+        out = {
+            "metric": "grid-point-updates/s, Poisson {}^{} multigrid".format(N, ndim),
+            "value": value,
+            "unit": "grid-point-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "3D Poisson 512^3 multigrid (9 levels) Adam epoch, 1xMI355X"
+                if (ndim, N) == (3, 512)
+                else "{}D Poisson {}^{} multigrid Adam epoch".format(ndim, N, ndim),
+                "cells_per_gpu": run.local_cells,
+                "levels": run.nlvl,
+                "optimizer": "adam lr=0.005",
+                "decomposition": "slab x{}".format(world) if world > 1 else "none",
+            },
+            "roofline": {
+                "kernel": "k_adam<{}>".format("double" if wordsize == 8 else "float"),
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": adam_bytes,
+                "avg_launch_ms": adam_ms,
+            },
+            "epoch_roofline": {
+                "algorithmic_bytes_per_update": abytes,
+                "achieved": value * abytes / world / 1e9,
+                "frac": value * abytes / world / 1e9 / HBM_PEAK_GBS,
+                "unit": "GB/s per GPU",
+            },
+            "kernel_ms": kt,
+            "loss_after": loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ndim, args.cpu_N if ndim == 3 else min(N, 2048))
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

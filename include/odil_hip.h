@@ -1,0 +1,169 @@
+/*
+ * odil_hip.h -- C-ABI of the MI355X-native (gfx950) ODIL hot path.
+ *
+ * The reference (cselab/odil v0.1.8) is pure Python and has no FFI boundary of its
+ * own: its device arithmetic goes through the `mod` namespace into XLA / TensorFlow
+ * (reference src/odil/backend.py:12-317).  This library is what a ROCm `mod` +
+ * `Problem` bind instead.  Each entry point below cites the reference code whose
+ * arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - `extern "C"`, plain pointers and sizes; no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer into caller-owned memory (the Python
+ *     host passes torch tensor storage); the library never allocates, frees or
+ *     retains device memory; scratch space is passed in explicitly.
+ *   - arrays are C-order, contiguous; `shape` is the ARRAY shape (not cells),
+ *     `ndim` <= ODIL_MAX_NDIM; `loc` is ODIL's location string, one of 'c' (cell),
+ *     'n' (node), '.' (axis not refined) per axis (reference core.py:606-616).
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = default stream).
+ *     Kernels are enqueued and the call returns; no host synchronisation inside.
+ *   - return value: 0 on success, <0 on error (ODIL_E_*); the message is
+ *     available from `odil_last_error()` (thread-local).
+ *   - suffix `_f32` / `_f64` selects the arithmetic type (reference runtime.py:77).
+ */
+#ifndef ODIL_HIP_H
+#define ODIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODIL_MAX_NDIM 4
+#define ODIL_MAX_LEVELS 32
+#define ODIL_E_INVAL (-1)  /* bad argument */
+#define ODIL_E_LAUNCH (-2) /* HIP launch / runtime failure */
+#define ODIL_E_NODEV (-3)  /* no usable gfx950 device */
+
+/* ---- library ---------------------------------------------------------------- */
+const char* odil_last_error(void);
+int odil_version(void);
+/* Number of HIP devices visible, or <0.  Does not create a context. */
+int odil_device_count(void);
+/* Bytes of scratch every reduction-carrying call needs (`partials`). */
+size_t odil_reduce_workspace_bytes(void);
+
+/* ---- multigrid transfers (reference core.py:606-755) ------------------------- */
+/* fine = add_scale * add + P(coarse_scale * coarse); `add` may be NULL (then fine =
+ * P(coarse)).  Replaces `interp_to_finer(method="stack")` (core.py:606-700) and one
+ * step of `Domain.multigrid_to_regular` (core.py:258-262).  `cshape` = coarse array
+ * shape; fine shape per axis: 'c' 2n, 'n' 2n-1, '.' n. */
+int odil_interp_add_f64(const double* coarse, const double* add, double* fine, const int64_t* cshape, int ndim,
+                        const char* loc, double coarse_scale, double add_scale, void* stream);
+int odil_interp_add_f32(const float* coarse, const float* add, float* fine, const int64_t* cshape, int ndim,
+                        const char* loc, float coarse_scale, float add_scale, void* stream);
+/* gcoarse = P^T gfine (the cotangent autodiff produces for core.py:606-700);
+ * if `gscaled` != NULL also gscaled = scale * gcoarse. */
+int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
+                        const char* loc, double scale, void* stream);
+int odil_interp_adj_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
+                        const char* loc, float scale, void* stream);
+/* coarse = R(fine): full weighting `restrict_to_coarser(method="conv")`
+ * (core.py:703-755, backend.py:112-126).  `fshape` = fine array shape. */
+int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
+                      void* stream);
+int odil_restrict_f32(const float* fine, float* coarse, const int64_t* fshape, int ndim, const char* loc,
+                      void* stream);
+
+/* u = sum_l P^l (factor_l * w_l): `Domain.multigrid_to_regular` (core.py:245-263).
+ * terms / work / grads are HOST arrays of device pointers, factors / shapes HOST arrays.
+ * terms[l]: level arrays fine->coarse, shapes[l*ndim..]: their array shapes,
+ * work[l] (1 <= l <= nlvl-2): scratch of level l's size for the partial sums
+ * (work[0] and work[nlvl-1] are ignored); `u` has level 0's shape. */
+int odil_mg_synth_f64(const double* const* terms, const double* factors, double* const* work, double* u,
+                      const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
+int odil_mg_synth_f32(const float* const* terms, const float* factors, float* const* work, float* u,
+                      const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
+/* grads[l] = factor_l * (P^T)^l gu: transpose of the above (what jax.value_and_grad /
+ * tf.GradientTape return for the level arrays, core.py:1100 / :1062).  work[l]
+ * (1 <= l <= nlvl-1) is needed only for levels whose factor != 1. */
+int odil_mg_synth_adj_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
+                          const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
+int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
+                          const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
+
+/* ---- stencil access: Context.field (reference core.py:910-975) ---------------- */
+/* out = trim(roll(pad(src), -shift)): 'c'->'n' zero-pad at the low end, periodic roll,
+ * 'n'->'c' drop last (core.py:956-969).  `sshape` = source array shape. */
+int odil_field_gather_f64(const double* src, double* out, const int64_t* sshape, int ndim, const char* field_loc,
+                          const char* loc, const int64_t* shift, void* stream);
+int odil_field_gather_f32(const float* src, float* out, const int64_t* sshape, int ndim, const char* field_loc,
+                          const char* loc, const int64_t* shift, void* stream);
+/* gsrc (+)= transpose of the gather applied to g; accumulate != 0 adds into gsrc. */
+int odil_field_scatter_f64(const double* g, double* gsrc, const int64_t* sshape, int ndim, const char* field_loc,
+                           const char* loc, const int64_t* shift, int accumulate, void* stream);
+int odil_field_scatter_f32(const float* g, float* gsrc, const int64_t* sshape, int ndim, const char* field_loc,
+                           const char* loc, const int64_t* shift, int accumulate, void* stream);
+
+/* ---- loss reduction (reference core.py:1093-1095) ----------------------------- */
+/* out[0] = mean(x^2) (square != 0) or mean(x) over n elements, accumulated in f64 in
+ * a fixed order (deterministic).  `partials`: odil_reduce_workspace_bytes() scratch. */
+int odil_mean_reduce_f64(const double* x, int64_t n, int square, double* partials, double* out, void* stream);
+int odil_mean_reduce_f32(const float* x, int64_t n, int square, double* partials, float* out, void* stream);
+
+/* ---- Poisson workload (reference examples/poisson/poisson.py:57-113) ---------- */
+/* fu = sum_i (u+ - 2u + u-)/h2[i] - rhs with zero-Dirichlet ghosts by extrap_quadh
+ * (poisson.py:57-68, core.py:1439-1445); loss[0] = mean(fu^2) (core.py:1093).
+ * `fu` may be NULL (loss only).  `shape`: cell shape, ndim <= 3; h2[i] = step_i^2. */
+int odil_poisson_residual_f64(const double* u, const double* rhs, double* fu, const int64_t* shape, int ndim,
+                              const double* h2, double* partials, double* loss, void* stream);
+int odil_poisson_residual_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
+                              const float* h2, double* partials, float* loss, void* stream);
+/* gu = J^T (scale * fu): cotangent of the operator above; scale = 2/size gives
+ * d mean(fu^2)/du (core.py:1093-1101). */
+int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,
+                             double scale, void* stream);
+int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, int ndim, const float* h2,
+                             float scale, void* stream);
+/* Per-shift Jacobian coefficient arrays d(sum fu)/d u_shift as
+ * `Problem.eval_operator_grad` returns them under `distinct_shift`
+ * (core.py:1313-1361): coeffs holds 2*ndim+1 arrays of `shape`, order
+ * [centre, (-1 axis 0), (+1 axis 0), (-1 axis 1), ...]. */
+int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream);
+int odil_poisson_jac_coeffs_f32(float* coeffs, const int64_t* shape, int ndim, const float* h2, void* stream);
+
+/* ---- optimizers (reference optimizer.py:256-341) ------------------------------ */
+/* AdamNativeOptimizer._step (optimizer.py:311-319) on a flat vector:
+ *   m += (g-m)*one_minus_b1; v += (g^2-v)*one_minus_b2; x -= (m*alpha)/(sqrt(v)+eps). */
+int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t n, double alpha,
+                       double one_minus_b1, double one_minus_b2, double eps, void* stream);
+int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
+                       float one_minus_b2, float eps, void* stream);
+/* y += a * x  (GdOptimizer: x -= lr*g, optimizer.py:270; Newton update util.py:177). */
+int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream);
+int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);
+/* out[k] = sum_i a[k*lda + i] * b[i], k < nvec, deterministic, f64 accumulation.
+ * `partials`: nvec * odil_reduce_workspace_bytes() scratch. */
+int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64_t n, double* partials,
+                  double* out, void* stream);
+int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,
+                  void* stream);
+/* y = beta * y + sum_k coef[k] * a[k*lda + :]  (coef on DEVICE, length nvec). */
+int odil_lincomb_f64(double* y, double beta, const double* a, int64_t lda, int nvec, const double* coef, int64_t n,
+                     void* stream);
+int odil_lincomb_f32(float* y, float beta, const float* a, int64_t lda, int nvec, const float* coef, int64_t n,
+                     void* stream);
+
+/* ---- Newton: matrix-free normal equations (reference core.py:1113-1217,
+ *      linsolver.py:17-26) ------------------------------------------------------- */
+/* y = M x  where row r of M has coefficients coeffs[s][r] on columns roll(-shift_s):
+ * the CSR matrix `field_to_matrix` builds (core.py:1144-1171), kept as coefficient
+ * arrays.  `shifts`: nshift*ndim int64. transpose != 0 applies M^T. */
+int odil_stencil_apply_f64(const double* coeffs, const int64_t* shifts, int nshift, const double* x, double* y,
+                           const int64_t* shape, int ndim, int transpose, void* stream);
+int odil_stencil_apply_f32(const float* coeffs, const int64_t* shifts, int nshift, const float* x, float* y,
+                           const int64_t* shape, int ndim, int transpose, void* stream);
+/* CSR assembly of the same matrix (core.py:1144-1171, :1214): indptr[n+1], indices,
+ * data of nnz = nshift*n entries, columns offset by `col_offset`; rows keep ODIL's
+ * order (ascending shift index within a row, not sorted by column). */
+int odil_csr_assemble_f64(const double* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
+                          int64_t col_offset, int64_t* indptr, int64_t* indices, double* data, void* stream);
+int odil_csr_assemble_f32(const float* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
+                          int64_t col_offset, int64_t* indptr, int64_t* indices, float* data, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODIL_HIP_H */

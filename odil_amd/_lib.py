@@ -1,0 +1,135 @@
+"""ctypes binding of the C-ABI library `libodil_hip.so` (include/odil_hip.h).
+
+The library is the product's only compute path.  There is no CPU fallback: if the
+shared object is missing, or a call is made with tensors that are not on a HIP
+device, the call raises.
+"""
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libodil_hip.so")
+
+_P = c_void_p
+_I64P = ctypes.POINTER(c_int64)
+
+# name -> argument types with R standing for the real type (c_double / c_float).
+_R = "real"
+_SIGNATURES = {
+    "interp_add": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _R, _P],
+    "interp_adj": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _P],
+    "restrict": [_P, _P, _I64P, c_int, c_char_p, _P],
+    "mg_synth": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
+    "mg_synth_adj": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
+    "field_gather": [_P, _P, _I64P, c_int, c_char_p, c_char_p, _I64P, _P],
+    "field_scatter": [_P, _P, _I64P, c_int, c_char_p, c_char_p, _I64P, c_int, _P],
+    "mean_reduce": [_P, c_int64, c_int, _P, _P, _P],
+    "poisson_residual": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
+    "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
+    "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
+    "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P],
+    "axpy": [_P, _P, c_int64, _R, _P],
+    "dots": [_P, c_int64, c_int, _P, c_int64, _P, _P, _P],
+    "lincomb": [_P, _R, _P, c_int64, c_int, _P, c_int64, _P],
+    "stencil_apply": [_P, _I64P, c_int, _P, _P, _I64P, c_int, c_int, _P],
+    "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],
+}
+
+EXPORTED = ["odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes"] + [
+    "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
+]
+
+_lib = None
+
+
+class OdilHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OdilHipError(
+            "HIP extension not built: {} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C odil_amd/csrc`. There is no CPU fallback.".format(LIB_PATH)
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.odil_last_error.restype = c_char_p
+    lib.odil_last_error.argtypes = []
+    lib.odil_version.restype = c_int
+    lib.odil_device_count.restype = c_int
+    lib.odil_reduce_workspace_bytes.restype = c_size_t
+    for name, sig in _SIGNATURES.items():
+        for suffix, real in (("f64", c_double), ("f32", c_float)):
+            fn = getattr(lib, "odil_{}_{}".format(name, suffix))
+            fn.restype = c_int
+            fn.argtypes = [real if a is _R else a for a in sig]
+    _lib = lib
+    return lib
+
+
+def suffix_of(dtype):
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise TypeError("unsupported dtype {} (float32 / float64 only)".format(dtype))
+
+
+def call(name, dtype, *args):
+    """Calls odil_<name>_<f32|f64>(*args); raises OdilHipError on a non-zero status."""
+    lib = load()
+    fn = getattr(lib, "odil_{}_{}".format(name, suffix_of(dtype)))
+    status = fn(*args)
+    if status != 0:
+        raise OdilHipError("odil_{}: {} (status {})".format(name, lib.odil_last_error().decode(), status))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor, got {}".format(type(t).__name__))
+    if not t.is_cuda:
+        raise OdilHipError("tensor is on '{}': the HIP kernels need device memory (no CPU fallback)".format(t.device))
+    if not t.is_contiguous():
+        raise OdilHipError("tensor must be contiguous (C order)")
+    return c_void_p(t.data_ptr())
+
+
+def i64(values):
+    values = [int(v) for v in values]
+    return (c_int64 * len(values))(*values)
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise OdilHipError("level arrays must be contiguous device tensors")
+    return arr
+
+
+def host_reals(values, dtype):
+    np_dtype = np.float64 if dtype == torch.float64 else np.float32
+    arr = np.ascontiguousarray(np.asarray(values, dtype=np_dtype))
+    return arr, arr.ctypes.data_as(c_void_p)
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def reduce_workspace_elems():
+    return load().odil_reduce_workspace_bytes() // 8

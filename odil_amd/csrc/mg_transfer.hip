@@ -1,0 +1,531 @@
+// Multigrid transfers of the ODIL hot path on gfx950:
+//   P   : interp_to_finer   (reference src/odil/core.py:606-700, 'stack' summation order)
+//   P^T : its transpose     (what autodiff yields, core.py:1100 / :1062)
+//   R   : restrict_to_coarser (core.py:703-755)
+// plus the level loops of Domain.multigrid_to_regular (core.py:245-263) and its adjoint.
+//
+// All three are HBM-bound streaming kernels: each workgroup owns row segments handed out
+// by the XCD-aware schedule of common.h, lanes run along the contiguous last axis, every
+// lane writes 2 consecutive fine values (16 B for f64).  The coarse operand is 1/2^d of
+// the fine traffic and is served from L1/L2.
+#include "common.h"
+
+namespace odil {
+
+// ------------------------------------------------------------------------------------
+// Taps of the 1-D prolongation for one fine index k on an axis of type `loc` with n
+// coarse points.  In the reference's (r) order (core.py:675-687): r = 0 first.
+// 'c': k = 2i+s reads padded index (i+s)+r-1, weights s ? (3,1) : (1,3), sum 4.
+// 'n': k = 2i+s reads i (+ i+1 if s), weights 1, sum 1+s.   '.': identity.
+// Out-of-range 'c' indices (-1, n) are ghosts: 2*u[clamp] - u[reflect], evaluated
+// JOINTLY over all 'c' axes (core.py:640-643), hence the per-tap clamp/reflect pair.
+// ------------------------------------------------------------------------------------
+struct Taps {
+  int cnt;
+  int64_t cl[2], rf[2];
+  int w[2];
+  bool out[2];
+  int sum;
+};
+
+__device__ __host__ inline Taps make_taps(int loc, int64_t k, int64_t n) {
+  Taps t;
+  t.cnt = 1;
+  t.cl[0] = t.rf[0] = k;
+  t.cl[1] = t.rf[1] = 0;
+  t.w[0] = 1;
+  t.w[1] = 0;
+  t.out[0] = t.out[1] = false;
+  t.sum = 1;
+  if (loc == kCell) {
+    int64_t i = k >> 1;
+    int s = (int)(k & 1);
+    t.cnt = 2;
+    t.sum = 4;
+    t.w[0] = s ? 3 : 1;
+    t.w[1] = s ? 1 : 3;
+    for (int r = 0; r < 2; ++r) {
+      int64_t j = i + s + r - 1;
+      bool o = j < 0 || j >= n;
+      t.out[r] = o;
+      t.cl[r] = j < 0 ? 0 : (j >= n ? n - 1 : j);
+      t.rf[r] = j < 0 ? 1 : (j >= n ? n - 2 : j);
+    }
+  } else if (loc == kNode) {
+    int64_t i = k >> 1;
+    int s = (int)(k & 1);
+    t.cl[0] = t.rf[0] = i;
+    if (s) {
+      t.cnt = 2;
+      t.sum = 2;
+      t.w[1] = 1;
+      t.cl[1] = t.rf[1] = i + 1;
+    }
+  }
+  return t;
+}
+
+struct InterpArgs {
+  int64_t cn[4];  // coarse array shape (canonical 4-D)
+  int64_t fn[4];  // fine array shape
+  int loc[4];
+  RowSched sched;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_add(const T* __restrict__ coarse, const T* __restrict__ add,
+                                                       T* __restrict__ fine, InterpArgs a, T cscale, T ascale) {
+  const int64_t cs2 = a.cn[3], cs1 = a.cn[2] * cs2, cs0 = a.cn[1] * cs1;
+  const int64_t fs2 = a.fn[3], fs1 = a.fn[2] * fs2, fs0 = a.fn[1] * fs1;
+  const int64_t npairs = (a.fn[3] + 1) / 2;
+  RowIter it = sched_begin(a.sched);
+  for (; it.t < it.count; it.t += it.step) {
+    int64_t zz, y, xs;
+    sched_decode(a.sched, it, zz, y, xs);
+    const int64_t f0 = zz / a.fn[1], f1 = zz - f0 * a.fn[1], f2 = y;
+    // Leading-axis taps: uniform over the workgroup.
+    const Taps t0 = make_taps(a.loc[0], f0, a.cn[0]);
+    const Taps t1 = make_taps(a.loc[1], f1, a.cn[1]);
+    const Taps t2 = make_taps(a.loc[2], f2, a.cn[2]);
+    const int64_t p = xs * kBlock + threadIdx.x;
+    if (p >= npairs) continue;
+    const int64_t k0 = 2 * p;
+    const int nout = (k0 + 1 < a.fn[3]) ? 2 : 1;
+    Taps tx[2];
+    tx[0] = make_taps(a.loc[3], k0, a.cn[3]);
+    tx[1] = make_taps(a.loc[3], k0 + 1 < a.fn[3] ? k0 + 1 : k0, a.cn[3]);
+    T acc[2] = {T(0), T(0)};
+    for (int r0 = 0; r0 < t0.cnt; ++r0)
+      for (int r1 = 0; r1 < t1.cnt; ++r1)
+        for (int r2 = 0; r2 < t2.cnt; ++r2) {
+          const int wl = t0.w[r0] * t1.w[r1] * t2.w[r2];
+          const bool ol = t0.out[r0] || t1.out[r1] || t2.out[r2];
+          const int64_t bcl = t0.cl[r0] * cs0 + t1.cl[r1] * cs1 + t2.cl[r2] * cs2;
+          const int64_t brf = t0.rf[r0] * cs0 + t1.rf[r1] * cs1 + t2.rf[r2] * cs2;
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            if (o >= nout) break;
+            for (int r3 = 0; r3 < tx[o].cnt; ++r3) {
+              T val;
+              if (ol || tx[o].out[r3]) {
+                val = T(2) * (cscale * coarse[bcl + tx[o].cl[r3]]) - cscale * coarse[brf + tx[o].rf[r3]];
+              } else {
+                val = cscale * coarse[bcl + tx[o].cl[r3]];
+              }
+              acc[o] = acc[o] + T(wl * tx[o].w[r3]) * val;
+            }
+          }
+        }
+    const int sl = t0.sum * t1.sum * t2.sum;
+    const int64_t fbase = f0 * fs0 + f1 * fs1 + f2 * fs2 + k0;
+    for (int o = 0; o < nout; ++o) {
+      T v = acc[o] / T(sl * tx[o].sum);
+      if (add) v = ascale * add[fbase + o] + v;
+      fine[fbase + o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// P^T in gather form.  With gpad = (tensor-product transpose onto the padded coarse
+// grid), the joint ghost rule upad = 2*u[clamp] - u[reflect] gives
+//   gc[J] = 2 * sum_{j: clamp(j)=J} gpad[j] - sum_{j: reflect(j)=J} gpad[j],
+// and both sums stay separable: per axis the 1-D weights W(j,k) are summed over
+//   C(J) = {J} + {-1 if J==0} + {n if J==n-1}   resp.   R(J) = {J} + {-1 if J==1} + {n if J==n-2}.
+// 1-D weights: 'c' W(j,k) = {1,3,3,1}/4 at k-2j = -1..2; 'n' {1/2,1,1/2} at k-2j = -1..1.
+// ------------------------------------------------------------------------------------
+struct AdjTaps {
+  int64_t k0;  // first fine index of the window
+  int cnt;     // window length (<= 6)
+  float wc[6], wr[6];
+  bool special;  // wc != wr somewhere
+};
+
+__device__ inline float w_cell(int64_t j, int64_t k, int64_t F) {
+  if (k < 0 || k >= F) return 0.f;
+  int64_t d = k - 2 * j;
+  return (d == 0 || d == 1) ? 0.75f : ((d == -1 || d == 2) ? 0.25f : 0.f);
+}
+
+__device__ inline AdjTaps make_adj_taps(int loc, int64_t J, int64_t n, int64_t F) {
+  AdjTaps t;
+  t.special = false;
+  if (loc == kCell) {
+    const bool c_lo = J == 0, c_hi = J == n - 1, r_lo = J == 1, r_hi = J == n - 2;
+    t.special = c_lo || c_hi || r_lo || r_hi;
+    if (t.special) {
+      t.k0 = 2 * J - 2;
+      t.cnt = 6;
+    } else {
+      t.k0 = 2 * J - 1;
+      t.cnt = 4;
+    }
+    for (int i = 0; i < 6; ++i) {
+      int64_t k = t.k0 + i;
+      float w = i < t.cnt ? w_cell(J, k, F) : 0.f;
+      float lo = w_cell(-1, k, F), hi = w_cell(n, k, F);
+      t.wc[i] = i < t.cnt ? w + (c_lo ? lo : 0.f) + (c_hi ? hi : 0.f) : 0.f;
+      t.wr[i] = i < t.cnt ? w + (r_lo ? lo : 0.f) + (r_hi ? hi : 0.f) : 0.f;
+    }
+  } else if (loc == kNode) {
+    t.k0 = 2 * J - 1;
+    t.cnt = 3;
+    for (int i = 0; i < 6; ++i) {
+      int64_t k = t.k0 + i;
+      float w = (i < 3 && k >= 0 && k < F) ? (i == 1 ? 1.f : 0.5f) : 0.f;
+      t.wc[i] = t.wr[i] = w;
+    }
+  } else {
+    t.k0 = J;
+    t.cnt = 1;
+    for (int i = 0; i < 6; ++i) t.wc[i] = t.wr[i] = i == 0 ? 1.f : 0.f;
+  }
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj(const T* __restrict__ gfine, T* __restrict__ gcoarse,
+                                                       T* __restrict__ gscaled, InterpArgs a, T scale) {
+  const int64_t cs2 = a.cn[3], cs1 = a.cn[2] * cs2, cs0 = a.cn[1] * cs1;
+  const int64_t fs2 = a.fn[3], fs1 = a.fn[2] * fs2, fs0 = a.fn[1] * fs1;
+  RowIter it = sched_begin(a.sched);
+  for (; it.t < it.count; it.t += it.step) {
+    int64_t zz, y, xs;
+    sched_decode(a.sched, it, zz, y, xs);
+    const int64_t c0 = zz / a.cn[1], c1 = zz - c0 * a.cn[1], c2 = y;
+    const AdjTaps t0 = make_adj_taps(a.loc[0], c0, a.cn[0], a.fn[0]);
+    const AdjTaps t1 = make_adj_taps(a.loc[1], c1, a.cn[1], a.fn[1]);
+    const AdjTaps t2 = make_adj_taps(a.loc[2], c2, a.cn[2], a.fn[2]);
+    const int64_t c3 = xs * kBlock + threadIdx.x;
+    if (c3 >= a.cn[3]) continue;
+    const AdjTaps t3 = make_adj_taps(a.loc[3], c3, a.cn[3], a.fn[3]);
+    const bool special = t0.special || t1.special || t2.special || t3.special;
+    T sc = T(0), sr = T(0);
+    for (int i0 = 0; i0 < t0.cnt; ++i0) {
+      if (t0.wc[i0] == 0.f && t0.wr[i0] == 0.f) continue;
+      for (int i1 = 0; i1 < t1.cnt; ++i1) {
+        if (t1.wc[i1] == 0.f && t1.wr[i1] == 0.f) continue;
+        for (int i2 = 0; i2 < t2.cnt; ++i2) {
+          if (t2.wc[i2] == 0.f && t2.wr[i2] == 0.f) continue;
+          const T wcl = T(t0.wc[i0] * t1.wc[i1] * t2.wc[i2]);
+          const T wrl = T(t0.wr[i0] * t1.wr[i1] * t2.wr[i2]);
+          const int64_t base = (t0.k0 + i0) * fs0 + (t1.k0 + i1) * fs1 + (t2.k0 + i2) * fs2;
+          for (int i3 = 0; i3 < t3.cnt; ++i3) {
+            if (t3.wc[i3] == 0.f && t3.wr[i3] == 0.f) continue;
+            const T g = gfine[base + t3.k0 + i3];
+            sc = sc + (wcl * T(t3.wc[i3])) * g;
+            if (special) sr = sr + (wrl * T(t3.wr[i3])) * g;
+          }
+        }
+      }
+    }
+    const T v = special ? T(2) * sc - sr : sc;
+    const int64_t ci = c0 * cs0 + c1 * cs1 + c2 * cs2 + c3;
+    gcoarse[ci] = v;
+    if (gscaled) gscaled[ci] = scale * v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Restriction: 'c' [1,1]/2, 'n' [1,2,1]/4 on linearly extrapolated ghosts (joint rule
+// 2*u[clamp]-u[reflect] over the 'n' axes, core.py:736-739), stride 2 VALID on every
+// axis including '.' (backend.py:118-119).
+// ------------------------------------------------------------------------------------
+struct ResTaps {
+  int cnt;
+  int64_t cl[3], rf[3];
+  bool out[3];
+  float w[3];
+};
+
+__device__ inline ResTaps make_res_taps(int loc, int64_t j, int64_t n) {
+  ResTaps t;
+  if (loc == kCell) {
+    t.cnt = 2;
+    for (int i = 0; i < 2; ++i) {
+      t.cl[i] = t.rf[i] = 2 * j + i;
+      t.out[i] = false;
+      t.w[i] = 0.5f;
+    }
+  } else if (loc == kNode) {
+    t.cnt = 3;
+    for (int i = 0; i < 3; ++i) {
+      int64_t q = 2 * j - 1 + i;
+      t.out[i] = q < 0 || q >= n;
+      t.cl[i] = q < 0 ? 0 : (q >= n ? n - 1 : q);
+      t.rf[i] = q < 0 ? 1 : (q >= n ? n - 2 : q);
+      t.w[i] = i == 1 ? 0.5f : 0.25f;
+    }
+  } else {
+    t.cnt = 1;
+    t.cl[0] = t.rf[0] = 2 * j;
+    t.out[0] = false;
+    t.w[0] = 1.f;
+  }
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_restrict(const T* __restrict__ fine, T* __restrict__ coarse,
+                                                     InterpArgs a) {
+  const int64_t cs2 = a.cn[3], cs1 = a.cn[2] * cs2, cs0 = a.cn[1] * cs1;
+  const int64_t fs2 = a.fn[3], fs1 = a.fn[2] * fs2, fs0 = a.fn[1] * fs1;
+  RowIter it = sched_begin(a.sched);
+  for (; it.t < it.count; it.t += it.step) {
+    int64_t zz, y, xs;
+    sched_decode(a.sched, it, zz, y, xs);
+    const int64_t c0 = zz / a.cn[1], c1 = zz - c0 * a.cn[1], c2 = y;
+    const ResTaps t0 = make_res_taps(a.loc[0], c0, a.fn[0]);
+    const ResTaps t1 = make_res_taps(a.loc[1], c1, a.fn[1]);
+    const ResTaps t2 = make_res_taps(a.loc[2], c2, a.fn[2]);
+    const int64_t c3 = xs * kBlock + threadIdx.x;
+    if (c3 >= a.cn[3]) continue;
+    const ResTaps t3 = make_res_taps(a.loc[3], c3, a.fn[3]);
+    T acc = T(0);
+    for (int i0 = 0; i0 < t0.cnt; ++i0)
+      for (int i1 = 0; i1 < t1.cnt; ++i1)
+        for (int i2 = 0; i2 < t2.cnt; ++i2)
+          for (int i3 = 0; i3 < t3.cnt; ++i3) {
+            const bool o = t0.out[i0] || t1.out[i1] || t2.out[i2] || t3.out[i3];
+            const int64_t icl = t0.cl[i0] * fs0 + t1.cl[i1] * fs1 + t2.cl[i2] * fs2 + t3.cl[i3];
+            T val = fine[icl];
+            if (o) {
+              const int64_t irf = t0.rf[i0] * fs0 + t1.rf[i1] * fs1 + t2.rf[i2] * fs2 + t3.rf[i3];
+              val = T(2) * val - fine[irf];
+            }
+            acc = acc + T(t0.w[i0] * t1.w[i1] * t2.w[i2] * t3.w[i3]) * val;
+          }
+    coarse[c0 * cs0 + c1 * cs1 + c2 * cs2 + c3] = acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scale_copy(const T* __restrict__ x, T* __restrict__ y, int64_t n, T a) {
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) y[i] = a * x[i];
+}
+
+// ------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------
+static int fill_interp_args(InterpArgs& a, const int64_t* cshape, int ndim, const char* loc) {
+  if (ndim < 1 || ndim > ODIL_MAX_NDIM) {
+    set_error("ndim=%d out of range [1,%d]", ndim, ODIL_MAX_NDIM);
+    return ODIL_E_INVAL;
+  }
+  if (parse_loc(loc, ndim, a.loc)) {
+    set_error("invalid loc='%s' for ndim=%d", loc ? loc : "(null)", ndim);
+    return ODIL_E_INVAL;
+  }
+  canon_shape(cshape, ndim, a.cn);
+  for (int i = 0; i < 4; ++i) {
+    if (a.cn[i] < 1 || (a.loc[i] != kNone && a.cn[i] < 2)) {
+      set_error("coarse extent %lld on a refined axis must be >= 2", (long long)a.cn[i]);
+      return ODIL_E_INVAL;
+    }
+    a.fn[i] = a.loc[i] == kCell ? 2 * a.cn[i] : (a.loc[i] == kNode ? 2 * a.cn[i] - 1 : a.cn[i]);
+  }
+  return 0;
+}
+
+template <typename T>
+static int interp_add(const T* coarse, const T* add, T* fine, const int64_t* cshape, int ndim, const char* loc,
+                      T cscale, T ascale, void* stream) {
+  InterpArgs a;
+  if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
+  if (!coarse || !fine) {
+    set_error("interp_add: null pointer");
+    return ODIL_E_INVAL;
+  }
+  const int64_t npairs = (a.fn[3] + 1) / 2;
+  a.sched = make_sched(a.fn[0] * a.fn[1], a.fn[2], (npairs + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_interp_add<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, coarse, add,
+                     fine, a, cscale, ascale);
+  return check_launch("k_interp_add");
+}
+
+template <typename T>
+static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* cshape, int ndim, const char* loc,
+                      T scale, void* stream) {
+  InterpArgs a;
+  if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
+  if (!gfine || !gcoarse) {
+    set_error("interp_adj: null pointer");
+    return ODIL_E_INVAL;
+  }
+  a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_interp_adj<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, gfine,
+                     gcoarse, gscaled, a, scale);
+  return check_launch("k_interp_adj");
+}
+
+template <typename T>
+static int restrict_(const T* fine, T* coarse, const int64_t* fshape, int ndim, const char* loc, void* stream) {
+  InterpArgs a;
+  if (ndim < 1 || ndim > ODIL_MAX_NDIM || parse_loc(loc, ndim, a.loc)) {
+    set_error("restrict: invalid ndim=%d / loc", ndim);
+    return ODIL_E_INVAL;
+  }
+  canon_shape(fshape, ndim, a.fn);
+  for (int i = 0; i < 4; ++i) {
+    const int64_t n = a.fn[i];
+    // VALID stride-2 output sizes on the padded array: 'c' (n-2)/2+1, 'n' (n+2-3)/2+1, '.' (n-1)/2+1.
+    a.cn[i] = a.loc[i] == kCell ? (n - 2) / 2 + 1 : (n - 1) / 2 + 1;
+    if (a.loc[i] == kCell && n < 2) {
+      set_error("restrict: extent %lld too small", (long long)n);
+      return ODIL_E_INVAL;
+    }
+  }
+  if (!fine || !coarse) {
+    set_error("restrict: null pointer");
+    return ODIL_E_INVAL;
+  }
+  a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_restrict<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, fine, coarse, a);
+  return check_launch("k_restrict");
+}
+
+static int check_levels(const int64_t* shapes, int nlvl, int ndim, const char* loc) {
+  if (nlvl < 1 || nlvl > ODIL_MAX_LEVELS || !shapes) {
+    set_error("nlvl=%d out of range [1,%d]", nlvl, ODIL_MAX_LEVELS);
+    return ODIL_E_INVAL;
+  }
+  int l4[4];
+  if (ndim < 1 || ndim > ODIL_MAX_NDIM || parse_loc(loc, ndim, l4)) {
+    set_error("invalid ndim=%d / loc", ndim);
+    return ODIL_E_INVAL;
+  }
+  for (int l = 1; l < nlvl; ++l)
+    for (int d = 0; d < ndim; ++d) {
+      const int64_t c = shapes[l * ndim + d], f = shapes[(l - 1) * ndim + d];
+      const char t = loc[d];
+      const int64_t expect = t == 'c' ? 2 * c : (t == 'n' ? 2 * c - 1 : c);
+      if (f != expect) {
+        set_error("level %d axis %d: fine extent %lld does not refine coarse extent %lld (loc '%c')", l, d,
+                  (long long)f, (long long)c, t);
+        return ODIL_E_INVAL;
+      }
+    }
+  return 0;
+}
+
+// res_{L-1} = f_{L-1} w_{L-1};  res_l = f_l w_l + P(res_{l+1})   (core.py:258-262)
+template <typename T>
+static int mg_synth(const T* const* terms, const T* factors, T* const* work, T* u, const int64_t* shapes, int nlvl,
+                    int ndim, const char* loc, void* stream) {
+  if (int e = check_levels(shapes, nlvl, ndim, loc)) return e;
+  if (!terms || !u) {
+    set_error("mg_synth: null pointer");
+    return ODIL_E_INVAL;
+  }
+  if (nlvl == 1) {  // u = f_0 * w_0
+    int64_t n0 = 1;
+    for (int d = 0; d < ndim; ++d) n0 *= shapes[d];
+    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_for(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, terms[0],
+                       u, n0, factors ? factors[0] : T(1));
+    return check_launch("k_scale_copy");
+  }
+  const T* coarse = terms[nlvl - 1];
+  T cscale = factors ? factors[nlvl - 1] : T(1);
+  for (int l = nlvl - 2; l >= 0; --l) {
+    T* out = l == 0 ? u : (work ? work[l] : nullptr);
+    if (!out) {
+      set_error("mg_synth: work[%d] is null", l);
+      return ODIL_E_INVAL;
+    }
+    if (int e = interp_add<T>(coarse, terms[l], out, shapes + (l + 1) * ndim, ndim, loc, cscale,
+                              factors ? factors[l] : T(1), stream))
+      return e;
+    coarse = out;
+    cscale = T(1);
+  }
+  return 0;
+}
+
+// g'_0 = gu; g'_{l+1} = P^T g'_l; grads_l = f_l g'_l.
+template <typename T>
+static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const* work, const int64_t* shapes,
+                        int nlvl, int ndim, const char* loc, void* stream) {
+  if (int e = check_levels(shapes, nlvl, ndim, loc)) return e;
+  if (!gu || !grads) {
+    set_error("mg_synth_adj: null pointer");
+    return ODIL_E_INVAL;
+  }
+  // Level 0: grads[0] = f_0 * gu (grads[0] may alias gu when f_0 == 1).
+  const T f0 = factors ? factors[0] : T(1);
+  if (grads[0] && (grads[0] != gu || f0 != T(1))) {
+    const int64_t* s0 = shapes;
+    int64_t n0 = 1;
+    for (int d = 0; d < ndim; ++d) n0 *= s0[d];
+    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_for(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, gu,
+                       grads[0], n0, f0);
+    if (int e = check_launch("k_scale_copy")) return e;
+  }
+  const T* gfine = gu;  // the chain itself is unscaled
+  for (int l = 1; l < nlvl; ++l) {
+    const T f = factors ? factors[l] : T(1);
+    T* unscaled = grads[l];
+    T* scaled = nullptr;
+    if (f != T(1)) {
+      // later levels read the unscaled cotangent: keep it in work[l]
+      if (!work || !work[l]) {
+        set_error("mg_synth_adj: work[%d] needed for factor != 1", l);
+        return ODIL_E_INVAL;
+      }
+      unscaled = work[l];
+      scaled = grads[l];
+    }
+    if (int e = interp_adj<T>(gfine, unscaled, scaled, shapes + l * ndim, ndim, loc, f, stream)) return e;
+    gfine = unscaled;
+  }
+  return 0;
+}
+
+}  // namespace odil
+
+using namespace odil;
+
+extern "C" {
+
+int odil_interp_add_f64(const double* coarse, const double* add, double* fine, const int64_t* cshape, int ndim,
+                        const char* loc, double coarse_scale, double add_scale, void* stream) {
+  return interp_add<double>(coarse, add, fine, cshape, ndim, loc, coarse_scale, add_scale, stream);
+}
+int odil_interp_add_f32(const float* coarse, const float* add, float* fine, const int64_t* cshape, int ndim,
+                        const char* loc, float coarse_scale, float add_scale, void* stream) {
+  return interp_add<float>(coarse, add, fine, cshape, ndim, loc, coarse_scale, add_scale, stream);
+}
+int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
+                        const char* loc, double scale, void* stream) {
+  return interp_adj<double>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream);
+}
+int odil_interp_adj_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
+                        const char* loc, float scale, void* stream) {
+  return interp_adj<float>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream);
+}
+int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
+                      void* stream) {
+  return restrict_<double>(fine, coarse, fshape, ndim, loc, stream);
+}
+int odil_restrict_f32(const float* fine, float* coarse, const int64_t* fshape, int ndim, const char* loc,
+                      void* stream) {
+  return restrict_<float>(fine, coarse, fshape, ndim, loc, stream);
+}
+int odil_mg_synth_f64(const double* const* terms, const double* factors, double* const* work, double* u,
+                      const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {
+  return mg_synth<double>(terms, factors, work, u, shapes, nlvl, ndim, loc, stream);
+}
+int odil_mg_synth_f32(const float* const* terms, const float* factors, float* const* work, float* u,
+                      const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {
+  return mg_synth<float>(terms, factors, work, u, shapes, nlvl, ndim, loc, stream);
+}
+int odil_mg_synth_adj_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
+                          const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {
+  return mg_synth_adj<double>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream);
+}
+int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
+                          const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {
+  return mg_synth_adj<float>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// Newton building blocks of the ODIL hot path on gfx950: the sparse Jacobian that
+// Problem.linearize / field_to_matrix assemble on the host with scipy.sparse
+// (reference src/odil/core.py:1113-1217) is kept as per-shift coefficient arrays
+// (core.py:1313-1361) and applied matrix-free, M and M^T, for the normal equations
+// M^T M d = -M^T r (linsolver.py:17-26); a CSR export is provided for parity checks
+// and host solvers.
+#include "common.h"
+
+namespace odil {
+
+constexpr int kMaxShifts = 32;
+
+struct ShiftArgs {
+  int64_t n[4];
+  int nshift;
+  int64_t shift[kMaxShifts][4];
+};
+
+__device__ inline int64_t shifted_index(const ShiftArgs& a, int64_t i, int s, int sign) {
+  int64_t rem = i, idx = 0, stride = 1;
+  for (int d = 3; d >= 0; --d) {
+    const int64_t id = rem % a.n[d];
+    rem /= a.n[d];
+    int64_t p = (id + sign * a.shift[s][d]) % a.n[d];
+    if (p < 0) p += a.n[d];
+    idx += p * stride;
+    stride *= a.n[d];
+  }
+  return idx;
+}
+
+// y[r] = sum_s c_s[r] x[r + shift_s]   (cols = roll(arange, -shift), core.py:1158)
+// y[j] = sum_s c_s[j - shift_s] x[j - shift_s]   (transpose)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_stencil_apply(const T* __restrict__ coeffs, const T* __restrict__ x,
+                                                         T* __restrict__ y, ShiftArgs a, int transpose) {
+  const int64_t size = a.n[0] * a.n[1] * a.n[2] * a.n[3];
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += nthreads) {
+    T acc = T(0);
+    for (int s = 0; s < a.nshift; ++s) {
+      if (!transpose) {
+        acc = acc + coeffs[(int64_t)s * size + i] * x[shifted_index(a, i, s, +1)];
+      } else {
+        const int64_t r = shifted_index(a, i, s, -1);
+        acc = acc + coeffs[(int64_t)s * size + r] * x[r];
+      }
+    }
+    y[i] = acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_csr_assemble(const T* __restrict__ coeffs, ShiftArgs a, int64_t col_offset,
+                                                        int64_t* __restrict__ indptr, int64_t* __restrict__ indices,
+                                                        T* __restrict__ data) {
+  const int64_t size = a.n[0] * a.n[1] * a.n[2] * a.n[3];
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += nthreads) {
+    indptr[i] = i * a.nshift;
+    if (i == size - 1) indptr[size] = size * a.nshift;
+    for (int s = 0; s < a.nshift; ++s) {
+      indices[i * a.nshift + s] = col_offset + shifted_index(a, i, s, +1);
+      data[i * a.nshift + s] = coeffs[(int64_t)s * size + i];
+    }
+  }
+}
+
+static int fill_shifts(ShiftArgs& a, const int64_t* shifts, int nshift, const int64_t* shape, int ndim) {
+  if (ndim < 1 || ndim > ODIL_MAX_NDIM || !shape || !shifts || nshift < 1 || nshift > kMaxShifts) {
+    set_error("stencil: invalid ndim=%d or nshift=%d (max %d)", ndim, nshift, kMaxShifts);
+    return ODIL_E_INVAL;
+  }
+  canon_shape(shape, ndim, a.n);
+  a.nshift = nshift;
+  for (int s = 0; s < nshift; ++s)
+    for (int d = 0; d < 4; ++d) {
+      const int i = d - (4 - ndim);
+      a.shift[s][d] = i >= 0 ? shifts[s * ndim + i] : 0;
+    }
+  return 0;
+}
+
+template <typename T>
+static int stencil_apply(const T* coeffs, const int64_t* shifts, int nshift, const T* x, T* y, const int64_t* shape,
+                         int ndim, int transpose, void* stream) {
+  ShiftArgs a;
+  if (int e = fill_shifts(a, shifts, nshift, shape, ndim)) return e;
+  if (!coeffs || !x || !y) {
+    set_error("stencil_apply: null pointer");
+    return ODIL_E_INVAL;
+  }
+  hipLaunchKernelGGL(k_stencil_apply<T>, dim3(grid_for(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     coeffs, x, y, a, transpose);
+  return check_launch("k_stencil_apply");
+}
+
+template <typename T>
+static int csr_assemble(const T* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
+                        int64_t col_offset, int64_t* indptr, int64_t* indices, T* data, void* stream) {
+  ShiftArgs a;
+  if (int e = fill_shifts(a, shifts, nshift, shape, ndim)) return e;
+  if (!coeffs || !indptr || !indices || !data) {
+    set_error("csr_assemble: null pointer");
+    return ODIL_E_INVAL;
+  }
+  hipLaunchKernelGGL(k_csr_assemble<T>, dim3(grid_for(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     coeffs, a, col_offset, indptr, indices, data);
+  return check_launch("k_csr_assemble");
+}
+
+}  // namespace odil
+
+using namespace odil;
+
+extern "C" {
+int odil_stencil_apply_f64(const double* coeffs, const int64_t* shifts, int nshift, const double* x, double* y,
+                           const int64_t* shape, int ndim, int transpose, void* stream) {
+  return stencil_apply<double>(coeffs, shifts, nshift, x, y, shape, ndim, transpose, stream);
+}
+int odil_stencil_apply_f32(const float* coeffs, const int64_t* shifts, int nshift, const float* x, float* y,
+                           const int64_t* shape, int ndim, int transpose, void* stream) {
+  return stencil_apply<float>(coeffs, shifts, nshift, x, y, shape, ndim, transpose, stream);
+}
+int odil_csr_assemble_f64(const double* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
+                          int64_t col_offset, int64_t* indptr, int64_t* indices, double* data, void* stream) {
+  return csr_assemble<double>(coeffs, shifts, nshift, shape, ndim, col_offset, indptr, indices, data, stream);
+}
+int odil_csr_assemble_f32(const float* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
+                          int64_t col_offset, int64_t* indptr, int64_t* indices, float* data, void* stream) {
+  return csr_assemble<float>(coeffs, shifts, nshift, shape, ndim, col_offset, indptr, indices, data, stream);
+}
+}

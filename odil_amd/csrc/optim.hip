@@ -1,0 +1,176 @@
+// Optimizer updates and flat-vector algebra of the ODIL hot path on gfx950
+// (reference src/odil/optimizer.py:256-341; L-BFGS / CG building blocks).
+// Pure HBM streaming: 16 B per lane, grid capped at 8 workgroups per CU, grid-stride.
+#include "common.h"
+
+namespace odil {
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+  static constexpr int N = 2;
+  typedef double2 type;
+};
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  typedef float4 type;
+};
+
+template <typename T>
+__device__ inline void adam_one(T& x, T& m, T& v, T g, T alpha, T omb1, T omb2, T eps) {
+  // optimizer.py:316-318
+  m = m + (g - m) * omb1;
+  v = v + (g * g - v) * omb2;
+  x = x - (m * alpha) / (sqrt(v) + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restrict__ m, T* __restrict__ v,
+                                                const T* __restrict__ g, int64_t n, T alpha, T omb1, T omb2, T eps,
+                                                int vec_ok) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type VT;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  if (vec_ok) {
+    const int64_t nv = n / V;
+    for (int64_t i = tid; i < nv; i += nthreads) {
+      VT xv = reinterpret_cast<VT*>(x)[i], mv = reinterpret_cast<VT*>(m)[i], vv = reinterpret_cast<VT*>(v)[i];
+      const VT gv = reinterpret_cast<const VT*>(g)[i];
+      T* xp = reinterpret_cast<T*>(&xv);
+      T* mp = reinterpret_cast<T*>(&mv);
+      T* vp = reinterpret_cast<T*>(&vv);
+      const T* gp = reinterpret_cast<const T*>(&gv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) adam_one<T>(xp[k], mp[k], vp[k], gp[k], alpha, omb1, omb2, eps);
+      reinterpret_cast<VT*>(x)[i] = xv;
+      reinterpret_cast<VT*>(m)[i] = mv;
+      reinterpret_cast<VT*>(v)[i] = vv;
+    }
+    for (int64_t i = nv * V + tid; i < n; i += nthreads) adam_one<T>(x[i], m[i], v[i], g[i], alpha, omb1, omb2, eps);
+  } else {
+    for (int64_t i = tid; i < n; i += nthreads) adam_one<T>(x[i], m[i], v[i], g[i], alpha, omb1, omb2, eps);
+  }
+}
+
+static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+static int adam_step(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, void* stream) {
+  if (!x || !m || !v || !g || n < 0) {
+    set_error("adam_step: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  const int vec_ok = aligned16(x) && aligned16(m) && aligned16(v) && aligned16(g);
+  hipLaunchKernelGGL(k_adam<T>, dim3(grid_for(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, (hipStream_t)stream, x, m,
+                     v, g, n, alpha, omb1, omb2, eps, vec_ok);
+  return check_launch("k_adam");
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_axpy(T* __restrict__ y, const T* __restrict__ x, int64_t n, T a) {
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) y[i] = y[i] + a * x[i];
+}
+
+template <typename T>
+static int axpy(T* y, const T* x, int64_t n, T a, void* stream) {
+  if (!y || !x || n < 0) {
+    set_error("axpy: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, x, n, a);
+  return check_launch("k_axpy");
+}
+
+// out[k] = <a_k, b>: blockIdx.y = k; contiguous chunk per workgroup; fixed order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
+                                                int64_t n, double* __restrict__ partials) {
+  const T* ak = a + (int64_t)blockIdx.y * lda;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  int64_t hi = lo + per;
+  if (hi > n) hi = n;
+  double local = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) local += (double)ak[i] * (double)b[i];
+  const double total = block_sum(local);
+  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * kMaxPartials + blockIdx.x] = total;
+}
+
+template <typename T>
+static int dots(const T* a, int64_t lda, int nvec, const T* b, int64_t n, double* partials, T* out, void* stream) {
+  if (!a || !b || !partials || !out || n < 1 || nvec < 1 || nvec > 65535) {
+    set_error("dots: null pointer, n < 1 or nvec=%d out of range", nvec);
+    return ODIL_E_INVAL;
+  }
+  int grid = grid_for(n, kBlock * 8);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_dots<T>, dim3(grid, nvec), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b, n, partials);
+  if (int e = check_launch("k_dots")) return e;
+  return launch_final_reduce<T>(partials, grid, kMaxPartials, nvec, 1.0, out, (hipStream_t)stream);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lincomb(T* __restrict__ y, T beta, const T* __restrict__ a, int64_t lda,
+                                                   int nvec, const T* __restrict__ coef, int64_t n) {
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+    T acc = beta == T(0) ? T(0) : beta * y[i];
+    for (int k = 0; k < nvec; ++k) acc = acc + coef[k] * a[(int64_t)k * lda + i];
+    y[i] = acc;
+  }
+}
+
+template <typename T>
+static int lincomb(T* y, T beta, const T* a, int64_t lda, int nvec, const T* coef, int64_t n, void* stream) {
+  if (!y || n < 0 || nvec < 0 || (nvec > 0 && (!a || !coef))) {
+    set_error("lincomb: null pointer or negative size");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_lincomb<T>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, beta, a, lda,
+                     nvec, coef, n);
+  return check_launch("k_lincomb");
+}
+
+}  // namespace odil
+
+using namespace odil;
+
+extern "C" {
+int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t n, double alpha,
+                       double one_minus_b1, double one_minus_b2, double eps, void* stream) {
+  return adam_step<double>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, stream);
+}
+int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
+                       float one_minus_b2, float eps, void* stream) {
+  return adam_step<float>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, stream);
+}
+int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream) {
+  return axpy<double>(y, x, n, a, stream);
+}
+int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream) {
+  return axpy<float>(y, x, n, a, stream);
+}
+int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64_t n, double* partials,
+                  double* out, void* stream) {
+  return dots<double>(a, lda, nvec, b, n, partials, out, stream);
+}
+int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,
+                  void* stream) {
+  return dots<float>(a, lda, nvec, b, n, partials, out, stream);
+}
+int odil_lincomb_f64(double* y, double beta, const double* a, int64_t lda, int nvec, const double* coef, int64_t n,
+                     void* stream) {
+  return lincomb<double>(y, beta, a, lda, nvec, coef, n, stream);
+}
+int odil_lincomb_f32(float* y, float beta, const float* a, int64_t lda, int nvec, const float* coef, int64_t n,
+                     void* stream) {
+  return lincomb<float>(y, beta, a, lda, nvec, coef, n, stream);
+}
+}

@@ -1,0 +1,335 @@
+// Poisson workload of the ODIL hot path on gfx950
+// (reference examples/poisson/poisson.py:57-113; extrap_quadh core.py:1439-1445):
+//   residual  fu = sum_i (u+ - 2u + u-)/h_i^2 - rhs, zero-Dirichlet ghosts, + mean(fu^2)
+//   adjoint   gu = J^T (scale * fu)
+//   jacobian  per-shift coefficient arrays (core.py:1313-1361 under distinct_shift)
+//
+// HBM-bound 7-point stencils.  Lanes run along x with 16 B per lane (2 x f64 / 4 x f32);
+// the XCD-aware row schedule (common.h) keeps the y+-1 / z+-1 re-reads inside one XCD's
+// L2, so HBM sees each of u, rhs once and fu once.  The loss is reduced in a fixed order
+// (per-thread running sum -> wave shuffle -> LDS -> one partial per workgroup -> final
+// kernel), so it is bit-reproducible run to run.
+#include "common.h"
+
+namespace odil {
+
+struct StencilArgs {
+  int64_t n[3];     // canonical (Z, Y, X) cell shape
+  int active[3];    // axis takes part in the Laplacian
+  RowSched sched;
+};
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  static constexpr int N = 2;
+};
+template <>
+struct VecOf<float> {
+  static constexpr int N = 4;
+};
+
+template <typename T, int N>
+struct alignas(N * sizeof(T)) Pack {
+  T v[N];
+};
+
+template <typename T, int N>
+__device__ inline void load_vec(const T* __restrict__ p, int64_t valid, T out[N]) {
+  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
+    Pack<T, N> q = *reinterpret_cast<const Pack<T, N>*>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = q.v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = i < valid ? p[i] : T(0);
+  }
+}
+
+template <typename T, int N>
+__device__ inline void store_vec(T* __restrict__ p, int64_t valid, const T in[N]) {
+  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
+    Pack<T, N> q;
+#pragma unroll
+    for (int i = 0; i < N; ++i) q.v[i] = in[i];
+    *reinterpret_cast<Pack<T, N>*>(p) = q;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < valid) p[i] = in[i];
+  }
+}
+
+// One axis of poisson.py:57-68 + :112: ghosts by extrap_quadh(q+-, q, 0), then (qp - 2q + qm)/h2.
+template <typename T>
+__device__ inline T axis_term(T q, T qwm, T qwp, bool lo, bool hi, T h2) {
+  const T qm = lo ? (qwp - T(6) * q) / T(3) : qwm;
+  const T qp = hi ? (qwm - T(6) * q) / T(3) : qwp;
+  return (qp - T(2) * q + qm) / h2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict__ u, const T* __restrict__ rhs,
+                                                            T* __restrict__ fu, StencilArgs a, T h2z, T h2y, T h2x,
+                                                            double* __restrict__ partials) {
+  constexpr int V = VecOf<T>::N;
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
+  double local = 0.0;
+  RowIter it = sched_begin(a.sched);
+  for (; it.t < it.count; it.t += it.step) {
+    int64_t z, y, xs;
+    sched_decode(a.sched, it, z, y, xs);
+    const int64_t x0 = (xs * kBlock + threadIdx.x) * V;
+    if (x0 >= X) continue;
+    const int64_t valid = X - x0 < V ? X - x0 : V;
+    const int64_t row = z * sz + y * sy;
+    T c[V], r[V], out[V];
+    load_vec<T, V>(u + row + x0, valid, c);
+    load_vec<T, V>(rhs + row + x0, valid, r);
+    T ym[V], yp[V], zm[V], zp[V];
+    if (a.active[1]) {
+      const int64_t rm = z * sz + (y == 0 ? Y - 1 : y - 1) * sy;
+      const int64_t rp = z * sz + (y == Y - 1 ? 0 : y + 1) * sy;
+      load_vec<T, V>(u + rm + x0, valid, ym);
+      load_vec<T, V>(u + rp + x0, valid, yp);
+    }
+    if (a.active[0]) {
+      const int64_t rm = (z == 0 ? Z - 1 : z - 1) * sz + y * sy;
+      const int64_t rp = (z == Z - 1 ? 0 : z + 1) * sz + y * sy;
+      load_vec<T, V>(u + rm + x0, valid, zm);
+      load_vec<T, V>(u + rp + x0, valid, zp);
+    }
+    // x neighbours of the pack: periodic like mod.roll (core.py:963); the wrapped values
+    // are discarded by the where() masks exactly as in the reference.
+    const T left = u[row + (x0 == 0 ? X - 1 : x0 - 1)];
+    const int64_t xr = x0 + valid;
+    const T right = u[row + (xr >= X ? 0 : xr)];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      if (i >= valid) break;
+      const int64_t x = x0 + i;
+      const T q = c[i];
+      T acc = T(0);
+      bool first = true;
+      if (a.active[0]) {
+        acc = axis_term<T>(q, zm[i], zp[i], z == 0, z == Z - 1, h2z);
+        first = false;
+      }
+      if (a.active[1]) {
+        const T t = axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h2y);
+        acc = first ? t : acc + t;
+        first = false;
+      }
+      {
+        const T xm = i == 0 ? left : c[i - 1];
+        const T xp = (i == valid - 1) ? right : c[i + 1 < V ? i + 1 : i];
+        const T t = axis_term<T>(q, xm, xp, x == 0, x == X - 1, h2x);
+        acc = first ? t : acc + t;
+      }
+      const T f = acc - r[i];
+      out[i] = f;
+      local += (double)(f * f);
+    }
+    if (fu) store_vec<T, V>(fu + row + x0, valid, out);
+  }
+  const double total = block_sum(local);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// Row i of the 1-D operator: cm(i) u[i-1] + c0(i) u[i] + cp(i) u[i+1], all / h2, with
+//   cm(i) = [i != 0] + [i == n-1]/3,  cp(i) = [i != n-1] + [i == 0]/3,
+//   c0(i) = -2 - 2[i == 0] - 2[i == n-1]          (poisson.py:57-68).
+// Transpose: g[j] = cm(j+1) fb[j+1] + c0(j) fb[j] + cp(j-1) fb[j-1]  (periodic indices;
+// the masked coefficients vanish exactly where the roll wraps).
+template <typename T>
+__device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, T h2) {
+  const int64_t jp = j == n - 1 ? 0 : j + 1;
+  const int64_t jm = j == 0 ? n - 1 : j - 1;
+  // from row jp: cm(jp) * fb[jp]
+  T s = T(0);
+  if (jp != 0) s = s + fbp;
+  if (jp == n - 1) s = s + fbp / T(3);
+  // from row jm: cp(jm) * fb[jm]
+  if (jm != n - 1) s = s + fbm;
+  if (jm == 0) s = s + fbm / T(3);
+  // from row j
+  T c0 = T(-2);
+  if (j == 0) c0 = c0 - T(2);
+  if (j == n - 1) c0 = c0 - T(2);
+  s = s + c0 * fb;
+  return s / h2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict__ fu, T* __restrict__ gu,
+                                                           StencilArgs a, T h2z, T h2y, T h2x, T scale) {
+  constexpr int V = VecOf<T>::N;
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
+  RowIter it = sched_begin(a.sched);
+  for (; it.t < it.count; it.t += it.step) {
+    int64_t z, y, xs;
+    sched_decode(a.sched, it, z, y, xs);
+    const int64_t x0 = (xs * kBlock + threadIdx.x) * V;
+    if (x0 >= X) continue;
+    const int64_t valid = X - x0 < V ? X - x0 : V;
+    const int64_t row = z * sz + y * sy;
+    T c[V], out[V], ym[V], yp[V], zm[V], zp[V];
+    load_vec<T, V>(fu + row + x0, valid, c);
+    if (a.active[1]) {
+      load_vec<T, V>(fu + z * sz + (y == 0 ? Y - 1 : y - 1) * sy + x0, valid, ym);
+      load_vec<T, V>(fu + z * sz + (y == Y - 1 ? 0 : y + 1) * sy + x0, valid, yp);
+    }
+    if (a.active[0]) {
+      load_vec<T, V>(fu + (z == 0 ? Z - 1 : z - 1) * sz + y * sy + x0, valid, zm);
+      load_vec<T, V>(fu + (z == Z - 1 ? 0 : z + 1) * sz + y * sy + x0, valid, zp);
+    }
+    const T left = fu[row + (x0 == 0 ? X - 1 : x0 - 1)];
+    const int64_t xr = x0 + valid;
+    const T right = fu[row + (xr >= X ? 0 : xr)];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      if (i >= valid) break;
+      const int64_t x = x0 + i;
+      const T fb = scale * c[i];
+      T g = T(0);
+      if (a.active[0]) g = g + adj_axis<T>(fb, scale * zm[i], scale * zp[i], z, Z, h2z);
+      if (a.active[1]) g = g + adj_axis<T>(fb, scale * ym[i], scale * yp[i], y, Y, h2y);
+      const T xm = scale * (i == 0 ? left : c[i - 1]);
+      const T xp = scale * ((i == valid - 1) ? right : c[i + 1 < V ? i + 1 : i]);
+      g = g + adj_axis<T>(fb, xm, xp, x, X, h2x);
+      out[i] = g;
+    }
+    store_vec<T, V>(gu + row + x0, valid, out);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_poisson_jac(T* __restrict__ coeffs, StencilArgs a, int ndim, T h2z, T h2y,
+                                                       T h2x) {
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t size = Z * Y * X;
+  const T h2[3] = {h2z, h2y, h2x};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
+    const int64_t idx[3] = {z, y, x};
+    T c0 = T(0);
+    int slot = 1;
+    for (int ax = 3 - ndim; ax < 3; ++ax) {
+      const bool lo = idx[ax] == 0, hi = idx[ax] == a.n[ax] - 1;
+      const T one = T(1);
+      const T cm = (lo ? T(0) : one) + (hi ? one / T(3) : T(0));
+      const T cp = (hi ? T(0) : one) + (lo ? one / T(3) : T(0));
+      const T cc = T(-2) * one + (lo ? T(-2) * one : T(0)) + (hi ? T(-2) * one : T(0));
+      coeffs[(int64_t)slot * size + i] = cm / h2[ax];
+      coeffs[(int64_t)(slot + 1) * size + i] = cp / h2[ax];
+      c0 = c0 + cc / h2[ax];
+      slot += 2;
+    }
+    coeffs[i] = c0;
+  }
+}
+
+template <typename T>
+static int fill_args(StencilArgs& a, const int64_t* shape, int ndim, const T* h2, T h[3]) {
+  if (ndim < 1 || ndim > 3 || !shape || !h2) {
+    set_error("poisson: ndim=%d out of range [1,3] or null shape/h2", ndim);
+    return ODIL_E_INVAL;
+  }
+  for (int i = 0; i < 3; ++i) {
+    a.n[i] = 1;
+    a.active[i] = 0;
+    h[i] = T(1);
+  }
+  for (int i = 0; i < ndim; ++i) {
+    const int c = 3 - ndim + i;
+    a.n[c] = shape[i];
+    a.active[c] = 1;
+    h[c] = h2[i];
+    if (shape[i] < 2) {
+      set_error("poisson: extent %lld on axis %d must be >= 2", (long long)shape[i], i);
+      return ODIL_E_INVAL;
+    }
+  }
+  const int per = kBlock * VecOf<T>::N;
+  a.sched = make_sched(a.n[0], a.n[1], (a.n[2] + per - 1) / per);
+  return 0;
+}
+
+template <typename T>
+static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shape, int ndim, const T* h2,
+                            double* partials, T* loss, void* stream) {
+  StencilArgs a;
+  T h[3];
+  if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  if (!u || !rhs || !partials || !loss) {
+    set_error("poisson_residual: null pointer");
+    return ODIL_E_INVAL;
+  }
+  const int grid = sched_grid(a.sched);
+  hipLaunchKernelGGL(k_poisson_residual<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a, h[0],
+                     h[1], h[2], partials);
+  if (int e = check_launch("k_poisson_residual")) return e;
+  const double size = (double)(a.n[0] * a.n[1] * a.n[2]);
+  return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
+}
+
+template <typename T>
+static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, const T* h2, T scale, void* stream) {
+  StencilArgs a;
+  T h[3];
+  if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  if (!fu || !gu) {
+    set_error("poisson_adjoint: null pointer");
+    return ODIL_E_INVAL;
+  }
+  hipLaunchKernelGGL(k_poisson_adjoint<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, fu, gu, a,
+                     h[0], h[1], h[2], scale);
+  return check_launch("k_poisson_adjoint");
+}
+
+template <typename T>
+static int poisson_jac(T* coeffs, const int64_t* shape, int ndim, const T* h2, void* stream) {
+  StencilArgs a;
+  T h[3];
+  if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  if (!coeffs) {
+    set_error("poisson_jac_coeffs: null pointer");
+    return ODIL_E_INVAL;
+  }
+  const int64_t size = a.n[0] * a.n[1] * a.n[2];
+  hipLaunchKernelGGL(k_poisson_jac<T>, dim3(grid_for(size, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coeffs, a,
+                     ndim, h[0], h[1], h[2]);
+  return check_launch("k_poisson_jac");
+}
+
+}  // namespace odil
+
+using namespace odil;
+
+extern "C" {
+int odil_poisson_residual_f64(const double* u, const double* rhs, double* fu, const int64_t* shape, int ndim,
+                              const double* h2, double* partials, double* loss, void* stream) {
+  return poisson_residual<double>(u, rhs, fu, shape, ndim, h2, partials, loss, stream);
+}
+int odil_poisson_residual_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
+                              const float* h2, double* partials, float* loss, void* stream) {
+  return poisson_residual<float>(u, rhs, fu, shape, ndim, h2, partials, loss, stream);
+}
+int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,
+                             double scale, void* stream) {
+  return poisson_adjoint<double>(fu, gu, shape, ndim, h2, scale, stream);
+}
+int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, int ndim, const float* h2,
+                             float scale, void* stream) {
+  return poisson_adjoint<float>(fu, gu, shape, ndim, h2, scale, stream);
+}
+int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream) {
+  return poisson_jac<double>(coeffs, shape, ndim, h2, stream);
+}
+int odil_poisson_jac_coeffs_f32(float* coeffs, const int64_t* shape, int ndim, const float* h2, void* stream) {
+  return poisson_jac<float>(coeffs, shape, ndim, h2, stream);
+}
+}  // extern "C"

@@ -1,0 +1,296 @@
+"""Tensor-level wrappers of the HIP kernels (torch = device memory + streams only).
+
+Each function allocates its output with torch, passes raw device pointers through
+the C-ABI (`_lib.call`) on the current HIP stream and returns tensors.  Names and
+semantics follow the reference functions cited in include/odil_hip.h.
+"""
+
+import math
+from ctypes import c_int, c_int64
+
+import torch
+
+from . import _lib
+from ._lib import call, host_reals, i64, ptr, ptr_array, stream_ptr
+
+_workspace = {}
+
+
+def reduce_workspace(device, nquant=1):
+    """Per-device scratch for the deterministic reductions (f64 partial sums)."""
+    key = (str(device), nquant)
+    ws = _workspace.get(key)
+    if ws is None:
+        ws = torch.empty(_lib.reduce_workspace_elems() * nquant, dtype=torch.float64, device=device)
+        _workspace[key] = ws
+    return ws
+
+
+def fine_shape(cshape, loc):
+    return tuple({"c": 2 * s, "n": 2 * s - 1, ".": s}[l] for s, l in zip(cshape, loc))
+
+
+def coarse_shape(fshape, loc):
+    """Output shape of restrict_to_coarser (stride-2 VALID on every axis)."""
+    return tuple((s - 2) // 2 + 1 if l == "c" else (s - 1) // 2 + 1 for s, l in zip(fshape, loc))
+
+
+def _real(dtype, v):
+    return float(v)
+
+
+def interp_add(coarse, loc, add=None, coarse_scale=1.0, add_scale=1.0, out=None):
+    """out = add_scale*add + P(coarse_scale*coarse)  (reference core.py:606-700, :258-262)."""
+    fshape = fine_shape(coarse.shape, loc)
+    if out is None:
+        out = torch.empty(fshape, dtype=coarse.dtype, device=coarse.device)
+    assert tuple(out.shape) == fshape, (out.shape, fshape)
+    if add is not None:
+        assert tuple(add.shape) == fshape and add.dtype == coarse.dtype
+    call(
+        "interp_add", coarse.dtype, ptr(coarse), ptr(add), ptr(out), i64(coarse.shape), c_int(coarse.dim()),
+        loc.encode(), coarse_scale, add_scale, stream_ptr(),
+    )
+    return out
+
+
+def interp_to_finer(u, loc, depth=1):
+    for _ in range(depth):
+        u = interp_add(u, loc)
+    return u
+
+
+def interp_adj(gfine, loc, cshape, scale=None, out=None):
+    """P^T gfine (and optionally scale * P^T gfine)."""
+    cshape = tuple(int(s) for s in cshape)
+    assert tuple(gfine.shape) == fine_shape(cshape, loc), (gfine.shape, cshape, loc)
+    if out is None:
+        out = torch.empty(cshape, dtype=gfine.dtype, device=gfine.device)
+    scaled = None
+    if scale is not None:
+        scaled = torch.empty_like(out)
+    call(
+        "interp_adj", gfine.dtype, ptr(gfine), ptr(out), ptr(scaled), i64(cshape), c_int(len(cshape)), loc.encode(),
+        1.0 if scale is None else float(scale), stream_ptr(),
+    )
+    return out if scale is None else (out, scaled)
+
+
+def restrict_to_coarser(u, loc, depth=1):
+    """Full weighting (reference core.py:703-755)."""
+    for _ in range(depth):
+        out = torch.empty(coarse_shape(u.shape, loc), dtype=u.dtype, device=u.device)
+        call("restrict", u.dtype, ptr(u), ptr(out), i64(u.shape), c_int(u.dim()), loc.encode(), stream_ptr())
+        u = out
+    return u
+
+
+def _shapes_flat(tensors):
+    flat = []
+    for t in tensors:
+        flat += list(t.shape)
+    return i64(flat)
+
+
+def mg_synth(terms, loc, factors=None, work=None, out=None):
+    """u = sum_l P^l (f_l w_l)  (reference core.py:245-263)."""
+    nlvl = len(terms)
+    dtype, device = terms[0].dtype, terms[0].device
+    if out is None:
+        out = torch.empty_like(terms[0])
+    if work is None:
+        work = [None] + [torch.empty_like(t) for t in terms[1:-1]] + [None]
+        work = work[:nlvl]
+    fac = host_reals(factors, dtype) if factors is not None else (None, None)
+    call(
+        "mg_synth", dtype, ptr_array(terms), fac[1], ptr_array(work), ptr(out), _shapes_flat(terms), c_int(nlvl),
+        c_int(terms[0].dim()), loc.encode(), stream_ptr(),
+    )
+    return out
+
+
+def mg_synth_adj(gu, shapes, loc, factors=None, grads=None):
+    """[f_l (P^T)^l gu]  (cotangent of mg_synth)."""
+    nlvl = len(shapes)
+    dtype, device = gu.dtype, gu.device
+    nontrivial = factors is not None and any(float(f) != 1.0 for f in factors)
+    if grads is None:
+        first = torch.empty_like(gu) if (nontrivial and float(factors[0]) != 1.0) else gu
+        grads = [first] + [torch.empty(tuple(s), dtype=dtype, device=device) for s in shapes[1:]]
+    work = [None] * nlvl
+    if nontrivial:
+        work = [None] + [torch.empty(tuple(s), dtype=dtype, device=device) for s in shapes[1:]]
+    fac = host_reals(factors, dtype) if factors is not None else (None, None)
+    flat = []
+    for s in shapes:
+        flat += list(s)
+    call(
+        "mg_synth_adj", dtype, ptr(gu), ptr_array(grads), fac[1], ptr_array(work), i64(flat), c_int(nlvl),
+        c_int(gu.dim()), loc.encode(), stream_ptr(),
+    )
+    return grads
+
+
+def field_gather(src, field_loc, shift=None, loc=None):
+    """Context.field access (reference core.py:955-969): pad, periodic roll, trim."""
+    loc = loc or field_loc
+    ndim = src.dim()
+    shift = tuple(shift) if shift else (0,) * ndim
+    oshape = tuple(
+        s + (1 if (lf == "c" and l == "n") else 0) - (1 if (lf == "n" and l == "c") else 0)
+        for s, lf, l in zip(src.shape, field_loc, loc)
+    )
+    out = torch.empty(oshape, dtype=src.dtype, device=src.device)
+    call(
+        "field_gather", src.dtype, ptr(src), ptr(out), i64(src.shape), c_int(ndim), field_loc.encode(), loc.encode(),
+        i64(shift), stream_ptr(),
+    )
+    return out
+
+
+def field_scatter(g, src_shape, field_loc, shift=None, loc=None, out=None):
+    """Transpose of field_gather; accumulates into `out` if given."""
+    loc = loc or field_loc
+    ndim = len(src_shape)
+    shift = tuple(shift) if shift else (0,) * ndim
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(tuple(src_shape), dtype=g.dtype, device=g.device)
+    call(
+        "field_scatter", g.dtype, ptr(g), ptr(out), i64(src_shape), c_int(ndim), field_loc.encode(), loc.encode(),
+        i64(shift), c_int(1 if accumulate else 0), stream_ptr(),
+    )
+    return out
+
+
+def mean_reduce(x, square=True, out=None):
+    """mean(x**2) or mean(x) as a 0-d device tensor, deterministic (reference core.py:1093)."""
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty((), dtype=x.dtype, device=x.device)
+    call(
+        "mean_reduce", x.dtype, ptr(x), c_int64(x.numel()), c_int(1 if square else 0),
+        ptr(reduce_workspace(x.device)), ptr(out), stream_ptr(),
+    )
+    return out
+
+
+def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True):
+    """fu = Lap(u) - rhs with zero-Dirichlet ghosts, loss = mean(fu**2)
+    (reference examples/poisson/poisson.py:89-113, core.py:1093)."""
+    assert u.shape == rhs.shape and u.dtype == rhs.dtype
+    if fu is None and want_fu:
+        fu = torch.empty_like(u)
+    if loss is None:
+        loss = torch.empty((), dtype=u.dtype, device=u.device)
+    h2a, h2p = host_reals(h2, u.dtype)
+    call(
+        "poisson_residual", u.dtype, ptr(u), ptr(rhs), ptr(fu), i64(u.shape), c_int(u.dim()), h2p,
+        ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
+    )
+    return fu, loss
+
+
+def poisson_adjoint(fu, h2, scale, out=None):
+    """gu = J^T (scale * fu)."""
+    if out is None:
+        out = torch.empty_like(fu)
+    h2a, h2p = host_reals(h2, fu.dtype)
+    call("poisson_adjoint", fu.dtype, ptr(fu), ptr(out), i64(fu.shape), c_int(fu.dim()), h2p, float(scale), stream_ptr())
+    return out
+
+
+def poisson_jac_coeffs(shape, h2, dtype, device):
+    """(2*ndim+1, *shape) coefficient arrays [centre, -1 ax0, +1 ax0, ...] (reference core.py:1313-1361)."""
+    ndim = len(shape)
+    out = torch.empty((2 * ndim + 1,) + tuple(shape), dtype=dtype, device=device)
+    h2a, h2p = host_reals(h2, dtype)
+    call("poisson_jac_coeffs", dtype, ptr(out), i64(shape), c_int(ndim), h2p, stream_ptr())
+    return out
+
+
+def adam_step(x, m, v, g, alpha, one_minus_b1, one_minus_b2, eps):
+    """In-place AdamNativeOptimizer._step on flat vectors (reference optimizer.py:311-319)."""
+    assert x.numel() == m.numel() == v.numel() == g.numel()
+    call(
+        "adam_step", x.dtype, ptr(x), ptr(m), ptr(v), ptr(g), c_int64(x.numel()), float(alpha), float(one_minus_b1),
+        float(one_minus_b2), float(eps), stream_ptr(),
+    )
+
+
+def axpy(y, x, a):
+    """y += a * x in place."""
+    assert y.numel() == x.numel() and y.dtype == x.dtype
+    call("axpy", y.dtype, ptr(y), ptr(x), c_int64(y.numel()), float(a), stream_ptr())
+    return y
+
+
+def dots(a, b, out=None):
+    """out[k] = <a[k], b> for a of shape (nvec, n); deterministic, f64 accumulation."""
+    if a.dim() == 1:
+        a = a[None]
+    nvec, n = a.shape
+    assert b.numel() == n and a.stride(1) == 1
+    if out is None:
+        out = torch.empty(nvec, dtype=a.dtype, device=a.device)
+    call(
+        "dots", a.dtype, ptr_strided(a), c_int64(a.stride(0)), c_int(nvec), ptr(b), c_int64(n),
+        ptr(reduce_workspace(a.device, nvec)), ptr(out), stream_ptr(),
+    )
+    return out
+
+
+def ptr_strided(a):
+    import ctypes
+
+    if not a.is_cuda:
+        raise _lib.OdilHipError("tensor is on '{}': the HIP kernels need device memory".format(a.device))
+    return ctypes.c_void_p(a.data_ptr())
+
+
+def lincomb(y, beta, a, coef):
+    """y = beta*y + sum_k coef[k] * a[k]  (coef: device tensor)."""
+    if a.dim() == 1:
+        a = a[None]
+    nvec, n = a.shape
+    assert y.numel() == n and coef.numel() == nvec and a.stride(1) == 1
+    call(
+        "lincomb", y.dtype, ptr(y), float(beta), ptr_strided(a), c_int64(a.stride(0)), c_int(nvec), ptr(coef),
+        c_int64(n), stream_ptr(),
+    )
+    return y
+
+
+def stencil_apply(coeffs, shifts, x, transpose=False, out=None):
+    """y = M x or M^T x for the stencil matrix with per-shift coefficient arrays
+    (reference core.py:1144-1171)."""
+    nshift = len(shifts)
+    ndim = x.dim()
+    if out is None:
+        out = torch.empty_like(x)
+    flat = []
+    for s in shifts:
+        flat += list(s)
+    call(
+        "stencil_apply", x.dtype, ptr(coeffs), i64(flat), c_int(nshift), ptr(x), ptr(out), i64(x.shape), c_int(ndim),
+        c_int(1 if transpose else 0), stream_ptr(),
+    )
+    return out
+
+
+def csr_assemble(coeffs, shifts, shape, col_offset=0):
+    """(indptr, indices, data) of the stencil matrix (reference core.py:1144-1171)."""
+    nshift = len(shifts)
+    size = math.prod(shape)
+    dev = coeffs.device
+    indptr = torch.empty(size + 1, dtype=torch.int64, device=dev)
+    indices = torch.empty(size * nshift, dtype=torch.int64, device=dev)
+    data = torch.empty(size * nshift, dtype=coeffs.dtype, device=dev)
+    flat = []
+    for s in shifts:
+        flat += list(s)
+    call(
+        "csr_assemble", coeffs.dtype, ptr(coeffs), i64(flat), c_int(nshift), i64(shape), c_int(len(shape)),
+        c_int64(col_offset), ptr(indptr), ptr(indices), ptr(data), stream_ptr(),
+    )
+    return indptr, indices, data

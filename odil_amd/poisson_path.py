@@ -1,0 +1,128 @@
+"""Device-resident driver of the reference's hot loop for the Poisson workload.
+
+One `epoch()` = what `AdamNativeOptimizer.run` does per iteration
+(reference src/odil/optimizer.py:331-336) for `examples/poisson/poisson.py`:
+  loss_grad:  u = multigrid_to_regular(w)         core.py:245-263   -> mg_synth
+              fu = Lap(u) - rhs, loss = mean(fu^2) poisson.py:89-113 -> poisson_residual
+              grads = d loss / d w_l              core.py:1100       -> poisson_adjoint + mg_synth_adj
+  step:       Adam update of every level array    optimizer.py:311-319 -> adam_step
+The multigrid unknowns of all levels live in ONE packed device buffer (the layout of
+`Domain.pack_state`, core.py:436-443), so the optimizer update is a single launch and
+the level arrays are views.  Nothing crosses to the host inside an epoch; the loss stays
+a device scalar until asked for.
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def mg_cshapes(cshape, mg_axes=None, mg_nlvl=None):
+    """Level cell-shapes fine->coarse (reference core.py:65-73)."""
+    ndim = len(cshape)
+    mg_axes = mg_axes or [True] * ndim
+    nlvl_max = min(int(round(math.log2(n))) if ax else max(cshape) for n, ax in zip(cshape, mg_axes))
+    nlvl = nlvl_max if mg_nlvl is None else min(mg_nlvl, nlvl_max)
+    return [tuple(n >> lvl if ax else n for n, ax in zip(cshape, mg_axes)) for lvl in range(nlvl)]
+
+
+def hat_reference(cshape, dtype, device):
+    """Reference solution 'hat' on cell centres (reference examples/poisson/poisson.py:21-24).
+    Synthetic-input generation only (torch elementwise); not part of the timed path."""
+    xs = []
+    for n in cshape:
+        x = torch.linspace(0.0, 1.0, n + 1, dtype=torch.float64, device=device)[:-1]
+        x = x + (x[1] - x[0]) * 0.5 if n > 1 else x
+        xs.append(x)
+    grids = torch.meshgrid(*xs, indexing="ij")
+    u = torch.ones(cshape, dtype=torch.float64, device=device)
+    for x in grids:
+        u = u * ((1 - x) * x * 5)
+    p = 5
+    u = (u**p / (1 + u**p)) ** (1 / p)
+    return u.to(dtype)
+
+
+class PoissonMultigridAdam:
+    def __init__(self, ndim, N, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
+                 epsilon=1e-7, multigrid=True, world=1, rank=0):
+        if world != 1:
+            raise NotImplementedError("slab decomposition: see odil_amd/slab.py")
+        self.ndim, self.N, self.dtype, self.device = ndim, N, dtype, device
+        self.loc = "c" * ndim
+        cshape = (N,) * ndim
+        self.cshape = cshape
+        self.shapes = mg_cshapes(cshape) if multigrid else [cshape]
+        self.nlvl = len(self.shapes)
+        self.sizes = [math.prod(s) for s in self.shapes]
+        self.local_cells = math.prod(cshape)
+        self.global_cells = self.local_cells * world
+        self.n_unknowns_local = sum(self.sizes)
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        self.npdt = npdt
+        step = [(npdt(1) - npdt(0)) / n for n in cshape]  # core.py:199-200 in the domain dtype
+        self.h2 = [s**2 for s in step]
+        n = self.n_unknowns_local
+        self.x = torch.zeros(n, dtype=dtype, device=device)
+        self.m = torch.zeros(n, dtype=dtype, device=device)
+        self.v = torch.zeros(n, dtype=dtype, device=device)
+        self.g = torch.zeros(n, dtype=dtype, device=device)
+        self.w = [t.view(s) for t, s in zip(self.x.split(self.sizes), self.shapes)]
+        self.gw = [t.view(s) for t, s in zip(self.g.split(self.sizes), self.shapes)]
+        self.u = torch.empty(cshape, dtype=dtype, device=device) if self.nlvl > 1 else self.w[0]
+        self.fu = torch.empty(cshape, dtype=dtype, device=device)
+        self.loss = torch.zeros((), dtype=dtype, device=device)
+        self.work = [None] + [torch.empty(s, dtype=dtype, device=device) for s in self.shapes[1:-1]] + [None]
+        self.work = self.work[: self.nlvl]
+        # rhs = discrete Laplacian of the reference solution (poisson.py:71-86): same kernel, rhs = 0
+        ref_u = hat_reference(cshape, dtype, device)
+        self.ref_u = ref_u
+        self.rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        self.lr, self.b1, self.b2, self.eps = npdt(lr), npdt(beta_1), npdt(beta_2), epsilon
+        self.t = 0
+
+    def loss_grad(self, timers=None):
+        def tic(name):
+            if timers is None:
+                return None
+            a, b = timers.section(name)
+            a.record()
+            return b
+
+        def toc(b):
+            if b is not None:
+                b.record()
+
+        if self.nlvl > 1:
+            b = tic("mg_synth")
+            ops.mg_synth(self.w, self.loc, work=self.work, out=self.u)
+            toc(b)
+        b = tic("residual")
+        ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
+        toc(b)
+        b = tic("adjoint")
+        ops.poisson_adjoint(self.fu, self.h2, self.npdt(2) / self.npdt(self.fu.numel()), out=self.gw[0])
+        toc(b)
+        if self.nlvl > 1:
+            b = tic("mg_synth_adj")
+            ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
+            toc(b)
+        return self.loss
+
+    def epoch(self, timers=None):
+        self.loss_grad(timers)
+        self.t += 1
+        t = self.npdt(self.t)
+        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)  # optimizer.py:313-315
+        if timers is not None:
+            a, b = timers.section("adam")
+            a.record()
+        ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        if timers is not None:
+            b.record()
+
+    def last_loss(self):
+        return float(self.loss)

@@ -1,0 +1,350 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the oracle and
+the golden fixtures generated from the reference.  f64 tolerances are a few ulp-scale
+(1e-13 relative to the array's max); the north_star loss-trajectory tolerance is 1e-6."""
+
+import numpy as np
+import pytest
+import torch
+from conftest import load_golden
+
+from oracle import odil_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def to(x, dev):
+    return torch.tensor(np.ascontiguousarray(x), device=dev)
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b)))) if b.size else 0.0
+
+
+INTERP_CASES = [str(c) for c in load_golden("interp")["cases"]]
+
+
+@pytest.mark.parametrize("loc", INTERP_CASES)
+def test_interp_and_adjoint_vs_golden(dev, loc):
+    from odil_amd import ops
+
+    g = load_golden("interp")
+    u = g[f"{loc}/u"]
+    fine = ops.interp_add(to(u, dev), loc)
+    # same summation order as the reference 'stack' path and no FMA contraction: bit-exact
+    assert np.array_equal(fine.cpu().numpy(), g[f"{loc}/fine"])
+    if f"{loc}/fine2" in g:
+        assert np.array_equal(ops.interp_to_finer(to(u, dev), loc, depth=2).cpu().numpy(), g[f"{loc}/fine2"])
+    gu = ops.interp_adj(to(g[f"{loc}/gfine"], dev), loc, u.shape)
+    assert rel(gu, g[f"{loc}/gu"]) < 1e-14
+
+
+@pytest.mark.parametrize(
+    "loc,shape", [("ccc", (5, 6, 7)), ("ncc", (5, 4, 6)), ("cc", (33, 130)), ("c", (700,)), ("cn", (9, 300))]
+)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_interp_random_vs_oracle(dev, loc, shape, dtype):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal(shape).astype(dtype)
+    add = rng.standard_normal(onp.fine_shape(shape, loc)).astype(dtype)
+    out = ops.interp_add(to(u, dev), loc, add=to(add, dev), coarse_scale=0.5, add_scale=2.0)
+    ref = dtype(2.0) * add + onp.interp_to_finer(dtype(0.5) * u, loc)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    gf = rng.standard_normal(onp.fine_shape(shape, loc)).astype(dtype)
+    gu, gs = ops.interp_adj(to(gf, dev), loc, shape, scale=3.0)
+    refg = onp.interp_to_finer_adj(gf, loc, shape)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    assert rel(gu, refg) < tol
+    assert rel(gs, dtype(3.0) * refg) < tol
+
+
+def test_interp_exact_on_linear_functions(dev):
+    """reference tests/test_mg_interp.py:11-32 through the HIP kernel."""
+    from odil_amd import ops
+
+    for ndim in [1, 2, 3, 4]:
+        for loc in {s[:ndim] for s in ["cccc", "nnnn", "cnnn", "nccc"]}:
+            cshapeh = tuple(3 + np.arange(ndim))
+            cshape = tuple(2 * np.array(cshapeh))
+
+            def func(xx):
+                return sum(x * np.sqrt(i + 1) for i, x in enumerate(xx))
+
+            u = func(onp.points(cshape, loc))
+            uh = func(onp.points(cshapeh, loc))
+            ui = ops.interp_add(to(uh, dev), loc).cpu().numpy()
+            assert np.max(np.abs(ui - u)) <= 100 * np.finfo(np.float64).eps
+
+
+def test_restrict_exact_on_linear_functions_with_jumps(dev):
+    """reference tests/test_mg_restrict.py:11-41 through the HIP kernel, + oracle parity."""
+    from odil_amd import ops
+
+    for ndim in [1, 2, 3, 4]:
+        for loc in {s[:ndim] for s in ["cccc", "nnnn", "cnnn", "nccc"]}:
+            cshapeh = tuple(3 + np.arange(ndim))
+            cshape = tuple(2 * np.array(cshapeh))
+
+            def func(xx):
+                res = np.zeros_like(xx[0])
+                for i in range(len(xx)):
+                    res += xx[i] * (i + 1)
+                    res += np.where(xx[i] == 0, 10.0, 0.0)
+                    res += np.where(xx[i] == 1, 10.0, 0.0)
+                return res
+
+            u = func(onp.points(cshape, loc))
+            uh = func(onp.points(cshapeh, loc))
+            uhr = ops.restrict_to_coarser(to(u, dev), loc).cpu().numpy()
+            assert np.max(np.abs(uhr - uh)) <= 100 * np.finfo(np.float64).eps, (ndim, loc)
+    rng = np.random.default_rng(5)
+    for loc, shape in [("cc", (8, 12)), ("nn", (9, 13)), ("c.n", (6, 5, 7)), ("ccc", (8, 4, 6))]:
+        u = rng.standard_normal(shape)
+        assert rel(ops.restrict_to_coarser(to(u, dev), loc), onp.restrict_to_coarser(u, loc)) < 1e-14
+
+
+MG_CASES = [str(c) for c in load_golden("mg")["cases"]]
+
+
+@pytest.mark.parametrize("name", MG_CASES)
+def test_mg_synth_and_adjoint_vs_golden(dev, name):
+    from odil_amd import ops
+
+    g = load_golden("mg")
+    nlvl = int(g[f"{name}/nlvl"])
+    loc = str(g[f"{name}/loc"])
+    axes = [bool(a) for a in g[f"{name}/axes"]]
+    factors = [float(f) for f in g[f"{name}/factors"]]
+    iloc = onp.mg_loc(loc, axes)
+    terms = [to(g[f"{name}/w{i}"], dev) for i in range(nlvl)]
+    u = ops.mg_synth(terms, iloc, factors=factors)
+    assert np.array_equal(u.cpu().numpy(), g[f"{name}/u"])
+    grads = ops.mg_synth_adj(to(g[f"{name}/gu"], dev), [t.shape for t in terms], iloc, factors=factors)
+    for i in range(nlvl):
+        assert rel(grads[i], g[f"{name}/g{i}"]) < 1e-14
+
+
+def test_field_access_vs_golden(dev):
+    from odil_amd import ops
+
+    g = load_golden("field_access")
+    for name in g["cases"]:
+        floc, loc = str(g[f"{name}/field_loc"]), str(g[f"{name}/loc"])
+        shift = tuple(int(s) for s in g[f"{name}/shift"])
+        a = g[f"{name}/a"]
+        out = ops.field_gather(to(a, dev), floc, shift, loc)
+        assert np.array_equal(out.cpu().numpy(), g[f"{name}/out"])
+        ga = ops.field_scatter(to(g[f"{name}/g"], dev), a.shape, floc, shift, loc)
+        assert np.array_equal(ga.cpu().numpy(), g[f"{name}/ga"])
+
+
+@pytest.mark.parametrize(
+    "name", ["poisson_1d_N256", "poisson_2d_N32", "poisson_3d_N16", "poisson_2d_N8", "poisson_3d_N8"]
+)
+def test_poisson_loss_grad_vs_golden(dev, name):
+    from odil_amd import ops
+
+    g = load_golden(name)
+    ndim, N, nlvl = int(g["ndim"]), int(g["N"]), int(g["nlvl"])
+    cshape = (N,) * ndim
+    dw = onp.step(cshape)
+    h2 = [d**2 for d in dw]
+    loc = "c" * ndim
+    terms = [to(g[f"rand/w{i}"], dev) for i in range(nlvl)]
+    rhs = to(g["rhs"], dev)
+    u = ops.mg_synth(terms, loc)
+    fu, loss = ops.poisson_residual(u, rhs, h2)
+    assert rel(fu, g["rand/fu"]) < 1e-14
+    assert abs(float(loss) - float(g["rand/loss"])) <= 1e-13 * float(g["rand/loss"])
+    gu = ops.poisson_adjoint(fu, h2, 2.0 / fu.numel())
+    grads = ops.mg_synth_adj(gu, [t.shape for t in terms], loc)
+    for i in range(nlvl):
+        assert rel(grads[i], g[f"rand/g{i}"]) < 1e-13
+    # loss-only call
+    _, loss2 = ops.poisson_residual(u, rhs, h2, want_fu=False)
+    assert float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize("shape", [(7,), (5, 9), (3, 4, 5), (2, 2, 2), (6, 1030)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_poisson_ragged_shapes_vs_oracle(dev, shape, dtype):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(7)
+    dw = onp.step(shape, dtype=dtype)
+    h2 = [d**2 for d in dw]
+    u = rng.standard_normal(shape).astype(dtype)
+    rhs = rng.standard_normal(shape).astype(dtype)
+    fu, loss = ops.poisson_residual(to(u, dev), to(rhs, dev), h2)
+    fref = onp.poisson_residual(u, rhs, dw)
+    tol = 1e-14 if dtype == np.float64 else 1e-6
+    assert rel(fu, fref) < tol
+    lref = np.mean(np.square(fref.astype(np.float64)))
+    assert abs(float(loss) - lref) <= (1e-13 if dtype == np.float64 else 1e-6) * lref
+    fb = rng.standard_normal(shape).astype(dtype)
+    gu = ops.poisson_adjoint(to(fb, dev), h2, 1.0)
+    assert rel(gu, onp.poisson_adjoint(fb, dw)) < (1e-13 if dtype == np.float64 else 1e-5)
+    coeffs = ops.poisson_jac_coeffs(shape, h2, to(u, dev).dtype, dev).cpu().numpy()
+    ref = onp.poisson_jac_coeffs(shape, dw, dtype=dtype)
+    ndim = len(shape)
+    order = [(0,) * ndim]
+    for i in range(ndim):
+        order += [tuple(-1 if j == i else 0 for j in range(ndim)), tuple(1 if j == i else 0 for j in range(ndim))]
+    for k, s in enumerate(order):
+        assert rel(coeffs[k], ref[s]) < tol
+
+
+def test_mean_reduce(dev):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(3)
+    for n in [1, 63, 1000, 100003]:
+        x = rng.standard_normal(n)
+        assert abs(float(ops.mean_reduce(to(x, dev))) - np.mean(x**2)) <= 1e-14 * np.mean(x**2)
+        assert abs(float(ops.mean_reduce(to(x, dev), square=False)) - np.mean(x)) <= 1e-14
+    x32 = rng.standard_normal(5000).astype(np.float32)
+    assert abs(float(ops.mean_reduce(to(x32, dev))) - np.mean(x32.astype(np.float64) ** 2)) < 1e-6
+    # determinism
+    x = to(rng.standard_normal(1 << 20), dev)
+    assert float(ops.mean_reduce(x)) == float(ops.mean_reduce(x))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_adam_step_vs_oracle(dev, dtype):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(11)
+    n = 10007
+    x, g = rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+    m, v = (rng.standard_normal(n) * 0.1).astype(dtype), (rng.random(n) * 0.1).astype(dtype)
+    t = dtype
+    lr, b1, b2, eps = t(0.005), t(0.9), t(0.999), 1e-7
+    epoch = t(3)
+    alpha = lr * np.sqrt(1 - b2**epoch) / (1 - b1**epoch)
+    xr, mr, vr = onp.adam_step([x], [m], [v], [g], 3, 0.005, dtype=dtype)
+    tx, tm, tv, tg = to(x, dev), to(m, dev), to(v, dev), to(g, dev)
+    ops.adam_step(tx, tm, tv, tg, alpha, 1 - b1, 1 - b2, eps)
+    if dtype == np.float64:
+        assert np.array_equal(tm.cpu().numpy(), mr[0]) and np.array_equal(tv.cpu().numpy(), vr[0])
+        assert rel(tx, xr[0]) < 1e-15
+    else:
+        assert rel(tm, mr[0]) < 1e-6 and rel(tv, vr[0]) < 1e-6 and rel(tx, xr[0]) < 1e-6
+    # unaligned views take the scalar path
+    ops.adam_step(tx[1:], tm[1:], tv[1:], tg[1:], alpha, 1 - b1, 1 - b2, eps)
+
+
+def test_vector_ops(dev):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(13)
+    n, k = 5003, 7
+    a, b = rng.standard_normal((k, n)), rng.standard_normal(n)
+    d = ops.dots(to(a, dev), to(b, dev)).cpu().numpy()
+    assert np.max(np.abs(d - a @ b)) < 1e-11
+    y = rng.standard_normal(n)
+    coef = rng.standard_normal(k)
+    ty = to(y, dev)
+    ops.lincomb(ty, 0.5, to(a, dev), to(coef, dev))
+    assert rel(ty, 0.5 * y + coef @ a) < 1e-13
+    ty = to(y, dev)
+    ops.axpy(ty, to(b, dev), -0.25)
+    assert rel(ty, y - 0.25 * b) < 1e-15
+
+
+def test_adam_trajectory_poisson_vs_golden(dev):
+    """Loss trajectory of the reference AdamNativeOptimizer on Poisson MG, tolerance 1e-6 rel."""
+    from odil_amd import ops
+
+    for name in ["poisson_1d_N256", "poisson_2d_N32", "poisson_3d_N16"]:
+        g = load_golden(name)
+        ndim, N, nlvl = int(g["ndim"]), int(g["N"]), int(g["nlvl"])
+        cshape = (N,) * ndim
+        loc = "c" * ndim
+        dw = onp.step(cshape)
+        h2 = [d**2 for d in dw]
+        shapes = onp.mg_cshapes(cshape)
+        sizes = [int(np.prod(s)) for s in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
+        m, v, gflat = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+        views = [t.view(s) for t, s in zip(flat.split(sizes), shapes)]
+        gviews = [t.view(s) for t, s in zip(gflat.split(sizes), shapes)]
+        rhs = to(g["rhs"], dev)
+        losses = []
+        ref = g["adam/losses"]
+        lr, b1, b2 = np.float64(0.005), np.float64(0.9), np.float64(0.999)
+        for epoch in range(1, len(ref) + 1):
+            u = ops.mg_synth(views, loc)
+            fu, loss = ops.poisson_residual(u, rhs, h2)
+            ops.poisson_adjoint(fu, h2, 2.0 / fu.numel(), out=gviews[0])
+            ops.mg_synth_adj(gviews[0], shapes, loc, grads=gviews)
+            losses.append(float(loss))
+            e = np.float64(epoch)
+            alpha = lr * np.sqrt(1 - b2**e) / (1 - b1**e)
+            ops.adam_step(flat, m, v, gflat, alpha, 1 - b1, 1 - b2, 1e-7)
+        assert np.max(np.abs(np.array(losses) - ref) / ref) < 1e-6, name
+        for i in range(nlvl):
+            assert rel(views[i], g[f"adam/w{i}"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["newton_poisson_1d_N8", "newton_poisson_2d_N6", "newton_poisson_3d_N4"])
+def test_newton_blocks_vs_golden(dev, name):
+    import scipy.sparse as sp
+
+    from odil_amd import ops
+
+    g = load_golden(name)
+    u0 = g["u0"]
+    shape = u0.shape
+    ndim = len(shape)
+    dw = onp.step(shape)
+    h2 = [d**2 for d in dw]
+    coeffs = ops.poisson_jac_coeffs(shape, h2, torch.float64, dev)
+    shifts = [(0,) * ndim]
+    for i in range(ndim):
+        shifts += [tuple(-1 if j == i else 0 for j in range(ndim)), tuple(1 if j == i else 0 for j in range(ndim))]
+    for k, s in enumerate(shifts):
+        assert rel(coeffs[k], g["coeff/" + ",".join(str(v) for v in s)]) < 1e-14
+    indptr, indices, data = [t.cpu().numpy() for t in ops.csr_assemble(coeffs, shifts, shape)]
+    M = sp.csr_array((data, indices, indptr), shape=(u0.size, u0.size)).toarray()
+    assert rel(M, g["matrix"]) < 1e-14
+    x = np.random.default_rng(0).standard_normal(shape)
+    assert rel(ops.stencil_apply(coeffs, shifts, to(x, dev)), (g["matrix"] @ x.ravel()).reshape(shape)) < 1e-13
+    assert (
+        rel(ops.stencil_apply(coeffs, shifts, to(x, dev), transpose=True), (g["matrix"].T @ x.ravel()).reshape(shape))
+        < 1e-13
+    )
+
+
+def test_large_roundtrip_properties(dev):
+    """Size-independent properties at a large size (no oracle): <P x, y> == <x, P^T y>,
+    linearity of the residual and <J u, f> == <u, J^T f>."""
+    from odil_amd import ops
+
+    torch.manual_seed(0)
+    cs = (64, 64, 64)
+    x = torch.randn(cs, dtype=torch.float64, device=dev)
+    y = torch.randn(tuple(2 * s for s in cs), dtype=torch.float64, device=dev)
+    lhs = float((ops.interp_add(x, "ccc") * y).sum())
+    rhs = float((x * ops.interp_adj(y, "ccc", cs)).sum())
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1.0)
+    shape = (128, 128, 128)
+    h2 = [(1.0 / s) ** 2 for s in shape]
+    u1, u2 = [torch.randn(shape, dtype=torch.float64, device=dev) for _ in range(2)]
+    zero = torch.zeros_like(u1)
+    f1, _ = ops.poisson_residual(u1, zero, h2)
+    f2, _ = ops.poisson_residual(u2, zero, h2)
+    f12, _ = ops.poisson_residual(u1 + u2, zero, h2)
+    assert float((f12 - f1 - f2).abs().max()) <= 1e-9 * float(f12.abs().max())
+    g2 = ops.poisson_adjoint(f2, h2, 1.0)
+    a, b = float((f1 * f2).sum()), float((u1 * g2).sum())
+    assert abs(a - b) <= 1e-10 * abs(a)
