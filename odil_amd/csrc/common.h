@@ -13,7 +13,8 @@ namespace odil {
 // MI355X: 8 XCDs x 32 CUs; a launch needs >> 256 workgroups, and each XCD has a private L2.
 constexpr int kNumXcd = 8;
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kMaxPartials = 4096;   // doubles of reduction scratch per reduced quantity
+constexpr int kMaxPartials = 65536;  // doubles of reduction scratch per reduced quantity
+constexpr int kDotPartials = 1024;   // partial sums per vector in odil_dots
 constexpr int kGridCap = 2048;       // 256 CUs x 8 resident workgroups
 
 void set_error(const char* fmt, ...);
@@ -72,51 +73,126 @@ inline int grid_for(int64_t work_items, int per_block) {
 // sums therefore accumulate in a fixed order: reductions are deterministic.
 // ---------------------------------------------------------------------------
 struct RowSched {
-  int64_t Z, Y, XS;  // planes, rows per plane, x-segments per row
-  int64_t Yc;        // rows per XCD chunk
+  int Z, Y, XS;  // planes, rows per plane, x-segments per row
+  int Yc;        // rows per XCD chunk
 };
 
 inline RowSched make_sched(int64_t Z, int64_t Y, int64_t XS) {
   RowSched s;
-  s.Z = Z;
-  s.Y = Y;
-  s.XS = XS;
-  s.Yc = (Y + kNumXcd - 1) / kNumXcd;
+  s.Z = (int)Z;
+  s.Y = (int)Y;
+  s.XS = (int)XS;
+  s.Yc = (int)((Y + kNumXcd - 1) / kNumXcd);
   return s;
 }
 
+// Items must be countable in 31 bits (checked by the host wrappers via sched_ok).
+inline bool sched_ok(int64_t Z, int64_t Y, int64_t XS) { return Z * Y * XS < (int64_t)1 << 31; }
+
 inline int sched_grid(const RowSched& s) {
   // Same number of workgroups per XCD; enough to cover the largest chunk, capped.
-  int64_t per_xcd = s.Z * s.Yc * s.XS;
+  int64_t per_xcd = (int64_t)s.Z * s.Yc * s.XS;
   int64_t cap = kGridCap / kNumXcd;
   if (per_xcd > cap) per_xcd = cap;
   if (per_xcd < 1) per_xcd = 1;
   return (int)(per_xcd * kNumXcd);
 }
 
+// ---------------------------------------------------------------------------
+// One-unit-per-workgroup schedule for the z-marching kernels.
+//
+// A unit is (zc, y, xs): a z-chunk of planes, one row (or row tile), one x-segment.  The
+// workgroup keeps the z-1 / z / z+1 values of its column in registers while it marches, so
+// z re-reads never leave the CU; rows y+-1 belong to workgroups of the SAME XCD (XCD k owns
+// y-chunk k) that march in step, so they are L2 hits.  When Y is too small to split eight
+// ways the z-chunks are split instead; tiny problems fall back to plain order.
+// ---------------------------------------------------------------------------
+struct UnitSched {
+  int ZCH, Y, XS;   // number of z-chunks, rows, x-segments
+  int ZC;           // planes per z-chunk
+  int axis;         // 1: XCD-chunk along Y, 0: along ZCH, -1: none
+  int chunk;        // chunk length along `axis`
+  int per_xcd;      // units per XCD (grid = 8 * per_xcd), or total units when axis < 0
+};
+
+inline UnitSched make_unit_sched(int64_t Z, int64_t Y, int64_t XS) {
+  UnitSched s;
+  int64_t zc = (Z * Y * XS) / (2 * kGridCap);
+  if (zc < 1) zc = 1;
+  if (zc > 64) zc = 64;
+  if (zc > Z) zc = Z;
+  s.ZC = (int)zc;
+  s.ZCH = (int)((Z + zc - 1) / zc);
+  s.Y = (int)Y;
+  s.XS = (int)XS;
+  if (Y >= 4 * kNumXcd) {
+    s.axis = 1;
+    s.chunk = (int)((Y + kNumXcd - 1) / kNumXcd);
+    s.per_xcd = s.ZCH * s.chunk * s.XS;
+  } else if (s.ZCH >= kNumXcd) {
+    s.axis = 0;
+    s.chunk = (s.ZCH + kNumXcd - 1) / kNumXcd;
+    s.per_xcd = s.chunk * s.Y * s.XS;
+  } else {
+    s.axis = -1;
+    s.chunk = 0;
+    s.per_xcd = s.ZCH * s.Y * s.XS;
+  }
+  return s;
+}
+
+inline int unit_grid(const UnitSched& s) { return s.axis < 0 ? s.per_xcd : s.per_xcd * kNumXcd; }
+
+#ifdef __HIPCC__
+// Returns false when this workgroup has no unit (padding of an uneven chunk).
+__device__ inline bool unit_decode(const UnitSched& s, int& zc, int& y, int& xs) {
+  if (s.axis < 0) {
+    const int i = blockIdx.x;
+    xs = i % s.XS;
+    const int r = i / s.XS;
+    y = r % s.Y;
+    zc = r / s.Y;
+    return true;
+  }
+  const int k = blockIdx.x % kNumXcd, i = blockIdx.x / kNumXcd;
+  xs = i % s.XS;
+  const int r = i / s.XS;
+  if (s.axis == 1) {
+    y = k * s.chunk + r % s.chunk;
+    zc = r / s.chunk;
+    return y < s.Y;
+  }
+  y = r % s.Y;
+  zc = k * s.chunk + r / s.Y;
+  return zc < s.ZCH;
+}
+#endif
+
 #ifdef __HIPCC__
 struct RowIter {
-  int64_t t, step, count, y0, ny;
+  int t, step, count, y0, ny;
 };
 
 __device__ inline RowIter sched_begin(const RowSched& s) {
   RowIter it;
-  int k = blockIdx.x % kNumXcd;
+  const int k = blockIdx.x % kNumXcd;
   it.t = blockIdx.x / kNumXcd;
   it.step = gridDim.x / kNumXcd;
-  it.y0 = (int64_t)k * s.Yc;
-  int64_t y1 = it.y0 + s.Yc;
+  it.y0 = k * s.Yc;
+  int y1 = it.y0 + s.Yc;
   if (y1 > s.Y) y1 = s.Y;
   it.ny = y1 > it.y0 ? y1 - it.y0 : 0;
   it.count = s.Z * it.ny * s.XS;
   return it;
 }
 
-__device__ inline void sched_decode(const RowSched& s, const RowIter& it, int64_t& z, int64_t& y, int64_t& xs) {
-  int64_t per_plane = it.ny * s.XS;
-  z = it.t / per_plane;
-  int64_t r = it.t - z * per_plane;
-  int64_t yl = r / s.XS;
+template <typename I>
+__device__ inline void sched_decode(const RowSched& s, const RowIter& it, I& z, I& y, I& xs) {
+  const int per_plane = it.ny * s.XS;
+  const int zi = it.t / per_plane;
+  const int r = it.t - zi * per_plane;
+  const int yl = r / s.XS;
+  z = zi;
   xs = r - yl * s.XS;
   y = it.y0 + yl;
 }

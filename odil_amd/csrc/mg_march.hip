@@ -1,0 +1,294 @@
+// z-marching multigrid transfers for the all-cell 3-D layout ('ccc', the Poisson hot path).
+// Same arithmetic as mg_fast.hip / mg_transfer.hip; what changes is the data movement:
+//
+// P  : a thread owns a coarse column (jy, jx) and walks coarse planes, holding the 3x3x3
+//      coarse neighbourhood in registers (9 new values per plane); every step emits the
+//      two fine planes 2jz, 2jz+1 as 16 B stores.  Fine traffic is touched exactly once.
+// P^T: a thread owns a coarse column and walks coarse planes; each FINE plane is reduced
+//      over its (y, x) window once (rows as three 16 B packs) and the per-plane sums slide
+//      through a 6-entry register window, so every fine value is loaded once per owner.
+#include "mg_transfer.h"
+
+namespace odil {
+
+template <typename T>
+struct alignas(2 * sizeof(T)) Pack2 {
+  T a, b;
+};
+
+struct MarchArgs {
+  int cn[3], fn[3];  // (z, y, x) coarse / fine extents
+  int tx, ty;
+  UnitSched usched;
+};
+
+struct Tap3 {
+  int cl[3], rf[3];
+  bool out[3];
+};
+
+__device__ inline Tap3 tap3(int j, int n) {
+  Tap3 t;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int q = j + d - 1;
+    t.out[d] = q < 0 || q >= n;
+    t.cl[d] = q < 0 ? 0 : (q >= n ? n - 1 : q);
+    t.rf[d] = q < 0 ? 1 : (q >= n ? n - 2 : q);
+  }
+  return t;
+}
+
+// 3x3 coarse values of (padded) plane q in [-1, n]: ghosts by the joint rule (core.py:640-643).
+template <typename T>
+__device__ inline void load_plane9(const T* __restrict__ coarse, int q, int cnz, int64_t cplane, int cnx,
+                                   const Tap3& ty, const Tap3& tx, T cscale, T v[3][3]) {
+  const bool oz = q < 0 || q >= cnz;
+  const int zcl = q < 0 ? 0 : (q >= cnz ? cnz - 1 : q);
+  const int zrf = q < 0 ? 1 : (q >= cnz ? cnz - 2 : q);
+  const T* ccl = coarse + zcl * cplane;
+  const T* crf = coarse + zrf * cplane;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      T val = cscale * ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[dx]];
+      if (oz || ty.out[dy] || tx.out[dx]) val = T(2) * val - cscale * crf[(int64_t)ty.rf[dy] * cnx + tx.rf[dx]];
+      v[dy][dx] = val;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict__ coarse, const T* __restrict__ add,
+                                                             T* __restrict__ fine, MarchArgs a, T cscale, T ascale) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Tap3 tx = tap3(jx, cnx), ty = tap3(jy, cny);
+  T v[3][3][3];
+  load_plane9<T>(coarse, z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[0]);
+  load_plane9<T>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[1]);
+  const T r64 = T(1) / T(64);  // exact: sum of weights 4*4*4
+  for (int jz = z0; jz < z1; ++jz) {
+    // issue the fine-grid addend loads first: they are the HBM stream of this kernel
+    Pack2<T> ad[2][2];
+    const int64_t fbase = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx;
+    if (add) {
+#pragma unroll
+      for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+          ad[sz][sy] = *reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx);
+    }
+    load_plane9<T>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[2]);
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy) {
+        T o[2];
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          // reference order (rz, ry, rx), rx fastest; weights per axis: parity == r ? 1 : 3
+          T s = T(0);
+#pragma unroll
+          for (int rz = 0; rz < 2; ++rz)
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+              for (int rx = 0; rx < 2; ++rx) {
+                const int w = (sz == rz ? 1 : 3) * (sy == ry ? 1 : 3) * (sx == rx ? 1 : 3);
+                s = s + T(w) * v[sz + rz][sy + ry][sx + rx];
+              }
+          o[sx] = s * r64;
+        }
+        if (add) {
+          o[0] = ascale * ad[sz][sy].a + o[0];
+          o[1] = ascale * ad[sz][sy].b + o[1];
+        }
+        Pack2<T> pk;
+        pk.a = o[0];
+        pk.b = o[1];
+        *reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx) = pk;
+      }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        v[0][dy][dx] = v[1][dy][dx];
+        v[1][dy][dx] = v[2][dy][dx];
+      }
+  }
+}
+
+// 1-D adjoint weights on a 'c' axis for coarse index J: window of 6 fine indices from 2J-2.
+struct Adj6 {
+  float wc[6], wr[6];
+  bool special;
+};
+
+__device__ inline Adj6 adj6(int J, int n) {
+  Adj6 t;
+  const int F = 2 * n;
+  const bool c_lo = J == 0, c_hi = J == n - 1, r_lo = J == 1, r_hi = J == n - 2;
+  t.special = c_lo || c_hi || r_lo || r_hi;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int k = 2 * J - 2 + i;
+    const float w = w_cell(J, k, F), lo = w_cell(-1, k, F), hi = w_cell(n, k, F);
+    t.wc[i] = w + (c_lo ? lo : 0.f) + (c_hi ? hi : 0.f);
+    t.wr[i] = w + (r_lo ? lo : 0.f) + (r_hi ? hi : 0.f);
+  }
+  return t;
+}
+
+// (y, x) reduction of fine plane f for the coarse column (jy, jx): rc with the C weights,
+// rr with the R weights (only evaluated when the column touches a boundary in y or x).
+template <typename T>
+__device__ inline void reduce_plane(const T* __restrict__ gfine, int f, int fnz, int64_t fplane, int fny, int fnx,
+                                    int jy, int jx, const Adj6& ay, const Adj6& ax, bool xy_special, T& rc, T& rr) {
+  rc = T(0);
+  rr = T(0);
+  if (f < 0 || f >= fnz) return;
+  const T* gp = gfine + (int64_t)f * fplane;
+#pragma unroll
+  for (int iy = 0; iy < 6; ++iy) {
+    if (ay.wc[iy] == 0.f && ay.wr[iy] == 0.f) continue;
+    const T* row = gp + (int64_t)(2 * jy - 2 + iy) * fnx;
+    T g[6];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int fx = 2 * (jx - 1 + q);
+      if (fx >= 0 && fx < fnx) {
+        const Pack2<T> pk = *reinterpret_cast<const Pack2<T>*>(row + fx);
+        g[2 * q] = pk.a;
+        g[2 * q + 1] = pk.b;
+      } else {
+        g[2 * q] = g[2 * q + 1] = T(0);
+      }
+    }
+    T xc, xr;
+    if (!ax.special) {
+      xc = (T(0.25) * g[1] + T(0.75) * g[2]) + (T(0.75) * g[3] + T(0.25) * g[4]);
+      xr = xc;
+    } else {
+      xc = T(0);
+      xr = T(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        xc = xc + T(ax.wc[i]) * g[i];
+        xr = xr + T(ax.wr[i]) * g[i];
+      }
+    }
+    rc = rc + T(ay.wc[iy]) * xc;
+    if (xy_special) rr = rr + T(ay.wr[iy]) * xr;
+  }
+  if (!xy_special) rr = rc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict__ gfine, T* __restrict__ gcoarse,
+                                                             T* __restrict__ gscaled, MarchArgs a, T scale) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Adj6 ax = adj6(jx, cnx), ay = adj6(jy, cny);
+  const bool xy_special = ax.special || ay.special;
+  // window of plane sums for fine planes 2jz-2 .. 2jz+3
+  T wc[6], wr[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    reduce_plane<T>(gfine, 2 * z0 - 2 + i, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[i], wr[i]);
+  for (int jz = z0; jz < z1; ++jz) {
+    reduce_plane<T>(gfine, 2 * jz + 2, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[4], wr[4]);
+    reduce_plane<T>(gfine, 2 * jz + 3, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[5], wr[5]);
+    const bool z_special = jz == 0 || jz == 1 || jz == cnz - 2 || jz == cnz - 1;
+    T v;
+    if (!z_special && !xy_special) {
+      v = (T(0.25) * wc[1] + T(0.75) * wc[2]) + (T(0.75) * wc[3] + T(0.25) * wc[4]);
+    } else {
+      T sc = T(0), sr = T(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float zc_w, zr_w;
+        const int k = 2 * jz - 2 + i;
+        const float w = w_cell(jz, k, fnz), lo = w_cell(-1, k, fnz), hi = w_cell(cnz, k, fnz);
+        zc_w = w + (jz == 0 ? lo : 0.f) + (jz == cnz - 1 ? hi : 0.f);
+        zr_w = w + (jz == 1 ? lo : 0.f) + (jz == cnz - 2 ? hi : 0.f);
+        sc = sc + T(zc_w) * wc[i];
+        sr = sr + T(zr_w) * wr[i];
+      }
+      v = T(2) * sc - sr;
+    }
+    const int64_t ci = (int64_t)jz * cplane + (int64_t)jy * cnx + jx;
+    gcoarse[ci] = v;
+    if (gscaled) gscaled[ci] = scale * v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wc[i] = wc[i + 2];
+      wr[i] = wr[i + 2];
+    }
+  }
+}
+
+static bool march_setup(MarchArgs& m, const InterpArgs& a) {
+  // exactly (1 | '.'), 'c', 'c', 'c'
+  if (a.loc[1] != kCell || a.loc[2] != kCell || a.loc[3] != kCell) return false;
+  if (a.cn[0] != 1 || a.loc[0] != kNone) return false;
+  for (int i = 0; i < 3; ++i) {
+    if (a.fn[i + 1] >= (1 << 30)) return false;
+    m.cn[i] = (int)a.cn[i + 1];
+    m.fn[i] = (int)a.fn[i + 1];
+  }
+  if (m.cn[0] < 4) return false;  // tiny levels: the per-plane kernel is as good
+  int tx = 1;
+  while (tx < m.cn[2] && tx < kBlock) tx *= 2;
+  m.tx = tx;
+  m.ty = kBlock / tx;
+  const int64_t ytiles = (m.cn[1] + m.ty - 1) / m.ty, xtiles = (m.cn[2] + m.tx - 1) / m.tx;
+  if ((int64_t)m.cn[0] * ytiles * xtiles >= ((int64_t)1 << 31)) return false;
+  m.usched = make_unit_sched(m.cn[0], ytiles, xtiles);
+  return true;
+}
+
+template <typename T>
+int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a, T cscale, T ascale,
+                     hipStream_t stream) {
+  MarchArgs m;
+  if (!march_setup(m, a)) return 0;
+  hipLaunchKernelGGL(k_interp_add_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine, m,
+                     cscale, ascale);
+  const int e = check_launch("k_interp_add_march");
+  return e ? e : 1;
+}
+
+template <typename T>
+int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream) {
+  MarchArgs m;
+  if (!march_setup(m, a)) return 0;
+  hipLaunchKernelGGL(k_interp_adj_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
+                     gscaled, m, scale);
+  const int e = check_launch("k_interp_adj_march");
+  return e ? e : 1;
+}
+
+template int interp_add_march<double>(const double*, const double*, double*, const InterpArgs&, double, double,
+                                      hipStream_t);
+template int interp_add_march<float>(const float*, const float*, float*, const InterpArgs&, float, float, hipStream_t);
+template int interp_adj_march<double>(const double*, double*, double*, const InterpArgs&, double, hipStream_t);
+template int interp_adj_march<float>(const float*, float*, float*, const InterpArgs&, float, hipStream_t);
+
+}  // namespace odil

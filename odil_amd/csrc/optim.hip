@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ a, int64_
   double local = 0.0;
   for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) local += (double)ak[i] * (double)b[i];
   const double total = block_sum(local);
-  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * kMaxPartials + blockIdx.x] = total;
+  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * kDotPartials + blockIdx.x] = total;
 }
 
 template <typename T>
@@ -109,10 +109,10 @@ static int dots(const T* a, int64_t lda, int nvec, const T* b, int64_t n, double
     return ODIL_E_INVAL;
   }
   int grid = grid_for(n, kBlock * 8);
-  if (grid > 1024) grid = 1024;
+  if (grid > kDotPartials) grid = kDotPartials;
   hipLaunchKernelGGL(k_dots<T>, dim3(grid, nvec), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b, n, partials);
   if (int e = check_launch("k_dots")) return e;
-  return launch_final_reduce<T>(partials, grid, kMaxPartials, nvec, 1.0, out, (hipStream_t)stream);
+  return launch_final_reduce<T>(partials, grid, kDotPartials, nvec, 1.0, out, (hipStream_t)stream);
 }
 
 template <typename T>

@@ -9,6 +9,8 @@
 // L2, so HBM sees each of u, rhs once and fu once.  The loss is reduced in a fixed order
 // (per-thread running sum -> wave shuffle -> LDS -> one partial per workgroup -> final
 // kernel), so it is bit-reproducible run to run.
+#include <math.h>
+
 #include "common.h"
 
 namespace odil {
@@ -16,7 +18,7 @@ namespace odil {
 struct StencilArgs {
   int64_t n[3];     // canonical (Z, Y, X) cell shape
   int active[3];    // axis takes part in the Laplacian
-  RowSched sched;
+  UnitSched usched;
 };
 
 template <typename T>
@@ -61,78 +63,105 @@ __device__ inline void store_vec(T* __restrict__ p, int64_t valid, const T in[N]
   }
 }
 
-// One axis of poisson.py:57-68 + :112: ghosts by extrap_quadh(q+-, q, 0), then (qp - 2q + qm)/h2.
+// x / h2 -- as a multiplication when h2 is an exact power of two (bit-identical), else a
+// true division: the f64 divide is ~35 VALU instructions and three of them per cell are
+// enough to make this HBM-bound kernel VALU-bound.
 template <typename T>
-__device__ inline T axis_term(T q, T qwm, T qwp, bool lo, bool hi, T h2) {
-  const T qm = lo ? (qwp - T(6) * q) / T(3) : qwm;
-  const T qp = hi ? (qwm - T(6) * q) / T(3) : qwp;
-  return (qp - T(2) * q + qm) / h2;
-}
+struct H2 {
+  T h2[3], inv[3];
+  int mul_ok[3];
+};
 
 template <typename T>
+__device__ inline T div_h2(T v, const H2<T>& h, int ax) {
+  return h.mul_ok[ax] ? v * h.inv[ax] : v / h.h2[ax];
+}
+
+// One axis of poisson.py:57-68 + :112: ghosts by extrap_quadh(q+-, q, 0), then (qp - 2q + qm)/h2.
+// The extrapolation (a division by 3) is evaluated only where a boundary is touched.
+template <typename T>
+__device__ inline T axis_term(T q, T qwm, T qwp, bool lo, bool hi, const H2<T>& h, int ax) {
+  T qm = qwm, qp = qwp;
+  if (lo || hi) {
+    if (lo) qm = (qwp - T(6) * q) / T(3);
+    if (hi) qp = (qwm - T(6) * q) / T(3);
+  }
+  return div_h2<T>(qp - T(2) * q + qm, h, ax);
+}
+
+// z-marching 7-point kernels.  A workgroup owns one x-segment of one row and walks a chunk
+// of planes; each lane keeps its own z-1 / z / z+1 values in registers, so every element of
+// the marched array is loaded once by its owner (+ once per y-neighbour, an L2 hit inside
+// the XCD).  Loads of the next plane are issued before the current plane is consumed.
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict__ u, const T* __restrict__ rhs,
-                                                            T* __restrict__ fu, StencilArgs a, T h2z, T h2y, T h2x,
+                                                            T* __restrict__ fu, StencilArgs a, H2<T> h,
                                                             double* __restrict__ partials) {
   constexpr int V = VecOf<T>::N;
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
   double local = 0.0;
-  RowIter it = sched_begin(a.sched);
-  for (; it.t < it.count; it.t += it.step) {
-    int64_t z, y, xs;
-    sched_decode(a.sched, it, z, y, xs);
-    const int64_t x0 = (xs * kBlock + threadIdx.x) * V;
-    if (x0 >= X) continue;
+  int zc, yi, xs;
+  const bool have = unit_decode(a.usched, zc, yi, xs);
+  const int64_t x0 = ((int64_t)xs * kBlock + threadIdx.x) * V;
+  if (have && x0 < X) {
+    const int64_t y = yi;
     const int64_t valid = X - x0 < V ? X - x0 : V;
-    const int64_t row = z * sz + y * sy;
-    T c[V], r[V], out[V];
-    load_vec<T, V>(u + row + x0, valid, c);
-    load_vec<T, V>(rhs + row + x0, valid, r);
-    T ym[V], yp[V], zm[V], zp[V];
-    if (a.active[1]) {
-      const int64_t rm = z * sz + (y == 0 ? Y - 1 : y - 1) * sy;
-      const int64_t rp = z * sz + (y == Y - 1 ? 0 : y + 1) * sy;
-      load_vec<T, V>(u + rm + x0, valid, ym);
-      load_vec<T, V>(u + rp + x0, valid, yp);
-    }
-    if (a.active[0]) {
-      const int64_t rm = (z == 0 ? Z - 1 : z - 1) * sz + y * sy;
-      const int64_t rp = (z == Z - 1 ? 0 : z + 1) * sz + y * sy;
-      load_vec<T, V>(u + rm + x0, valid, zm);
-      load_vec<T, V>(u + rp + x0, valid, zp);
-    }
-    // x neighbours of the pack: periodic like mod.roll (core.py:963); the wrapped values
-    // are discarded by the where() masks exactly as in the reference.
-    const T left = u[row + (x0 == 0 ? X - 1 : x0 - 1)];
-    const int64_t xr = x0 + valid;
-    const T right = u[row + (xr >= X ? 0 : xr)];
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      if (i >= valid) break;
-      const int64_t x = x0 + i;
-      const T q = c[i];
-      T acc = T(0);
-      bool first = true;
-      if (a.active[0]) {
-        acc = axis_term<T>(q, zm[i], zp[i], z == 0, z == Z - 1, h2z);
-        first = false;
-      }
+    const int64_t z0 = (int64_t)zc * a.usched.ZC;
+    const int64_t z1 = z0 + a.usched.ZC < Z ? z0 + a.usched.ZC : Z;
+    const int64_t ym_off = (y == 0 ? Y - 1 : y - 1) * sy + x0, yp_off = (y == Y - 1 ? 0 : y + 1) * sy + x0;
+    const int64_t c_off = y * sy + x0;
+    const int64_t xl = y * sy + (x0 == 0 ? X - 1 : x0 - 1);
+    const int64_t xr = y * sy + (x0 + valid >= X ? 0 : x0 + valid);
+    T um[V], uc[V], up[V];
+    if (a.active[0]) load_vec<T, V>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
+    load_vec<T, V>(u + z0 * sz + c_off, valid, uc);
+    for (int64_t z = z0; z < z1; ++z) {
+      const int64_t pz = z * sz;
+      if (a.active[0]) load_vec<T, V>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
+      T r[V], ym[V], yp[V], out[V];
+      load_vec<T, V>(rhs + pz + c_off, valid, r);
       if (a.active[1]) {
-        const T t = axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h2y);
-        acc = first ? t : acc + t;
-        first = false;
+        load_vec<T, V>(u + pz + ym_off, valid, ym);
+        load_vec<T, V>(u + pz + yp_off, valid, yp);
       }
-      {
-        const T xm = i == 0 ? left : c[i - 1];
-        const T xp = (i == valid - 1) ? right : c[i + 1 < V ? i + 1 : i];
-        const T t = axis_term<T>(q, xm, xp, x == 0, x == X - 1, h2x);
-        acc = first ? t : acc + t;
+      // x neighbours of the pack: periodic like mod.roll (core.py:963); the wrapped values
+      // are discarded by the where() masks exactly as in the reference.
+      const T left = u[pz + xl];
+      const T right = u[pz + xr];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        if (i >= valid) break;
+        const int64_t x = x0 + i;
+        const T q = uc[i];
+        T acc = T(0);
+        bool first = true;
+        if (a.active[0]) {
+          acc = axis_term<T>(q, um[i], up[i], z == 0, z == Z - 1, h, 0);
+          first = false;
+        }
+        if (a.active[1]) {
+          const T t = axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h, 1);
+          acc = first ? t : acc + t;
+          first = false;
+        }
+        {
+          const T xm = i == 0 ? left : uc[i - 1];
+          const T xp = (i == valid - 1) ? right : uc[i + 1 < V ? i + 1 : i];
+          const T t = axis_term<T>(q, xm, xp, x == 0, x == X - 1, h, 2);
+          acc = first ? t : acc + t;
+        }
+        const T f = acc - r[i];
+        out[i] = f;
+        local += (double)(f * f);
       }
-      const T f = acc - r[i];
-      out[i] = f;
-      local += (double)(f * f);
+      if (fu) store_vec<T, V>(fu + pz + c_off, valid, out);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        um[i] = uc[i];
+        uc[i] = up[i];
+      }
     }
-    if (fu) store_vec<T, V>(fu + row + x0, valid, out);
   }
   const double total = block_sum(local);
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -144,65 +173,80 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
 // Transpose: g[j] = cm(j+1) fb[j+1] + c0(j) fb[j] + cp(j-1) fb[j-1]  (periodic indices;
 // the masked coefficients vanish exactly where the roll wraps).
 template <typename T>
-__device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, T h2) {
-  const int64_t jp = j == n - 1 ? 0 : j + 1;
-  const int64_t jm = j == 0 ? n - 1 : j - 1;
-  // from row jp: cm(jp) * fb[jp]
-  T s = T(0);
-  if (jp != 0) s = s + fbp;
-  if (jp == n - 1) s = s + fbp / T(3);
-  // from row jm: cp(jm) * fb[jm]
-  if (jm != n - 1) s = s + fbm;
-  if (jm == 0) s = s + fbm / T(3);
-  // from row j
-  T c0 = T(-2);
-  if (j == 0) c0 = c0 - T(2);
-  if (j == n - 1) c0 = c0 - T(2);
-  s = s + c0 * fb;
-  return s / h2;
+__device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, const H2<T>& h, int ax) {
+  T s;
+  if (j >= 2 && j < n - 2) {
+    // interior: (fb[j+1] + fb[j-1]) - 2 fb[j]
+    s = (fbp + fbm) + T(-2) * fb;
+  } else {
+    const int64_t jp = j == n - 1 ? 0 : j + 1;
+    const int64_t jm = j == 0 ? n - 1 : j - 1;
+    s = T(0);
+    // from row jp: cm(jp) * fb[jp]
+    if (jp != 0) s = s + fbp;
+    if (jp == n - 1) s = s + fbp / T(3);
+    // from row jm: cp(jm) * fb[jm]
+    if (jm != n - 1) s = s + fbm;
+    if (jm == 0) s = s + fbm / T(3);
+    // from row j
+    T c0 = T(-2);
+    if (j == 0) c0 = c0 - T(2);
+    if (j == n - 1) c0 = c0 - T(2);
+    s = s + c0 * fb;
+  }
+  return div_h2<T>(s, h, ax);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict__ fu, T* __restrict__ gu,
-                                                           StencilArgs a, T h2z, T h2y, T h2x, T scale) {
+                                                           StencilArgs a, H2<T> h, T scale) {
   constexpr int V = VecOf<T>::N;
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
-  RowIter it = sched_begin(a.sched);
-  for (; it.t < it.count; it.t += it.step) {
-    int64_t z, y, xs;
-    sched_decode(a.sched, it, z, y, xs);
-    const int64_t x0 = (xs * kBlock + threadIdx.x) * V;
-    if (x0 >= X) continue;
-    const int64_t valid = X - x0 < V ? X - x0 : V;
-    const int64_t row = z * sz + y * sy;
-    T c[V], out[V], ym[V], yp[V], zm[V], zp[V];
-    load_vec<T, V>(fu + row + x0, valid, c);
+  int zc, yi, xs;
+  if (!unit_decode(a.usched, zc, yi, xs)) return;
+  const int64_t x0 = ((int64_t)xs * kBlock + threadIdx.x) * V;
+  if (x0 >= X) return;
+  const int64_t y = yi;
+  const int64_t valid = X - x0 < V ? X - x0 : V;
+  const int64_t z0 = (int64_t)zc * a.usched.ZC;
+  const int64_t z1 = z0 + a.usched.ZC < Z ? z0 + a.usched.ZC : Z;
+  const int64_t ym_off = (y == 0 ? Y - 1 : y - 1) * sy + x0, yp_off = (y == Y - 1 ? 0 : y + 1) * sy + x0;
+  const int64_t c_off = y * sy + x0;
+  const int64_t xl = y * sy + (x0 == 0 ? X - 1 : x0 - 1);
+  const int64_t xr = y * sy + (x0 + valid >= X ? 0 : x0 + valid);
+  T fm[V], fc[V], fp[V];
+  if (a.active[0]) load_vec<T, V>(fu + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, fm);
+  load_vec<T, V>(fu + z0 * sz + c_off, valid, fc);
+  for (int64_t z = z0; z < z1; ++z) {
+    const int64_t pz = z * sz;
+    if (a.active[0]) load_vec<T, V>(fu + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, fp);
+    T ym[V], yp[V], out[V];
     if (a.active[1]) {
-      load_vec<T, V>(fu + z * sz + (y == 0 ? Y - 1 : y - 1) * sy + x0, valid, ym);
-      load_vec<T, V>(fu + z * sz + (y == Y - 1 ? 0 : y + 1) * sy + x0, valid, yp);
+      load_vec<T, V>(fu + pz + ym_off, valid, ym);
+      load_vec<T, V>(fu + pz + yp_off, valid, yp);
     }
-    if (a.active[0]) {
-      load_vec<T, V>(fu + (z == 0 ? Z - 1 : z - 1) * sz + y * sy + x0, valid, zm);
-      load_vec<T, V>(fu + (z == Z - 1 ? 0 : z + 1) * sz + y * sy + x0, valid, zp);
-    }
-    const T left = fu[row + (x0 == 0 ? X - 1 : x0 - 1)];
-    const int64_t xr = x0 + valid;
-    const T right = fu[row + (xr >= X ? 0 : xr)];
+    const T left = fu[pz + xl];
+    const T right = fu[pz + xr];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       if (i >= valid) break;
       const int64_t x = x0 + i;
-      const T fb = scale * c[i];
+      const T fb = scale * fc[i];
       T g = T(0);
-      if (a.active[0]) g = g + adj_axis<T>(fb, scale * zm[i], scale * zp[i], z, Z, h2z);
-      if (a.active[1]) g = g + adj_axis<T>(fb, scale * ym[i], scale * yp[i], y, Y, h2y);
-      const T xm = scale * (i == 0 ? left : c[i - 1]);
-      const T xp = scale * ((i == valid - 1) ? right : c[i + 1 < V ? i + 1 : i]);
-      g = g + adj_axis<T>(fb, xm, xp, x, X, h2x);
+      if (a.active[0]) g = g + adj_axis<T>(fb, scale * fm[i], scale * fp[i], z, Z, h, 0);
+      if (a.active[1]) g = g + adj_axis<T>(fb, scale * ym[i], scale * yp[i], y, Y, h, 1);
+      const T xm = scale * (i == 0 ? left : fc[i - 1]);
+      const T xp = scale * ((i == valid - 1) ? right : fc[i + 1 < V ? i + 1 : i]);
+      g = g + adj_axis<T>(fb, xm, xp, x, X, h, 2);
       out[i] = g;
     }
-    store_vec<T, V>(gu + row + x0, valid, out);
+    store_vec<T, V>(gu + pz + c_off, valid, out);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      fm[i] = fc[i];
+      fc[i] = fp[i];
+    }
   }
 }
 
@@ -217,7 +261,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jac(T* __restrict__ coeffs, 
     const int64_t idx[3] = {z, y, x};
     T c0 = T(0);
     int slot = 1;
-    for (int ax = 3 - ndim; ax < 3; ++ax) {
+    for (int ax = 0; ax < 3; ++ax) {
+      if (!a.active[ax]) continue;
       const bool lo = idx[ax] == 0, hi = idx[ax] == a.n[ax] - 1;
       const T one = T(1);
       const T cm = (lo ? T(0) : one) + (hi ? one / T(3) : T(0));
@@ -233,6 +278,18 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jac(T* __restrict__ coeffs, 
 }
 
 template <typename T>
+static H2<T> make_h2(const T h[3]) {
+  H2<T> r;
+  for (int i = 0; i < 3; ++i) {
+    int e;
+    r.h2[i] = h[i];
+    r.inv[i] = T(1) / h[i];
+    r.mul_ok[i] = frexp((double)h[i], &e) == 0.5 && r.inv[i] * h[i] == T(1);
+  }
+  return r;
+}
+
+template <typename T>
 static int fill_args(StencilArgs& a, const int64_t* shape, int ndim, const T* h2, T h[3]) {
   if (ndim < 1 || ndim > 3 || !shape || !h2) {
     set_error("poisson: ndim=%d out of range [1,3] or null shape/h2", ndim);
@@ -243,8 +300,11 @@ static int fill_args(StencilArgs& a, const int64_t* shape, int ndim, const T* h2
     a.active[i] = 0;
     h[i] = T(1);
   }
+  // Canonical (Z, Y, X): the slowest real axis is the marched one.  ndim 3 -> (n0, n1, n2),
+  // ndim 2 -> (n0, 1, n1), ndim 1 -> (1, 1, n0).  Axis terms are still summed in axis order.
+  static const int map3[3][3] = {{2, 0, 0}, {0, 2, 0}, {0, 1, 2}};
   for (int i = 0; i < ndim; ++i) {
-    const int c = 3 - ndim + i;
+    const int c = map3[ndim - 1][i];
     a.n[c] = shape[i];
     a.active[c] = 1;
     h[c] = h2[i];
@@ -254,7 +314,16 @@ static int fill_args(StencilArgs& a, const int64_t* shape, int ndim, const T* h2
     }
   }
   const int per = kBlock * VecOf<T>::N;
-  a.sched = make_sched(a.n[0], a.n[1], (a.n[2] + per - 1) / per);
+  const int64_t XS = (a.n[2] + per - 1) / per;
+  if (a.n[0] * a.n[1] * XS >= ((int64_t)1 << 31)) {
+    set_error("poisson: grid too large for one launch");
+    return ODIL_E_INVAL;
+  }
+  a.usched = make_unit_sched(a.n[0], a.n[1], XS);
+  if (unit_grid(a.usched) > kMaxPartials) {
+    set_error("poisson: %d workgroups exceed the reduction workspace", unit_grid(a.usched));
+    return ODIL_E_INVAL;
+  }
   return 0;
 }
 
@@ -268,9 +337,9 @@ static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shap
     set_error("poisson_residual: null pointer");
     return ODIL_E_INVAL;
   }
-  const int grid = sched_grid(a.sched);
-  hipLaunchKernelGGL(k_poisson_residual<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a, h[0],
-                     h[1], h[2], partials);
+  const int grid = unit_grid(a.usched);
+  hipLaunchKernelGGL(k_poisson_residual<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a,
+                     make_h2<T>(h), partials);
   if (int e = check_launch("k_poisson_residual")) return e;
   const double size = (double)(a.n[0] * a.n[1] * a.n[2]);
   return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
@@ -285,8 +354,8 @@ static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, c
     set_error("poisson_adjoint: null pointer");
     return ODIL_E_INVAL;
   }
-  hipLaunchKernelGGL(k_poisson_adjoint<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, fu, gu, a,
-                     h[0], h[1], h[2], scale);
+  hipLaunchKernelGGL(k_poisson_adjoint<T>, dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream, fu, gu, a,
+                     make_h2<T>(h), scale);
   return check_launch("k_poisson_adjoint");
 }
 
