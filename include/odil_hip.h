@@ -134,8 +134,17 @@ int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, 
 /* y += a * x  (GdOptimizer: x -= lr*g, optimizer.py:270; Newton update util.py:177). */
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream);
 int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);
+/* y = a * (adev ? adev[0] : 1) * x: the cotangent of the loss terms, d mean(f^2)/df =
+ * (2/n) * gout * f (core.py:1093-1101); `adev` is an optional DEVICE scalar. */
+int odil_scale_f64(const double* x, double* y, int64_t n, double a, const double* adev, void* stream);
+int odil_scale_f32(const float* x, float* y, int64_t n, float a, const float* adev, void* stream);
+/* y = a (.) b (accumulate == 0) or y += a (.) b: one CSR block of the Jacobian applied as
+ * coefficient array times gathered field (core.py:1144-1171). */
+int odil_addcmul_f64(double* y, const double* a, const double* b, int64_t n, int accumulate, void* stream);
+int odil_addcmul_f32(float* y, const float* a, const float* b, int64_t n, int accumulate, void* stream);
 /* out[k] = sum_i a[k*lda + i] * b[i], k < nvec, deterministic, f64 accumulation.
- * `partials`: nvec * odil_reduce_workspace_bytes() scratch. */
+ * `partials`: odil_dots_workspace_bytes(nvec) scratch. */
+size_t odil_dots_workspace_bytes(int nvec);
 int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64_t n, double* partials,
                   double* out, void* stream);
 int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,

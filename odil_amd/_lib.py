@@ -34,13 +34,17 @@ _SIGNATURES = {
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
     "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P],
     "axpy": [_P, _P, c_int64, _R, _P],
+    "scale": [_P, _P, c_int64, _R, _P, _P],
+    "addcmul": [_P, _P, _P, c_int64, c_int, _P],
     "dots": [_P, c_int64, c_int, _P, c_int64, _P, _P, _P],
     "lincomb": [_P, _R, _P, c_int64, c_int, _P, c_int64, _P],
     "stencil_apply": [_P, _I64P, c_int, _P, _P, _I64P, c_int, c_int, _P],
     "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],
 }
 
-EXPORTED = ["odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes"] + [
+EXPORTED = [
+    "odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes", "odil_dots_workspace_bytes",
+] + [
     "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
 ]
 
@@ -67,6 +71,8 @@ def load():
     lib.odil_version.restype = c_int
     lib.odil_device_count.restype = c_int
     lib.odil_reduce_workspace_bytes.restype = c_size_t
+    lib.odil_dots_workspace_bytes.restype = c_size_t
+    lib.odil_dots_workspace_bytes.argtypes = [c_int]
     for name, sig in _SIGNATURES.items():
         for suffix, real in (("f64", c_double), ("f32", c_float)):
             fn = getattr(lib, "odil_{}_{}".format(name, suffix))

@@ -1,0 +1,1039 @@
+"""Domain / State / Context / Problem: the operator API of the reference
+(reference src/odil/core.py) on top of the HIP kernels.
+
+User `operator(ctx)` callbacks written for the reference run unchanged: they see the
+same `ctx.field / ctx.neural_net / ctx.step / ctx.indices / ...` and the same `mod`
+names.  What differs is who does the work:
+
+  * multigrid synthesis `u = sum_l P^l (f_l w_l)` (core.py:245-263)  -> odil_mg_synth,
+    cotangent -> odil_mg_synth_adj                                   (one launch chain)
+  * `ctx.field(key, *shift, loc)` pad + roll + trim (core.py:955-969) -> odil_field_gather,
+    cotangent -> odil_field_scatter
+  * loss terms mean(f^2) (core.py:1093)                              -> odil_mean_reduce,
+    cotangent -> odil_scale
+  * interp_to_finer / restrict_to_coarser (core.py:606-755)          -> odil_interp_add / odil_restrict
+  * affine stencil operators (Poisson) are recognised from their Jacobian coefficients and
+    evaluated by the fused residual / adjoint kernels (see fused.py)
+  * Jacobian rows (core.py:1144-1171) stay on the device as coefficient arrays
+    (`LinearizedOperator`), applied matrix-free for the normal equations.
+
+Reverse-mode differentiation of the user's pointwise arithmetic is torch.autograd
+bookkeeping over device tensors; there is no CPU path.
+"""
+
+import math
+import pickle
+
+import numpy as np
+import torch
+
+from . import ops
+from .backend import ModRocm, numpy_dtype, torch_dtype
+
+
+def assert_equal(first, second, msg=""):
+    if not (first == second):
+        raise ValueError("Expected equal '{:}' and '{:}'{}".format(first, second, msg))
+
+
+# ======================================================================================
+# State containers (reference core.py:506-603): plain attribute holders.
+# ======================================================================================
+class Field:
+    def __init__(self, array=None, loc=None, cshape=None):
+        self.array = array  # data array
+        self.loc = loc  # one of 'c' / 'n' per direction
+        self.cshape = cshape  # grid size in cells
+
+    def __repr__(self):
+        return "odil.Field({}, loc='{}', cshape={:})".format(repr(self.array), self.loc, self.cshape)
+
+    __str__ = __repr__
+
+
+class MultigridField:
+    def __init__(self, terms=None, loc=None, factors=None, axes=None, method=None):
+        self.terms = terms  # list of Field, fine -> coarse
+        self.loc = loc
+        self.factors = factors  # factor of each term, defaults to 1
+        self.axes = axes  # per axis: decompose it or not
+        self.method = method  # 'stack' | 'conv': same values, one HIP kernel here
+
+
+class NeuralNet:
+    def __init__(self, weights=None, biases=None, func_in=None, func_out=None, activation=None):
+        self.weights = weights  # list of (no, ni) matrices
+        self.biases = biases  # list of (no,) vectors
+        self.func_in = func_in
+        self.func_out = func_out
+        self.activation = activation or "tanh"
+
+
+class Array:
+    def __init__(self, array=None, shape=None):
+        self.array = array
+        self.shape = shape
+
+    def __repr__(self):
+        return "odil.Array({}, shape={:})".format(repr(self.array), self.shape)
+
+    __str__ = __repr__
+
+
+class State:
+    def __init__(self, fields=None, initialized=False):
+        self.fields = fields if fields is not None else dict()
+        self.initialized = initialized
+
+
+# ======================================================================================
+# HIP kernels as differentiable building blocks
+# ======================================================================================
+class _MgSynthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, factors, *terms):
+        ctx.loc, ctx.factors = loc, factors
+        ctx.shapes = [tuple(t.shape) for t in terms]
+        return ops.mg_synth([t.contiguous() for t in terms], loc, factors=factors)
+
+    @staticmethod
+    def backward(ctx, gu):
+        grads = ops.mg_synth_adj(gu.contiguous(), ctx.shapes, ctx.loc, factors=ctx.factors)
+        return (None, None) + tuple(grads)
+
+
+class _FieldAccessFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, field_loc, shift, loc):
+        ctx.meta = (tuple(src.shape), field_loc, shift, loc)
+        return ops.field_gather(src.contiguous(), field_loc, shift, loc)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, field_loc, shift, loc = ctx.meta
+        return ops.field_scatter(g.contiguous(), shape, field_loc, shift, loc), None, None, None
+
+
+class _MeanFn(torch.autograd.Function):
+    """mean(x^2) (square=True) or mean(x): deterministic two-stage reduction."""
+
+    @staticmethod
+    def forward(ctx, x, square):
+        x = x.contiguous()
+        ctx.square = square
+        ctx.save_for_backward(x)
+        return ops.mean_reduce(x, square=square)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        n = x.numel()
+        gout = gout.contiguous().to(x.dtype)
+        if ctx.square:
+            return ops.scale(x, 2.0 / n, adev=gout.reshape(1)), None
+        return ops.scale(torch.ones_like(x), 1.0 / n, adev=gout.reshape(1)), None
+
+
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, loc):
+        ctx.loc, ctx.shape = loc, tuple(u.shape)
+        return ops.interp_add(u.contiguous(), loc)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.interp_adj(g.contiguous(), ctx.loc, ctx.shape), None
+
+
+def _as_tensor(u, mod):
+    if isinstance(u, torch.Tensor):
+        return u
+    mod = mod or _default_mod()
+    return mod.array(u)
+
+
+def _default_mod():
+    from . import runtime
+
+    return runtime.get_mod()
+
+
+def interp_to_finer(u, loc=None, method=None, mod=None, depth=1):
+    """Linear prolongation (reference core.py:606-700).  `method` ('conv' | 'stack') selects
+    between two formulations of the SAME values in the reference; here both names run the
+    one HIP kernel, which reproduces the 'stack' summation order."""
+    method = method or "stack"
+    if method not in ["conv", "stack"]:
+        raise ValueError("Unknown method='{}'".format(method))
+    u = _as_tensor(u, mod)
+    loc = loc or "c" * u.dim()
+    assert_equal(len(loc), u.dim())
+    for l in loc:
+        assert l in "cn.", "Invalid loc={}".format(loc)
+    for _ in range(depth):
+        u = _InterpFn.apply(u, loc)
+    return u
+
+
+def restrict_to_coarser(u, loc=None, method=None, mod=None, depth=1):
+    """Full-weighting restriction (reference core.py:703-755)."""
+    method = method or "conv"
+    if method not in ["conv"]:
+        raise ValueError("Unknown method='{}'".format(method))
+    u = _as_tensor(u, mod)
+    loc = loc or "c" * u.dim()
+    assert_equal(len(loc), u.dim())
+    for l in loc:
+        assert l in "cn.", "Invalid loc={}".format(loc)
+    if u.requires_grad:
+        raise NotImplementedError("restrict_to_coarser is not differentiable yet (poisson --mgloss); see DESIGN.md")
+    return ops.restrict_to_coarser(u.contiguous(), loc, depth=depth)
+
+
+def check_multigrid_cshapes(cshapes, axes=None):
+    """Level n must halve level n-1 on every decomposed axis (reference core.py:758-776)."""
+    if not len(cshapes):
+        return
+    dim = len(cshapes[0])
+    axes = axes or [True] * dim
+    assert_equal(len(axes), dim)
+    for i in range(1, len(cshapes)):
+        for j in range(dim):
+            if axes[j]:
+                assert_equal(cshapes[i - 1][j], cshapes[i][j] * 2, " with cshapes={:}".format(cshapes))
+
+
+# ======================================================================================
+# Neural networks (reference core.py:779-862) -- only as used inside stencils
+# ======================================================================================
+def make_neural_net(layers, dtype, mod, initializer="lecun", func_in=None, func_out=None, activation=None):
+    def get_scale(ni, no):
+        if initializer == "legacy":
+            return np.sqrt(1.0 / ni)
+        elif initializer == "glorot":
+            return np.sqrt(6.0 / (ni + no))
+        elif initializer == "lecun":
+            return np.sqrt(3.0 / ni)
+        elif initializer == "he":
+            return np.sqrt(6.0 / ni)
+        raise ValueError("Unknown initializer=" + initializer)
+
+    weights, biases = [], []
+    for ni, no in zip(layers[:-1], layers[1:]):
+        scale = get_scale(ni, no)
+        weights.append(mod.random.uniform(shape=(no, ni), minval=-scale, maxval=scale, dtype=dtype))
+        biases.append(mod.zeros(no, dtype=dtype))
+    return NeuralNet(weights, biases, func_in=func_in, func_out=func_out, activation=activation)
+
+
+def eval_neural_net(net, inputs, mod, frozen=False):
+    """Dense MLP applied pointwise to grid arrays (reference core.py:807-862)."""
+    weights, biases = net.weights, net.biases
+    assert_equal(len(weights), len(biases), "Weights and biases do not match")
+    assert_equal(weights[0].shape[1], len(inputs), "Weights and inputs do not match")
+    for w, b in zip(weights, biases):
+        assert_equal(w.shape[0], b.shape[0])
+    if frozen:
+        weights = [mod.stop_gradient(w) for w in weights]
+        biases = [mod.stop_gradient(b) for b in biases]
+    func_act = {"tanh": mod.tanh, "relu": mod.relu, "none": lambda x: x}[net.activation]
+    if net.func_in is not None:
+        inputs = net.func_in(*inputs)
+    tmp = mod.stack([mod.cast(v, weights[0].dtype) for v in inputs], axis=0)
+    tmp = torch.movedim(tmp, 0, -1)[..., None]  # (..., ni, 1): columns of inputs
+    n = len(weights)
+    for i in range(n):
+        tmp = mod.matmul(weights[i], tmp) + biases[i][:, None]
+        if i < n - 1:
+            tmp = func_act(tmp)
+    tmp = torch.movedim(tmp[..., 0], -1, 0)
+    outputs = [tmp[i] for i in range(tmp.shape[0])]
+    if net.func_out is not None:
+        outputs = net.func_out(*outputs)
+    return outputs
+
+
+# ======================================================================================
+# Domain (reference core.py:11-504)
+# ======================================================================================
+class Domain:
+    def __init__(self, cshape, dimnames=None, lower=0.0, upper=1.0, dtype=None, multigrid=False,
+                 mg_convert_all=True, mg_nlvl=None, mg_factors=None, mg_axes=None, mg_interp=None, mod=None):
+        ndim = len(cshape)
+        dimnames = dimnames or ["x", "y", "z"][:ndim]
+        if mod is None:
+            mod = _default_mod()
+        assert_equal(len(dimnames), ndim, f"with dimnames={dimnames}")
+        self.ndim = ndim
+        self.cshape = tuple(int(c) for c in cshape)
+        self.dimnames = dimnames
+        if dtype is None:
+            from . import runtime
+
+            dtype = runtime.dtype
+        dtype = numpy_dtype(dtype) if isinstance(dtype, torch.dtype) else np.dtype(dtype)
+        self.dtype = dtype.type
+        self.lower = (np.ones(ndim, dtype=dtype) * lower).astype(dtype)
+        self.upper = (np.ones(ndim, dtype=dtype) * upper).astype(dtype)
+        self.mod = mod
+        self.multigrid = multigrid
+        if multigrid:
+            self.mg_factors = mg_factors
+            mg_axes = mg_axes or [True] * ndim
+            nlvl_max = min(int(round(np.log2(n))) if ax else max(cshape) for n, ax in zip(cshape, mg_axes))
+            if mg_nlvl is not None:
+                assert mg_nlvl >= 1
+                mg_nlvl = min(mg_nlvl, nlvl_max)
+            else:
+                mg_nlvl = nlvl_max
+            self.mg_nlvl = mg_nlvl
+            self.mg_cshapes = [
+                tuple(int(n) >> lvl if ax else int(n) for n, ax in zip(cshape, mg_axes)) for lvl in range(mg_nlvl)
+            ]
+            check_multigrid_cshapes(self.mg_cshapes, mg_axes)
+            self.mg_axes = mg_axes
+            self.mg_interp = mg_interp
+            self.mg_convert_all = mg_convert_all
+
+    # ---- geometry: host-side NumPy, results handed to the device by mod.meshgrid ----
+    @staticmethod
+    def _names_to_indices(dims, dimnames):
+        res = dims if dims is not None and len(dims) else range(len(dimnames))
+        return tuple(dimnames.index(i) if isinstance(i, str) else i for i in res)
+
+    def cast(self, value, dtype=None):
+        return self.mod.cast(value, dtype or self.dtype)
+
+    def _points_1d(self, d, loc):
+        if loc == "c":
+            x = np.linspace(self.lower[d], self.upper[d], self.cshape[d], endpoint=False, dtype=self.dtype)
+            if len(x) > 1:
+                x += (x[1] - x[0]) * 0.5
+            return x
+        elif loc == "n":
+            return np.linspace(self.lower[d], self.upper[d], self.cshape[d] + 1, dtype=self.dtype)
+        raise ValueError("Unknown loc=" + loc)
+
+    def points_1d(self, *dims, loc=None):
+        loc = loc or "c" * self.ndim
+        idims = self._names_to_indices(dims, self.dimnames)
+        res = [self._points_1d(idim, c) for idim, c in zip(idims, loc)]
+        return res[0] if len(dims) == 1 else res
+
+    def points(self, *dims, loc=None):
+        loc = loc or "c" * self.ndim
+        assert_equal(len(loc), self.ndim, f"with loc={loc}")
+        dimnames = [v for v, c in zip(self.dimnames, loc) if c != "."]
+        idims = self._names_to_indices(dims, dimnames)
+        xx = [self._points_1d(d, loc[d]) for d in range(self.ndim) if loc[d] != "."]
+        data = self.mod.meshgrid(*xx, indexing="ij")
+        res = tuple(data[i] for i in idims)
+        return res[0] if len(dims) == 1 else res
+
+    def _indices_1d(self, d, loc):
+        if loc == "c":
+            return np.arange(self.cshape[d], dtype=int)
+        elif loc == "n":
+            return np.arange(self.cshape[d] + 1, dtype=int)
+        raise ValueError("Unknown loc=" + loc)
+
+    def indices(self, *dims, loc=None):
+        loc = loc or "c" * self.ndim
+        dimnames = [v for v, c in zip(self.dimnames, loc) if c in "cn"]
+        idims = self._names_to_indices(dims, dimnames)
+        xx = [self._indices_1d(d, loc[d]) for d in range(self.ndim) if loc[d] in "cn"]
+        data = self.mod.meshgrid(*xx, indexing="ij")
+        res = tuple(data[i] for i in idims)
+        return res[0] if len(dims) == 1 else res
+
+    @staticmethod
+    def _get_field_shape(cshape, loc=None):
+        loc = loc or "c" * len(cshape)
+        assert all(c in "cn" for c in loc)
+        return tuple(int(s) + 1 if c == "n" else int(s) for s, c in zip(cshape, loc))
+
+    def get_field_shape(self, loc=None):
+        return self._get_field_shape(self.cshape, loc=loc)
+
+    def size(self, *dims, loc=None):
+        loc = loc or "c" * self.ndim
+        assert_equal(len(loc), self.ndim, f"with loc={loc}")
+        idims = self._names_to_indices(dims, self.dimnames)
+        res = [self.cshape[i] + (1 if loc[i] == "n" else 0) for i in idims]
+        for i in idims:
+            if loc[i] not in "cn":
+                raise ValueError("Unknown loc=" + loc[i])
+        return res[0] if len(dims) == 1 else res
+
+    def step_by_dim(self, i):
+        return (self.upper[i] - self.lower[i]) / self.cshape[i]
+
+    def step(self, *dims):
+        idims = self._names_to_indices(dims, self.dimnames)
+        res = tuple(self.step_by_dim(i) for i in idims)
+        return res[0] if len(dims) == 1 else res
+
+    # ---- multigrid decomposition -------------------------------------------------------
+    def _mg_loc(self, mgfield):
+        axes = mgfield.axes or self.mg_axes
+        return "".join(l if ax else "." for l, ax in zip(mgfield.loc, axes))
+
+    def multigrid_to_regular(self, mgfield):
+        """u = sum_l P^l (f_l w_l) (reference core.py:245-263) as one HIP launch chain."""
+        factors = mgfield.factors or self.mg_factors or [1] * len(mgfield.terms)
+        axes = mgfield.axes or self.mg_axes
+        assert_equal(len(factors), len(mgfield.terms))
+        assert_equal(len(axes), len(mgfield.terms[0].cshape))
+        arrays = [term.array for term in mgfield.terms]
+        if all(float(f) == 1.0 for f in factors):
+            factors = None
+        else:
+            factors = tuple(float(f) for f in factors)
+        res = _MgSynthFn.apply(self._mg_loc(mgfield), factors, *arrays)
+        return Field(res, loc=mgfield.loc)
+
+    def get_regular_array(self, field):
+        if isinstance(field, (Field, Array)):
+            return field.array
+        elif isinstance(field, MultigridField):
+            return self.multigrid_to_regular(field).array
+        raise TypeError("Expected Field or MultigridField got {}".format(type(field).__name__))
+
+    def regular_to_multigrid(self, field, cshapes=None, factors=None, method=None):
+        """Level 0 <- u / f_0, coarser levels zero (reference core.py:276-297)."""
+        mod = self.mod
+        if isinstance(field, (MultigridField, NeuralNet)):
+            raise TypeError("Expected Field or ndarray, got type {}".format(type(field).__name__))
+        field = self.init_field(field)
+        cshapes = cshapes or self.mg_cshapes
+        factors = factors or self.mg_factors or [1] * len(cshapes)
+        assert_equal(len(cshapes), len(factors))
+        method = method or self.mg_interp
+        terms = [Field(field.array / factors[0], loc=field.loc, cshape=field.cshape)]
+        for cshape in cshapes[1:]:
+            array = mod.zeros(self._get_field_shape(cshape, loc=field.loc), dtype=self.dtype)
+            terms.append(Field(array, loc=field.loc, cshape=cshape))
+        return MultigridField(terms=terms, loc=field.loc, factors=factors, method=method)
+
+    # ---- state initialisation (reference core.py:299-359) -------------------------------
+    def init_field(self, field):
+        mod = self.mod
+        if field is None:
+            return self.init_field(Field(None, loc="c" * self.ndim, cshape=self.cshape))
+        elif isinstance(field, np.ndarray) or mod.is_tensor(field):
+            return self.init_field(Field(field, loc="c" * len(field.shape), cshape=tuple(field.shape)))
+        elif isinstance(field, Field):
+            cshape = field.cshape or self.cshape
+            ndim = len(cshape)
+            loc = field.loc or "c" * ndim
+            assert_equal(len(loc), ndim)
+            array = field.array
+            if array is None:
+                array = mod.zeros(self._get_field_shape(cshape, loc=loc), dtype=self.dtype)
+            array = mod.variable(array, dtype=self.dtype)
+            assert_equal(tuple(array.shape), self._get_field_shape(cshape, loc=loc))
+            return Field(array, loc=loc, cshape=cshape)
+        elif isinstance(field, MultigridField):
+            return MultigridField(
+                [self.init_field(term) for term in field.terms], loc=field.loc, factors=field.factors,
+                axes=field.axes, method=field.method,
+            )
+        elif isinstance(field, NeuralNet):
+            weights = [mod.variable(w, dtype=self.dtype) for w in field.weights]
+            biases = [mod.variable(b, dtype=self.dtype) for b in field.biases]
+            return NeuralNet(weights, biases, func_in=field.func_in, func_out=field.func_out,
+                             activation=field.activation)
+        elif isinstance(field, list):
+            u = mod.cast(mod.array(np.array(field)), self.dtype)
+            return self.init_field(Array(u, shape=tuple(u.shape)))
+        elif isinstance(field, Array):
+            array = field.array
+            if array is None:
+                array = mod.zeros(field.shape, dtype=self.dtype)
+            return Array(mod.variable(array, dtype=self.dtype), field.shape)
+        raise TypeError("Unknown field type '{}'".format(type(field).__name__))
+
+    def init_state(self, state):
+        fields = dict()
+        for key in state.fields:
+            field = self.init_field(state.fields[key])
+            if self.multigrid and self.mg_convert_all and not isinstance(field, (MultigridField, NeuralNet, Array)):
+                field = self.regular_to_multigrid(state.fields[key])
+            fields[key] = field
+        return State(fields=fields, initialized=True)
+
+    # ---- flattening: defines the unknown-vector layout (reference core.py:361-469) -------
+    def arrays_from_field(self, field):
+        if isinstance(field, Field):
+            return [field.array]
+        elif isinstance(field, MultigridField):
+            return [term.array for term in field.terms]
+        elif isinstance(field, NeuralNet):
+            return field.weights + field.biases
+        elif isinstance(field, Array):
+            return [field.array]
+        raise TypeError("Unknown field type '{}'".format(type(field).__name__))
+
+    def arrays_from_state(self, state):
+        res = []
+        for key in state.fields:
+            res += self.arrays_from_field(state.fields[key])
+        return res
+
+    @staticmethod
+    def arrays_to_field(arrays, field):
+        if isinstance(field, (Field, Array)):
+            field.array = arrays[0]
+            return 1
+        elif isinstance(field, MultigridField):
+            for i, term in enumerate(field.terms):
+                term.array = arrays[i]
+            return len(field.terms)
+        elif isinstance(field, NeuralNet):
+            nw, nb = len(field.weights), len(field.biases)
+            for i in range(nw):
+                field.weights[i] = arrays[i]
+            for i in range(nb):
+                field.biases[i] = arrays[nw + i]
+            return nw + nb
+        raise TypeError("Unknown field type '{}'".format(type(field).__name__))
+
+    @staticmethod
+    def arrays_to_state(arrays, state):
+        offset = 0
+        for key in state.fields:
+            offset += Domain.arrays_to_field(arrays[offset:], state.fields[key])
+        return offset
+
+    def pack_field(self, field):
+        mod = self.mod
+        return mod.concatenate([mod.flatten(f) for f in self.arrays_from_field(field)], axis=0)
+
+    def pack_state(self, state):
+        mod = self.mod
+        return mod.concatenate([mod.flatten(f) for f in self.arrays_from_state(state)], axis=0)
+
+    def _unpack(self, packed, arrays):
+        mod = self.mod
+        sizes = [math.prod(a.shape) for a in arrays]
+        split = mod.split_by_sizes(mod.cast(packed, self.dtype)[: sum(sizes)], sizes)
+        return [mod.reshape(s, a.shape) for s, a in zip(split, arrays)], sum(sizes)
+
+    def unpack_field(self, packed, field):
+        arrays, n = self._unpack(packed, self.arrays_from_field(field))
+        self.arrays_to_field(arrays, field)
+        return n
+
+    def unpack_state(self, packed, state):
+        arrays, n = self._unpack(packed, self.arrays_from_state(state))
+        self.arrays_to_state(arrays, state)
+        return n
+
+    def make_neural_net(self, layers, initializer="lecun", func_in=None, func_out=None, activation=None):
+        return make_neural_net(layers, self.dtype, self.mod, initializer, func_in, func_out, activation)
+
+    # ---- post-processing accessors (reference core.py:474-499) ---------------------------
+    def field(self, state, key, *shift):
+        field = state.fields[key]
+        if not isinstance(field, (Field, MultigridField, Array)):
+            raise TypeError(
+                "Expected Field or MultigridField, got type {} for field '{}'".format(type(field).__name__, key)
+            )
+        if isinstance(field, Array):
+            if len(shift):
+                raise RuntimeError("Array requires an empty shift")
+            return field.array
+        shift = shift or (0,) * self.ndim
+        if len(shift) != self.ndim:
+            raise RuntimeError("Expected {} shift components, got shift={}".format(self.ndim, shift))
+        with torch.no_grad():
+            array = self.get_regular_array(field)
+            if any(shift):
+                array = ops.field_gather(array.contiguous(), field.loc, tuple(int(s) for s in shift), field.loc)
+        return array
+
+    def neural_net(self, state, key):
+        net = state.fields[key]
+        if not isinstance(net, NeuralNet):
+            raise TypeError("Expected NeuralNet, got type {} for key='{}'".format(type(net).__name__, key))
+
+        def res(*inputs):
+            with torch.no_grad():
+                return eval_neural_net(net, inputs, self.mod)
+
+        return res
+
+    def get_context(self, state, extra=None, tracers=None):
+        return Context(self, state, extra=extra, tracers=tracers)
+
+
+# ======================================================================================
+# Context: stencil access (reference core.py:865-990)
+# ======================================================================================
+class Context:
+    class Raw:
+        def __init__(self, value):
+            self.value = value
+
+    def __init__(self, domain, state, watch_func=None, extra=None, tracers=None, distinct_shift=False):
+        self.domain = domain
+        self.state = state
+        self.watch_func = watch_func or (lambda _: None)
+        self.extra = extra
+        self._tracers = tracers
+        self.tracers_accessed = False
+        self.dtype = domain.dtype
+        self.mod = domain.mod
+        self.distinct_shift = distinct_shift
+        self.desc_to_array = dict()  # (key, shift, loc) -> array
+        self.key_to_array_jac = dict()  # unknowns that need a dense Jacobian
+        self.step = domain.step
+        self.size = domain.size
+        self.indices = domain.indices
+        self.points = domain.points
+
+    @property
+    def tracers(self):
+        self.tracers_accessed = True
+        return self._tracers
+
+    def cast(self, value, dtype=None):
+        return self.mod.cast(value, dtype or self.dtype)
+
+    def field(self, key, *shift, loc=None, frozen=False):
+        domain = self.domain
+        mod = domain.mod
+        field = self.state.fields[key]
+        if not isinstance(field, (Field, MultigridField, Array)):
+            raise TypeError(
+                "Expected Field or MultigridField, got type {} for key='{}'".format(type(field).__name__, key)
+            )
+        if isinstance(field, Array):
+            if len(shift):
+                raise RuntimeError("Array requires an empty shift")
+            self.watch_func(field.array)
+            self.key_to_array_jac[(key, None, None)] = field.array
+            return mod.stop_gradient(field.array) if frozen else field.array
+        shift_src = (0,) * domain.ndim
+        shift = tuple(int(s) for s in shift) or shift_src
+        loc = loc or field.loc
+        if len(shift) != domain.ndim:
+            raise RuntimeError("Expected {} shift components, got shift={}".format(domain.ndim, shift))
+        desc = (key, shift, loc)
+        desc_src = (key, shift_src, field.loc)
+        if desc in self.desc_to_array:
+            array = self.desc_to_array[desc]
+        else:
+            if desc_src in self.desc_to_array:
+                array_src = self.desc_to_array[desc_src]
+            else:
+                array_src = domain.get_regular_array(field)  # multigrid synthesis happens once per key
+                if self.distinct_shift:
+                    array_src = self._symbol(array_src)
+                self.desc_to_array[desc_src] = array_src
+            if desc == desc_src:
+                array = array_src
+            else:
+                src = array_src.detach() if self.distinct_shift else array_src
+                # pad ('c'->'n'), periodic roll by -shift, trim ('n'->'c'): one gather kernel
+                array = _FieldAccessFn.apply(src, field.loc, shift, loc)
+                if self.distinct_shift:
+                    array = self._symbol(array)
+                self.desc_to_array[desc] = array
+        if frozen:
+            array = mod.stop_gradient(array)
+        return array
+
+    @staticmethod
+    def _symbol(array):
+        """An independent differentiation variable holding `array` (distinct_shift mode,
+        reference core.py:950-953, :970-971)."""
+        return array.detach().clone().requires_grad_(True)
+
+    def neural_net(self, key, frozen=False):
+        domain = self.domain
+        net = self.state.fields[key]
+        if not isinstance(net, NeuralNet):
+            raise TypeError("Expected NeuralNet, got type {} for key='{}'".format(type(net).__name__, key))
+        arrays = domain.arrays_from_field(net)
+        self.watch_func(arrays)
+        if self.distinct_shift:
+            self.key_to_array_jac[(key, None, None)] = arrays
+
+        def res(*inputs):
+            return eval_neural_net(net, inputs, self.mod, frozen=frozen)
+
+        return res
+
+
+# ======================================================================================
+# Linearised operator kept on the device (reference core.py:1113-1217)
+# ======================================================================================
+class LinearizedOperator:
+    """M of `Problem.linearize`, as the pieces ODIL assembles it from: per output rows, per
+    (key, shift, loc) a coefficient array (one CSR entry per row, core.py:1144-1171) and per
+    Array / NeuralNet unknown a dense block (core.py:1189-1203).  Applies M and M^T with the
+    HIP kernels; `to_scipy()` exports the same CSR matrix the reference returns."""
+
+    def __init__(self, domain, state):
+        self.domain = domain
+        self.key_to_offset, self.key_to_size, self.key_to_field = dict(), dict(), dict()
+        offset = 0
+        for key, field in state.fields.items():
+            size = sum(math.prod(a.shape) for a in domain.arrays_from_field(field))
+            self.key_to_offset[key], self.key_to_size[key], self.key_to_field[key] = offset, size, field
+            offset += size
+        self.ncols = offset
+        self.blocks = []  # (row_offset, nrows, kind, key, payload)
+        self.nrows = 0
+        self.dtype = torch_dtype(domain.dtype)
+        self.device = domain.mod.device
+
+    def add_output(self, value_shape, grad):
+        nrows = math.prod(value_shape)
+        row0 = self.nrows
+        for (key, shift, loc), garray in grad.items():
+            if garray is None:
+                continue
+            if isinstance(garray, list) and all(a is None for a in garray):
+                continue
+            field = self.key_to_field[key]
+            if shift is None or len(value_shape) < len(shift):
+                if isinstance(garray, list):
+                    garray = torch.cat([a.reshape(nrows, -1) for a in garray], dim=1)
+                dense = garray.reshape(nrows, -1).contiguous()
+                self.blocks.append((row0, nrows, "dense", key, dense))
+            else:
+                if not isinstance(field, Field):
+                    raise TypeError("Expected Field, got type {} for key='{}'".format(type(field).__name__, key))
+                self.blocks.append((row0, nrows, "stencil", key, (garray.contiguous(), tuple(shift), loc,
+                                                                  tuple(value_shape))))
+        self.nrows += nrows
+
+    @property
+    def shape(self):
+        return (self.nrows, self.ncols)
+
+    def _field_view(self, x, key):
+        off, size = self.key_to_offset[key], self.key_to_size[key]
+        return x[off : off + size]
+
+    def matvec(self, x):
+        """y = M x (device vectors)."""
+        y = torch.zeros(self.nrows, dtype=self.dtype, device=self.device)
+        for row0, nrows, kind, key, payload in self.blocks:
+            xk = self._field_view(x, key)
+            if kind == "dense":
+                ops.lincomb(y[row0 : row0 + nrows], 1.0, payload.t().contiguous(), xk.contiguous())
+            else:
+                coeff, shift, loc, vshape = payload
+                field = self.key_to_field[key]
+                gathered = ops.field_gather(xk.reshape(field.array.shape).contiguous(), field.loc, shift, loc)
+                ops.addcmul(y[row0 : row0 + nrows], coeff.reshape(-1), gathered.reshape(-1))
+        return y
+
+    def rmatvec(self, y):
+        """x = M^T y."""
+        x = torch.zeros(self.ncols, dtype=self.dtype, device=self.device)
+        for row0, nrows, kind, key, payload in self.blocks:
+            yk = y[row0 : row0 + nrows]
+            xk = self._field_view(x, key)
+            if kind == "dense":
+                ops.lincomb(xk, 1.0, payload.contiguous(), yk.contiguous())
+            else:
+                coeff, shift, loc, vshape = payload
+                field = self.key_to_field[key]
+                prod = torch.empty(nrows, dtype=self.dtype, device=self.device)
+                ops.addcmul(prod, coeff.reshape(-1), yk.contiguous(), accumulate=False)
+                ops.field_scatter(prod.reshape(vshape), field.array.shape, field.loc, shift, loc,
+                                  out=xk.reshape(field.array.shape))
+        return x
+
+    def normal_diagonal(self):
+        """diag(M^T M) = column sums of squares (Jacobi preconditioner / dampdiag)."""
+        d = torch.zeros(self.ncols, dtype=self.dtype, device=self.device)
+        for row0, nrows, kind, key, payload in self.blocks:
+            dk = self._field_view(d, key)
+            if kind == "dense":
+                ones = torch.ones(nrows, dtype=self.dtype, device=self.device)
+                sq = torch.empty_like(payload)
+                ops.addcmul(sq.reshape(-1), payload.reshape(-1), payload.reshape(-1), accumulate=False)
+                ops.lincomb(dk, 1.0, sq, ones)
+            else:
+                coeff, shift, loc, vshape = payload
+                field = self.key_to_field[key]
+                sq = torch.empty(nrows, dtype=self.dtype, device=self.device)
+                ops.addcmul(sq, coeff.reshape(-1), coeff.reshape(-1), accumulate=False)
+                ops.field_scatter(sq.reshape(vshape), field.array.shape, field.loc, shift, loc,
+                                  out=dk.reshape(field.array.shape))
+        return d
+
+    def to_scipy(self, modsp=None):
+        """The CSR matrix of reference core.py:1170-1214 (host, for inspection / parity)."""
+        import scipy.sparse as sp
+
+        modsp = modsp or sp
+        npdt = numpy_dtype(self.dtype)
+        matrix = modsp.csr_array((self.nrows, self.ncols), dtype=npdt)
+        for row0, nrows, kind, key, payload in self.blocks:
+            off = self.key_to_offset[key]
+            if kind == "dense":
+                m = modsp.csr_array(payload.cpu().numpy())
+                block = modsp.csr_array((m.data, m.indices + off, m.indptr), shape=(nrows, self.ncols))
+            else:
+                coeff, shift, loc, vshape = payload
+                field = self.key_to_field[key]
+                size = self.key_to_size[key]
+                # cols = offset + arange, then pad (constant 0) / roll / trim exactly as the
+                # reference does (core.py:1147-1164): padded entries point at absolute column 0.
+                cols = (torch.arange(size, dtype=torch.float64, device=self.device) + off).reshape(field.array.shape)
+                cols = ops.field_gather(cols.contiguous(), field.loc, shift, loc).reshape(-1).cpu().numpy()
+                rows = np.arange(nrows)
+                block = modsp.csr_array(
+                    (coeff.reshape(-1).cpu().numpy(), (rows, cols.astype(np.int64))), shape=(nrows, self.ncols)
+                )
+            full = modsp.vstack(
+                [modsp.csr_array((row0, self.ncols), dtype=npdt), block,
+                 modsp.csr_array((self.nrows - row0 - nrows, self.ncols), dtype=npdt)]
+            ).tocsr()
+            matrix = matrix + full
+        return matrix.tocsr()
+
+
+# ======================================================================================
+# Problem (reference core.py:993-1386)
+# ======================================================================================
+class Problem:
+    def __init__(self, operator, domain, extra=None, tracers=None, jit=None):
+        """operator: callable(ctx) returning a list of arrays / (name, array) / Context.Raw."""
+        self.domain = domain
+        self.operator = operator
+        self.extra = extra
+        if tracers is None:
+            tracers = dict()
+        if "epoch" not in tracers:
+            tracers["epoch"] = 0
+        self.tracers = tracers
+        if jit is None:
+            from . import runtime
+
+            jit = runtime.enable_jit
+        self.jit = jit
+        self._names = None
+        self._fused = None  # fused evaluator (fused.py) once the operator has been recognised
+        self._fused_checked = False
+        if not isinstance(domain.mod, ModRocm):
+            raise NotImplementedError("Unsupported mod={:}".format(domain.mod))
+
+    # ---- helpers -----------------------------------------------------------------------
+    @staticmethod
+    def _split_outputs(ff):
+        assert isinstance(ff, (tuple, list)) and len(ff), "Operator must return a non-empty list"
+        names = [f[0] if isinstance(f, tuple) else "" for f in ff]
+        nonempty = [name for name in names if name]
+        assert len(nonempty) == len(set(nonempty)), "Name of fields must be unique, got {}".format(nonempty)
+        values = [f[1] if isinstance(f, tuple) else f for f in ff]
+        return names, values
+
+    def _shadow_state(self, state, arrays):
+        """A state of the same structure whose arrays are `arrays` (no copies)."""
+        fields = dict()
+        for key, field in state.fields.items():
+            if isinstance(field, Field):
+                fields[key] = Field(None, loc=field.loc, cshape=field.cshape)
+            elif isinstance(field, MultigridField):
+                fields[key] = MultigridField(
+                    [Field(None, loc=t.loc, cshape=t.cshape) for t in field.terms], loc=field.loc,
+                    factors=field.factors, axes=field.axes, method=field.method,
+                )
+            elif isinstance(field, NeuralNet):
+                fields[key] = NeuralNet(list(field.weights), list(field.biases), func_in=field.func_in,
+                                        func_out=field.func_out, activation=field.activation)
+            elif isinstance(field, Array):
+                fields[key] = Array(None, field.shape)
+            else:
+                raise TypeError("Unknown field type '{}'".format(type(field).__name__))
+        shadow = State(fields=fields, initialized=True)
+        self.domain.arrays_to_state(arrays, shadow)
+        return shadow
+
+    # ---- loss + gradient (reference core.py:1038-1111, 1219-1241) --------------------------
+    def eval_loss_grad_device(self, state):
+        """Like eval_loss_grad but loss / terms / norms stay 0-d DEVICE tensors (no host sync)."""
+        if not state.initialized:
+            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+        if not self._fused_checked:
+            self._fused_checked = True
+            from . import fused, runtime
+
+            if runtime.enable_fuse:
+                self._fused = fused.detect(self, state)
+        if self._fused is not None:
+            return self._fused.eval_loss_grad(state)
+        return self._eval_loss_grad_generic(state)
+
+    def _eval_loss_grad_generic(self, state):
+        domain = self.domain
+        arrays = domain.arrays_from_state(state)
+        leaves = [a.detach().requires_grad_(True) for a in arrays]
+        shadow = self._shadow_state(state, leaves)
+        with torch.enable_grad():
+            ctx = Context(domain, shadow, extra=self.extra, tracers=self.tracers)
+            names, values = self._split_outputs(self.operator(ctx))
+            terms = [
+                _MeanFn.apply(v.value, False) if isinstance(v, Context.Raw) else _MeanFn.apply(v, True)
+                for v in values
+            ]
+            loss = terms[0]
+            for t in terms[1:]:
+                loss = loss + t
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(a) for g, a in zip(grads, arrays)]
+        loss = loss.detach()
+        terms = [t.detach() for t in terms]
+        norms = [t if isinstance(v, Context.Raw) else torch.sqrt(t) for t, v in zip(terms, values)]
+        self._names = names
+        return loss, grads, terms, names, norms
+
+    def eval_loss_grad(self, state):
+        """loss (np scalar), grads (list of device arrays), terms, names, norms
+        (reference core.py:1219-1241; `np.array(loss)` is the per-call host sync there too)."""
+        loss, grads, terms, names, norms = self.eval_loss_grad_device(state)
+        to_np = lambda t: np.array(t.detach().cpu().numpy()) if isinstance(t, torch.Tensor) else np.array(t)
+        return to_np(loss), grads, list(map(to_np, terms)), names, list(map(to_np, norms))
+
+    # ---- operator values (reference core.py:1243-1311) -------------------------------------
+    def eval_operator(self, state):
+        if not state.initialized:
+            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+        with torch.no_grad():
+            ctx = Context(self.domain, state, extra=self.extra, tracers=self.tracers)
+            names, values = self._split_outputs(self.operator(ctx))
+            values = [v.value if isinstance(v, Context.Raw) else v for v in values]
+        return values, names
+
+    # ---- per-shift gradients (reference core.py:1313-1383) ---------------------------------
+    def eval_operator_grad(self, state):
+        """values, grads (per output: dict (key, shift, loc) -> coefficient array, plus dense
+        Jacobians for Array / NeuralNet unknowns under (key, None, None)), names."""
+        if not state.initialized:
+            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+        domain = self.domain
+        arrays = domain.arrays_from_state(state)
+        leaves = [a.detach().requires_grad_(True) for a in arrays]
+        shadow = self._shadow_state(state, leaves)
+        with torch.enable_grad():
+            ctx = Context(domain, shadow, extra=self.extra, tracers=self.tracers, distinct_shift=True)
+            names, values = self._split_outputs(self.operator(ctx))
+            values = [v.value if isinstance(v, Context.Raw) else v for v in values]
+            grads = []
+            for v in values:
+                g = dict()
+                descs = list(ctx.desc_to_array.keys())
+                symbols = [ctx.desc_to_array[d] for d in descs]
+                if v.requires_grad and symbols:
+                    gg = torch.autograd.grad(v.sum(), symbols, retain_graph=True, allow_unused=True)
+                else:
+                    gg = [None] * len(symbols)
+                g.update(dict(zip(descs, gg)))
+                for jkey, arr in ctx.key_to_array_jac.items():
+                    g[jkey] = self._dense_jacobian(v, arr)
+                grads.append(g)
+        values = [v.detach() for v in values]
+        return values, grads, names
+
+    @staticmethod
+    def _dense_jacobian(v, arr):
+        """d v / d arr with shape v.shape + arr.shape (tf's tape.jacobian, core.py:1347-1349)."""
+        arrs = arr if isinstance(arr, list) else [arr]
+        if not v.requires_grad:
+            return [None for _ in arrs] if isinstance(arr, list) else None
+        flat = v.reshape(-1)
+        rows = [[] for _ in arrs]
+        for i in range(flat.numel()):
+            gg = torch.autograd.grad(flat[i], arrs, retain_graph=True, allow_unused=True)
+            for k, (g, a) in enumerate(zip(gg, arrs)):
+                rows[k].append(g if g is not None else torch.zeros_like(a))
+        jacs = [torch.stack(r).reshape(tuple(v.shape) + tuple(a.shape)) for r, a in zip(rows, arrs)]
+        if all(float(j.abs().max()) == 0 for j in jacs):
+            return [None for _ in arrs] if isinstance(arr, list) else None
+        return jacs if isinstance(arr, list) else jacs[0]
+
+    def linearize_device(self, state):
+        """(vector, LinearizedOperator): operator(V) ~= M (V - V0) + vector, on the device."""
+        if not state.initialized:
+            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+        values, grads, names = self.eval_operator_grad(state)
+        op = LinearizedOperator(self.domain, state)
+        for value, grad in zip(values, grads):
+            op.add_output(tuple(value.shape), grad)
+        vector = torch.cat([v.reshape(-1) for v in values])
+        return vector, op
+
+    def linearize(self, state, modsp=None):
+        """Reference signature (core.py:1113-1217): returns (vector, scipy-like CSR matrix)."""
+        vector, op = self.linearize_device(state)
+        return vector, op.to_scipy(modsp)
+
+    def get_context(self, state):
+        return self.domain.get_context(state, extra=self.extra, tracers=self.tracers)
+
+
+# ======================================================================================
+# Checkpoints (reference core.py:1389-1436), extrapolation helpers (core.py:1439-1457)
+# ======================================================================================
+def _to_numpy(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.array(a)
+
+
+def checkpoint_save(domain, state, path):
+    fields = dict()
+    for key in state.fields:
+        fields[key] = [_to_numpy(a) for a in domain.arrays_from_field(state.fields[key])]
+    with open(path, "wb") as f:
+        pickle.dump({"fields": fields}, f)
+
+
+def checkpoint_load(domain, state, path, skip_missing=True, keys=None):
+    with open(path, "rb") as f:
+        data = pickle.load(f).get("fields", dict())
+    keys = keys or state.fields.keys()
+    for key in keys:
+        if key not in data:
+            if not skip_missing:
+                raise RuntimeError(f"Field {key} not found in {path}")
+            continue
+        arrays = data[key]
+        if not isinstance(arrays, list):
+            arrays = [arrays]
+        arrays = [domain.mod.variable(a, dtype=domain.dtype) for a in arrays]
+        domain.arrays_to_field(arrays, state.fields[key])
+
+
+def extrap_quadh(u0, u1, u1p):
+    "Quadratic extrapolation from points 0, 1, 1.5 to point 2."
+    return (u0 - 6 * u1 + 8 * u1p) / 3
+
+
+def extrap_quad(u0, u1, u2):
+    "Quadratic extrapolation from points 0, 1, 2 to point 3."
+    return u0 - 3 * u1 + 3 * u2
+
+
+def extrap_linear(u0, u1):
+    "Linear extrapolation from points 0, 1 to point 2."
+    return 2 * u1 - u0
+
+
+def struct_to_numpy(mod, d):
+    if mod.is_tensor(d):
+        return _to_numpy(d)
+    if isinstance(d, dict):
+        for key in d:
+            d[key] = struct_to_numpy(mod, d[key])
+        return d
+    if isinstance(d, list):
+        return [struct_to_numpy(mod, a) for a in d]
+    if isinstance(d, tuple):
+        return tuple(struct_to_numpy(mod, a) for a in d)
+    return d

@@ -87,6 +87,49 @@ static int axpy(T* y, const T* x, int64_t n, T a, void* stream) {
   return check_launch("k_axpy");
 }
 
+// y = a * (adev ? *adev : 1) * x   (cotangent of mean(x^2): 2/n * gout * x, core.py:1093)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, T* __restrict__ y, int64_t n, T a,
+                                                 const T* __restrict__ adev) {
+  const T f = adev ? a * adev[0] : a;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) y[i] = f * x[i];
+}
+
+template <typename T>
+static int scale(const T* x, T* y, int64_t n, T a, const T* adev, void* stream) {
+  if (!x || !y || n < 0) {
+    set_error("scale: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_scale<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, y, n, a, adev);
+  return check_launch("k_scale");
+}
+
+// y (+)= a (.) b
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_addcmul(T* __restrict__ y, const T* __restrict__ a, const T* __restrict__ b,
+                                                   int64_t n, int accumulate) {
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+    const T v = a[i] * b[i];
+    y[i] = accumulate ? y[i] + v : v;
+  }
+}
+
+template <typename T>
+static int addcmul(T* y, const T* a, const T* b, int64_t n, int accumulate, void* stream) {
+  if (!y || !a || !b || n < 0) {
+    set_error("addcmul: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_addcmul<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, a, b, n,
+                     accumulate);
+  return check_launch("k_addcmul");
+}
+
 // out[k] = <a_k, b>: blockIdx.y = k; contiguous chunk per workgroup; fixed order.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ a, int64_t lda, const T* __restrict__ b,
@@ -156,6 +199,18 @@ int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream)
 }
 int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream) {
   return axpy<float>(y, x, n, a, stream);
+}
+int odil_scale_f64(const double* x, double* y, int64_t n, double a, const double* adev, void* stream) {
+  return scale<double>(x, y, n, a, adev, stream);
+}
+int odil_scale_f32(const float* x, float* y, int64_t n, float a, const float* adev, void* stream) {
+  return scale<float>(x, y, n, a, adev, stream);
+}
+int odil_addcmul_f64(double* y, const double* a, const double* b, int64_t n, int accumulate, void* stream) {
+  return addcmul<double>(y, a, b, n, accumulate, stream);
+}
+int odil_addcmul_f32(float* y, const float* a, const float* b, int64_t n, int accumulate, void* stream) {
+  return addcmul<float>(y, a, b, n, accumulate, stream);
 }
 int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64_t n, double* partials,
                   double* out, void* stream) {

@@ -81,6 +81,7 @@ int odil_device_count(void) {
   return n;
 }
 size_t odil_reduce_workspace_bytes(void) { return (size_t)kMaxPartials * sizeof(double); }
+size_t odil_dots_workspace_bytes(int nvec) { return (size_t)(nvec < 1 ? 1 : nvec) * kDotPartials * sizeof(double); }
 
 int odil_mean_reduce_f64(const double* x, int64_t n, int square, double* partials, double* out, void* stream) {
   return mean_reduce<double>(x, n, square, partials, out, stream);

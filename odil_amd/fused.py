@@ -1,0 +1,191 @@
+"""Recognition of affine stencil operators and their fused evaluation.
+
+A user `operator(ctx)` is arbitrary Python over `mod`, so only framework-owned arithmetic
+can be hand-written generically.  But an operator that is AFFINE in a single cell-centred
+field is completely determined by its per-shift Jacobian coefficient arrays (what
+`Problem.eval_operator_grad` returns, reference core.py:1313-1361) and its value at one
+state.  `detect()` evaluates the user's operator through the generic path at two probe
+states; if (a) the coefficient arrays do not depend on the state, (b) they equal the
+coefficients of the zero-Dirichlet Laplacian of the Poisson example (reference
+examples/poisson/poisson.py:57-113) for this domain's steps, and (c) the operator did not
+read `ctx.tracers`, then `fu = Lap(u) - rhs_eff` with `rhs_eff = Lap(u_A) - f(u_A)`, and
+the problem is routed to the fused HIP kernels (residual + loss, adjoint, multigrid
+synthesis / P^T chain).  Anything else keeps the generic path.  Like `jax.jit` in the
+reference (core.py:1107), this bakes `extra` in at first evaluation.  ODIL_FUSE=0 disables it.
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class PoissonEvaluator:
+    """Fused loss + gradient of `fu = Lap(u) - rhs` for a (multigrid) cell-centred unknown."""
+
+    def __init__(self, cshape, shapes, rhs, h2, name="", dtype=torch.float64, device=None):
+        self.cshape = tuple(cshape)
+        self.ndim = len(cshape)
+        self.loc = "c" * self.ndim
+        self.shapes = [tuple(s) for s in shapes]
+        self.nlvl = len(shapes)
+        self.sizes = [math.prod(s) for s in self.shapes]
+        self.rhs = rhs
+        self.h2 = list(h2)
+        self.names = [name]
+        self.dtype, self.device = dtype, device
+        self.npdt = np.float64 if dtype == torch.float64 else np.float32
+        n = sum(self.sizes)
+        self.g = torch.zeros(n, dtype=dtype, device=device)
+        self.gw = [t.view(s) for t, s in zip(self.g.split(self.sizes), self.shapes)]
+        self.u = torch.empty(self.cshape, dtype=dtype, device=device) if self.nlvl > 1 else None
+        self.fu = torch.empty(self.cshape, dtype=dtype, device=device)
+        self.loss = torch.zeros((), dtype=dtype, device=device)
+        self.work = ([None] + [torch.empty(s, dtype=dtype, device=device) for s in self.shapes[1:-1]] + [None])[
+            : self.nlvl
+        ]
+        self.scale = self.npdt(2) / self.npdt(self.fu.numel())
+
+    def loss_grad_arrays(self, arrays, timers=None):
+        """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer)."""
+
+        def tic(name):
+            if timers is None:
+                return None
+            a, b = timers.section(name)
+            a.record()
+            return b
+
+        def toc(b):
+            if b is not None:
+                b.record()
+
+        if self.nlvl > 1:
+            b = tic("mg_synth")
+            u = ops.mg_synth(arrays, self.loc, work=self.work, out=self.u)
+            toc(b)
+        else:
+            u = arrays[0]
+        b = tic("residual")
+        ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
+        toc(b)
+        b = tic("adjoint")
+        ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        toc(b)
+        if self.nlvl > 1:
+            b = tic("mg_synth_adj")
+            ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
+            toc(b)
+        return self.loss, self.gw
+
+    def eval_loss_grad(self, state):
+        (field,) = state.fields.values()
+        arrays = [t.array for t in field.terms] if hasattr(field, "terms") else [field.array]
+        arrays = [a if a.is_contiguous() else a.contiguous() for a in arrays]
+        loss, grads = self.loss_grad_arrays(arrays)
+        return loss, list(grads), [loss], self.names, [torch.sqrt(loss)]
+
+
+def _close(a, b, rtol):
+    scale = max(float(b.abs().max()), 1e-300)
+    return float((a - b).abs().max()) <= rtol * scale
+
+
+def detect(problem, state):
+    """Returns a fused evaluator for `problem`, or None to keep the generic path."""
+    from .core import Context, Field, MultigridField, State
+
+    domain = problem.domain
+    if len(state.fields) != 1:
+        return None
+    (key, field), = state.fields.items()
+    ndim = domain.ndim
+    if ndim > 3 or field.loc != "c" * ndim:
+        return None
+    if isinstance(field, MultigridField):
+        if field.factors is not None and any(float(f) != 1.0 for f in field.factors):
+            return None
+        axes = field.axes or domain.mg_axes
+        if axes is not None and not all(axes):
+            return None
+        shapes = [tuple(t.array.shape) for t in field.terms]
+    elif isinstance(field, Field):
+        shapes = [tuple(field.array.shape)]
+    else:
+        return None
+    cshape = tuple(domain.cshape)
+    if shapes[0] != cshape or any(s < 2 for s in cshape):
+        return None
+    dtype = shapes and (field.terms[0].array if isinstance(field, MultigridField) else field.array).dtype
+    device = domain.mod.device
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    h2 = [npdt(domain.step_by_dim(i)) ** 2 for i in range(ndim)]
+    rtol = 1e-11 if dtype == torch.float64 else 1e-4
+
+    gen = torch.Generator(device="cpu").manual_seed(12345)
+    probes = []
+    for _ in range(2):
+        u = torch.randn(cshape, generator=gen, dtype=torch.float64).to(dtype).to(device)
+        pstate = State(fields={key: Field(u, loc=field.loc, cshape=cshape)}, initialized=True)
+        try:
+            accessed = [False]
+            values, grads, names = _probe(problem, pstate, accessed)
+        except Exception:
+            return None
+        if accessed[0] or len(values) != 1 or tuple(values[0].shape) != cshape:
+            return None
+        probes.append((u, values[0], grads[0], names))
+    (ua, fa, ga, names), (ub, fb, gb, _) = probes
+    want = [(0,) * ndim]
+    for i in range(ndim):
+        want += [tuple(-1 if j == i else 0 for j in range(ndim)), tuple(1 if j == i else 0 for j in range(ndim))]
+    if any(k[0] != key or k[2] != field.loc for k in ga):
+        return None
+    if sorted(k[1] for k in ga) != sorted(want):
+        return None
+    coeffs = ops.poisson_jac_coeffs(cshape, h2, dtype, device)
+    for slot, shift in enumerate(want):
+        a, b = ga.get((key, shift, field.loc)), gb.get((key, shift, field.loc))
+        if a is None or b is None:
+            return None
+        if not _close(a, b, rtol) or not _close(a, coeffs[slot], rtol):
+            return None
+    zero = torch.zeros(cshape, dtype=dtype, device=device)
+    lap_a, _ = ops.poisson_residual(ua, zero, h2)
+    rhs_eff = lap_a - fa
+    fb_fused, _ = ops.poisson_residual(ub, rhs_eff, h2)
+    if not _close(fb_fused, fb, 1e-9 if dtype == torch.float64 else 1e-3):
+        return None
+    from .util import printlog
+
+    try:
+        printlog("odil_amd: operator recognised as zero-Dirichlet Poisson stencil -> fused HIP kernels")
+    except Exception:
+        pass
+    return PoissonEvaluator(cshape, shapes, rhs_eff.contiguous(), h2, name=names[0], dtype=dtype, device=device)
+
+
+def _probe(problem, pstate, accessed):
+    """eval_operator_grad on a probe state, recording whether the operator read ctx.tracers."""
+    from . import core
+
+    domain = problem.domain
+    arrays = domain.arrays_from_state(pstate)
+    leaves = [a.detach().requires_grad_(True) for a in arrays]
+    shadow = problem._shadow_state(pstate, leaves)
+    with torch.enable_grad():
+        ctx = core.Context(domain, shadow, extra=problem.extra, tracers=problem.tracers, distinct_shift=True)
+        names, values = problem._split_outputs(problem.operator(ctx))
+        accessed[0] = ctx.tracers_accessed or bool(ctx.key_to_array_jac)
+        if any(isinstance(v, core.Context.Raw) for v in values):
+            accessed[0] = True
+            return [], [], names
+        grads = []
+        for v in values:
+            descs = list(ctx.desc_to_array.keys())
+            symbols = [ctx.desc_to_array[d] for d in descs]
+            gg = torch.autograd.grad(v.sum(), symbols, allow_unused=True, retain_graph=True)
+            grads.append(dict(zip(descs, gg)))
+    return [v.detach() for v in values], grads, names

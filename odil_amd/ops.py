@@ -225,6 +225,35 @@ def axpy(y, x, a):
     return y
 
 
+def scale(x, a, adev=None, out=None):
+    """out = a * (adev[0] if adev is given) * x."""
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    call("scale", x.dtype, ptr(x), ptr(out), c_int64(x.numel()), float(a), ptr(adev), stream_ptr())
+    return out
+
+
+def addcmul(y, a, b, accumulate=True):
+    """y (+)= a * b elementwise, in place."""
+    assert y.numel() == a.numel() == b.numel()
+    call("addcmul", y.dtype, ptr(y), ptr(a), ptr(b), c_int64(y.numel()), c_int(1 if accumulate else 0), stream_ptr())
+    return y
+
+
+_dots_ws = {}
+
+
+def dots_workspace(device, nvec):
+    key = str(device)
+    ws = _dots_ws.get(key)
+    need = _lib.load().odil_dots_workspace_bytes(nvec) // 8
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float64, device=device)
+        _dots_ws[key] = ws
+    return ws
+
+
 def dots(a, b, out=None):
     """out[k] = <a[k], b> for a of shape (nvec, n); deterministic, f64 accumulation."""
     if a.dim() == 1:
@@ -235,7 +264,7 @@ def dots(a, b, out=None):
         out = torch.empty(nvec, dtype=a.dtype, device=a.device)
     call(
         "dots", a.dtype, ptr_strided(a), c_int64(a.stride(0)), c_int(nvec), ptr(b), c_int64(n),
-        ptr(reduce_workspace(a.device, nvec)), ptr(out), stream_ptr(),
+        ptr(dots_workspace(a.device, nvec)), ptr(out), stream_ptr(),
     )
     return out
 

@@ -1,0 +1,590 @@
+"""Optimizers of the hot loop (reference src/odil/optimizer.py:1-357), device-resident.
+
+  AdamNativeOptimizer  optimizer.py:280-341  -> odil_adam_step (one launch over the packed state)
+  GdOptimizer          optimizer.py:256-277  -> odil_axpy
+  LbfgsbOptimizer      optimizer.py:29-117   -> the unbounded case of L-BFGS-B 3.0, which the
+      reference reaches through scipy.optimize.fmin_l_bfgs_b (scipy 1.16.2 pinned, uv.lock:1499),
+      restated here from the published algorithm (Byrd, Lu, Nocedal & Zhu 1995; Morales &
+      Nocedal 2011; line search dcsrch/dcstep of More' & Thuente 1994): compact
+      representation B = theta I - W M W^T, step d = -B^{-1} g, identical update / skip /
+      restart rules and the same dcsrch constants (ftol 1e-3, gtol 0.9, xtol 0.1).  The n-vectors
+      (x, g, d and the 2m history vectors) never leave the device: the reference round-trips
+      the full vector through host float64 on every evaluation (optimizer.py:63-88); here only
+      O(m) dot products and the scalar line-search state are on the host.
+`adam_tf` and `lbfgs` (TensorFlow-Probability) are TensorFlow-specific duplicates and not provided.
+"""
+
+import math
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class Optimizer:
+    def __init__(self, name=None, displayname=None, dtype=None):
+        self.name = name
+        self.displayname = displayname if displayname is not None else name
+        self.dtype = dtype
+        self.pinfo = None
+        self.evals = 0
+
+    def run(self, x0, loss_grad, epochs, callback=None, epoch_start=0, **kwargs):
+        optinfo = Namespace()
+        optinfo.evals = 0
+        optinfo.epochs = 0
+        return x0, optinfo
+
+
+class EarlyStopError(Exception):
+    def __init__(self, msg, optinfo):
+        super().__init__(msg)
+        self.optinfo = optinfo
+
+
+# --------------------------------------------------------------------------------------
+# Packed state: all unknown arrays in one flat device buffer, arrays are views
+# (the layout of Domain.pack_state, reference core.py:436-443).
+# --------------------------------------------------------------------------------------
+def pack_like(arrays, dtype=None):
+    sizes = [int(a.numel()) for a in arrays]
+    dtype = dtype or arrays[0].dtype
+    flat = torch.empty(sum(sizes), dtype=dtype, device=arrays[0].device)
+    views = [t.view(a.shape) for t, a in zip(flat.split(sizes), arrays)]
+    return flat, views
+
+
+def flat_base(arrays):
+    """If `arrays` are adjacent views of one contiguous buffer (in order), returns that flat view."""
+    if not arrays:
+        return None
+    a0 = arrays[0]
+    ptr = a0.data_ptr()
+    esize = a0.element_size()
+    storage = a0.untyped_storage()
+    total = 0
+    for a in arrays:
+        if not a.is_contiguous() or a.dtype != a0.dtype or a.untyped_storage().data_ptr() != storage.data_ptr():
+            return None
+        if a.data_ptr() != ptr + total * esize:
+            return None
+        total += a.numel()
+    offset = (ptr - storage.data_ptr()) // esize
+    return torch.empty(0, dtype=a0.dtype, device=a0.device).set_(storage, offset, (total,), (1,))
+
+
+def copy_into(flat, views, arrays):
+    base = flat_base(arrays)
+    if base is not None and base.dtype == flat.dtype:
+        if base.data_ptr() != flat.data_ptr():
+            flat.copy_(base)
+        return
+    for v, a in zip(views, arrays):
+        v.copy_(a)
+
+
+class AdamNativeOptimizer(Optimizer):
+    def __init__(self, dtype=None, mod=None, **kwargs):
+        super().__init__(name="adamn", displayname="AdamNative", dtype=dtype)
+        self.mod = mod
+
+    def run(self, x0, loss_grad, epochs=None, callback=None, lr=1e-3, epoch_start=0, beta_1=0.9, beta_2=0.999,
+            epsilon=1e-7, jit=True, **kwargs):
+        """Keras-convention Adam (epsilon outside the sqrt), reference optimizer.py:286-341."""
+        tdtype = x0[0].dtype
+        npdt = np.float64 if tdtype == torch.float64 else np.float32
+        lr, beta_1, beta_2 = npdt(lr), npdt(beta_1), npdt(beta_2)
+        xf, x = pack_like(x0)
+        copy_into(xf, x, x0)
+        mf = torch.zeros_like(xf)
+        vf = torch.zeros_like(xf)
+        gf, gviews = None, None
+        for epoch in range(epoch_start + 1, epoch_start + epochs + 1):
+            self.evals += 1
+            loss, grads, pinfo = loss_grad(x)
+            g = flat_base(grads)
+            if g is None or g.dtype != tdtype or g.numel() != xf.numel():
+                if gf is None:
+                    gf, gviews = pack_like(x)
+                copy_into(gf, gviews, grads)
+                g = gf
+            t = npdt(epoch - epoch_start)
+            alpha = lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
+            ops.adam_step(xf, mf, vf, g, alpha, 1 - beta_1, 1 - beta_2, epsilon)
+            if epoch > 0 and callback is not None:
+                callback(x, epoch, pinfo)
+        optinfo = Namespace()
+        optinfo.epochs = epochs
+        optinfo.evals = self.evals
+        return x, optinfo
+
+
+class GdOptimizer(Optimizer):
+    def __init__(self, dtype=None, mod=None, **kwargs):
+        super().__init__(name="gd", displayname="GD", dtype=dtype)
+        self.mod = mod
+
+    def run(self, x0, loss_grad, epochs=None, callback=None, lr=1e-3, epoch_start=0, **kwargs):
+        xf, x = pack_like(x0)
+        copy_into(xf, x, x0)
+        for epoch in range(epoch_start + 1, epoch_start + epochs + 1):
+            self.evals += 1
+            loss, grads, pinfo = loss_grad(x)
+            for xi, gi in zip(x, grads):
+                ops.axpy(xi, gi.contiguous(), -float(lr))  # x -= lr * g (optimizer.py:270)
+            if epoch > 0 and callback is not None:
+                callback(x, epoch, pinfo)
+        optinfo = Namespace()
+        optinfo.epochs = epochs
+        optinfo.evals = self.evals
+        return x, optinfo
+
+
+# --------------------------------------------------------------------------------------
+# More'-Thuente line search (MINPACK-2 dcsrch / dcstep), scalar state on the host.
+# --------------------------------------------------------------------------------------
+def _dcstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
+    sgnd = dp * (dx / abs(dx))
+    if fp > fx:  # case 1: higher function value -> minimum bracketed
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt((theta / s) ** 2 - (dx / s) * (dp / s))
+        if stp < stx:
+            gamma = -gamma
+        p = (gamma - dx) + theta
+        q = ((gamma - dx) + gamma) + dp
+        r = p / q
+        stpc = stx + r * (stp - stx)
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx)
+        if abs(stpc - stx) < abs(stpq - stx):
+            stpf = stpc
+        else:
+            stpf = stpc + (stpq - stpc) / 2.0
+        brackt = True
+    elif sgnd < 0.0:  # case 2: derivatives of opposite sign
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt((theta / s) ** 2 - (dx / s) * (dp / s))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = ((gamma - dp) + gamma) + dx
+        r = p / q
+        stpc = stp + r * (stx - stp)
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+        brackt = True
+    elif abs(dp) < abs(dx):  # case 3: derivative magnitude decreases
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt(max(0.0, (theta / s) ** 2 - (dx / s) * (dp / s)))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = (gamma + (dx - dp)) + gamma
+        r = p / q
+        if r < 0.0 and gamma != 0.0:
+            stpc = stp + r * (stx - stp)
+        elif stp > stx:
+            stpc = stpmax
+        else:
+            stpc = stpmin
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        if brackt:
+            stpf = stpc if abs(stpc - stp) < abs(stpq - stp) else stpq
+            if stp > stx:
+                stpf = min(stp + 0.66 * (sty - stp), stpf)
+            else:
+                stpf = max(stp + 0.66 * (sty - stp), stpf)
+        else:
+            stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+            stpf = min(stpmax, stpf)
+            stpf = max(stpmin, stpf)
+    else:  # case 4
+        if brackt:
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp
+            s = max(abs(theta), abs(dy), abs(dp))
+            gamma = s * math.sqrt((theta / s) ** 2 - (dy / s) * (dp / s))
+            if stp > sty:
+                gamma = -gamma
+            p = (gamma - dp) + theta
+            q = ((gamma - dp) + gamma) + dy
+            r = p / q
+            stpf = stp + r * (sty - stp)
+        elif stp > stx:
+            stpf = stpmax
+        else:
+            stpf = stpmin
+    if fp > fx:
+        sty, fy, dy = stp, fp, dp
+    else:
+        if sgnd < 0.0:
+            sty, fy, dy = stx, fx, dx
+        stx, fx, dx = stp, fp, dp
+    return stx, fx, dx, sty, fy, dy, stpf, brackt
+
+
+class _Dcsrch:
+    """One line search: call start() then step(f, g) until task is not 'FG'."""
+
+    XTRAPL, XTRAPU = 1.1, 4.0
+
+    def __init__(self, ftol=1e-3, gtol=0.9, xtol=0.1, stpmin=0.0, stpmax=1e10):
+        self.ftol, self.gtol, self.xtol, self.stpmin, self.stpmax = ftol, gtol, xtol, stpmin, stpmax
+
+    def start(self, stp, f, g):
+        if stp < self.stpmin:
+            return stp, "ERROR: STP .LT. STPMIN"
+        if stp > self.stpmax:
+            return stp, "ERROR: STP .GT. STPMAX"
+        if g >= 0.0:
+            return stp, "ERROR: INITIAL G .GE. ZERO"
+        self.brackt = False
+        self.stage = 1
+        self.finit, self.ginit = f, g
+        self.gtest = self.ftol * g
+        self.width = self.stpmax - self.stpmin
+        self.width1 = self.width / 0.5
+        self.stx, self.fx, self.gx = 0.0, f, g
+        self.sty, self.fy, self.gy = 0.0, f, g
+        self.stmin = 0.0
+        self.stmax = stp + self.XTRAPU * stp
+        return stp, "FG"
+
+    def step(self, stp, f, g):
+        ftest = self.finit + stp * self.gtest
+        if self.stage == 1 and f <= ftest and g >= 0.0:
+            self.stage = 2
+        task = "FG"
+        if self.brackt and (stp <= self.stmin or stp >= self.stmax):
+            task = "WARNING: ROUNDING ERRORS PREVENT PROGRESS"
+        if self.brackt and self.stmax - self.stmin <= self.xtol * self.stmax:
+            task = "WARNING: XTOL TEST SATISFIED"
+        if stp == self.stpmax and f <= ftest and g <= self.gtest:
+            task = "WARNING: STP = STPMAX"
+        if stp == self.stpmin and (f > ftest or g >= self.gtest):
+            task = "WARNING: STP = STPMIN"
+        if f <= ftest and abs(g) <= self.gtol * (-self.ginit):
+            task = "CONVERGENCE"
+        if task != "FG":
+            return stp, task
+        if self.stage == 1 and f <= self.fx and f > ftest:
+            fm = f - stp * self.gtest
+            fxm = self.fx - self.stx * self.gtest
+            fym = self.fy - self.sty * self.gtest
+            gm = g - self.gtest
+            gxm = self.gx - self.gtest
+            gym = self.gy - self.gtest
+            self.stx, fxm, gxm, self.sty, fym, gym, stp, self.brackt = _dcstep(
+                self.stx, fxm, gxm, self.sty, fym, gym, stp, fm, gm, self.brackt, self.stmin, self.stmax
+            )
+            self.fx = fxm + self.stx * self.gtest
+            self.fy = fym + self.sty * self.gtest
+            self.gx = gxm + self.gtest
+            self.gy = gym + self.gtest
+        else:
+            self.stx, self.fx, self.gx, self.sty, self.fy, self.gy, stp, self.brackt = _dcstep(
+                self.stx, self.fx, self.gx, self.sty, self.fy, self.gy, stp, f, g, self.brackt, self.stmin, self.stmax
+            )
+        if self.brackt:
+            if abs(self.sty - self.stx) >= 0.66 * self.width1:
+                stp = self.stx + 0.5 * (self.sty - self.stx)
+            self.width1 = self.width
+            self.width = abs(self.sty - self.stx)
+        if self.brackt:
+            self.stmin = min(self.stx, self.sty)
+            self.stmax = max(self.stx, self.sty)
+        else:
+            self.stmin = stp + self.XTRAPL * (stp - self.stx)
+            self.stmax = stp + self.XTRAPU * (stp - self.stx)
+        stp = max(stp, self.stpmin)
+        stp = min(stp, self.stpmax)
+        if (self.brackt and (stp <= self.stmin or stp >= self.stmax)) or (
+            self.brackt and self.stmax - self.stmin <= self.xtol * self.stmax
+        ):
+            stp = self.stx
+        return stp, "FG"
+
+
+class LbfgsVectors:
+    """The n-vector algebra L-BFGS needs, on HIP kernels.  (Tests substitute a NumPy double
+    to exercise the scalar logic on CPU.)"""
+
+    def __init__(self, n, m, device):
+        self.n, self.m, self.device = n, m, device
+        self.ws = torch.zeros((m, n), dtype=torch.float64, device=device)
+        self.wy = torch.zeros((m, n), dtype=torch.float64, device=device)
+
+    def new(self):
+        return torch.zeros(self.n, dtype=torch.float64, device=self.device)
+
+    def copy(self, dst, src):
+        dst.copy_(src)
+
+    def dot(self, a, b):
+        return float(ops.dots(a[None], b)[0])
+
+    def dots(self, mat, nrows, b):
+        """[<mat[k], b>] for k < nrows, as a host float64 array."""
+        if nrows == 0:
+            return np.zeros(0)
+        return ops.dots(mat[:nrows], b).cpu().numpy()
+
+    def max_abs(self, a):
+        return float(a.abs().max())
+
+    def axpy(self, y, x, a):
+        ops.axpy(y, x, a)
+
+    def set_axpy(self, out, t, d, a):
+        """out = t + a * d."""
+        out.copy_(t)
+        ops.axpy(out, d, a)
+
+    def scale_into(self, dst, src, a):
+        ops.scale(src, a, out=dst)
+
+    def lincomb(self, y, beta, mat, nrows, coef):
+        if nrows:
+            ops.lincomb(y, beta, mat[:nrows], torch.as_tensor(coef, dtype=torch.float64, device=self.device))
+        elif beta != 1.0:
+            ops.scale(y, beta, out=y)
+
+    def sub_into(self, dst, a, b):
+        """dst = a - b."""
+        dst.copy_(a)
+        ops.axpy(dst, b, -1.0)
+
+
+def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, maxfun=math.inf, callback=None):
+    """L-BFGS-B 3.0 without bounds.  `x`: flat vector (updated in place); `fg(x) -> (f, g)`
+    with g written/returned as a flat vector; `vec`: vector backend.  Returns
+    dict(task, warnflag, nit, funcalls, f)."""
+    epsmch = np.finfo(np.float64).eps
+    n = vec.n
+    ws, wy = vec.ws, vec.wy
+    sy = np.zeros((m, m))  # sy[i, j] = s_i . y_j (logical order, oldest first)
+    ss = np.zeros((m, m))
+    yy = np.zeros((m, m))
+    slots = []  # physical row of logical history entry i
+    theta = 1.0
+    col = 0
+    nit = 0
+    nfev = 0
+    nskip = 0
+    big = 1e10
+    t = vec.new()  # x at the start of the line search
+    r = vec.new()  # g at the start of the line search, later y
+    d = vec.new()
+    g = vec.new()
+
+    f, gnew = fg(x)
+    vec.copy(g, gnew)
+    nfev += 1
+    sbgnrm = vec.max_abs(g)
+    info = dict(task="START", warnflag=2)
+    if sbgnrm <= pgtol:
+        return dict(task="CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL", warnflag=0, nit=0, funcalls=nfev, f=f)
+
+    while True:
+        # ---- search direction d = -B^{-1} g (compact representation) --------------------
+        if col == 0:
+            vec.scale_into(d, g, -1.0 / theta)
+        else:
+            order = slots  # logical -> physical
+            p1 = vec.dots(wy, len(order), g)
+            p2 = vec.dots(ws, len(order), g)
+            # physical -> logical order
+            yg = np.array([p1[k] for k in order])
+            sg = np.array([p2[k] for k in order]) * theta
+            D = np.diag(np.diag(sy[:col, :col]))
+            Rbar = np.triu(sy[:col, :col])  # s_i.y_j for i <= j
+            N = np.zeros((2 * col, 2 * col))
+            N[:col, :col] = -D - yy[:col, :col] / theta
+            N[:col, col:] = -Rbar.T
+            N[col:, :col] = -Rbar
+            q = np.linalg.solve(N, np.concatenate([yg, sg]))
+            # d = -g/theta - (1/theta^2) (Y q1 + theta S q2)
+            vec.scale_into(d, g, -1.0 / theta)
+            c1 = np.zeros(len(order))
+            c2 = np.zeros(len(order))
+            for i, k in enumerate(order):
+                c1[k] = -q[i] / theta**2
+                c2[k] = -q[col + i] / theta
+            vec.lincomb(d, 1.0, wy, len(order), c1)
+            vec.lincomb(d, 1.0, ws, len(order), c2)
+
+        # ---- line search (lnsrlb) ------------------------------------------------------------
+        dtd = vec.dot(d, d)
+        dnorm = math.sqrt(dtd)
+        stpmx = big
+        stp = min(1.0 / dnorm, stpmx) if (nit == 0) else 1.0
+        vec.copy(t, x)
+        vec.copy(r, g)
+        fold = f
+        gd = vec.dot(g, d)
+        gdold = gd
+        ls_failed = False
+        if gd >= 0.0:
+            ls_failed = True  # not a descent direction (info = -4)
+        else:
+            search = _Dcsrch(stpmax=stpmx)
+            stp, task = search.start(stp, f, gd)
+            ifun = 0
+            while task == "FG":
+                ifun += 1
+                nfev += 1
+                iback = ifun - 1
+                if iback >= maxls:
+                    ls_failed = True
+                    break
+                vec.set_axpy(x, t, d, stp)
+                f, gnew = fg(x)
+                vec.copy(g, gnew)
+                gd = vec.dot(g, d)
+                stp, task = search.step(stp, f, gd)
+                if nfev > maxfun:
+                    break
+            if task.startswith("ERROR"):
+                ls_failed = True
+        if ls_failed:
+            vec.copy(x, t)
+            vec.copy(g, r)
+            f = fold
+            if col == 0:
+                return dict(task="ABNORMAL_TERMINATION_IN_LNSRCH", warnflag=2, nit=nit, funcalls=nfev, f=f)
+            # refresh the memory and restart with the steepest-descent step
+            col, slots, theta = 0, [], 1.0
+            continue
+
+        # ---- new iterate ---------------------------------------------------------------------
+        nit += 1
+        sbgnrm = vec.max_abs(g)
+        if callback is not None:
+            callback(x)
+        if nit >= maxiter:
+            return dict(task="STOP: TOTAL NO. of ITERATIONS REACHED LIMIT", warnflag=1, nit=nit, funcalls=nfev, f=f)
+        if nfev > maxfun:
+            return dict(task="STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT", warnflag=1, nit=nit,
+                        funcalls=nfev, f=f)
+        if sbgnrm <= pgtol:
+            return dict(task="CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL", warnflag=0, nit=nit, funcalls=nfev, f=f)
+        ddum = max(abs(fold), abs(f), 1.0)
+        if (fold - f) <= epsmch * factr * ddum:
+            return dict(task="CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH", warnflag=0, nit=nit, funcalls=nfev, f=f)
+
+        # ---- BFGS update (matupd) ----------------------------------------------------------------
+        vec.sub_into(r, g, r)  # y = g_new - g_old
+        rr = vec.dot(r, r)
+        if stp == 1.0:
+            dr = gd - gdold
+            ddum = -gdold
+        else:
+            dr = (gd - gdold) * stp
+            vec.scale_into(d, d, stp)  # s = stp * d
+            ddum = -gdold * stp
+        if dr <= epsmch * ddum:
+            nskip += 1
+            continue
+        if col < m:
+            slot = col
+            slots.append(slot)
+            col += 1
+        else:
+            slot = slots.pop(0)
+            slots.append(slot)
+            sy[:-1, :-1] = sy[1:, 1:]
+            ss[:-1, :-1] = ss[1:, 1:]
+            yy[:-1, :-1] = yy[1:, 1:]
+        vec.copy(ws[slot], d)
+        vec.copy(wy[slot], r)
+        theta = rr / dr
+        # new row / column of S^T Y, S^T S, Y^T Y
+        nphys = len(slots)
+        s_y = vec.dots(ws, nphys, r)  # s_k . y_new
+        y_s = vec.dots(wy, nphys, d)  # y_k . s_new
+        s_s = vec.dots(ws, nphys, d)
+        y_y = vec.dots(wy, nphys, r)
+        c = col - 1
+        for i, k in enumerate(slots):
+            sy[i, c] = s_y[k]
+            sy[c, i] = y_s[k]
+            ss[i, c] = ss[c, i] = s_s[k]
+            yy[i, c] = yy[c, i] = y_y[k]
+        sy[c, c] = dr
+        ss[c, c] = stp * stp * dtd if stp != 1.0 else dtd
+        yy[c, c] = rr
+
+
+class LbfgsbOptimizer(Optimizer):
+    def __init__(self, pgtol=1e-16, m=50, maxls=50, factr=0, dtype=None, mod=None, **kwargs):
+        super().__init__(name="lbfgsb", displayname="L-BFGS-B", dtype=dtype)
+        self.mod = mod
+        self.pgtol, self.m, self.maxls, self.factr = pgtol, m, maxls, factr
+
+    def run(self, x0, loss_grad, epochs=None, callback=None, epoch_start=0, **kwargs):
+        self.epoch = epoch_start
+        tdtype = x0[0].dtype
+        device = x0[0].device
+        # evaluation buffer in the domain dtype, L-BFGS vectors in float64 (optimizer.py:63-71, 90-91)
+        xe, xviews = pack_like(x0)
+        copy_into(xe, xviews, x0)
+        n = xe.numel()
+        x = xe if tdtype == torch.float64 else xe.to(torch.float64)
+        gbuf = torch.zeros(n, dtype=torch.float64, device=device)
+        gviews = [t.view(a.shape) for t, a in zip(gbuf.split([a.numel() for a in x0]), x0)]
+
+        def fg(xflat):
+            self.evals += 1
+            if xflat.data_ptr() != xe.data_ptr():
+                xe.copy_(xflat)  # cast to the evaluation dtype
+            loss, grads, pinfo = loss_grad(xviews)
+            self.pinfo = pinfo
+            base = flat_base(grads)
+            if base is not None and base.dtype == torch.float64 and base.numel() == n:
+                g = base
+            else:
+                for gv, gi in zip(gviews, grads):
+                    gv.copy_(gi)
+                g = gbuf
+            return float(loss), g
+
+        def callback_wrap(xflat):
+            self.epoch += 1
+            if callback:
+                if xflat.data_ptr() != xe.data_ptr():
+                    xe.copy_(xflat)
+                callback(xviews, self.epoch, self.pinfo)
+
+        vec = LbfgsVectors(n, self.m, device)
+        res = lbfgsb_minimize(
+            x, fg, vec, maxiter=epochs, m=self.m, maxls=self.maxls, pgtol=self.pgtol, factr=self.factr,
+            callback=callback_wrap,
+        )
+        if x.data_ptr() != xe.data_ptr():
+            xe.copy_(x)
+        optinfo = Namespace()
+        optinfo.warnflag = res["warnflag"]
+        optinfo.task = res["task"]
+        optinfo.evals = res["funcalls"]
+        optinfo.epochs = res["nit"]
+        if optinfo.warnflag not in [0, 1] or optinfo.epochs < epochs:
+            raise EarlyStopError(
+                ", ".join("{:}={:}".format(k, res.get(k, "")) for k in ["warnflag", "task", "funcalls", "nit"]),
+                optinfo,
+            )
+        return xviews, optinfo
+
+
+def make_optimizer(name, dtype=None, mod=None, **kwargs):
+    if name == "lbfgsb":
+        return LbfgsbOptimizer(dtype=dtype, mod=mod, **kwargs)
+    elif name == "adam" or name == "adamn":
+        return AdamNativeOptimizer(dtype=dtype, mod=mod, **kwargs)
+    elif name == "gd":
+        return GdOptimizer(dtype=dtype, mod=mod, **kwargs)
+    elif name in ("lbfgs", "adam_tf"):
+        raise ValueError("Optimizer '{}' is TensorFlow-specific; use 'lbfgsb' / 'adam'".format(name))
+    raise ValueError("Unknown optimizer '{}'".format(name))

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .fused import PoissonEvaluator
 
 
 def mg_cshapes(cshape, mg_axes=None, mg_nlvl=None):
@@ -69,48 +70,20 @@ class PoissonMultigridAdam:
         self.x = torch.zeros(n, dtype=dtype, device=device)
         self.m = torch.zeros(n, dtype=dtype, device=device)
         self.v = torch.zeros(n, dtype=dtype, device=device)
-        self.g = torch.zeros(n, dtype=dtype, device=device)
         self.w = [t.view(s) for t, s in zip(self.x.split(self.sizes), self.shapes)]
-        self.gw = [t.view(s) for t, s in zip(self.g.split(self.sizes), self.shapes)]
-        self.u = torch.empty(cshape, dtype=dtype, device=device) if self.nlvl > 1 else self.w[0]
-        self.fu = torch.empty(cshape, dtype=dtype, device=device)
-        self.loss = torch.zeros((), dtype=dtype, device=device)
-        self.work = [None] + [torch.empty(s, dtype=dtype, device=device) for s in self.shapes[1:-1]] + [None]
-        self.work = self.work[: self.nlvl]
         # rhs = discrete Laplacian of the reference solution (poisson.py:71-86): same kernel, rhs = 0
         ref_u = hat_reference(cshape, dtype, device)
         self.ref_u = ref_u
-        self.rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        self.ev = PoissonEvaluator(cshape, self.shapes, rhs, self.h2, name="", dtype=dtype, device=device)
+        self.g = self.ev.g
+        self.loss = self.ev.loss
         self.lr, self.b1, self.b2, self.eps = npdt(lr), npdt(beta_1), npdt(beta_2), epsilon
         self.t = 0
 
     def loss_grad(self, timers=None):
-        def tic(name):
-            if timers is None:
-                return None
-            a, b = timers.section(name)
-            a.record()
-            return b
-
-        def toc(b):
-            if b is not None:
-                b.record()
-
-        if self.nlvl > 1:
-            b = tic("mg_synth")
-            ops.mg_synth(self.w, self.loc, work=self.work, out=self.u)
-            toc(b)
-        b = tic("residual")
-        ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
-        toc(b)
-        b = tic("adjoint")
-        ops.poisson_adjoint(self.fu, self.h2, self.npdt(2) / self.npdt(self.fu.numel()), out=self.gw[0])
-        toc(b)
-        if self.nlvl > 1:
-            b = tic("mg_synth_adj")
-            ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
-            toc(b)
-        return self.loss
+        loss, _ = self.ev.loss_grad_arrays(self.w, timers)
+        return loss
 
     def epoch(self, timers=None):
         self.loss_grad(timers)

@@ -1,0 +1,343 @@
+"""Driver loops and run-time bookkeeping (reference src/odil/util.py).
+
+On the hot path: `optimize_grad` (util.py:190-240), `optimize_newton` (util.py:152-187),
+`optimize` (util.py:243-246).  Kept as thin Python host code like the reference; the
+difference is that nothing is pulled to the host per epoch: `pinfo` converts its device
+scalars lazily, only when a callback actually reads them (the reference's
+`np.array(loss)` in core.py:1238-1240 is a device->host sync every epoch).
+`make_callback` / `setup_outdir` / `add_arguments` keep the reference's flag names,
+`pinfo` keys and the throughput formula (util.py:408-419); history / plotting / checkpoint
+file formats are outside the hot path.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .optimizer import EarlyStopError, Optimizer, make_optimizer  # noqa: F401
+
+g_log_file = sys.stderr
+g_log_echo = False
+
+
+def assert_equal(first, second, msg=""):
+    if not (first == second):
+        raise ValueError("Expected equal '{:}' and '{:}'{}".format(first, second, msg))
+
+
+def set_log_file(f=None, echo=None):
+    global g_log_file, g_log_echo
+    if f is not None:
+        g_log_file = f
+    if echo is not None:
+        g_log_echo = echo
+
+
+def printlog(*msg):
+    m = " ".join(map(str, msg)) + "\n"
+    if g_log_echo and g_log_file != sys.stderr:
+        sys.stderr.write(m)
+        sys.stderr.flush()
+    g_log_file.write(m)
+    g_log_file.flush()
+
+
+class LazyPinfo(dict):
+    """pinfo = {terms, names, norms, loss} whose device scalars become NumPy on first read."""
+
+    @staticmethod
+    def _conv(v):
+        if isinstance(v, torch.Tensor):
+            return np.array(v.detach().cpu().numpy())
+        if isinstance(v, list):
+            return [LazyPinfo._conv(a) for a in v]
+        return v
+
+    def __getitem__(self, key):
+        v = LazyPinfo._conv(dict.__getitem__(self, key))
+        dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+# --------------------------------------------------------------------------------------
+# Arguments: same flag names / defaults as reference util.py:70-149
+# --------------------------------------------------------------------------------------
+_ARGS = [
+    ("--epochs", int, None, "Maximum epochs, defaults to product of plot_every and frames"),
+    ("--every_factor", float, 1, "Multiplier for all *_every options"),
+    ("--plot_every", int, 5, "Epochs between plots"),
+    ("--report_every", int, 10, "Epochs between reports to stdout"),
+    ("--history_every", int, 1, "Epochs between entries of training history"),
+    ("--checkpoint_every", int, 0, "Epochs between checkpoints"),
+    ("--frames", int, 10, "Frames to plot. Zero disables first frame."),
+    ("--outdir", str, ".", "Output directory"),
+    ("--optimizer", str, "adamn", "Optimizer"),
+    ("--seed", int, 1000, "Seed for numpy.random and the backend"),
+    ("--plot_title", int, 0, "Enable title in plots"),
+    ("--plotext", str, "pdf", "Extension of plots"),
+    ("--history_full", int, 0, "Number of epochs to write history at every point"),
+    ("--montage", int, 1, "Run montage after plotting"),
+    ("--double", int, None, "Double precision. Defaults to runtime.dtype"),
+    ("--echo", int, 0, "Echo log to stderr"),
+    ("--epoch_start", int, 0, "Initial value of epoch"),
+    ("--frame_start", int, 0, "Initial value of frame"),
+    ("--checkpoint", str, None, "Continue from checkpoint in state_*.pickle"),
+    ("--checkpoint_train", str, None, "Continue from history in state_*_train.pickle"),
+    ("--callback_update_state", int, 0, "Update state after callback"),
+    ("--bfgs_m", int, 50, "History size for L-BFGS"),
+    ("--bfgs_maxls", int, 50, "Max evaluations in line search"),
+    ("--bfgs_pgtol", float, None, "Convergence tolerance for L-BFGS-B"),
+    ("--adam_epsilon", float, None, "Parameter epsilon in Adam"),
+    ("--adam_beta_1", float, None, "Parameter beta_1 in Adam"),
+    ("--adam_beta_2", float, None, "Parameter beta_2 in Adam"),
+    ("--multigrid", int, 0, "Use multigrid decomposition"),
+    ("--dump_data", int, 1, "Dump data_*.pickle with every plot"),
+    ("--jac_nsmp0", int, 50, "(unused) Jacobi optimizer option"),
+    ("--jac_nsmp1", int, 1, "(unused) Jacobi optimizer option"),
+    ("--jac_factor", float, 1, "(unused) Jacobi optimizer option"),
+    ("--jac_epsilon", float, 1e-8, "(unused) Jacobi optimizer option"),
+]
+
+
+def add_arguments(parser):
+    for flag, typ, default, hlp in _ARGS:
+        parser.add_argument(flag, type=typ, default=default, help=hlp)
+    parser.add_argument("--mg_interp", type=str, default="stack", choices=["conv", "stack"],
+                        help="Multigrid interpolation method (both run the same HIP kernel)")
+    parser.add_argument("--nn_initializer", type=str, default="legacy", choices=["legacy", "glorot", "lecun", "he"],
+                        help="Initializer for weights of neural networks")
+
+
+def setup_outdir(args, relpath_args=None):
+    """Output directory, args.json, train.log, epoch bookkeeping, seeds (reference util.py:281-334)."""
+    from . import runtime
+
+    outdir = args.outdir
+    os.makedirs(outdir, exist_ok=True)
+    with open(os.path.join(outdir, "args.json"), "w") as f:
+        env = {k: os.environ.get(k, "") for k in ["ODIL_BACKEND", "ODIL_JIT", "ODIL_MT", "ODIL_DTYPE", "ODIL_FUSE"]}
+        d = dict(vars(args), **env, runtime_backend=runtime.backend_name, runtime_dtype=runtime.dtype_name,
+                 runtime_jit=runtime.enable_jit, runtime_gpu=True)
+        json.dump(d, f, sort_keys=True, indent=4, default=str)
+    os.chdir(outdir)
+    set_log_file(open("train.log", "w"), echo=args.echo)
+    for k in relpath_args or []:
+        if getattr(args, k):
+            setattr(args, k, os.path.relpath(getattr(args, k), start=outdir))
+
+    def mulint(v, k):
+        return None if v is None else max(1, round(v * k))
+
+    args.plot_every = mulint(args.plot_every, args.every_factor)
+    args.history_every = mulint(args.history_every, args.every_factor)
+    args.report_every = mulint(args.report_every, args.every_factor)
+    if args.epochs is None:
+        args.epochs = args.frames * args.plot_every
+    if args.seed is not None:
+        np.random.seed(args.seed)
+        runtime.get_mod().random.set_seed(args.seed)
+    printlog(" ".join(sys.argv))
+
+
+class _CsvHistory:
+    """Minimal column store -> train.csv (same column names as reference util.py:423-444)."""
+
+    def __init__(self, csvpath):
+        self.csvpath = csvpath
+        self.rows = []
+        self.cur = dict()
+
+    def append(self, key, value):
+        self.cur[key] = float(np.array(value)) if not isinstance(value, str) else value
+
+    def write(self):
+        self.rows.append(self.cur)
+        self.cur = dict()
+        keys = []
+        for r in self.rows:
+            for k in r:
+                if k not in keys:
+                    keys.append(k)
+        with open(self.csvpath, "w") as f:
+            f.write(",".join(keys) + "\n")
+            for r in self.rows:
+                f.write(",".join(str(r.get(k, "")) for k in keys) + "\n")
+
+
+def make_callback(problem, args=None, epoch_func=None, report_func=None, history_func=None, checkpoint_func=None,
+                  plot_func=None):
+    cbinfo = argparse.Namespace()
+    cbinfo.walltime = 0
+    cbinfo.epoch = 0
+    cbinfo.time_callback = 0
+    cbinfo.time_start = time.time()
+    cbinfo.problem = problem
+    cbinfo.args = args
+    cbinfo.frame = 0
+    cbinfo.history = _CsvHistory("train.csv") if getattr(args, "history_every", 0) else None
+
+    def callback(state, epoch, pinfo):
+        args = cbinfo.args
+        domain = problem.domain
+        t_in = time.time()
+        report = bool(args.report_every) and epoch % args.report_every == 0
+        hist = cbinfo.history is not None and (epoch % args.history_every == 0 or epoch < (args.history_full or 0))
+        plot = epoch % args.plot_every == 0 and bool(epoch or args.frames)
+        checkpoint = bool(args.checkpoint_every) and epoch % args.checkpoint_every == 0
+        cbinfo.task_report, cbinfo.task_history, cbinfo.task_plot, cbinfo.task_checkpoint = report, hist, plot, checkpoint
+        cbinfo.pinfo = pinfo
+        if isinstance(problem.tracers, dict):
+            problem.tracers["epoch"] = epoch
+        if epoch_func is not None:
+            epoch_func(problem, state, epoch, cbinfo)
+        if report or hist or plot or checkpoint:
+            torch.cuda.synchronize()  # attribute device time to the epochs, not to the callback
+        now = time.time()
+        cbinfo.time_callback += now - t_in
+        t_in = now
+        walltime = now - cbinfo.time_start - cbinfo.time_callback
+        if report:
+            printlog("\nepoch={:05d}".format(epoch))
+            if pinfo and "norms" in pinfo:
+                norms, names = pinfo["norms"], pinfo["names"]
+                printlog("residual: " + ", ".join(
+                    "{}:{:.5g}".format(name or str(i), float(np.array(norm)))
+                    for i, (norm, name) in enumerate(zip(norms, names))))
+            if report_func is not None:
+                report_func(problem, state, epoch, cbinfo)
+            if epoch > cbinfo.epoch:
+                wte = (walltime - cbinfo.walltime) / (epoch - cbinfo.epoch)
+                thr = np.prod(domain.cshape) / wte if wte > 0 else 0
+            else:
+                wte, thr = 0, 0
+            gpu_used = torch.cuda.memory_allocated() // (1 << 20) if torch.cuda.is_available() else 0
+            printlog("memory: gpu_used: {:} MiB".format(gpu_used))
+            printlog("walltime: {:.3f} s, walltime+callback: {:.3f} s, walltime/epoch: {:.3f} ms".format(
+                walltime, walltime + cbinfo.time_callback, wte * 1000))
+            printlog("throughput: {:.3f} Mcells/s".format(thr / 1e6))
+            cbinfo.walltime, cbinfo.epoch = walltime, epoch
+        if hist:
+            h = cbinfo.history
+            h.append("epoch", epoch)
+            h.append("frame", cbinfo.frame)
+            if pinfo and "norms" in pinfo:
+                for i, (norm, name) in enumerate(zip(pinfo["norms"], pinfo["names"])):
+                    h.append("norm_{:}".format(name or str(i)), norm)
+            if pinfo and "loss" in pinfo:
+                h.append("loss", pinfo["loss"])
+            h.append("walltime", np.round(walltime, 3))
+            if history_func is not None:
+                history_func(problem, state, epoch, h, cbinfo)
+            h.write()
+        if plot:
+            if plot_func is not None:
+                plot_func(problem, state, epoch, cbinfo.frame, cbinfo)
+            cbinfo.frame += 1
+        if checkpoint:
+            if checkpoint_func is not None:
+                checkpoint_func(problem, state, epoch, cbinfo)
+            else:
+                from .core import checkpoint_save
+
+                path = "checkpoint_{:06d}.pickle".format(epoch)
+                printlog(path)
+                checkpoint_save(domain, state, path)
+        cbinfo.time_callback += time.time() - t_in
+
+    callback.cbinfo = cbinfo
+    return callback
+
+
+# --------------------------------------------------------------------------------------
+# Driver loops
+# --------------------------------------------------------------------------------------
+def _pinfo(loss, terms, names, norms):
+    return LazyPinfo(terms=terms, names=names, norms=norms, loss=loss)
+
+
+def optimize_newton(args, problem, state, callback=None, **kwargs):
+    """x <- x + delta with (M^T M) delta = -M^T r per epoch (reference util.py:152-187)."""
+    from .linsolver import solve
+
+    domain = problem.domain
+
+    def eval_pinfo(state):
+        loss, _, terms, names, norms = problem.eval_loss_grad_device(state)
+        return _pinfo(loss, terms, names, norms)
+
+    opt = Optimizer(name="newton", displayname="Newton")
+    printlog("Running {} optimizer".format(opt.displayname))
+    pinfo = eval_pinfo(state)
+    if callback:
+        callback(state, args.epoch_start, pinfo)
+    for epoch in range(args.epoch_start, args.epochs):
+        vector, matrix = problem.linearize_device(state)
+        opt.evals += 1
+        linstatus = dict()
+        delta = solve(matrix, -vector, args, linstatus, getattr(args, "linsolver", "direct"))
+        if getattr(args, "linsolver_verbose", 0):
+            printlog(linstatus)
+        packed = domain.pack_state(state)
+        domain.unpack_state(packed + delta, state)
+        if callback:
+            pinfo = eval_pinfo(state)
+            pinfo["linsolver"] = linstatus
+            callback(state, epoch + 1, pinfo)
+    arrays = domain.arrays_from_state(state)
+    optinfo = argparse.Namespace()
+    optinfo.epochs = args.epochs
+    optinfo.evals = args.epochs
+    return arrays, optinfo
+
+
+def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
+    """Gradient-based optimisation (reference util.py:190-240)."""
+    domain = problem.domain
+    mod = domain.mod
+
+    def loss_grad(arrays):
+        domain.arrays_to_state(arrays, state)
+        loss, grads, terms, names, norms = problem.eval_loss_grad_device(state)
+        return loss, grads, _pinfo(loss, terms, names, norms)
+
+    def callback_wrap(arrays, epoch, pinfo):
+        domain.arrays_to_state(arrays, state)
+        callback(state, epoch, pinfo)
+        if getattr(args, "callback_update_state", 0):
+            new = domain.arrays_from_state(state)
+            for i in range(len(new)):
+                arrays[i] = new[i]
+
+    for src, dst in [("bfgs_m", "m"), ("bfgs_pgtol", "pgtol"), ("bfgs_maxls", "maxls"), ("adam_epsilon", "epsilon"),
+                     ("adam_beta_1", "beta_1"), ("adam_beta_2", "beta_2")]:
+        if getattr(args, src, None) is not None:
+            kwargs[dst] = getattr(args, src)
+    opt = make_optimizer(optname, dtype=domain.dtype, mod=mod, **kwargs)
+    printlog("Running {} optimizer".format(opt.displayname))
+    arrays = domain.arrays_from_state(state)
+    _, _, pinfo = loss_grad(arrays)
+    if callback:
+        callback(state, args.epoch_start, pinfo)
+    arrays, optinfo = opt.run(
+        arrays, loss_grad=loss_grad, epochs=args.epochs - args.epoch_start,
+        callback=callback_wrap if callback else None, epoch_start=args.epoch_start, lr=args.lr, **kwargs,
+    )
+    domain.arrays_to_state(arrays, state)
+    return arrays, optinfo
+
+
+def optimize(args, optname, problem, state, callback, **kwargs):
+    if optname == "newton":
+        return optimize_newton(args, problem, state, callback, **kwargs)
+    return optimize_grad(args, optname, problem, state, callback, **kwargs)

@@ -1,0 +1,256 @@
+"""GPU tests of the operator API: user callbacks written for the reference run through
+Domain / Context / Problem on the HIP kernels and reproduce the reference's numbers
+(golden fixtures) -- reference tests test_optimize.py / test_newton.py restated."""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, load_golden
+
+import odil_amd as odil
+from oracle import odil_np as onp
+
+sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mod():
+    assert torch.cuda.is_available()
+    return odil.runtime.get_mod()
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def rel(a, b):
+    a = npy(a) if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b))))
+
+
+def poisson_args(ndim, N, multigrid=1, **kw):
+    import poisson
+
+    args = poisson.parse_args([])
+    args.ndim, args.N, args.multigrid = ndim, N, multigrid
+    for k, v in kw.items():
+        setattr(args, k, v)
+    args.epoch_start = 0
+    return poisson, args
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("name", ["poisson_1d_N256", "poisson_2d_N32", "poisson_3d_N16"])
+def test_poisson_problem_loss_grad_vs_golden(mod, name, fuse, monkeypatch):
+    g = load_golden(name)
+    ndim, N, nlvl = int(g["ndim"]), int(g["N"]), int(g["nlvl"])
+    monkeypatch.setattr(odil.runtime, "enable_fuse", fuse)
+    poisson, args = poisson_args(ndim, N)
+    problem, state = poisson.make_problem(args)
+    domain = problem.domain
+    assert rel(problem.extra.rhs, g["rhs"]) < 1e-13
+    arrays = [mod.array(g[f"rand/w{i}"]) for i in range(nlvl)]
+    domain.arrays_to_state(arrays, state)
+    loss, grads, terms, names, norms = problem.eval_loss_grad(state)
+    assert (problem._fused is not None) == fuse
+    assert isinstance(loss, np.ndarray) and loss.shape == ()
+    assert abs(float(loss) - float(g["rand/loss"])) <= 1e-12 * float(g["rand/loss"])
+    assert abs(float(norms[0]) - np.sqrt(float(g["rand/loss"]))) <= 1e-12 * float(norms[0])
+    for i in range(nlvl):
+        assert rel(grads[i], g[f"rand/g{i}"]) < 1e-12
+    values, names2 = problem.eval_operator(state)
+    assert rel(values[0], g["rand/fu"]) < 1e-13
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_adam_trajectory_through_optimize_grad(mod, fuse, monkeypatch):
+    """reference AdamNativeOptimizer loss trajectory, tolerance 1e-6 relative (north_star)."""
+    monkeypatch.setattr(odil.runtime, "enable_fuse", fuse)
+    for name in ["poisson_1d_N256", "poisson_2d_N32", "poisson_3d_N16"]:
+        g = load_golden(name)
+        ref = g["adam/losses"]
+        poisson, args = poisson_args(int(g["ndim"]), int(g["N"]), epochs=len(ref), lr=0.005)
+        problem, state = poisson.make_problem(args)
+        losses = []
+
+        def callback(state, epoch, pinfo):
+            losses.append(float(pinfo["loss"]))
+
+        odil.util.optimize_grad(args, "adam", problem, state, callback)
+        # callback sees the loss evaluated BEFORE each update, plus the initial evaluation (epoch 0)
+        got = np.array(losses[1:])
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref) / ref) < 1e-6, name
+        arrays = problem.domain.arrays_from_state(state)
+        for i in range(int(g["nlvl"])):
+            assert rel(arrays[i], g[f"adam/w{i}"]) < 1e-7
+
+
+def test_lbfgsb_trajectory_vs_golden(mod):
+    g = load_golden("lbfgsb_poisson_2d_N32")
+    ref = g["iter_losses"]
+    poisson, args = poisson_args(2, 32, epochs=int(g["epochs"]))
+    problem, state = poisson.make_problem(args)
+    losses = []
+
+    def callback(state, epoch, pinfo):
+        losses.append(float(pinfo["loss"]))
+
+    odil.util.optimize_grad(args, "lbfgsb", problem, state, callback)
+    got = np.array(losses[1:])
+    n = min(len(got), len(ref))
+    assert n >= 20
+    relerr = np.abs(got[:n] - ref[:n]) / ref[:n]
+    assert relerr[:12].max() < 1e-6, relerr
+
+
+def test_poisson_f32_no_multigrid_generic_path(mod, monkeypatch):
+    g = load_golden("poisson_2d_N16_f32_nomg")
+    monkeypatch.setattr(odil.runtime, "enable_fuse", False)
+    poisson, args = poisson_args(2, 16, multigrid=0, double=0)
+    problem, state = poisson.make_problem(args)
+    state.fields["u"].array = mod.array(g["rand/w0"])
+    loss, grads, *_ = problem.eval_loss_grad(state)
+    assert grads[0].dtype == torch.float32
+    assert abs(float(loss) - float(g["rand/loss"])) <= 1e-5 * float(g["rand/loss"])
+    assert rel(grads[0], g["rand/g0"]) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# reference tests/test_newton.py:11-44 (operator) and :115-148 (check), same data as the golden
+# ---------------------------------------------------------------------------------------
+def newton_operator(ctx):
+    mod = ctx.mod
+    extra = ctx.extra
+    res = []
+    u_xm = ctx.field("ufx", 0, 0, loc="cc")  # face (i-1/2, j) seen from cell (i, j)
+    u_xp = ctx.field("ufx", 1, 0, loc="cc")  # face (i+1/2, j)
+    hx = ctx.step("x")
+    res += [(u_xp - u_xm) / hx - extra.ref["dudx"]]
+    ufx = ctx.field("ufx")
+    ixfx = ctx.indices("x", loc="nc")
+    mask = mod.where(ixfx == 0, ctx.cast(1), ctx.cast(0))
+    res += [(ufx - extra.ref["ufx"]) * mask]
+    uc = ctx.field("uc")
+    res += [(u_xp + u_xm) * 0.5 - uc]
+    a = ctx.field("a")
+    res += [a - extra.ref["a"]]
+    net_out = ctx.neural_net("net")(*extra.ref["net_in"])
+    for i in range(extra.Nnet):
+        res += [(f"net{i}", net_out[i] - extra.ref["net_out"][i])]
+    return res
+
+
+def make_newton_problem(mod, g):
+    Nx, Ny, Na, Nnet = 3, 2, 5, 5
+    domain = odil.Domain(cshape=(Nx, Ny), dimnames=["x", "y"], lower=(0, 0), upper=(Nx, Ny), dtype=np.float64,
+                         multigrid=0)
+    net = odil.NeuralNet([g["x0/3"]], [g["x0/4"]], activation="none")
+    state = odil.State(fields={
+        "uc": odil.Field(g["x0/0"], loc="cc"),
+        "ufx": odil.Field(g["x0/1"], loc="nc"),
+        "a": odil.Array(g["x0/2"]),
+        "net": net,
+    })
+    state = domain.init_state(state)
+    extra = argparse.Namespace(Nnet=Nnet)
+    extra.ref = {k: mod.array(g[f"ref/{k}"]) for k in ["uc", "ufx", "dudx", "a", "net_in", "net_out"]}
+    return odil.Problem(newton_operator, domain, extra), state
+
+
+def test_newton_linearize_and_step_vs_golden(mod):
+    g = load_golden("test_newton")
+    problem, state = make_newton_problem(mod, g)
+    domain = problem.domain
+    vector, matrix = problem.linearize(state)
+    assert rel(vector, g["vector"]) < 1e-14
+    assert rel(matrix.toarray(), g["matrix"]) < 1e-13
+    # device operator: M x and M^T y agree with the assembled matrix
+    _, op = problem.linearize_device(state)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(op.shape[1]), rng.standard_normal(op.shape[0])
+    assert rel(op.matvec(mod.array(x)), g["matrix"] @ x) < 1e-13
+    assert rel(op.rmatvec(mod.array(y)), g["matrix"].T @ y) < 1e-13
+    assert rel(op.normal_diagonal(), np.sum(g["matrix"] ** 2, axis=0)) < 1e-13
+    # one Newton step through optimize_newton (normal equations, CG to round-off)
+    args = argparse.Namespace(epoch_start=0, epochs=1, linsolver="direct", linsolver_maxiter=None, linsolver_damp=0,
+                              linsolver_dampdiag=0, linsolver_tol=1e-10, linsolver_verbose=0)
+    odil.util.optimize_newton(args, problem, state)
+    arrays = domain.arrays_from_state(state)
+    for k, a in enumerate(arrays):
+        assert rel(a, g[f"x1/{k}"]) < 1e-9, k
+    # the reference test's own pass criterion: rms error < 1e-6 per field (test_newton.py:131-146)
+    ref = problem.extra.ref
+    for key in ["ufx", "uc", "a"]:
+        err = domain.field(state, key) - ref[key]
+        assert float(torch.sqrt(torch.mean(err**2))) < 1e-6
+    out = torch.stack(domain.neural_net(state, "net")(*ref["net_in"]))
+    assert float(torch.sqrt(torch.mean((out - ref["net_out"]) ** 2))) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["newton_poisson_1d_N8", "newton_poisson_2d_N6", "newton_poisson_3d_N4"])
+def test_newton_poisson_vs_golden(mod, name):
+    g = load_golden(name)
+    ndim, N = g["u0"].ndim, g["u0"].shape[0]
+    poisson, args = poisson_args(ndim, N, multigrid=0, epochs=1, linsolver="direct", linsolver_maxiter=None)
+    problem, state = poisson.make_problem(args)
+    state.fields["u"].array = mod.array(g["u0"])
+    vector, matrix = problem.linearize(state)
+    assert rel(vector, g["vector"]) < 1e-13
+    assert rel(matrix.toarray(), g["matrix"]) < 1e-13
+    odil.util.optimize_newton(args, problem, state)
+    assert rel(state.fields["u"].array, g["u1"]) < 1e-8
+    assert rel(state.fields["u"].array, g["ref_u"]) < 1e-8  # linear problem: one step solves it
+
+
+# ---------------------------------------------------------------------------------------
+# reference tests/test_optimize.py:10-113: fields at cc/nn/nc/cn + Array + NeuralNet, MG on
+# ---------------------------------------------------------------------------------------
+def optimize_operator(ctx):
+    extra = ctx.extra
+    res = []
+    for key in ["uc", "un", "ufx", "ufy"]:
+        res += [(key, ctx.field(key) - extra.ref[key])]
+    res += [("a", ctx.field("a") - extra.ref["a"])]
+    net_a = ctx.neural_net("net")(ctx.field("a"))[0]
+    res += [("net_a", net_a - extra.ref["net_a"])]
+    return res
+
+
+@pytest.mark.parametrize("opt", ["lbfgsb", "adamn"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_optimize_mixed_state(mod, opt, dtype):
+    mod.random.set_seed(1)
+    domain = odil.Domain(cshape=(8, 4), dimnames=["x", "y"], lower=(0, 0), upper=(2, 1), multigrid=1,
+                         mg_interp="stack", mg_axes=[True, True], dtype=dtype)
+    state = odil.State(fields={
+        "uc": odil.Field(np.zeros(domain.size(loc="cc")), loc="cc"),
+        "un": odil.Field(np.zeros(domain.size(loc="nn")), loc="nn"),
+        "ufx": odil.Field(np.zeros(domain.size(loc="nc")), loc="nc"),
+        "ufy": odil.Field(np.zeros(domain.size(loc="cn")), loc="cn"),
+        "a": odil.Array(np.zeros(5)),
+        "net": domain.make_neural_net([1, 7, 1]),
+    })
+    state = domain.init_state(state)
+    func = lambda x, y: x * 0.25 + y * 0.5
+    extra = argparse.Namespace()
+    extra.ref = {k: func(*domain.points(loc=l)) for k, l in [("uc", "cc"), ("un", "nn"), ("ufx", "nc"), ("ufy", "cn")]}
+    extra.ref["a"] = mod.array(np.arange(5, dtype=dtype))
+    extra.ref["net_a"] = extra.ref["a"] * 0.5
+    problem = odil.Problem(optimize_operator, domain, extra)
+    args = argparse.Namespace(epoch_start=0, epochs=1000, lr=0.1, bfgs_m=50, bfgs_maxls=50, bfgs_pgtol=None,
+                              adam_epsilon=None, adam_beta_1=None, adam_beta_2=None, callback_update_state=0)
+    try:
+        odil.util.optimize_grad(args, opt, problem, state, None)
+    except odil.EarlyStopError:
+        pass
+    error = [domain.field(state, key) - extra.ref[key] for key in ["uc", "un", "ufx", "ufy", "a"]]
+    error.append(domain.neural_net(state, "net")(domain.field(state, "a"))[0] - extra.ref["net_a"])
+    total = float(torch.sqrt(sum(torch.mean(torch.square(e)) for e in error)))
+    assert total < 1e-2, total
