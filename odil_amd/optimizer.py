@@ -353,9 +353,13 @@ class LbfgsVectors:
             ops.scale(y, beta, out=y)
 
     def sub_into(self, dst, a, b):
-        """dst = a - b."""
-        dst.copy_(a)
-        ops.axpy(dst, b, -1.0)
+        """dst = a - b (dst may alias b)."""
+        if dst.data_ptr() == b.data_ptr():
+            ops.scale(dst, -1.0, out=dst)
+            ops.axpy(dst, a, 1.0)
+        else:
+            dst.copy_(a)
+            ops.axpy(dst, b, -1.0)
 
 
 def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, maxfun=math.inf, callback=None):
