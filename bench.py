@@ -114,10 +114,20 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from odil_amd.poisson_path import PoissonMultigridAdam
+    from odil_amd.slab import SlabPoissonAdam, TorchDistComm
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     ndim, N = args.ndim, args.N
-    run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev, world=world, rank=rank)
+    comm = None
+    if world > 1:
+        # weak scaling: every rank owns an N^3 slab of the (world*N, N, N) grid
+        assert ndim == 3, "the slab decomposition is 3-D"
+        run = SlabPoissonAdam(N, rank, world, dtype=dtype, device=dev)
+        comm = TorchDistComm(rank, world)
+        step = lambda timers=None: run.epoch(comm, timers)
+    else:
+        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev)
+        step = lambda timers=None: run.epoch(timers)
 
     def barrier():
         if world > 1:
@@ -127,12 +137,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run.epoch()
+        step()
     barrier()
     timers = Timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run.epoch(timers)
+        step(timers)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -141,7 +151,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss = run.last_loss()
+    loss = run.last_loss(comm) if world > 1 else run.last_loss()
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps

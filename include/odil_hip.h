@@ -60,6 +60,14 @@ int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, c
                         const char* loc, double scale, void* stream);
 int odil_interp_adj_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
                         const char* loc, float scale, void* stream);
+/* Slab decomposition (no reference counterpart): the same transpose for an array
+ * whose axis 0 is CUT at its low / high end -- that end carries ghost planes of the
+ * neighbouring rank instead of being a wall, so the boundary (ghost-rule) weights are not
+ * applied there. */
+int odil_interp_adj_cut_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
+                            const char* loc, double scale, int cut_lo, int cut_hi, void* stream);
+int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
+                            const char* loc, float scale, int cut_lo, int cut_hi, void* stream);
 /* coarse = R(fine): full weighting `restrict_to_coarser(method="conv")`
  * (core.py:703-755, backend.py:112-126).  `fshape` = fine array shape. */
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
@@ -111,6 +119,14 @@ int odil_poisson_residual_f64(const double* u, const double* rhs, double* fu, co
                               const double* h2, double* partials, double* loss, void* stream);
 int odil_poisson_residual_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
                               const float* h2, double* partials, float* loss, void* stream);
+/* Slab variant: fu on every plane of the (ghost-extended) local array, but
+ * loss[0] = sum_{z0 <= z < z1} fu^2 / denom  (the rank's own planes over the GLOBAL size). */
+int odil_poisson_residual_slab_f64(const double* u, const double* rhs, double* fu, const int64_t* shape, int ndim,
+                                   const double* h2, int64_t z0, int64_t z1, double denom, double* partials,
+                                   double* loss, void* stream);
+int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
+                                   const float* h2, int64_t z0, int64_t z1, double denom, double* partials,
+                                   float* loss, void* stream);
 /* gu = J^T (scale * fu): cotangent of the operator above; scale = 2/size gives
  * d mean(fu^2)/du (core.py:1093-1101). */
 int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,

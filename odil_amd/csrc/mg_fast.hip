@@ -22,6 +22,7 @@ struct FastArgs {
   int cn[4], fn[4];
   int loc[4];
   int tx, ty;  // thread tile: tx lanes along coarse x, ty rows along coarse y
+  int cut_axis, cut_lo, cut_hi;
   RowSched sched;
 };
 
@@ -159,11 +160,11 @@ struct AdjWin {
   bool special;
 };
 
-__device__ inline AdjWin adj_window(int loc, int J, int n) {
+__device__ inline AdjWin adj_window(int loc, int J, int n, bool cut_lo, bool cut_hi) {
   AdjWin w;
   w.special = false;
   if (loc == kCell) {
-    w.special = J == 0 || J == n - 1 || J == 1 || J == n - 2;
+    w.special = ((J == 0 || J == 1) && !cut_lo) || ((J == n - 1 || J == n - 2) && !cut_hi);
     w.k0 = w.special ? 2 * J - 2 : 2 * J - 1;
     w.cnt = w.special ? 6 : 4;
   } else if (loc == kNode) {
@@ -176,11 +177,12 @@ __device__ inline AdjWin adj_window(int loc, int J, int n) {
   return w;
 }
 
-__device__ inline void adj_weight(int loc, int J, int n, int F, int k, float& wc, float& wr) {
+__device__ inline void adj_weight(int loc, int J, int n, int F, int k, bool cut_lo, bool cut_hi, float& wc,
+                                  float& wr) {
   if (loc == kCell) {
     const float w = w_cell(J, k, F), lo = w_cell(-1, k, F), hi = w_cell(n, k, F);
-    wc = w + (J == 0 ? lo : 0.f) + (J == n - 1 ? hi : 0.f);
-    wr = w + (J == 1 ? lo : 0.f) + (J == n - 2 ? hi : 0.f);
+    wc = w + (J == 0 && !cut_lo ? lo : 0.f) + (J == n - 1 && !cut_hi ? hi : 0.f);
+    wr = w + (J == 1 && !cut_lo ? lo : 0.f) + (J == n - 2 && !cut_hi ? hi : 0.f);
   } else if (loc == kNode) {
     const int d = k - 2 * J;
     wc = wr = (k >= 0 && k < F) ? (d == 0 ? 1.f : ((d == 1 || d == -1) ? 0.5f : 0.f)) : 0.f;
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_fast(const T* __restrict_
     int p, yt, xt;
     sched_decode(a.sched, it, p, yt, xt);
     const int c0 = p / a.cn[1], c1 = p - c0 * a.cn[1];
-    const AdjWin t0 = adj_window(a.loc[0], c0, a.cn[0]);
-    const AdjWin t1 = adj_window(a.loc[1], c1, a.cn[1]);
+    const bool l0 = a.cut_axis == 0 && a.cut_lo, h0 = a.cut_axis == 0 && a.cut_hi;
+    const bool l1 = a.cut_axis == 1 && a.cut_lo, h1 = a.cut_axis == 1 && a.cut_hi;
+    const AdjWin t0 = adj_window(a.loc[0], c0, a.cn[0], l0, h0);
+    const AdjWin t1 = adj_window(a.loc[1], c1, a.cn[1], l1, h1);
     const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
     if (jy >= cny || jx >= cnx) continue;
     const Adj6 ax = adj6(jx, cnx);
@@ -218,11 +222,11 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_fast(const T* __restrict_
     T sc = T(0), sr = T(0);
     for (int i0 = 0; i0 < t0.cnt; ++i0) {
       float w0c, w0r;
-      adj_weight(a.loc[0], c0, a.cn[0], a.fn[0], t0.k0 + i0, w0c, w0r);
+      adj_weight(a.loc[0], c0, a.cn[0], a.fn[0], t0.k0 + i0, l0, h0, w0c, w0r);
       if (w0c == 0.f && w0r == 0.f) continue;
       for (int i1 = 0; i1 < t1.cnt; ++i1) {
         float w1c, w1r;
-        adj_weight(a.loc[1], c1, a.cn[1], a.fn[1], t1.k0 + i1, w1c, w1r);
+        adj_weight(a.loc[1], c1, a.cn[1], a.fn[1], t1.k0 + i1, l1, h1, w1c, w1r);
         if (w1c == 0.f && w1r == 0.f) continue;
         const T wcl = T(w0c * w1c), wrl = T(w0r * w1r);
         const T* gp = gfine + ((t0.k0 + i0) * (int64_t)a.fn[1] + (t1.k0 + i1)) * fplane;
@@ -278,6 +282,10 @@ static bool fast_setup(FastArgs& f, const InterpArgs& a, bool& yc) {
     f.fn[i] = (int)a.fn[i];
     f.loc[i] = a.loc[i];
   }
+  f.cut_axis = a.cut_axis;
+  f.cut_lo = a.cut_lo;
+  f.cut_hi = a.cut_hi;
+  if (a.cut_axis >= 2) return false;  // cuts on the y / x axes go through the generic kernel
   // Thread tile: as many lanes along coarse x as useful (power of two, <= 256).
   int tx = 1;
   while (tx < f.cn[3] && tx < kBlock) tx *= 2;

@@ -19,6 +19,7 @@ struct alignas(2 * sizeof(T)) Pack2 {
 struct MarchArgs {
   int cn[3], fn[3];  // (z, y, x) coarse / fine extents
   int tx, ty;
+  int cut_lo, cut_hi;  // z end is an interior slab interface (ghost planes), not a wall
   UnitSched usched;
 };
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
   for (int jz = z0; jz < z1; ++jz) {
     reduce_plane<T>(gfine, 2 * jz + 2, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[4], wr[4]);
     reduce_plane<T>(gfine, 2 * jz + 3, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[5], wr[5]);
-    const bool z_special = jz == 0 || jz == 1 || jz == cnz - 2 || jz == cnz - 1;
+    const bool z_special = ((jz == 0 || jz == 1) && !a.cut_lo) || ((jz == cnz - 2 || jz == cnz - 1) && !a.cut_hi);
     T v;
     if (!z_special && !xy_special) {
       v = (T(0.25) * wc[1] + T(0.75) * wc[2]) + (T(0.75) * wc[3] + T(0.25) * wc[4]);
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
         float zc_w, zr_w;
         const int k = 2 * jz - 2 + i;
         const float w = w_cell(jz, k, fnz), lo = w_cell(-1, k, fnz), hi = w_cell(cnz, k, fnz);
-        zc_w = w + (jz == 0 ? lo : 0.f) + (jz == cnz - 1 ? hi : 0.f);
-        zr_w = w + (jz == 1 ? lo : 0.f) + (jz == cnz - 2 ? hi : 0.f);
+        zc_w = w + (jz == 0 && !a.cut_lo ? lo : 0.f) + (jz == cnz - 1 && !a.cut_hi ? hi : 0.f);
+        zr_w = w + (jz == 1 && !a.cut_lo ? lo : 0.f) + (jz == cnz - 2 && !a.cut_hi ? hi : 0.f);
         sc = sc + T(zc_w) * wc[i];
         sr = sr + T(zr_w) * wr[i];
       }
@@ -254,6 +255,9 @@ static bool march_setup(MarchArgs& m, const InterpArgs& a) {
     m.fn[i] = (int)a.fn[i + 1];
   }
   if (m.cn[0] < 4) return false;  // tiny levels: the per-plane kernel is as good
+  m.cut_lo = a.cut_axis == 1 ? a.cut_lo : 0;
+  m.cut_hi = a.cut_axis == 1 ? a.cut_hi : 0;
+  if (a.cut_axis >= 0 && a.cut_axis != 1) return false;
   int tx = 1;
   while (tx < m.cn[2] && tx < kBlock) tx *= 2;
   m.tx = tx;

@@ -61,6 +61,9 @@ struct InterpArgs {
   int64_t cn[4];  // coarse array shape (canonical 4-D)
   int64_t fn[4];  // fine array shape
   int loc[4];
+  // slab decomposition: array axis 0 (canonical index cut_axis) is cut at its low / high end,
+  // i.e. that end is an interior interface with ghost planes, not a physical boundary
+  int cut_axis, cut_lo, cut_hi;
   RowSched sched;
 };
 
@@ -85,11 +88,13 @@ __device__ inline float w_cell(int64_t j, int64_t k, int64_t F) {
   return (d == 0 || d == 1) ? 0.75f : ((d == -1 || d == 2) ? 0.25f : 0.f);
 }
 
-__device__ inline AdjTaps make_adj_taps(int loc, int64_t J, int64_t n, int64_t F) {
+__device__ inline AdjTaps make_adj_taps(int loc, int64_t J, int64_t n, int64_t F, bool cut_lo = false,
+                                       bool cut_hi = false) {
   AdjTaps t;
   t.special = false;
   if (loc == kCell) {
-    const bool c_lo = J == 0, c_hi = J == n - 1, r_lo = J == 1, r_hi = J == n - 2;
+    const bool c_lo = J == 0 && !cut_lo, c_hi = J == n - 1 && !cut_hi, r_lo = J == 1 && !cut_lo,
+               r_hi = J == n - 2 && !cut_hi;
     t.special = c_lo || c_hi || r_lo || r_hi;
     if (t.special) {
       t.k0 = 2 * J - 2;

@@ -76,12 +76,16 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj(const T* __restrict__ gfi
     int64_t zz, y, xs;
     sched_decode(a.sched, it, zz, y, xs);
     const int64_t c0 = zz / a.cn[1], c1 = zz - c0 * a.cn[1], c2 = y;
-    const AdjTaps t0 = make_adj_taps(a.loc[0], c0, a.cn[0], a.fn[0]);
-    const AdjTaps t1 = make_adj_taps(a.loc[1], c1, a.cn[1], a.fn[1]);
-    const AdjTaps t2 = make_adj_taps(a.loc[2], c2, a.cn[2], a.fn[2]);
+    const AdjTaps t0 = make_adj_taps(a.loc[0], c0, a.cn[0], a.fn[0], a.cut_axis == 0 && a.cut_lo,
+                                        a.cut_axis == 0 && a.cut_hi);
+    const AdjTaps t1 = make_adj_taps(a.loc[1], c1, a.cn[1], a.fn[1], a.cut_axis == 1 && a.cut_lo,
+                                        a.cut_axis == 1 && a.cut_hi);
+    const AdjTaps t2 = make_adj_taps(a.loc[2], c2, a.cn[2], a.fn[2], a.cut_axis == 2 && a.cut_lo,
+                                        a.cut_axis == 2 && a.cut_hi);
     const int64_t c3 = xs * kBlock + threadIdx.x;
     if (c3 >= a.cn[3]) continue;
-    const AdjTaps t3 = make_adj_taps(a.loc[3], c3, a.cn[3], a.fn[3]);
+    const AdjTaps t3 = make_adj_taps(a.loc[3], c3, a.cn[3], a.fn[3], a.cut_axis == 3 && a.cut_lo,
+                                        a.cut_axis == 3 && a.cut_hi);
     const bool special = t0.special || t1.special || t2.special || t3.special;
     T sc = T(0), sr = T(0);
     for (int i0 = 0; i0 < t0.cnt; ++i0) {
@@ -201,6 +205,8 @@ static int fill_interp_args(InterpArgs& a, const int64_t* cshape, int ndim, cons
     return ODIL_E_INVAL;
   }
   canon_shape(cshape, ndim, a.cn);
+  a.cut_axis = -1;
+  a.cut_lo = a.cut_hi = 0;
   for (int i = 0; i < 4; ++i) {
     if (a.cn[i] < 1 || (a.loc[i] != kNone && a.cn[i] < 2)) {
       set_error("coarse extent %lld on a refined axis must be >= 2", (long long)a.cn[i]);
@@ -231,9 +237,14 @@ static int interp_add(const T* coarse, const T* add, T* fine, const int64_t* csh
 
 template <typename T>
 static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* cshape, int ndim, const char* loc,
-                      T scale, void* stream) {
+                      T scale, void* stream, int cut_lo = 0, int cut_hi = 0) {
   InterpArgs a;
   if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
+  if (cut_lo || cut_hi) {
+    a.cut_axis = 4 - ndim;
+    a.cut_lo = cut_lo;
+    a.cut_hi = cut_hi;
+  }
   if (!gfine || !gcoarse) {
     set_error("interp_adj: null pointer");
     return ODIL_E_INVAL;
@@ -389,6 +400,14 @@ int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, c
 int odil_interp_adj_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
                         const char* loc, float scale, void* stream) {
   return interp_adj<float>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream);
+}
+int odil_interp_adj_cut_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
+                            const char* loc, double scale, int cut_lo, int cut_hi, void* stream) {
+  return interp_adj<double>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream, cut_lo, cut_hi);
+}
+int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
+                            const char* loc, float scale, int cut_lo, int cut_hi, void* stream) {
+  return interp_adj<float>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream, cut_lo, cut_hi);
 }
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
                       void* stream) {

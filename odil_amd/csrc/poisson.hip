@@ -16,6 +16,7 @@
 namespace odil {
 
 struct StencilArgs {
+  int64_t loss_z0, loss_z1;  // planes (canonical z) that enter the loss
   int64_t n[3];     // canonical (Z, Y, X) cell shape
   int active[3];    // axis takes part in the Laplacian
   UnitSched usched;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
         }
         const T f = acc - r[i];
         out[i] = f;
-        local += (double)(f * f);
+        if (z >= a.loss_z0 && z < a.loss_z1) local += (double)(f * f);
       }
       if (fu) store_vec<T, V>(fu + pz + c_off, valid, out);
 #pragma unroll
@@ -329,10 +330,17 @@ static int fill_args(StencilArgs& a, const int64_t* shape, int ndim, const T* h2
 
 template <typename T>
 static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shape, int ndim, const T* h2,
-                            double* partials, T* loss, void* stream) {
+                            double* partials, T* loss, void* stream, int64_t z0 = 0, int64_t z1 = -1,
+                            double denom = 0.0) {
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  a.loss_z0 = z0;
+  a.loss_z1 = z1 < 0 ? a.n[0] : z1;
+  if (ndim < 3 && (z0 != 0 || z1 >= 0) && ndim != 2) {
+    set_error("poisson_residual_slab: a plane range needs ndim >= 2");
+    return ODIL_E_INVAL;
+  }
   if (!u || !rhs || !partials || !loss) {
     set_error("poisson_residual: null pointer");
     return ODIL_E_INVAL;
@@ -341,7 +349,7 @@ static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shap
   hipLaunchKernelGGL(k_poisson_residual<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a,
                      make_h2<T>(h), partials);
   if (int e = check_launch("k_poisson_residual")) return e;
-  const double size = (double)(a.n[0] * a.n[1] * a.n[2]);
+  const double size = denom > 0.0 ? denom : (double)(a.n[0] * a.n[1] * a.n[2]);
   return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
 }
 
@@ -386,6 +394,16 @@ int odil_poisson_residual_f64(const double* u, const double* rhs, double* fu, co
 int odil_poisson_residual_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
                               const float* h2, double* partials, float* loss, void* stream) {
   return poisson_residual<float>(u, rhs, fu, shape, ndim, h2, partials, loss, stream);
+}
+int odil_poisson_residual_slab_f64(const double* u, const double* rhs, double* fu, const int64_t* shape, int ndim,
+                                   const double* h2, int64_t z0, int64_t z1, double denom, double* partials,
+                                   double* loss, void* stream) {
+  return poisson_residual<double>(u, rhs, fu, shape, ndim, h2, partials, loss, stream, z0, z1, denom);
+}
+int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
+                                   const float* h2, int64_t z0, int64_t z1, double denom, double* partials,
+                                   float* loss, void* stream) {
+  return poisson_residual<float>(u, rhs, fu, shape, ndim, h2, partials, loss, stream, z0, z1, denom);
 }
 int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,
                              double scale, void* stream) {

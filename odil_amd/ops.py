@@ -60,8 +60,9 @@ def interp_to_finer(u, loc, depth=1):
     return u
 
 
-def interp_adj(gfine, loc, cshape, scale=None, out=None):
-    """P^T gfine (and optionally scale * P^T gfine)."""
+def interp_adj(gfine, loc, cshape, scale=None, out=None, cut=(False, False)):
+    """P^T gfine (and optionally scale * P^T gfine).  cut=(lo, hi): axis 0 is an interior slab
+    interface at that end (ghost planes), not a wall."""
     cshape = tuple(int(s) for s in cshape)
     assert tuple(gfine.shape) == fine_shape(cshape, loc), (gfine.shape, cshape, loc)
     if out is None:
@@ -70,8 +71,9 @@ def interp_adj(gfine, loc, cshape, scale=None, out=None):
     if scale is not None:
         scaled = torch.empty_like(out)
     call(
-        "interp_adj", gfine.dtype, ptr(gfine), ptr(out), ptr(scaled), i64(cshape), c_int(len(cshape)), loc.encode(),
-        1.0 if scale is None else float(scale), stream_ptr(),
+        "interp_adj_cut", gfine.dtype, ptr(gfine), ptr(out), ptr(scaled), i64(cshape), c_int(len(cshape)),
+        loc.encode(), 1.0 if scale is None else float(scale), c_int(1 if cut[0] else 0), c_int(1 if cut[1] else 0),
+        stream_ptr(),
     )
     return out if scale is None else (out, scaled)
 
@@ -175,19 +177,29 @@ def mean_reduce(x, square=True, out=None):
     return out
 
 
-def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True):
+def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, denom=None):
     """fu = Lap(u) - rhs with zero-Dirichlet ghosts, loss = mean(fu**2)
-    (reference examples/poisson/poisson.py:89-113, core.py:1093)."""
+    (reference examples/poisson/poisson.py:89-113, core.py:1093).  zrange=(z0, z1) / denom: slab
+    variant, loss = sum over planes z0 <= z < z1 of fu^2 / denom."""
     assert u.shape == rhs.shape and u.dtype == rhs.dtype
     if fu is None and want_fu:
         fu = torch.empty_like(u)
     if loss is None:
         loss = torch.empty((), dtype=u.dtype, device=u.device)
     h2a, h2p = host_reals(h2, u.dtype)
-    call(
-        "poisson_residual", u.dtype, ptr(u), ptr(rhs), ptr(fu), i64(u.shape), c_int(u.dim()), h2p,
-        ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
-    )
+    if zrange is None:
+        call(
+            "poisson_residual", u.dtype, ptr(u), ptr(rhs), ptr(fu), i64(u.shape), c_int(u.dim()), h2p,
+            ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
+        )
+    else:
+        from ctypes import c_double
+
+        call(
+            "poisson_residual_slab", u.dtype, ptr(u), ptr(rhs), ptr(fu), i64(u.shape), c_int(u.dim()), h2p,
+            c_int64(zrange[0]), c_int64(zrange[1]), c_double(float(denom)), ptr(reduce_workspace(u.device)), ptr(loss),
+            stream_ptr(),
+        )
     return fu, loss
 
 

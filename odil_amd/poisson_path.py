@@ -49,9 +49,7 @@ def hat_reference(cshape, dtype, device):
 
 class PoissonMultigridAdam:
     def __init__(self, ndim, N, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7, multigrid=True, world=1, rank=0):
-        if world != 1:
-            raise NotImplementedError("slab decomposition: see odil_amd/slab.py")
+                 epsilon=1e-7, multigrid=True):
         self.ndim, self.N, self.dtype, self.device = ndim, N, dtype, device
         self.loc = "c" * ndim
         cshape = (N,) * ndim
@@ -60,7 +58,7 @@ class PoissonMultigridAdam:
         self.nlvl = len(self.shapes)
         self.sizes = [math.prod(s) for s in self.shapes]
         self.local_cells = math.prod(cshape)
-        self.global_cells = self.local_cells * world
+        self.global_cells = self.local_cells
         self.n_unknowns_local = sum(self.sizes)
         npdt = np.float64 if dtype == torch.float64 else np.float32
         self.npdt = npdt

@@ -1,0 +1,263 @@
+"""Slab decomposition of the Poisson multigrid hot path over the GPUs of one node
+(no reference counterpart: the reference is single-device).
+
+Layout.  The global grid (P*Nz, Ny, Nx) is cut along axis 0; rank r owns Nz planes of
+every multigrid level (levels halve all axes, and the level count is set by the smallest
+axis, so every level keeps >= 2 planes per rank: no agglomeration is needed).  Each level
+array is stored ghost-extended: G = 2 extra planes at every interior interface, none at a
+wall.  Only the INNER ghost plane ever needs valid data; the outer one exists so that the
+unmodified single-GPU kernels, run on the extended array as if it were a whole domain,
+compute exact values on all owned planes (their wall formulas only ever touch the discarded
+ghost planes, except at true walls where they are the physics).  Two kernels know about
+the cut: P^T drops the wall weights at a cut end (`odil_interp_adj_cut`), and the residual
+restricts its loss sum to the owned planes (`odil_poisson_residual_slab`).
+
+Per epoch each rank exchanges single planes with its two neighbours over RCCL/xGMI
+(point-to-point, one direct link per neighbour pair):
+  1. the first / last owned plane of every level of w, packed in ONE message per neighbour;
+     P then produces u's inner ghost plane by itself (no exchange for u);
+  2. the first / last owned plane of fu (the adjoint reads fu at z +- 1);
+  3. before each level of the P^T chain, the first / last owned plane of that level's
+     cotangent (8 small messages).
+No field-sized collective exists; the loss needs one scalar all-reduce, issued only when a
+loss value is actually asked for.  Adam is local.
+
+The epoch is written as a generator that yields at every exchange, so the same code runs
+(a) one rank per GPU under torch.distributed (RCCL), (b) over gloo on CPU in the tests with
+an oracle-backed `ops` double, and (c) with several ranks emulated in one process on one
+GPU (tests), where the HIP kernels themselves are checked against the undivided domain.
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops as hip_ops
+from .poisson_path import mg_cshapes
+
+G = 2  # ghost planes per interior interface
+
+
+class SlabLevel:
+    def __init__(self, nz, ny, nx, rank, world):
+        self.nz, self.ny, self.nx = nz, ny, nx
+        self.g_lo = 0 if rank == 0 else G
+        self.g_hi = 0 if rank == world - 1 else G
+        self.shape = (self.g_lo + nz + self.g_hi, ny, nx)
+        self.size = math.prod(self.shape)
+        self.plane = ny * nx
+
+    def owned(self, a):
+        return a[self.g_lo : self.g_lo + self.nz]
+
+    def inner(self, a):
+        """View with ONE ghost plane per interior interface (what P takes as its coarse operand)."""
+        lo = self.g_lo - 1 if self.g_lo else 0
+        hi = a.shape[0] - (self.g_hi - 1 if self.g_hi else 0)
+        return a[lo:hi]
+
+
+def hat_reference_slab(levels0, N, rank, world, dtype, device):
+    """'hat' reference solution (reference examples/poisson/poisson.py:21-24) in normalised
+    coordinates of the global box, evaluated on this rank's ghost-extended planes."""
+    lv = levels0
+    nzg = N * world
+    z = (torch.arange(lv.shape[0], dtype=torch.float64, device=device) + (rank * N - lv.g_lo) + 0.5) / nzg
+    y = (torch.arange(lv.ny, dtype=torch.float64, device=device) + 0.5) / lv.ny
+    x = (torch.arange(lv.nx, dtype=torch.float64, device=device) + 0.5) / lv.nx
+    u = torch.ones(lv.shape, dtype=torch.float64, device=device)
+    for c, shp in ((z, (-1, 1, 1)), (y, (1, -1, 1)), (x, (1, 1, -1))):
+        u = u * ((1 - c) * c * 5).reshape(shp)
+    p = 5
+    return ((u**p / (1 + u**p)) ** (1 / p)).to(dtype)
+
+
+class SlabPoissonAdam:
+    """One rank of the slab-decomposed Poisson multigrid Adam loop (3-D, all cell-centred)."""
+
+    def __init__(self, N, rank, world, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
+                 epsilon=1e-7, ops=None, rhs_global=None):
+        self.ops = ops or hip_ops
+        self.N, self.rank, self.world = N, rank, world
+        self.dtype, self.device = dtype, device
+        self.npdt = np.float64 if dtype == torch.float64 else np.float32
+        cglobal = (N * world, N, N)
+        self.global_cells = math.prod(cglobal)
+        self.local_cells = N**3
+        shapes_global = mg_cshapes(cglobal)
+        self.nlvl = len(shapes_global)
+        self.levels = [SlabLevel(s[0] // world, s[1], s[2], rank, world) for s in shapes_global]
+        for lv in self.levels:
+            assert lv.nz >= 2, "every level needs >= 2 owned planes per rank"
+        self.h2 = [self.npdt(1.0 / N) ** 2] * 3  # box (world, 1, 1): uniform spacing 1/N
+        sizes = [lv.size for lv in self.levels]
+        n = sum(sizes)
+        self.n_unknowns_local = sum(lv.nz * lv.plane for lv in self.levels)
+        mk = lambda: torch.zeros(n, dtype=dtype, device=device)
+        self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
+        split = lambda f: [t.view(lv.shape) for t, lv in zip(f.split(sizes), self.levels)]
+        self.w, self.gw = split(self.x), split(self.g)
+        l0 = self.levels[0]
+        self.u = torch.zeros(l0.shape, dtype=dtype, device=device)
+        self.fu = torch.zeros(l0.shape, dtype=dtype, device=device)
+        self.work = [None] + [torch.zeros(lv.shape, dtype=dtype, device=device) for lv in self.levels[1:-1]] + [None]
+        self.loss_part = torch.zeros((), dtype=dtype, device=device)
+        if rhs_global is not None:
+            lo = rank * N - l0.g_lo
+            self.rhs = rhs_global[lo : lo + l0.shape[0]].to(device=device, dtype=dtype).contiguous()
+        else:
+            ref_u = hat_reference_slab(l0, N, rank, world, dtype, device)
+            self.rhs, _ = self.ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
+        self.t = 0
+        self.scale = self.npdt(2) / self.npdt(self.global_cells)
+
+    # ---- plane packing -----------------------------------------------------------------
+    def _pack(self, arrays, levels, side):
+        """First (side 'lo') or last ('hi') OWNED plane of each array, concatenated; None at a wall."""
+        if (side == "lo" and self.rank == 0) or (side == "hi" and self.rank == self.world - 1):
+            return None
+        parts = []
+        for a, lv in zip(arrays, levels):
+            k = lv.g_lo if side == "lo" else lv.g_lo + lv.nz - 1
+            parts.append(a[k].reshape(-1))
+        return torch.cat(parts) if len(parts) > 1 else parts[0].clone()
+
+    def _unpack(self, buf, arrays, levels, side):
+        """Received planes -> the INNER ghost plane on `side` of each array."""
+        if buf is None:
+            return
+        off = 0
+        for a, lv in zip(arrays, levels):
+            k = lv.g_lo - 1 if side == "lo" else lv.g_lo + lv.nz
+            a[k].copy_(buf[off : off + lv.plane].view(lv.ny, lv.nx))
+            off += lv.plane
+
+    def _exchange(self, arrays, levels):
+        """Generator step: swap boundary planes of `arrays` with both neighbours."""
+        recv_lo, recv_hi = yield (self._pack(arrays, levels, "lo"), self._pack(arrays, levels, "hi"))
+        self._unpack(recv_lo, arrays, levels, "lo")
+        self._unpack(recv_hi, arrays, levels, "hi")
+
+    # ---- one epoch -----------------------------------------------------------------------
+    def epoch_gen(self, timers=None):
+        ops, lv = self.ops, self.levels
+        L = self.nlvl
+
+        def tic(name):
+            if timers is None:
+                return None
+            a, b = timers.section(name)
+            a.record()
+            return b
+
+        def toc(b):
+            if b is not None:
+                b.record()
+
+        b = tic("halo")
+        yield from self._exchange(self.w, lv)
+        toc(b)
+        # u = w_0 + P(w_1 + P(...)): coarse operand with one ghost plane -> fine with two
+        b = tic("mg_synth")
+        coarse = lv[L - 1].inner(self.w[L - 1])
+        for l in range(L - 2, -1, -1):
+            out = self.u if l == 0 else self.work[l]
+            ops.interp_add(coarse.contiguous(), "ccc", add=self.w[l], out=out)
+            coarse = lv[l].inner(out)
+        toc(b)
+        b = tic("residual")
+        l0 = lv[0]
+        ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
+                             zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
+        toc(b)
+        b = tic("halo")
+        yield from self._exchange([self.fu], [l0])
+        toc(b)
+        b = tic("adjoint")
+        ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        toc(b)
+        for l in range(1, L):
+            b = tic("halo")
+            yield from self._exchange([self.gw[l - 1]], [lv[l - 1]])
+            toc(b)
+            b = tic("mg_synth_adj")
+            cview = lv[l].inner(self.gw[l])
+            ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview,
+                           cut=(self.rank > 0, self.rank < self.world - 1))
+            toc(b)
+        self.t += 1
+        t = self.npdt(self.t)
+        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
+        b = tic("adam")
+        ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        toc(b)
+
+    def epoch(self, comm, timers=None):
+        gen = self.epoch_gen(timers)
+        try:
+            msg = next(gen)
+            while True:
+                msg = gen.send(comm.exchange(*msg))
+        except StopIteration:
+            pass
+
+    def last_loss(self, comm=None):
+        """Global loss of the last epoch (sum of the ranks' partial means)."""
+        part = self.loss_part.clone()
+        if comm is not None:
+            part = comm.all_reduce_sum(part)
+        return float(part)
+
+    def owned_levels(self):
+        return [lv.owned(w) for lv, w in zip(self.levels, self.w)]
+
+
+class TorchDistComm:
+    """Neighbour exchange over torch.distributed (backend nccl = RCCL on ROCm; gloo in tests)."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def exchange(self, send_lo, send_hi):
+        dist = self.dist
+        ops, recv_lo, recv_hi = [], None, None
+        if send_lo is not None:
+            recv_lo = torch.empty_like(send_lo)
+            ops += [dist.P2POp(dist.isend, send_lo, self.rank - 1), dist.P2POp(dist.irecv, recv_lo, self.rank - 1)]
+        if send_hi is not None:
+            recv_hi = torch.empty_like(send_hi)
+            ops += [dist.P2POp(dist.isend, send_hi, self.rank + 1), dist.P2POp(dist.irecv, recv_hi, self.rank + 1)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return recv_lo, recv_hi
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t)
+        return t
+
+
+def run_lockstep(ranks, nepochs=1, timers=None):
+    """Several ranks emulated in ONE process (one GPU): advances every rank's epoch generator to
+    its next exchange, swaps the planes by device copies, continues."""
+    for _ in range(nepochs):
+        gens = [r.epoch_gen(timers if i == 0 else None) for i, r in enumerate(ranks)]
+        msgs = [next(g) for g in gens]
+        alive = True
+        while alive:
+            replies = []
+            for i in range(len(ranks)):
+                from_lo = msgs[i - 1][1].clone() if i > 0 and msgs[i - 1][1] is not None else None
+                from_hi = msgs[i + 1][0].clone() if i + 1 < len(ranks) and msgs[i + 1][0] is not None else None
+                replies.append((from_lo, from_hi))
+            new = []
+            for g, rep in zip(gens, replies):
+                try:
+                    new.append(g.send(rep))
+                except StopIteration:
+                    alive = False
+            msgs = new

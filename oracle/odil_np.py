@@ -150,8 +150,10 @@ def interp_to_finer(u, loc, depth=1):
     return interp_to_finer(out, loc, depth - 1)
 
 
-def _fold_pad(gpad, shape, loc, mode):
-    """Transpose of np.pad(mode) on the 'c' axes: scatter-add ghosts back."""
+def _fold_pad(gpad, shape, loc, mode, cut=(False, False)):
+    """Transpose of np.pad(mode) on the 'c' axes: scatter-add ghosts back.  `cut`: axis 0 is
+    an interior slab interface at its low / high end -- the padded entry there is not a
+    ghost of this array and is dropped (slab decomposition)."""
     g = gpad
     for ax, (n, l) in enumerate(zip(shape, loc)):
         if l != "c":
@@ -160,12 +162,15 @@ def _fold_pad(gpad, shape, loc, mode):
         out_shape = list(g.shape)
         out_shape[ax] = n
         out = np.zeros(out_shape, dtype=g.dtype)
-        np.add.at(out, tuple(idx if a == ax else slice(None) for a in range(g.ndim)), g)
+        lo = 1 if (ax == 0 and cut[0]) else 0
+        hi = n + 2 - (1 if (ax == 0 and cut[1]) else 0)
+        sel = tuple(slice(lo, hi) if a == ax else slice(None) for a in range(g.ndim))
+        np.add.at(out, tuple(idx[lo:hi] if a == ax else slice(None) for a in range(g.ndim)), g[sel])
         g = out
     return g
 
 
-def interp_to_finer_adj(gfine, loc, coarse_shape):
+def interp_to_finer_adj(gfine, loc, coarse_shape, cut=(False, False)):
     """P^T: cotangent of interp_to_finer (what autodiff yields, core.py:1100 / :1062)."""
     gfine = np.asarray(gfine)
     tables = _interp_tables(loc)
@@ -181,7 +186,7 @@ def interp_to_finer_adj(gfine, loc, coarse_shape):
                 continue
             src = tuple(slice(st + ra, st + ra + c) for st, ra, c in zip(start, r, count))
             gpad[src] += w * gs
-    return 2 * _fold_pad(gpad, coarse_shape, loc, "symmetric") - _fold_pad(gpad, coarse_shape, loc, "reflect")
+    return 2 * _fold_pad(gpad, coarse_shape, loc, "symmetric", cut) - _fold_pad(gpad, coarse_shape, loc, "reflect", cut)
 
 
 # --------------------------------------------------------------------------

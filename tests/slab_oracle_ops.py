@@ -1,0 +1,65 @@
+"""Test double of `odil_amd.ops` for the slab driver: the same call signatures, computed by
+the NumPy oracle on CPU tensors.  Lets the world_size-2 gloo test exercise the slab
+ALGORITHM (ghost layout, exchanges, cut flags, loss partials) without a GPU."""
+
+import numpy as np
+import torch
+
+from oracle import odil_np as onp
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def interp_add(coarse, loc, add=None, coarse_scale=1.0, add_scale=1.0, out=None):
+    res = onp.interp_to_finer(_np(coarse) * coarse_scale if coarse_scale != 1.0 else _np(coarse), loc)
+    if add is not None:
+        res = _np(add) * add_scale + res if add_scale != 1.0 else _np(add) + res
+    res = torch.from_numpy(np.ascontiguousarray(res))
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def interp_adj(gfine, loc, cshape, scale=None, out=None, cut=(False, False)):
+    res = torch.from_numpy(np.ascontiguousarray(onp.interp_to_finer_adj(_np(gfine), loc, tuple(cshape), cut=cut)))
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, denom=None):
+    dw = [np.sqrt(h) for h in h2]
+    f = onp.poisson_residual(_np(u), _np(rhs), dw)
+    if zrange is None:
+        val = np.mean(np.square(f))
+    else:
+        val = np.sum(np.square(f[zrange[0] : zrange[1]])) / denom
+    f = torch.from_numpy(np.ascontiguousarray(f))
+    if fu is not None:
+        fu.copy_(f)
+    else:
+        fu = f
+    if loss is None:
+        loss = torch.zeros((), dtype=u.dtype)
+    loss.fill_(float(val))
+    return fu, loss
+
+
+def poisson_adjoint(fu, h2, scale, out=None):
+    dw = [np.sqrt(h) for h in h2]
+    g = torch.from_numpy(np.ascontiguousarray(onp.poisson_adjoint(_np(fu) * scale, dw)))
+    if out is None:
+        return g
+    out.copy_(g)
+    return out
+
+
+def adam_step(x, m, v, g, alpha, one_minus_b1, one_minus_b2, eps):
+    xn, mn, vn, gn = _np(x), _np(m), _np(v), _np(g)
+    mn += (gn - mn) * one_minus_b1
+    vn += (np.square(gn) - vn) * one_minus_b2
+    xn -= (mn * alpha) / (np.sqrt(vn) + eps)
