@@ -425,6 +425,101 @@ def gen_test_newton():
     save("test_newton", **data)
 
 
+# ---------------------------------------------------------------- heat (A8, A17) and veltracer (A9)
+def gen_heat():
+    """reference examples/heat/heat.py:operator_odil with the inverse-problem terms switched on
+    (infer_k: conductivity MLP [1,5,5,1] evaluated inside the stencil on frozen u; imposed
+    points; annealed regularisation via ctx.tracers['epoch'])."""
+    heat = load_module("ref_heat", "/root/reference/examples/heat/heat.py")
+    rng = np.random.default_rng(606)
+    for tag, dtype in [("f64", np.float64), ("f32", np.float32)]:
+        Nt, Nx = 8, 16
+        domain = odil.Domain(cshape=(Nt, Nx), dimnames=("t", "x"), multigrid=True, dtype=dtype, mod=mod)
+        args = argparse.Namespace(
+            keep_frozen=1, keep_init=1, infer_k=1, kmax=0.1, kimp=2.0, kxreg=0.3, kxregdecay=50.0, ktreg=0.2,
+            ktregdecay=0.0, kwreg=0.05, kwregdecay=10.0,
+        )
+        tt, xx = domain.points()
+        t1, x1 = domain.points_1d()
+        init_u = heat.get_init_u(T(x1 * 0), T(x1), mod)
+        ref_u = heat.get_init_u(tt, xx, mod)
+        imp_mask = (rng.random((Nt, Nx)) < 0.2).astype(dtype)
+        extra = argparse.Namespace(
+            args=args, init_u=init_u, imp_mask=T(imp_mask), imp_size=int(imp_mask.sum()), imp_u=ref_u,
+        )
+        state = odil.State()
+        state.fields["u"] = np.zeros(domain.cshape, dtype=dtype)
+        layers = [1, 5, 5, 1]
+        weights = [rng.uniform(-1, 1, (no, ni)).astype(dtype) for ni, no in zip(layers[:-1], layers[1:])]
+        biases = [rng.uniform(-0.5, 0.5, (no,)).astype(dtype) for no in layers[1:]]
+        state.fields["k_net"] = odil.NeuralNet([T(w) for w in weights], [T(b) for b in biases])
+        state = domain.init_state(state)
+        arrays = [T((rng.standard_normal(tuple(a.shape)) * 0.3).astype(dtype)) if i < domain.mg_nlvl else a
+                  for i, a in enumerate(domain.arrays_from_state(state))]
+        epoch = 7
+        arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+        domain.arrays_to_state(arrays_l, state)
+        ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": epoch})
+        ff = heat.operator_odil(ctx)
+        names = [f[0] for f in ff]
+        values = [f[1] for f in ff]
+        terms = [mod.mean(mod.square(v)) for v in values]
+        loss = sum(terms)
+        grads = torch.autograd.grad(loss, arrays_l, allow_unused=True)
+        data = dict(Nt=np.array(Nt), Nx=np.array(Nx), epoch=np.array(epoch), names=np.array(names),
+                    init_u=npy(init_u), imp_mask=imp_mask, imp_u=npy(ref_u), imp_size=np.array(extra.imp_size),
+                    loss=npy(loss), nlvl=np.array(domain.mg_nlvl))
+        for k, v in vars(args).items():
+            data[f"args/{k}"] = np.array(v)
+        for i, (a, g) in enumerate(zip(arrays, grads)):
+            data[f"x{i}"] = npy(a)
+            data[f"g{i}"] = npy(g) if g is not None else np.zeros(tuple(a.shape), dtype=dtype)
+        for n, v, t in zip(names, values, terms):
+            data[f"value/{n}"] = npy(v)
+            data[f"term/{n}"] = npy(t)
+        save(f"heat_{tag}", **data)
+
+
+def gen_veltracer():
+    """reference examples/velocity_from_tracer/veltracer.py:operator_advection: fields u, vx, vy
+    at loc 'ncc', first-order upwinding selected by the sign of the FROZEN velocity."""
+    vt = load_module("ref_veltracer", "/root/reference/examples/velocity_from_tracer/veltracer.py")
+    rng = np.random.default_rng(707)
+    for tag, dtype in [("f64", np.float64), ("f32", np.float32)]:
+        Nt, Nx, Ny = 8, 8, 8
+        domain = odil.Domain(cshape=(Nt, Nx, Ny), dimnames=("t", "x", "y"), lower=(0, 0, 0), upper=(1, 1, 1),
+                             dtype=dtype, multigrid=True, mg_interp="stack", mod=mod)
+        args = argparse.Namespace(kxreg=0.01, ktreg=1.0, kimp=10.0)
+        x, y = domain.points("x", "y", loc=".cc")
+        u_init = vt.u_init_blob(npy(x), npy(y), 0).astype(dtype)
+        u_final = vt.u_init_blob(npy(x), npy(y), 1).astype(dtype)
+        extra = argparse.Namespace(args=args, u_init=T(u_init), u_final=T(u_final))
+        state = odil.State()
+        for key in ["u", "vx", "vy"]:
+            state.fields[key] = odil.Field(None, loc="ncc")
+        state = domain.init_state(state)
+        arrays = [T((rng.standard_normal(tuple(a.shape)) * 0.3).astype(dtype)) for a in domain.arrays_from_state(state)]
+        arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+        domain.arrays_to_state(arrays_l, state)
+        ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+        ff = vt.operator_advection(ctx)
+        values = list(ff)
+        terms = [mod.mean(mod.square(v)) for v in values]
+        loss = sum(terms)
+        grads = torch.autograd.grad(loss, arrays_l, allow_unused=True)
+        data = dict(Nt=np.array(Nt), Nx=np.array(Nx), Ny=np.array(Ny), u_init=u_init, u_final=u_final,
+                    loss=npy(loss), nlvl=np.array(domain.mg_nlvl), nout=np.array(len(values)))
+        for k, v in vars(args).items():
+            data[f"args/{k}"] = np.array(v)
+        for i, (a, g) in enumerate(zip(arrays, grads)):
+            data[f"x{i}"] = npy(a)
+            data[f"g{i}"] = npy(g) if g is not None else np.zeros(tuple(a.shape), dtype=dtype)
+        for i, (v, t) in enumerate(zip(values, terms)):
+            data[f"value/{i}"] = npy(v)
+            data[f"term/{i}"] = npy(t)
+        save(f"veltracer_{tag}", **data)
+
+
 # ---------------------------------------------------------------- reference tests as known-answer checks
 def check_reference_tests():
     """tests/test_mg_interp.py:11-32 on the shim: exact on linear functions."""
@@ -456,3 +551,5 @@ if __name__ == "__main__":
     gen_lbfgsb()
     gen_newton()
     gen_test_newton()
+    gen_heat()
+    gen_veltracer()

@@ -48,8 +48,11 @@ def import_reference():
     (the real one calls exit(1) without TF/JAX, reference runtime.py:37-44)."""
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)
+    # `examples/heat/heat.py:12,317` does `from odil.runtime import tf` and decorates a plot
+    # helper with `@tf.function()`: give it an inert stand-in (never used for arithmetic).
+    fake_tf = Namespace(function=lambda *a, **k: (lambda f: f))
     attrs = dict(
-        tf=None, jax=None, enable_jit=False, backend_name="shim", dtype=np.dtype("float64"), mod=ModShim()
+        tf=fake_tf, jax=None, enable_jit=False, backend_name="shim", dtype=np.dtype("float64"), mod=ModShim()
     )
     _stub_module("odil.runtime", attrs)
     _stub_module("odil.plot", dict())
