@@ -133,6 +133,14 @@ int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape,
                              double scale, void* stream);
 int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, int ndim, const float* h2,
                              float scale, void* stream);
+/* Fused: gu = (2/size) J^T (J u - rhs) and loss[0] = mean((J u - rhs)^2) in ONE pass over u and
+ * rhs; fu is never materialised (3 words per cell instead of 5).  3-D, last extent <= 512,
+ * every extent >= 4: `odil_poisson_loss_grad_supported` tells; otherwise use residual + adjoint. */
+int odil_poisson_loss_grad_supported(const int64_t* shape, int ndim);
+int odil_poisson_loss_grad_f64(const double* u, const double* rhs, double* gu, const int64_t* shape, int ndim,
+                               const double* h2, double* partials, double* loss, void* stream);
+int odil_poisson_loss_grad_f32(const float* u, const float* rhs, float* gu, const int64_t* shape, int ndim,
+                               const float* h2, double* partials, float* loss, void* stream);
 /* Per-shift Jacobian coefficient arrays d(sum fu)/d u_shift as
  * `Problem.eval_operator_grad` returns them under `distinct_shift`
  * (core.py:1313-1361): coeffs holds 2*ndim+1 arrays of `shape`, order

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libodil_hip.so")
+LIB_PATH = os.environ.get("ODIL_HIP_LIB") or os.path.join(_HERE, "libodil_hip.so")
 
 _P = c_void_p
 _I64P = ctypes.POINTER(c_int64)
@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mean_reduce": [_P, c_int64, c_int, _P, _P, _P],
     "poisson_residual": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_residual_slab": [_P, _P, _P, _I64P, c_int, _P, c_int64, c_int64, c_double, _P, _P, _P],
+    "poisson_loss_grad": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
     "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P],
@@ -46,6 +47,7 @@ _SIGNATURES = {
 
 EXPORTED = [
     "odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes", "odil_dots_workspace_bytes",
+    "odil_poisson_loss_grad_supported",
 ] + [
     "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
 ]
@@ -75,6 +77,8 @@ def load():
     lib.odil_reduce_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.argtypes = [c_int]
+    lib.odil_poisson_loss_grad_supported.restype = c_int
+    lib.odil_poisson_loss_grad_supported.argtypes = [_I64P, c_int]
     for name, sig in _SIGNATURES.items():
         for suffix, real in (("f64", c_double), ("f32", c_float)):
             fn = getattr(lib, "odil_{}_{}".format(name, suffix))

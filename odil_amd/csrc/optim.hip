@@ -10,12 +10,12 @@ struct Vec16;
 template <>
 struct Vec16<double> {
   static constexpr int N = 2;
-  typedef double2 type;
+  typedef double type __attribute__((ext_vector_type(2)));
 };
 template <>
 struct Vec16<float> {
   static constexpr int N = 4;
-  typedef float4 type;
+  typedef float type __attribute__((ext_vector_type(4)));
 };
 
 template <typename T>
@@ -37,17 +37,30 @@ __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restric
   if (vec_ok) {
     const int64_t nv = n / V;
     for (int64_t i = tid; i < nv; i += nthreads) {
+#ifdef ODIL_NT_LOAD
+      VT xv = __builtin_nontemporal_load(reinterpret_cast<VT*>(x) + i);
+      VT mv = __builtin_nontemporal_load(reinterpret_cast<VT*>(m) + i);
+      VT vv = __builtin_nontemporal_load(reinterpret_cast<VT*>(v) + i);
+      const VT gv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(g) + i);
+#else
       VT xv = reinterpret_cast<VT*>(x)[i], mv = reinterpret_cast<VT*>(m)[i], vv = reinterpret_cast<VT*>(v)[i];
       const VT gv = reinterpret_cast<const VT*>(g)[i];
+#endif
       T* xp = reinterpret_cast<T*>(&xv);
       T* mp = reinterpret_cast<T*>(&mv);
       T* vp = reinterpret_cast<T*>(&vv);
       const T* gp = reinterpret_cast<const T*>(&gv);
 #pragma unroll
       for (int k = 0; k < V; ++k) adam_one<T>(xp[k], mp[k], vp[k], gp[k], alpha, omb1, omb2, eps);
+#ifdef ODIL_NT_STORE
+      __builtin_nontemporal_store(xv, reinterpret_cast<VT*>(x) + i);
+      __builtin_nontemporal_store(mv, reinterpret_cast<VT*>(m) + i);
+      __builtin_nontemporal_store(vv, reinterpret_cast<VT*>(v) + i);
+#else
       reinterpret_cast<VT*>(x)[i] = xv;
       reinterpret_cast<VT*>(m)[i] = mv;
       reinterpret_cast<VT*>(v)[i] = vv;
+#endif
     }
     for (int64_t i = nv * V + tid; i < n; i += nthreads) adam_one<T>(x[i], m[i], v[i], g[i], alpha, omb1, omb2, eps);
   } else {

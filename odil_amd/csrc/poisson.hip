@@ -9,9 +9,7 @@
 // L2, so HBM sees each of u, rhs once and fu once.  The loss is reduced in a fixed order
 // (per-thread running sum -> wave shuffle -> LDS -> one partial per workgroup -> final
 // kernel), so it is bit-reproducible run to run.
-#include <math.h>
-
-#include "common.h"
+#include "poisson.h"
 
 namespace odil {
 
@@ -21,74 +19,6 @@ struct StencilArgs {
   int active[3];    // axis takes part in the Laplacian
   UnitSched usched;
 };
-
-template <typename T>
-struct VecOf;
-template <>
-struct VecOf<double> {
-  static constexpr int N = 2;
-};
-template <>
-struct VecOf<float> {
-  static constexpr int N = 4;
-};
-
-template <typename T, int N>
-struct alignas(N * sizeof(T)) Pack {
-  T v[N];
-};
-
-template <typename T, int N>
-__device__ inline void load_vec(const T* __restrict__ p, int64_t valid, T out[N]) {
-  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
-    Pack<T, N> q = *reinterpret_cast<const Pack<T, N>*>(p);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = q.v[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = i < valid ? p[i] : T(0);
-  }
-}
-
-template <typename T, int N>
-__device__ inline void store_vec(T* __restrict__ p, int64_t valid, const T in[N]) {
-  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
-    Pack<T, N> q;
-#pragma unroll
-    for (int i = 0; i < N; ++i) q.v[i] = in[i];
-    *reinterpret_cast<Pack<T, N>*>(p) = q;
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (i < valid) p[i] = in[i];
-  }
-}
-
-// x / h2 -- as a multiplication when h2 is an exact power of two (bit-identical), else a
-// true division: the f64 divide is ~35 VALU instructions and three of them per cell are
-// enough to make this HBM-bound kernel VALU-bound.
-template <typename T>
-struct H2 {
-  T h2[3], inv[3];
-  int mul_ok[3];
-};
-
-template <typename T>
-__device__ inline T div_h2(T v, const H2<T>& h, int ax) {
-  return h.mul_ok[ax] ? v * h.inv[ax] : v / h.h2[ax];
-}
-
-// One axis of poisson.py:57-68 + :112: ghosts by extrap_quadh(q+-, q, 0), then (qp - 2q + qm)/h2.
-// The extrapolation (a division by 3) is evaluated only where a boundary is touched.
-template <typename T>
-__device__ inline T axis_term(T q, T qwm, T qwp, bool lo, bool hi, const H2<T>& h, int ax) {
-  T qm = qwm, qp = qwp;
-  if (lo || hi) {
-    if (lo) qm = (qwp - T(6) * q) / T(3);
-    if (hi) qp = (qwm - T(6) * q) / T(3);
-  }
-  return div_h2<T>(qp - T(2) * q + qm, h, ax);
-}
 
 // z-marching 7-point kernels.  A workgroup owns one x-segment of one row and walks a chunk
 // of planes; each lane keeps its own z-1 / z / z+1 values in registers, so every element of
@@ -166,36 +96,6 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
   }
   const double total = block_sum(local);
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-
-// Row i of the 1-D operator: cm(i) u[i-1] + c0(i) u[i] + cp(i) u[i+1], all / h2, with
-//   cm(i) = [i != 0] + [i == n-1]/3,  cp(i) = [i != n-1] + [i == 0]/3,
-//   c0(i) = -2 - 2[i == 0] - 2[i == n-1]          (poisson.py:57-68).
-// Transpose: g[j] = cm(j+1) fb[j+1] + c0(j) fb[j] + cp(j-1) fb[j-1]  (periodic indices;
-// the masked coefficients vanish exactly where the roll wraps).
-template <typename T>
-__device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, const H2<T>& h, int ax) {
-  T s;
-  if (j >= 2 && j < n - 2) {
-    // interior: (fb[j+1] + fb[j-1]) - 2 fb[j]
-    s = (fbp + fbm) + T(-2) * fb;
-  } else {
-    const int64_t jp = j == n - 1 ? 0 : j + 1;
-    const int64_t jm = j == 0 ? n - 1 : j - 1;
-    s = T(0);
-    // from row jp: cm(jp) * fb[jp]
-    if (jp != 0) s = s + fbp;
-    if (jp == n - 1) s = s + fbp / T(3);
-    // from row jm: cp(jm) * fb[jm]
-    if (jm != n - 1) s = s + fbm;
-    if (jm == 0) s = s + fbm / T(3);
-    // from row j
-    T c0 = T(-2);
-    if (j == 0) c0 = c0 - T(2);
-    if (j == n - 1) c0 = c0 - T(2);
-    s = s + c0 * fb;
-  }
-  return div_h2<T>(s, h, ax);
 }
 
 template <typename T>
@@ -276,18 +176,6 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jac(T* __restrict__ coeffs, 
     }
     coeffs[i] = c0;
   }
-}
-
-template <typename T>
-static H2<T> make_h2(const T h[3]) {
-  H2<T> r;
-  for (int i = 0; i < 3; ++i) {
-    int e;
-    r.h2[i] = h[i];
-    r.inv[i] = T(1) / h[i];
-    r.mul_ok[i] = frexp((double)h[i], &e) == 0.5 && r.inv[i] * h[i] == T(1);
-  }
-  return r;
 }
 
 template <typename T>

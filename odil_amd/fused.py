@@ -47,6 +47,9 @@ class PoissonEvaluator:
             : self.nlvl
         ]
         self.scale = self.npdt(2) / self.npdt(self.fu.numel())
+        import os
+
+        self.one_pass = ops.poisson_loss_grad_supported(self.cshape) and bool(int(os.environ.get("ODIL_ONE_PASS", 0)))
 
     def loss_grad_arrays(self, arrays, timers=None):
         """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer)."""
@@ -68,12 +71,17 @@ class PoissonEvaluator:
             toc(b)
         else:
             u = arrays[0]
-        b = tic("residual")
-        ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
-        toc(b)
-        b = tic("adjoint")
-        ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
-        toc(b)
+        if self.one_pass:
+            b = tic("loss_grad")
+            ops.poisson_loss_grad(u, self.rhs, self.h2, out=self.gw[0], loss=self.loss)
+            toc(b)
+        else:
+            b = tic("residual")
+            ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
+            toc(b)
+            b = tic("adjoint")
+            ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+            toc(b)
         if self.nlvl > 1:
             b = tic("mg_synth_adj")
             ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)

@@ -203,6 +203,25 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
     return fu, loss
 
 
+def poisson_loss_grad_supported(shape):
+    return bool(_lib.load().odil_poisson_loss_grad_supported(i64(shape), c_int(len(shape))))
+
+
+def poisson_loss_grad(u, rhs, h2, out=None, loss=None):
+    """Fused gu = (2/size) J^T (J u - rhs), loss = mean((J u - rhs)^2) without materialising fu."""
+    assert u.shape == rhs.shape and u.dtype == rhs.dtype
+    if out is None:
+        out = torch.empty_like(u)
+    if loss is None:
+        loss = torch.empty((), dtype=u.dtype, device=u.device)
+    h2a, h2p = host_reals(h2, u.dtype)
+    call(
+        "poisson_loss_grad", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p,
+        ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
+    )
+    return out, loss
+
+
 def poisson_adjoint(fu, h2, scale, out=None):
     """gu = J^T (scale * fu)."""
     if out is None:

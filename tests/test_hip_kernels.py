@@ -189,6 +189,8 @@ def test_poisson_ragged_shapes_vs_oracle(dev, shape, dtype):
     fref = onp.poisson_residual(u, rhs, dw)
     tol = 1e-14 if dtype == np.float64 else 1e-6
     assert rel(fu, fref) < tol
+    # same operation order, no FMA contraction, exact x/3: the residual is BIT-IDENTICAL to NumPy's
+    assert np.array_equal(fu.cpu().numpy(), fref), "residual differs from the oracle in the last bits"
     lref = np.mean(np.square(fref.astype(np.float64)))
     assert abs(float(loss) - lref) <= (1e-13 if dtype == np.float64 else 1e-6) * lref
     fb = rng.standard_normal(shape).astype(dtype)
@@ -348,3 +350,28 @@ def test_large_roundtrip_properties(dev):
     g2 = ops.poisson_adjoint(f2, h2, 1.0)
     a, b = float((f1 * f2).sum()), float((u1 * g2).sum())
     assert abs(a - b) <= 1e-10 * abs(a)
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 4), (5, 7, 9), (16, 16, 16), (6, 9, 512), (12, 5, 130), (70, 6, 33)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_poisson_fused_loss_grad_vs_two_kernel_path_and_oracle(dev, shape, dtype):
+    from odil_amd import ops
+
+    assert ops.poisson_loss_grad_supported(shape)
+    assert not ops.poisson_loss_grad_supported((8, 8)) and not ops.poisson_loss_grad_supported((8, 8, 600))
+    rng = np.random.default_rng(17)
+    dw = onp.step(shape, dtype=dtype)
+    h2 = [d**2 for d in dw]
+    u = rng.standard_normal(shape).astype(dtype)
+    rhs = rng.standard_normal(shape).astype(dtype)
+    tu, trhs = to(u, dev), to(rhs, dev)
+    g1, loss1 = ops.poisson_loss_grad(tu, trhs, h2)
+    fu, loss2 = ops.poisson_residual(tu, trhs, h2)
+    g2 = ops.poisson_adjoint(fu, h2, dtype(2) / dtype(fu.numel()))
+    # same operation order as the two-kernel path: identical values
+    assert np.array_equal(g1.cpu().numpy(), g2.cpu().numpy())
+    tol = 1e-14 if dtype == np.float64 else 1e-6
+    assert abs(float(loss1) - float(loss2)) <= tol * abs(float(loss2))
+    fref = onp.poisson_residual(u, rhs, dw)
+    gref = onp.poisson_adjoint(2 * fref / fref.size, dw)
+    assert rel(g1, gref) < (1e-13 if dtype == np.float64 else 1e-5)
