@@ -133,6 +133,15 @@ int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape,
                              double scale, void* stream);
 int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, int ndim, const float* h2,
                              float scale, void* stream);
+/* The same adjoint with the Adam update of the array that gu is the gradient of fused in
+ * (AdamNativeOptimizer._step, optimizer.py:316-318, applied by the lane that forms gu[i]):
+ * gu is still written (the P^T chain reads it); x, m, v are updated in place. */
+int odil_poisson_adjoint_adam_f64(const double* fu, double* gu, double* x, double* m, double* v, const int64_t* shape,
+                                  int ndim, const double* h2, double scale, double alpha, double one_minus_b1,
+                                  double one_minus_b2, double eps, void* stream);
+int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m, float* v, const int64_t* shape,
+                                  int ndim, const float* h2, float scale, float alpha, float one_minus_b1,
+                                  float one_minus_b2, float eps, void* stream);
 /* Fused: gu = (2/size) J^T (J u - rhs) and loss[0] = mean((J u - rhs)^2) in ONE pass over u and
  * rhs; fu is never materialised (3 words per cell instead of 5).  3-D, last extent <= 512,
  * every extent >= 4: `odil_poisson_loss_grad_supported` tells; otherwise use residual + adjoint. */

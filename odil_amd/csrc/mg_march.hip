@@ -149,48 +149,72 @@ __device__ inline Adj6 adj6(int J, int n) {
   return t;
 }
 
-// (y, x) reduction of fine plane f for the coarse column (jy, jx): rc with the C weights,
-// rr with the R weights (only evaluated when the column touches a boundary in y or x).
-template <typename T>
-__device__ inline void reduce_plane(const T* __restrict__ gfine, int f, int fnz, int64_t fplane, int fny, int fnx,
-                                    int jy, int jx, const Adj6& ay, const Adj6& ax, bool xy_special, T& rc, T& rr) {
-  rc = T(0);
-  rr = T(0);
-  if (f < 0 || f >= fnz) return;
-  const T* gp = gfine + (int64_t)f * fplane;
+// (y, x) reduction of fine planes for the coarse column (jy, jx): rc with the C weights, rr
+// with the R weights.  All row loads of a call are issued back to back (addresses clamped into
+// range; out-of-range rows / pairs carry zero weights), and only then reduced: the kernel is
+// bound by how many HBM requests a wave keeps in flight, so loads must not sit behind branches.
+template <typename T, int NR, int NP>
+__device__ inline void reduce_planes(const T* __restrict__ gfine, const int (&f)[NP], int fnz, int64_t fplane, int fny,
+                                     int fnx, int jy, int jx, const Adj6& ay, const Adj6& ax, T (&rc)[NP],
+                                     T (&rr)[NP]) {
+  constexpr int R0 = (6 - NR) / 2;  // first row of the window that is loaded (NR = 4: rows 1..4)
+  Pack2<T> g[NP][NR][3];
 #pragma unroll
-  for (int iy = 0; iy < 6; ++iy) {
-    if (ay.wc[iy] == 0.f && ay.wr[iy] == 0.f) continue;
-    const T* row = gp + (int64_t)(2 * jy - 2 + iy) * fnx;
-    T g[6];
+  for (int p = 0; p < NP; ++p) {
+    const int fz = f[p] < 0 ? 0 : (f[p] >= fnz ? fnz - 1 : f[p]);
+    const T* gp = gfine + (int64_t)fz * fplane;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int fx = 2 * (jx - 1 + q);
-      if (fx >= 0 && fx < fnx) {
-        const Pack2<T> pk = *reinterpret_cast<const Pack2<T>*>(row + fx);
-        g[2 * q] = pk.a;
-        g[2 * q + 1] = pk.b;
-      } else {
-        g[2 * q] = g[2 * q + 1] = T(0);
+    for (int r = 0; r < NR; ++r) {
+      int fy = 2 * jy - 2 + R0 + r;
+      fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);
+      const T* row = gp + (int64_t)fy * fnx;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        int fx = 2 * (jx - 1 + q);
+        fx = fx < 0 ? 0 : (fx >= fnx ? fnx - 2 : fx);
+        g[p][r][q] = *reinterpret_cast<const Pack2<T>*>(row + fx);
       }
     }
-    T xc, xr;
-    if (!ax.special) {
-      xc = (T(0.25) * g[1] + T(0.75) * g[2]) + (T(0.75) * g[3] + T(0.25) * g[4]);
-      xr = xc;
-    } else {
-      xc = T(0);
-      xr = T(0);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        xc = xc + T(ax.wc[i]) * g[i];
-        xr = xr + T(ax.wr[i]) * g[i];
-      }
-    }
-    rc = rc + T(ay.wc[iy]) * xc;
-    if (xy_special) rr = rr + T(ay.wr[iy]) * xr;
   }
-  if (!xy_special) rr = rc;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    T sc = T(0), sr = T(0);
+    const bool inside = f[p] >= 0 && f[p] < fnz;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      T xc = T(0), xr = T(0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        xc = xc + T(ax.wc[2 * q]) * g[p][r][q].a;
+        xc = xc + T(ax.wc[2 * q + 1]) * g[p][r][q].b;
+        xr = xr + T(ax.wr[2 * q]) * g[p][r][q].a;
+        xr = xr + T(ax.wr[2 * q + 1]) * g[p][r][q].b;
+      }
+      sc = sc + T(ay.wc[R0 + r]) * xc;
+      sr = sr + T(ay.wr[R0 + r]) * xr;
+    }
+    rc[p] = inside ? sc : T(0);
+    rr[p] = inside ? sr : T(0);
+  }
+}
+
+template <typename T, int NP>
+__device__ inline void reduce_dispatch(const T* __restrict__ gfine, const int (&f)[NP], int fnz, int64_t fplane,
+                                       int fny, int fnx, int jy, int jx, const Adj6& ay, const Adj6& ax, T (&rc)[NP],
+                                       T (&rr)[NP]) {
+  if (ay.special) {
+    // boundary rows need the 6-row window: one plane at a time keeps the register count down
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int f1[1] = {f[p]};
+      T c1[1], r1[1];
+      reduce_planes<T, 6, 1>(gfine, f1, fnz, fplane, fny, fnx, jy, jx, ay, ax, c1, r1);
+      rc[p] = c1[0];
+      rr[p] = r1[0];
+    }
+  } else {
+    reduce_planes<T, 4, NP>(gfine, f, fnz, fplane, fny, fnx, jy, jx, ay, ax, rc, rr);
+  }
 }
 
 template <typename T>
@@ -210,12 +234,21 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
   const bool xy_special = ax.special || ay.special;
   // window of plane sums for fine planes 2jz-2 .. 2jz+3
   T wc[6], wr[6];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    reduce_plane<T>(gfine, 2 * z0 - 2 + i, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[i], wr[i]);
+  {
+    T c2[2], r2[2];
+    const int fa[2] = {2 * z0 - 2, 2 * z0 - 1}, fb[2] = {2 * z0, 2 * z0 + 1};
+    reduce_dispatch<T, 2>(gfine, fa, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+    wc[0] = c2[0], wc[1] = c2[1], wr[0] = r2[0], wr[1] = r2[1];
+    reduce_dispatch<T, 2>(gfine, fb, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+    wc[2] = c2[0], wc[3] = c2[1], wr[2] = r2[0], wr[3] = r2[1];
+  }
   for (int jz = z0; jz < z1; ++jz) {
-    reduce_plane<T>(gfine, 2 * jz + 2, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[4], wr[4]);
-    reduce_plane<T>(gfine, 2 * jz + 3, fnz, fplane, fny, fnx, jy, jx, ay, ax, xy_special, wc[5], wr[5]);
+    {
+      T c2[2], r2[2];
+      const int fn2[2] = {2 * jz + 2, 2 * jz + 3};
+      reduce_dispatch<T, 2>(gfine, fn2, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+      wc[4] = c2[0], wc[5] = c2[1], wr[4] = r2[0], wr[5] = r2[1];
+    }
     const bool z_special = ((jz == 0 || jz == 1) && !a.cut_lo) || ((jz == cnz - 2 || jz == cnz - 1) && !a.cut_hi);
     T v;
     if (!z_special && !xy_special) {

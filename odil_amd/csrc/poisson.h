@@ -23,45 +23,31 @@ struct alignas(N * sizeof(T)) Pack {
   T v[N];
 };
 
-template <typename T, int N>
+// Row-segment loads / stores of N consecutive values.  FULL (every active lane owns N valid
+// cells; decided on the host from X % N) compiles to one unconditional wide access per call, so
+// the loads of a step sit in one basic block and are all in flight together; global memory on
+// gfx950 needs only element alignment for a wide access.  !FULL is the ragged-tail path.
+template <typename T, int N, bool FULL>
 __device__ inline void load_vec(const T* __restrict__ p, int64_t valid, T out[N]) {
-  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
-    Pack<T, N> q = *reinterpret_cast<const Pack<T, N>*>(p);
+  if (FULL) {
+    typedef T VT __attribute__((ext_vector_type(N), aligned(sizeof(T))));
+    const VT q = *reinterpret_cast<const VT*>(p);
 #pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = q.v[i];
+    for (int i = 0; i < N; ++i) out[i] = q[i];
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = i < valid ? p[i] : T(0);
   }
 }
 
-// Streaming (non-temporal) access for data that is touched once per launch, so it does not
-// evict the neighbour rows / planes the stencils re-read from L2.
-template <typename V>
-__device__ inline void stream_store(V* p, const V& v) {
-#ifdef ODIL_NT_STORE
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-template <typename V>
-__device__ inline V stream_load(const V* p) {
-#ifdef ODIL_NT_LOAD
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-
-template <typename T, int N>
+template <typename T, int N, bool FULL>
 __device__ inline void store_vec(T* __restrict__ p, int64_t valid, const T in[N]) {
-  if (valid >= N && (reinterpret_cast<uintptr_t>(p) % (N * sizeof(T))) == 0) {
-    typedef T VT __attribute__((ext_vector_type(N)));
+  if (FULL) {
+    typedef T VT __attribute__((ext_vector_type(N), aligned(sizeof(T))));
     VT q;
 #pragma unroll
     for (int i = 0; i < N; ++i) q[i] = in[i];
-    stream_store(reinterpret_cast<VT*>(p), q);
+    *reinterpret_cast<VT*>(p) = q;
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -141,6 +127,24 @@ __device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, const H2<
     s = s + c0 * fb;
   }
   return div_h2<T>(s, h, ax);
+}
+
+// Optional Adam update of the finest level fused into the adjoint kernel (the lane that forms
+// gu[i] also owns x[i], m[i], v[i]): saves re-reading gu in the optimizer launch.
+template <typename T>
+struct AdamArgs {
+  T* x;
+  T* m;
+  T* v;
+  T alpha, omb1, omb2, eps;
+};
+
+template <typename T>
+__device__ inline void adam_update(T& x, T& m, T& v, T g, const AdamArgs<T>& a) {
+  // reference optimizer.py:316-318
+  m = m + (g - m) * a.omb1;
+  v = v + (g * g - v) * a.omb2;
+  x = x - (m * a.alpha) / (sqrt(v) + a.eps);
 }
 
 template <typename T>

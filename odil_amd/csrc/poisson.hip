@@ -24,7 +24,7 @@ struct StencilArgs {
 // of planes; each lane keeps its own z-1 / z / z+1 values in registers, so every element of
 // the marched array is loaded once by its owner (+ once per y-neighbour, an L2 hit inside
 // the XCD).  Loads of the next plane are issued before the current plane is consumed.
-template <typename T>
+template <typename T, bool FULL>
 __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict__ u, const T* __restrict__ rhs,
                                                             T* __restrict__ fu, StencilArgs a, H2<T> h,
                                                             double* __restrict__ partials) {
@@ -45,16 +45,16 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
     const int64_t xl = y * sy + (x0 == 0 ? X - 1 : x0 - 1);
     const int64_t xr = y * sy + (x0 + valid >= X ? 0 : x0 + valid);
     T um[V], uc[V], up[V];
-    if (a.active[0]) load_vec<T, V>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
-    load_vec<T, V>(u + z0 * sz + c_off, valid, uc);
+    if (a.active[0]) load_vec<T, V, FULL>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
+    load_vec<T, V, FULL>(u + z0 * sz + c_off, valid, uc);
     for (int64_t z = z0; z < z1; ++z) {
       const int64_t pz = z * sz;
-      if (a.active[0]) load_vec<T, V>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
+      if (a.active[0]) load_vec<T, V, FULL>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
       T r[V], ym[V], yp[V], out[V];
-      load_vec<T, V>(rhs + pz + c_off, valid, r);
+      load_vec<T, V, FULL>(rhs + pz + c_off, valid, r);
       if (a.active[1]) {
-        load_vec<T, V>(u + pz + ym_off, valid, ym);
-        load_vec<T, V>(u + pz + yp_off, valid, yp);
+        load_vec<T, V, FULL>(u + pz + ym_off, valid, ym);
+        load_vec<T, V, FULL>(u + pz + yp_off, valid, yp);
       }
       // x neighbours of the pack: periodic like mod.roll (core.py:963); the wrapped values
       // are discarded by the where() masks exactly as in the reference.
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
         out[i] = f;
         if (z >= a.loss_z0 && z < a.loss_z1) local += (double)(f * f);
       }
-      if (fu) store_vec<T, V>(fu + pz + c_off, valid, out);
+      if (fu) store_vec<T, V, FULL>(fu + pz + c_off, valid, out);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         um[i] = uc[i];
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-template <typename T>
+template <typename T, bool FULL>
 __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict__ fu, T* __restrict__ gu,
-                                                           StencilArgs a, H2<T> h, T scale) {
+                                                           StencilArgs a, H2<T> h, T scale, AdamArgs<T> ad) {
   constexpr int V = VecOf<T>::N;
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
@@ -117,15 +117,15 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict_
   const int64_t xl = y * sy + (x0 == 0 ? X - 1 : x0 - 1);
   const int64_t xr = y * sy + (x0 + valid >= X ? 0 : x0 + valid);
   T fm[V], fc[V], fp[V];
-  if (a.active[0]) load_vec<T, V>(fu + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, fm);
-  load_vec<T, V>(fu + z0 * sz + c_off, valid, fc);
+  if (a.active[0]) load_vec<T, V, FULL>(fu + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, fm);
+  load_vec<T, V, FULL>(fu + z0 * sz + c_off, valid, fc);
   for (int64_t z = z0; z < z1; ++z) {
     const int64_t pz = z * sz;
-    if (a.active[0]) load_vec<T, V>(fu + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, fp);
+    if (a.active[0]) load_vec<T, V, FULL>(fu + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, fp);
     T ym[V], yp[V], out[V];
     if (a.active[1]) {
-      load_vec<T, V>(fu + pz + ym_off, valid, ym);
-      load_vec<T, V>(fu + pz + yp_off, valid, yp);
+      load_vec<T, V, FULL>(fu + pz + ym_off, valid, ym);
+      load_vec<T, V, FULL>(fu + pz + yp_off, valid, yp);
     }
     const T left = fu[pz + xl];
     const T right = fu[pz + xr];
@@ -142,7 +142,18 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict_
       g = g + adj_axis<T>(fb, xm, xp, x, X, h, 2);
       out[i] = g;
     }
-    store_vec<T, V>(gu + pz + c_off, valid, out);
+    store_vec<T, V, FULL>(gu + pz + c_off, valid, out);
+    if (ad.x) {
+      T xv[V], mv[V], vv[V];
+      load_vec<T, V, FULL>(ad.x + pz + c_off, valid, xv);
+      load_vec<T, V, FULL>(ad.m + pz + c_off, valid, mv);
+      load_vec<T, V, FULL>(ad.v + pz + c_off, valid, vv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) adam_update<T>(xv[i], mv[i], vv[i], out[i], ad);
+      store_vec<T, V, FULL>(ad.x + pz + c_off, valid, xv);
+      store_vec<T, V, FULL>(ad.m + pz + c_off, valid, mv);
+      store_vec<T, V, FULL>(ad.v + pz + c_off, valid, vv);
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       fm[i] = fc[i];
@@ -234,15 +245,20 @@ static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shap
     return ODIL_E_INVAL;
   }
   const int grid = unit_grid(a.usched);
-  hipLaunchKernelGGL(k_poisson_residual<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a,
-                     make_h2<T>(h), partials);
+  if (a.n[2] % VecOf<T>::N == 0)
+    hipLaunchKernelGGL((k_poisson_residual<T, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu, a,
+                       make_h2<T>(h), partials);
+  else
+    hipLaunchKernelGGL((k_poisson_residual<T, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, fu,
+                       a, make_h2<T>(h), partials);
   if (int e = check_launch("k_poisson_residual")) return e;
   const double size = denom > 0.0 ? denom : (double)(a.n[0] * a.n[1] * a.n[2]);
   return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
 }
 
 template <typename T>
-static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, const T* h2, T scale, void* stream) {
+static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, const T* h2, T scale, void* stream,
+                           AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0)}) {
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
@@ -250,8 +266,12 @@ static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, c
     set_error("poisson_adjoint: null pointer");
     return ODIL_E_INVAL;
   }
-  hipLaunchKernelGGL(k_poisson_adjoint<T>, dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream, fu, gu, a,
-                     make_h2<T>(h), scale);
+  if (a.n[2] % VecOf<T>::N == 0)
+    hipLaunchKernelGGL((k_poisson_adjoint<T, true>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream,
+                       fu, gu, a, make_h2<T>(h), scale, ad);
+  else
+    hipLaunchKernelGGL((k_poisson_adjoint<T, false>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream,
+                       fu, gu, a, make_h2<T>(h), scale, ad);
   return check_launch("k_poisson_adjoint");
 }
 
@@ -300,6 +320,26 @@ int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape,
 int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, int ndim, const float* h2,
                              float scale, void* stream) {
   return poisson_adjoint<float>(fu, gu, shape, ndim, h2, scale, stream);
+}
+int odil_poisson_adjoint_adam_f64(const double* fu, double* gu, double* x, double* m, double* v, const int64_t* shape,
+                                  int ndim, const double* h2, double scale, double alpha, double one_minus_b1,
+                                  double one_minus_b2, double eps, void* stream) {
+  if (!x || !m || !v) {
+    set_error("poisson_adjoint_adam: null pointer");
+    return ODIL_E_INVAL;
+  }
+  return poisson_adjoint<double>(fu, gu, shape, ndim, h2, scale, stream,
+                                 AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+}
+int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m, float* v, const int64_t* shape,
+                                  int ndim, const float* h2, float scale, float alpha, float one_minus_b1,
+                                  float one_minus_b2, float eps, void* stream) {
+  if (!x || !m || !v) {
+    set_error("poisson_adjoint_adam: null pointer");
+    return ODIL_E_INVAL;
+  }
+  return poisson_adjoint<float>(fu, gu, shape, ndim, h2, scale, stream,
+                                AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
 }
 int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream) {
   return poisson_jac<double>(coeffs, shape, ndim, h2, stream);

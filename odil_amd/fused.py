@@ -51,8 +51,10 @@ class PoissonEvaluator:
 
         self.one_pass = ops.poisson_loss_grad_supported(self.cshape) and bool(int(os.environ.get("ODIL_ONE_PASS", 0)))
 
-    def loss_grad_arrays(self, arrays, timers=None):
-        """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer)."""
+    def loss_grad_arrays(self, arrays, timers=None, adam0=None):
+        """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer).
+        adam0 = (m0, v0, alpha, 1-b1, 1-b2, eps): also apply the Adam update of the finest level
+        array inside the adjoint launch (the caller then updates only the coarser levels)."""
 
         def tic(name):
             if timers is None:
@@ -80,7 +82,12 @@ class PoissonEvaluator:
             ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
             toc(b)
             b = tic("adjoint")
-            ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+            if adam0 is not None:
+                m0, v0, alpha, omb1, omb2, eps = adam0
+                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], m0, v0, alpha, omb1,
+                                         omb2, eps)
+            else:
+                ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
             toc(b)
         if self.nlvl > 1:
             b = tic("mg_synth_adj")
@@ -94,6 +101,21 @@ class PoissonEvaluator:
         arrays = [a if a.is_contiguous() else a.contiguous() for a in arrays]
         loss, grads = self.loss_grad_arrays(arrays)
         return loss, list(grads), [loss], self.names, [torch.sqrt(loss)]
+
+
+    def eval_loss_grad_adam(self, state, m, v, alpha, omb1, omb2, eps):
+        """eval_loss_grad + the Adam step of the finest level inside the adjoint launch.
+        Returns (..., done=1) or None when this configuration cannot fuse."""
+        import os
+
+        if self.nlvl < 2 or self.one_pass or not int(os.environ.get("ODIL_FUSE_ADAM0", 1)):
+            return None
+        (field,) = state.fields.values()
+        arrays = [t.array for t in field.terms]
+        if not all(a.is_contiguous() for a in arrays) or not (m[0].is_contiguous() and v[0].is_contiguous()):
+            return None
+        loss, grads = self.loss_grad_arrays(arrays, adam0=(m[0], v[0], alpha, omb1, omb2, eps))
+        return loss, list(grads), [loss], self.names, [torch.sqrt(loss)], 1
 
 
 def _close(a, b, rtol):

@@ -231,6 +231,18 @@ def poisson_adjoint(fu, h2, scale, out=None):
     return out
 
 
+def poisson_adjoint_adam(fu, h2, scale, out, x, m, v, alpha, one_minus_b1, one_minus_b2, eps):
+    """gu = J^T (scale * fu) written to `out`, and the Adam step of (x, m, v) with that gradient,
+    in the same launch (x, m, v: arrays of fu's shape, updated in place)."""
+    assert x.shape == fu.shape and m.numel() == v.numel() == fu.numel()
+    h2a, h2p = host_reals(h2, fu.dtype)
+    call(
+        "poisson_adjoint_adam", fu.dtype, ptr(fu), ptr(out), ptr(x), ptr(m), ptr(v), i64(fu.shape), c_int(fu.dim()),
+        h2p, float(scale), float(alpha), float(one_minus_b1), float(one_minus_b2), float(eps), stream_ptr(),
+    )
+    return out
+
+
 def poisson_jac_coeffs(shape, h2, dtype, device):
     """(2*ndim+1, *shape) coefficient arrays [centre, -1 ax0, +1 ax0, ...] (reference core.py:1313-1361)."""
     ndim = len(shape)

@@ -101,18 +101,30 @@ class AdamNativeOptimizer(Optimizer):
         mf = torch.zeros_like(xf)
         vf = torch.zeros_like(xf)
         gf, gviews = None, None
+        mviews = [t.view(a.shape) for t, a in zip(mf.split([a.numel() for a in x]), x)]
+        vviews = [t.view(a.shape) for t, a in zip(vf.split([a.numel() for a in x]), x)]
         for epoch in range(epoch_start + 1, epoch_start + epochs + 1):
             self.evals += 1
-            loss, grads, pinfo = loss_grad(x)
+            t = npdt(epoch - epoch_start)
+            alpha = lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
+            # A recognised problem may apply the update of its leading arrays inside its own
+            # gradient launch (core.Problem / fused.py): it then tells how many were done.
+            fused = getattr(loss_grad, "fused_adam", None)
+            done = 0
+            if fused is not None:
+                res = fused(x, mviews, vviews, alpha, 1 - beta_1, 1 - beta_2, epsilon)
+                if res is not None:
+                    loss, grads, pinfo, done = res
+            if not done:
+                loss, grads, pinfo = loss_grad(x)
             g = flat_base(grads)
             if g is None or g.dtype != tdtype or g.numel() != xf.numel():
                 if gf is None:
                     gf, gviews = pack_like(x)
                 copy_into(gf, gviews, grads)
                 g = gf
-            t = npdt(epoch - epoch_start)
-            alpha = lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
-            ops.adam_step(xf, mf, vf, g, alpha, 1 - beta_1, 1 - beta_2, epsilon)
+            n0 = sum(int(a.numel()) for a in x[:done])
+            ops.adam_step(xf[n0:], mf[n0:], vf[n0:], g[n0:], alpha, 1 - beta_1, 1 - beta_2, epsilon)
             if epoch > 0 and callback is not None:
                 callback(x, epoch, pinfo)
         optinfo = Namespace()

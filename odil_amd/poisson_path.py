@@ -49,7 +49,7 @@ def hat_reference(cshape, dtype, device):
 
 class PoissonMultigridAdam:
     def __init__(self, ndim, N, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7, multigrid=True):
+                 epsilon=1e-7, multigrid=True, rhs=None):
         self.ndim, self.N, self.dtype, self.device = ndim, N, dtype, device
         self.loc = "c" * ndim
         cshape = (N,) * ndim
@@ -72,26 +72,42 @@ class PoissonMultigridAdam:
         # rhs = discrete Laplacian of the reference solution (poisson.py:71-86): same kernel, rhs = 0
         ref_u = hat_reference(cshape, dtype, device)
         self.ref_u = ref_u
-        rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        if rhs is None:
+            rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
         self.ev = PoissonEvaluator(cshape, self.shapes, rhs, self.h2, name="", dtype=dtype, device=device)
         self.g = self.ev.g
         self.loss = self.ev.loss
         self.lr, self.b1, self.b2, self.eps = npdt(lr), npdt(beta_1), npdt(beta_2), epsilon
         self.t = 0
+        import os
+
+        self.fuse_adam0 = bool(int(os.environ.get("ODIL_FUSE_ADAM0", 1)))
 
     def loss_grad(self, timers=None):
         loss, _ = self.ev.loss_grad_arrays(self.w, timers)
         return loss
 
     def epoch(self, timers=None):
-        self.loss_grad(timers)
         self.t += 1
         t = self.npdt(self.t)
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)  # optimizer.py:313-315
+        omb1, omb2 = 1 - self.b1, 1 - self.b2
+        n0 = self.sizes[0]
+        fuse0 = self.fuse_adam0 and not self.ev.one_pass and self.nlvl > 1
+        if fuse0:
+            # the finest level is updated by the lane that forms its gradient (adjoint launch);
+            # the optimizer launch below covers only the coarser levels
+            m0, v0 = self.m[:n0].view(self.shapes[0]), self.v[:n0].view(self.shapes[0])
+            self.ev.loss_grad_arrays(self.w, timers, adam0=(m0, v0, alpha, omb1, omb2, self.eps))
+        else:
+            self.loss_grad(timers)
         if timers is not None:
             a, b = timers.section("adam")
             a.record()
-        ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        if fuse0:
+            ops.adam_step(self.x[n0:], self.m[n0:], self.v[n0:], self.g[n0:], alpha, omb1, omb2, self.eps)
+        else:
+            ops.adam_step(self.x, self.m, self.v, self.g, alpha, omb1, omb2, self.eps)
         if timers is not None:
             b.record()
 

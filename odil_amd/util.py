@@ -311,6 +311,21 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
         loss, grads, terms, names, norms = problem.eval_loss_grad_device(state)
         return loss, grads, _pinfo(loss, terms, names, norms)
 
+    def fused_adam(arrays, m, v, alpha, omb1, omb2, eps):
+        """loss + gradient with the Adam update of the leading array(s) applied inside the fused
+        gradient launch; None when the problem has no fused evaluator that can do it."""
+        ev = getattr(problem, "_fused", None)
+        if ev is None or not hasattr(ev, "eval_loss_grad_adam"):
+            return None
+        domain.arrays_to_state(arrays, state)
+        res = ev.eval_loss_grad_adam(state, m, v, alpha, omb1, omb2, eps)
+        if res is None:
+            return None
+        loss, grads, terms, names, norms, done = res
+        return loss, grads, _pinfo(loss, terms, names, norms), done
+
+    loss_grad.fused_adam = fused_adam
+
     def callback_wrap(arrays, epoch, pinfo):
         domain.arrays_to_state(arrays, state)
         callback(state, epoch, pinfo)

@@ -375,3 +375,33 @@ def test_poisson_fused_loss_grad_vs_two_kernel_path_and_oracle(dev, shape, dtype
     fref = onp.poisson_residual(u, rhs, dw)
     gref = onp.poisson_adjoint(2 * fref / fref.size, dw)
     assert rel(g1, gref) < (1e-13 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_device_resident_adam_driver_vs_golden(dev, fuse, monkeypatch):
+    """The bench driver (packed state, optional Adam-in-adjoint fusion) follows the reference's
+    AdamNativeOptimizer trajectory (1e-6 rel) and both variants agree bit for bit."""
+    from odil_amd.poisson_path import PoissonMultigridAdam
+
+    monkeypatch.setenv("ODIL_FUSE_ADAM0", str(fuse))
+    finals = []
+    for name in ["poisson_2d_N32", "poisson_3d_N16"]:
+        g = load_golden(name)
+        ref = g["adam/losses"]
+        run = PoissonMultigridAdam(int(g["ndim"]), int(g["N"]), device=dev, rhs=to(g["rhs"], dev))
+        assert run.fuse_adam0 == bool(fuse)
+        losses = []
+        for _ in range(len(ref)):
+            run.epoch()
+            losses.append(run.last_loss())
+        assert np.max(np.abs(np.array(losses) - ref) / ref) < 1e-6, name
+        for i in range(int(g["nlvl"])):
+            assert rel(run.w[i], g[f"adam/w{i}"]) < 1e-7
+        finals.append(run.x.clone())
+    test_device_resident_adam_driver_vs_golden.results = getattr(
+        test_device_resident_adam_driver_vs_golden, "results", {})
+    test_device_resident_adam_driver_vs_golden.results[fuse] = finals
+    res = test_device_resident_adam_driver_vs_golden.results
+    if 0 in res and 1 in res:
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)
