@@ -16,6 +16,25 @@ struct alignas(2 * sizeof(T)) Pack2 {
   T a, b;
 };
 
+// touch-once streams (fine addend in, fine result out) bypass L2 retention
+template <typename T>
+__device__ inline Pack2<T> stream_ld(const Pack2<T>* p) {
+  typedef T VT __attribute__((ext_vector_type(2)));
+  const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(p));
+  Pack2<T> r;
+  r.a = v[0];
+  r.b = v[1];
+  return r;
+}
+template <typename T>
+__device__ inline void stream_st(Pack2<T>* p, const Pack2<T>& x) {
+  typedef T VT __attribute__((ext_vector_type(2)));
+  VT v;
+  v[0] = x.a;
+  v[1] = x.b;
+  __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
+}
+
 struct MarchArgs {
   int cn[3], fn[3];  // (z, y, x) coarse / fine extents
   int tx, ty;
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
       for (int sz = 0; sz < 2; ++sz)
 #pragma unroll
         for (int sy = 0; sy < 2; ++sy)
-          ad[sz][sy] = *reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx);
+          ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx));
     }
     load_plane9<T>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[2]);
 #pragma unroll
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
         Pack2<T> pk;
         pk.a = o[0];
         pk.b = o[1];
-        *reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx) = pk;
+        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk);
       }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)

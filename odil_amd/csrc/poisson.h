@@ -27,11 +27,11 @@ struct alignas(N * sizeof(T)) Pack {
 // cells; decided on the host from X % N) compiles to one unconditional wide access per call, so
 // the loads of a step sit in one basic block and are all in flight together; global memory on
 // gfx950 needs only element alignment for a wide access.  !FULL is the ragged-tail path.
-template <typename T, int N, bool FULL>
+template <typename T, int N, bool FULL, bool STREAM = false>
 __device__ inline void load_vec(const T* __restrict__ p, int64_t valid, T out[N]) {
   if (FULL) {
     typedef T VT __attribute__((ext_vector_type(N), aligned(sizeof(T))));
-    const VT q = *reinterpret_cast<const VT*>(p);
+    const VT q = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const VT*>(p)) : *reinterpret_cast<const VT*>(p);
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = q[i];
   } else {
@@ -40,14 +40,17 @@ __device__ inline void load_vec(const T* __restrict__ p, int64_t valid, T out[N]
   }
 }
 
-template <typename T, int N, bool FULL>
+template <typename T, int N, bool FULL, bool STREAM = false>
 __device__ inline void store_vec(T* __restrict__ p, int64_t valid, const T in[N]) {
   if (FULL) {
     typedef T VT __attribute__((ext_vector_type(N), aligned(sizeof(T))));
     VT q;
 #pragma unroll
     for (int i = 0; i < N; ++i) q[i] = in[i];
-    *reinterpret_cast<VT*>(p) = q;
+    if (STREAM)
+      __builtin_nontemporal_store(q, reinterpret_cast<VT*>(p));
+    else
+      *reinterpret_cast<VT*>(p) = q;
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i)

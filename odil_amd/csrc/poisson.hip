@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
       const int64_t pz = z * sz;
       if (a.active[0]) load_vec<T, V, FULL>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
       T r[V], ym[V], yp[V], out[V];
-      load_vec<T, V, FULL>(rhs + pz + c_off, valid, r);
+      load_vec<T, V, FULL, true>(rhs + pz + c_off, valid, r);
       if (a.active[1]) {
         load_vec<T, V, FULL>(u + pz + ym_off, valid, ym);
         load_vec<T, V, FULL>(u + pz + yp_off, valid, yp);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
         out[i] = f;
         if (z >= a.loss_z0 && z < a.loss_z1) local += (double)(f * f);
       }
-      if (fu) store_vec<T, V, FULL>(fu + pz + c_off, valid, out);
+      if (fu) store_vec<T, V, FULL, true>(fu + pz + c_off, valid, out);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         um[i] = uc[i];
@@ -142,17 +142,19 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict_
       g = g + adj_axis<T>(fb, xm, xp, x, X, h, 2);
       out[i] = g;
     }
-    store_vec<T, V, FULL>(gu + pz + c_off, valid, out);
+    store_vec<T, V, FULL, true>(gu + pz + c_off, valid, out);
     if (ad.x) {
+      // x, m, v are touched exactly once per launch: streaming (non-temporal) accesses keep them
+      // from evicting the fu rows / planes the stencil re-reads from L2
       T xv[V], mv[V], vv[V];
-      load_vec<T, V, FULL>(ad.x + pz + c_off, valid, xv);
-      load_vec<T, V, FULL>(ad.m + pz + c_off, valid, mv);
-      load_vec<T, V, FULL>(ad.v + pz + c_off, valid, vv);
+      load_vec<T, V, FULL, true>(ad.x + pz + c_off, valid, xv);
+      load_vec<T, V, FULL, true>(ad.m + pz + c_off, valid, mv);
+      load_vec<T, V, FULL, true>(ad.v + pz + c_off, valid, vv);
 #pragma unroll
       for (int i = 0; i < V; ++i) adam_update<T>(xv[i], mv[i], vv[i], out[i], ad);
-      store_vec<T, V, FULL>(ad.x + pz + c_off, valid, xv);
-      store_vec<T, V, FULL>(ad.m + pz + c_off, valid, mv);
-      store_vec<T, V, FULL>(ad.v + pz + c_off, valid, vv);
+      store_vec<T, V, FULL, true>(ad.x + pz + c_off, valid, xv);
+      store_vec<T, V, FULL, true>(ad.m + pz + c_off, valid, mv);
+      store_vec<T, V, FULL, true>(ad.v + pz + c_off, valid, vv);
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) {

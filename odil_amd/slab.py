@@ -175,8 +175,20 @@ class SlabPoissonAdam:
         b = tic("halo")
         yield from self._exchange([self.fu], [l0])
         toc(b)
+        self.t += 1
+        t = self.npdt(self.t)
+        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
+        omb1, omb2 = 1 - self.b1, 1 - self.b2
+        n0 = lv[0].size
+        fuse0 = hasattr(ops, "poisson_adjoint_adam")
         b = tic("adjoint")
-        ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        if fuse0:
+            # Adam of the finest level inside the adjoint launch (as on one GPU, poisson_path.py)
+            ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], self.w[0],
+                                     self.m[:n0].view(lv[0].shape), self.v[:n0].view(lv[0].shape), alpha, omb1, omb2,
+                                     self.eps)
+        else:
+            ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
         toc(b)
         for l in range(1, L):
             b = tic("halo")
@@ -187,11 +199,11 @@ class SlabPoissonAdam:
             ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview,
                            cut=(self.rank > 0, self.rank < self.world - 1))
             toc(b)
-        self.t += 1
-        t = self.npdt(self.t)
-        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
         b = tic("adam")
-        ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        if fuse0:
+            ops.adam_step(self.x[n0:], self.m[n0:], self.v[n0:], self.g[n0:], alpha, omb1, omb2, self.eps)
+        else:
+            ops.adam_step(self.x, self.m, self.v, self.g, alpha, omb1, omb2, self.eps)
         toc(b)
 
     def epoch(self, comm, timers=None):
