@@ -108,8 +108,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        backend = os.environ.get("ODIL_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        ngpu = torch.cuda.device_count()
+        local_rank = local_rank % max(ngpu, 1)  # (tests may oversubscribe one GPU with gloo)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local_rank)
 
@@ -130,6 +136,7 @@ def main():
         step = lambda timers=None: run.epoch(timers)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
 
@@ -148,7 +155,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss = run.last_loss(comm) if world > 1 else run.last_loss()

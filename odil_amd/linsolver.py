@@ -96,11 +96,25 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
     tol = getattr(args, "linsolver_tol", 1e-10)
     if not torch.is_tensor(rhs):
         rhs = torch.as_tensor(np.asarray(rhs), dtype=matr.dtype, device=matr.device)
+    if linsolver not in ("direct", "directsq", "cg", "bicgstab", "multigrid", "lsqr"):
+        raise ValueError("Unknown linsolver=" + linsolver)
+    # Square Poisson stencil without damping: M d = rhs has the solution of the normal equations
+    # and is solved by geometric multigrid V-cycles (gmg.py) -- the only option that scales to
+    # 512^3.  `multigrid` always takes it when it applies, `direct` above 2e5 unknowns.
+    if not damp and not dampdiag and (linsolver == "multigrid" or (linsolver == "direct" and matr.ncols > 200000)):
+        from . import gmg
+
+        rec = gmg.recognise_poisson(matr)
+        if rec is not None:
+            shape, h2 = rec
+            solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
+            gtol = 1e-12 if linsolver == "direct" else tol
+            x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
+            return x.reshape(-1)
     if linsolver in ("direct", "directsq"):
         return cg_normal(matr, rhs, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=status)
-    elif linsolver in ("cg", "bicgstab", "multigrid", "lsqr"):
+    else:
         return cg_normal(matr, rhs, damp, dampdiag, tol=tol, maxiter=maxiter or 1000, status=status)
-    raise ValueError("Unknown linsolver=" + linsolver)
 
 
 def add_arguments(parser):

@@ -233,9 +233,19 @@ class TorchDistComm:
         import torch.distributed as dist
 
         self.dist, self.rank, self.world = dist, rank, world
+        # gloo moves host memory: device planes are staged (tests only; RCCL sends device memory)
+        self.stage = dist.get_backend() == "gloo"
 
     def exchange(self, send_lo, send_hi):
         dist = self.dist
+        dev = None
+        if self.stage:
+            for t in (send_lo, send_hi):
+                if t is not None and t.is_cuda:
+                    dev = t.device
+            if dev is not None:
+                send_lo = send_lo.cpu() if send_lo is not None else None
+                send_hi = send_hi.cpu() if send_hi is not None else None
         ops, recv_lo, recv_hi = [], None, None
         if send_lo is not None:
             recv_lo = torch.empty_like(send_lo)
@@ -246,9 +256,16 @@ class TorchDistComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if dev is not None:
+            recv_lo = recv_lo.to(dev) if recv_lo is not None else None
+            recv_hi = recv_hi.to(dev) if recv_hi is not None else None
         return recv_lo, recv_hi
 
     def all_reduce_sum(self, t):
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            return h.to(t.device)
         self.dist.all_reduce(t)
         return t
 

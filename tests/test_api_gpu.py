@@ -260,3 +260,35 @@ def test_optimize_mixed_state(mod, opt, dtype):
     error.append(domain.neural_net(state, "net")(domain.field(state, "a"))[0] - extra.ref["net_a"])
     total = float(torch.sqrt(sum(torch.mean(torch.square(e)) for e in error)))
     assert total < 1e-2, total
+
+
+@pytest.mark.parametrize("ndim,N", [(2, 64), (3, 32)])
+def test_newton_multigrid_solver(mod, ndim, N):
+    """`--linsolver multigrid`: V-cycles on the recognised Poisson stencil reach the Newton iterate
+    (= the exact discrete solution for this linear problem) in a handful of cycles."""
+    poisson, args = poisson_args(ndim, N, multigrid=0, epochs=1, linsolver="multigrid", linsolver_maxiter=None,
+                                 linsolver_tol=1e-11)
+    problem, state = poisson.make_problem(args)
+    statuses = []
+
+    def callback(state, epoch, pinfo):
+        if "linsolver" in pinfo:
+            statuses.append(pinfo["linsolver"])
+
+    odil.util.optimize_newton(args, problem, state, callback)
+    assert statuses and statuses[0]["method"] == "gmg-vcycle" and statuses[0]["niter"] <= 25, statuses
+    err = state.fields["u"].array - problem.extra.ref_u
+    assert float(err.abs().max()) < 1e-8
+    loss = problem.eval_loss_grad(state)[0]
+    assert float(loss) < 1e-10
+
+
+def test_newton_multigrid_matches_direct_small(mod):
+    g = load_golden("newton_poisson_3d_N4")
+    poisson, args = poisson_args(3, 4, multigrid=0, epochs=1, linsolver="multigrid", linsolver_maxiter=None,
+                                 linsolver_tol=1e-13)
+    problem, state = poisson.make_problem(args)
+    problem.extra.rhs = mod.array(g["rhs"])
+    state.fields["u"].array = mod.array(g["u0"])
+    odil.util.optimize_newton(args, problem, state)
+    assert rel(state.fields["u"].array, g["u1"]) < 1e-9

@@ -50,3 +50,34 @@ def test_emulated_ranks_equal_single_domain(world, N):
             got = ranks[r].owned_levels()[lvl]
             want = ref[r * nz : (r + 1) * nz]
             assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())), (lvl, r)
+
+
+def test_bench_two_ranks_over_torch_distributed_on_one_gpu(tmp_path):
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one
+    process per rank), with the gloo backend so that two ranks can share this box's single GPU:
+    exercises init, the TorchDistComm exchanges with real HIP kernels, barrier / max-over-ranks
+    timing and the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ODIL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2",
+           "--steps", "3", "--warmup", "1", "--N", "64", "--no_cpu_baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["decomposition"] == "slab x2"
+    assert d["value"] > 0 and np.isfinite(d["loss_after"])
+    # same problem on one rank pair emulated in-process
+    from odil_amd.slab import SlabPoissonAdam, run_lockstep
+
+    dev = torch.device("cuda:0")
+    ranks = [SlabPoissonAdam(64, r, 2, device=dev) for r in range(2)]
+    run_lockstep(ranks, 4)
+    want = sum(r.last_loss() for r in ranks)
+    assert abs(d["loss_after"] - want) <= 1e-10 * abs(want)
