@@ -168,7 +168,7 @@ def main():
         abytes, S = algorithmic_bytes_per_update(ndim, run.nlvl, wordsize)
         kt = timers.summary()
         n_unknowns = run.n_unknowns_local
-        if getattr(run, "fuse_adam0", False) and world == 1 and kt.get("adjoint", 0) > kt["adam"]:
+        if kt.get("adjoint", 0) > kt.get("adam", 0):
             # Dominant kernel: adjoint with the finest-level Adam update fused in:
             # read fu, x, m, v; write gu, x, m, v = 8 words per fine cell.
             dom_name = "k_poisson_adjoint<{}, true> (+Adam of the finest level)"

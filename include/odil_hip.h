@@ -68,6 +68,14 @@ int odil_interp_adj_cut_f64(const double* gfine, double* gcoarse, double* gscale
                             const char* loc, double scale, int cut_lo, int cut_hi, void* stream);
 int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
                             const char* loc, float scale, int cut_lo, int cut_hi, void* stream);
+/* ... and with the Adam update of the coarse array (x, m, v of gcoarse's shape) fused in, as in
+ * odil_mg_synth_adj_adam. */
+int odil_interp_adj_cut_adam_f64(const double* gfine, double* gcoarse, const int64_t* cshape, int ndim, const char* loc,
+                                 int cut_lo, int cut_hi, double* x, double* m, double* v, double alpha,
+                                 double one_minus_b1, double one_minus_b2, double eps, void* stream);
+int odil_interp_adj_cut_adam_f32(const float* gfine, float* gcoarse, const int64_t* cshape, int ndim, const char* loc,
+                                 int cut_lo, int cut_hi, float* x, float* m, float* v, float alpha,
+                                 float one_minus_b1, float one_minus_b2, float eps, void* stream);
 /* coarse = R(fine): full weighting `restrict_to_coarser(method="conv")`
  * (core.py:703-755, backend.py:112-126).  `fshape` = fine array shape. */
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
@@ -91,6 +99,19 @@ int odil_mg_synth_adj_f64(const double* gu, double* const* grads, const double* 
                           const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
 int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
                           const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream);
+
+/* The same chain with the Adam update (optimizer.py:316-318) of every level l >= 1 whose x[l] is
+ * non-NULL applied by the lane that forms grads[l][i] (x, m, v: HOST arrays of device pointers,
+ * entry 0 ignored): the optimizer launch over the coarse levels and its re-read of the
+ * gradients disappear.  grads are still written. */
+int odil_mg_synth_adj_adam_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
+                               const int64_t* shapes, int nlvl, int ndim, const char* loc, double* const* x,
+                               double* const* m, double* const* v, double alpha, double one_minus_b1,
+                               double one_minus_b2, double eps, void* stream);
+int odil_mg_synth_adj_adam_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
+                               const int64_t* shapes, int nlvl, int ndim, const char* loc, float* const* x,
+                               float* const* m, float* const* v, float alpha, float one_minus_b1, float one_minus_b2,
+                               float eps, void* stream);
 
 /* ---- stencil access: Context.field (reference core.py:910-975) ---------------- */
 /* out = trim(roll(pad(src), -shift)): 'c'->'n' zero-pad at the low end, periodic roll,

@@ -213,6 +213,30 @@ __device__ inline double block_sum(double v) {
 }
 #endif
 
+// Optional Adam update fused into the kernel that FORMS a gradient array (the lane that writes
+// g[i] also owns x[i], m[i], v[i]): saves re-reading g in a separate optimizer launch.
+template <typename T>
+struct AdamArgs {
+  T* x;
+  T* m;
+  T* v;
+  T alpha, omb1, omb2, eps;
+};
+
+#ifdef __HIPCC__
+template <typename T>
+__device__ inline void adam_update(T& x, T& m, T& v, T g, const AdamArgs<T>& a) {
+  // reference optimizer.py:316-318
+  m = m + (g - m) * a.omb1;
+  v = v + (g * g - v) * a.omb2;
+  x = x - (m * a.alpha) / (sqrt(v) + a.eps);
+}
+#endif
+
+// Plain Adam launch on a flat range (optim.hip), for paths that cannot fuse it.
+template <typename T>
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream);
+
 // Final stage of every reduction: out[q] = scale * sum(partials[q*stride .. +count)).
 template <typename T>
 int launch_final_reduce(const double* partials, int count, int stride, int nq, double scale, T* out,

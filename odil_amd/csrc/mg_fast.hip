@@ -193,7 +193,8 @@ __device__ inline void adj_weight(int loc, int J, int n, int F, int k, bool cut_
 
 template <typename T, bool YC>
 __global__ __launch_bounds__(kBlock) void k_interp_adj_fast(const T* __restrict__ gfine, T* __restrict__ gcoarse,
-                                                            T* __restrict__ gscaled, FastArgs a, T scale) {
+                                                            T* __restrict__ gscaled, FastArgs a, T scale,
+                                                            AdamArgs<T> ad) {
   const int cnx = a.cn[3], cny = a.cn[2];
   const int fnx = a.fn[3], fny = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
@@ -269,6 +270,13 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_fast(const T* __restrict_
     const int64_t ci = (int64_t)p * cplane + (int64_t)jy * cnx + jx;
     gcoarse[ci] = v;
     if (gscaled) gscaled[ci] = scale * v;
+    if (ad.x) {
+      T xv = ad.x[ci], mv = ad.m[ci], vv = ad.v[ci];
+      adam_update<T>(xv, mv, vv, gscaled ? scale * v : v, ad);
+      ad.x[ci] = xv;
+      ad.m[ci] = mv;
+      ad.v[ci] = vv;
+    }
   }
 }
 
@@ -316,7 +324,8 @@ int interp_add_fast(const T* coarse, const T* add, T* fine, const InterpArgs& a,
 }
 
 template <typename T>
-int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream) {
+int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream,
+                    const AdamArgs<T>& ad) {
   FastArgs f;
   bool yc;
   if (!fast_setup(f, a, yc)) return 0;
@@ -327,10 +336,10 @@ int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a,
   const int grid = sched_grid(f.sched);
   if (yc)
     hipLaunchKernelGGL((k_interp_adj_fast<T, true>), dim3(grid), dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, f,
-                       scale);
+                       scale, ad);
   else
     hipLaunchKernelGGL((k_interp_adj_fast<T, false>), dim3(grid), dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, f,
-                       scale);
+                       scale, ad);
   const int e = check_launch("k_interp_adj_fast");
   return e ? e : 1;
 }
@@ -338,7 +347,9 @@ int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a,
 template int interp_add_fast<double>(const double*, const double*, double*, const InterpArgs&, double, double,
                                      hipStream_t);
 template int interp_add_fast<float>(const float*, const float*, float*, const InterpArgs&, float, float, hipStream_t);
-template int interp_adj_fast<double>(const double*, double*, double*, const InterpArgs&, double, hipStream_t);
-template int interp_adj_fast<float>(const float*, float*, float*, const InterpArgs&, float, hipStream_t);
+template int interp_adj_fast<double>(const double*, double*, double*, const InterpArgs&, double, hipStream_t,
+                                     const AdamArgs<double>&);
+template int interp_adj_fast<float>(const float*, float*, float*, const InterpArgs&, float, hipStream_t,
+                                    const AdamArgs<float>&);
 
 }  // namespace odil

@@ -238,7 +238,8 @@ __device__ inline void reduce_dispatch(const T* __restrict__ gfine, const int (&
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict__ gfine, T* __restrict__ gcoarse,
-                                                             T* __restrict__ gscaled, MarchArgs a, T scale) {
+                                                             T* __restrict__ gscaled, MarchArgs a, T scale,
+                                                             AdamArgs<T> ad) {
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
@@ -289,6 +290,13 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
     const int64_t ci = (int64_t)jz * cplane + (int64_t)jy * cnx + jx;
     gcoarse[ci] = v;
     if (gscaled) gscaled[ci] = scale * v;
+    if (ad.x) {  // Adam of this level's array by the lane that formed its gradient
+      T xv = ad.x[ci], mv = ad.m[ci], vv = ad.v[ci];
+      adam_update<T>(xv, mv, vv, gscaled ? scale * v : v, ad);
+      ad.x[ci] = xv;
+      ad.m[ci] = mv;
+      ad.v[ci] = vv;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       wc[i] = wc[i + 2];
@@ -332,11 +340,12 @@ int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a
 }
 
 template <typename T>
-int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream) {
+int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream,
+                     const AdamArgs<T>& ad) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
   hipLaunchKernelGGL(k_interp_adj_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
-                     gscaled, m, scale);
+                     gscaled, m, scale, ad);
   const int e = check_launch("k_interp_adj_march");
   return e ? e : 1;
 }
@@ -344,7 +353,9 @@ int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a
 template int interp_add_march<double>(const double*, const double*, double*, const InterpArgs&, double, double,
                                       hipStream_t);
 template int interp_add_march<float>(const float*, const float*, float*, const InterpArgs&, float, float, hipStream_t);
-template int interp_adj_march<double>(const double*, double*, double*, const InterpArgs&, double, hipStream_t);
-template int interp_adj_march<float>(const float*, float*, float*, const InterpArgs&, float, hipStream_t);
+template int interp_adj_march<double>(const double*, double*, double*, const InterpArgs&, double, hipStream_t,
+                                      const AdamArgs<double>&);
+template int interp_adj_march<float>(const float*, float*, float*, const InterpArgs&, float, hipStream_t,
+                                     const AdamArgs<float>&);
 
 }  // namespace odil

@@ -132,13 +132,15 @@ template <typename T>
 int interp_add_fast(const T* coarse, const T* add, T* fine, const InterpArgs& a, T cscale, T ascale,
                     hipStream_t stream);
 template <typename T>
-int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream);
+int interp_adj_fast(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream,
+                    const AdamArgs<T>& ad);
 
 // z-marching variants (mg_march.hip): exactly 'ccc' (3-D, all cell-centred).
 template <typename T>
 int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a, T cscale, T ascale,
                      hipStream_t stream);
 template <typename T>
-int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream);
+int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream,
+                     const AdamArgs<T>& ad);
 
 }  // namespace odil

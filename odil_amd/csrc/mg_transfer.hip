@@ -237,7 +237,8 @@ static int interp_add(const T* coarse, const T* add, T* fine, const int64_t* csh
 
 template <typename T>
 static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* cshape, int ndim, const char* loc,
-                      T scale, void* stream, int cut_lo = 0, int cut_hi = 0) {
+                      T scale, void* stream, int cut_lo = 0, int cut_hi = 0,
+                      AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0)}) {
   InterpArgs a;
   if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
   if (cut_lo || cut_hi) {
@@ -249,12 +250,16 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
     set_error("interp_adj: null pointer");
     return ODIL_E_INVAL;
   }
-  if (int r = interp_adj_march<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream)) return r < 0 ? r : 0;
-  if (int r = interp_adj_fast<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream)) return r < 0 ? r : 0;
+  if (int r = interp_adj_march<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;
+  if (int r = interp_adj_fast<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;
   a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_interp_adj<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, gfine,
                      gcoarse, gscaled, a, scale);
-  return check_launch("k_interp_adj");
+  if (int e = check_launch("k_interp_adj")) return e;
+  if (ad.x)  // the generic kernel does not fuse the update: plain launch on this level
+    return adam_launch<T>(ad.x, ad.m, ad.v, gscaled ? gscaled : gcoarse, prod4(a.cn), ad.alpha, ad.omb1, ad.omb2, ad.eps,
+                          (hipStream_t)stream);
+  return 0;
 }
 
 template <typename T>
@@ -343,7 +348,9 @@ static int mg_synth(const T* const* terms, const T* factors, T* const* work, T* 
 // g'_0 = gu; g'_{l+1} = P^T g'_l; grads_l = f_l g'_l.
 template <typename T>
 static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const* work, const int64_t* shapes,
-                        int nlvl, int ndim, const char* loc, void* stream) {
+                        int nlvl, int ndim, const char* loc, void* stream, T* const* ax = nullptr,
+                        T* const* am = nullptr, T* const* av = nullptr, T alpha = T(0), T omb1 = T(0), T omb2 = T(0),
+                        T eps = T(0)) {
   if (int e = check_levels(shapes, nlvl, ndim, loc)) return e;
   if (!gu || !grads) {
     set_error("mg_synth_adj: null pointer");
@@ -373,7 +380,13 @@ static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const
       unscaled = work[l];
       scaled = grads[l];
     }
-    if (int e = interp_adj<T>(gfine, unscaled, scaled, shapes + l * ndim, ndim, loc, f, stream)) return e;
+    AdamArgs<T> ad{nullptr, nullptr, nullptr, alpha, omb1, omb2, eps};
+    if (ax && ax[l]) {
+      ad.x = ax[l];
+      ad.m = am[l];
+      ad.v = av[l];
+    }
+    if (int e = interp_adj<T>(gfine, unscaled, scaled, shapes + l * ndim, ndim, loc, f, stream, 0, 0, ad)) return e;
     gfine = unscaled;
   }
   return 0;
@@ -409,6 +422,18 @@ int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, 
                             const char* loc, float scale, int cut_lo, int cut_hi, void* stream) {
   return interp_adj<float>(gfine, gcoarse, gscaled, cshape, ndim, loc, scale, stream, cut_lo, cut_hi);
 }
+int odil_interp_adj_cut_adam_f64(const double* gfine, double* gcoarse, const int64_t* cshape, int ndim, const char* loc,
+                                 int cut_lo, int cut_hi, double* x, double* m, double* v, double alpha,
+                                 double one_minus_b1, double one_minus_b2, double eps, void* stream) {
+  return interp_adj<double>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0, stream, cut_lo, cut_hi,
+                            AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+}
+int odil_interp_adj_cut_adam_f32(const float* gfine, float* gcoarse, const int64_t* cshape, int ndim, const char* loc,
+                                 int cut_lo, int cut_hi, float* x, float* m, float* v, float alpha,
+                                 float one_minus_b1, float one_minus_b2, float eps, void* stream) {
+  return interp_adj<float>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0f, stream, cut_lo, cut_hi,
+                           AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+}
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
                       void* stream) {
   return restrict_<double>(fine, coarse, fshape, ndim, loc, stream);
@@ -432,6 +457,20 @@ int odil_mg_synth_adj_f64(const double* gu, double* const* grads, const double* 
 int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
                           const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {
   return mg_synth_adj<float>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream);
+}
+int odil_mg_synth_adj_adam_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
+                               const int64_t* shapes, int nlvl, int ndim, const char* loc, double* const* x,
+                               double* const* m, double* const* v, double alpha, double one_minus_b1,
+                               double one_minus_b2, double eps, void* stream) {
+  return mg_synth_adj<double>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream, x, m, v, alpha, one_minus_b1,
+                              one_minus_b2, eps);
+}
+int odil_mg_synth_adj_adam_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
+                               const int64_t* shapes, int nlvl, int ndim, const char* loc, float* const* x,
+                               float* const* m, float* const* v, float alpha, float one_minus_b1, float one_minus_b2,
+                               float eps, void* stream) {
+  return mg_synth_adj<float>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream, x, m, v, alpha, one_minus_b1,
+                             one_minus_b2, eps);
 }
 
 }  // extern "C"

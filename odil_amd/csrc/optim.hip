@@ -71,17 +71,29 @@ __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restric
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream);
+
+template <typename T>
 static int adam_step(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, void* stream) {
+  return adam_launch<T>(x, m, v, g, n, alpha, omb1, omb2, eps, (hipStream_t)stream);
+}
+
+template <typename T>
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream) {
   if (!x || !m || !v || !g || n < 0) {
     set_error("adam_step: null pointer or n < 0");
     return ODIL_E_INVAL;
   }
   if (n == 0) return 0;
   const int vec_ok = aligned16(x) && aligned16(m) && aligned16(v) && aligned16(g);
-  hipLaunchKernelGGL(k_adam<T>, dim3(grid_for(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, (hipStream_t)stream, x, m,
-                     v, g, n, alpha, omb1, omb2, eps, vec_ok);
+  hipLaunchKernelGGL(k_adam<T>, dim3(grid_for(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, stream, x, m, v, g, n, alpha,
+                     omb1, omb2, eps, vec_ok);
   return check_launch("k_adam");
 }
+template int adam_launch<double>(double*, double*, double*, const double*, int64_t, double, double, double, double,
+                                 hipStream_t);
+template int adam_launch<float>(float*, float*, float*, const float*, int64_t, float, float, float, float,
+                                hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_axpy(T* __restrict__ y, const T* __restrict__ x, int64_t n, T a) {

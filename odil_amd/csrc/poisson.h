@@ -132,24 +132,6 @@ __device__ inline T adj_axis(T fb, T fbm, T fbp, int64_t j, int64_t n, const H2<
   return div_h2<T>(s, h, ax);
 }
 
-// Optional Adam update of the finest level fused into the adjoint kernel (the lane that forms
-// gu[i] also owns x[i], m[i], v[i]): saves re-reading gu in the optimizer launch.
-template <typename T>
-struct AdamArgs {
-  T* x;
-  T* m;
-  T* v;
-  T alpha, omb1, omb2, eps;
-};
-
-template <typename T>
-__device__ inline void adam_update(T& x, T& m, T& v, T g, const AdamArgs<T>& a) {
-  // reference optimizer.py:316-318
-  m = m + (g - m) * a.omb1;
-  v = v + (g * g - v) * a.omb2;
-  x = x - (m * a.alpha) / (sqrt(v) + a.eps);
-}
-
 template <typename T>
 inline H2<T> make_h2(const T h[3]) {
   H2<T> r;

@@ -51,10 +51,11 @@ class PoissonEvaluator:
 
         self.one_pass = ops.poisson_loss_grad_supported(self.cshape) and bool(int(os.environ.get("ODIL_ONE_PASS", 0)))
 
-    def loss_grad_arrays(self, arrays, timers=None, adam0=None):
+    def loss_grad_arrays(self, arrays, timers=None, adam=None):
         """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer).
-        adam0 = (m0, v0, alpha, 1-b1, 1-b2, eps): also apply the Adam update of the finest level
-        array inside the adjoint launch (the caller then updates only the coarser levels)."""
+        adam = (m_levels, v_levels, alpha, 1-b1, 1-b2, eps): also apply the Adam update of EVERY
+        level array inside the launch that forms its gradient (adjoint for level 0, the P^T
+        chain for the others); no separate optimizer launch is needed then."""
 
         def tic(name):
             if timers is None:
@@ -82,16 +83,20 @@ class PoissonEvaluator:
             ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
             toc(b)
             b = tic("adjoint")
-            if adam0 is not None:
-                m0, v0, alpha, omb1, omb2, eps = adam0
-                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], m0, v0, alpha, omb1,
-                                         omb2, eps)
+            if adam is not None:
+                ml, vl, alpha, omb1, omb2, eps = adam
+                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], ml[0], vl[0], alpha,
+                                         omb1, omb2, eps)
             else:
                 ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
             toc(b)
         if self.nlvl > 1:
             b = tic("mg_synth_adj")
-            ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
+            if adam is not None:
+                ops.mg_synth_adj_adam(self.gw[0], self.shapes, self.loc, self.gw, arrays, ml, vl, alpha, omb1, omb2,
+                                      eps)
+            else:
+                ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
             toc(b)
         return self.loss, self.gw
 
@@ -104,18 +109,18 @@ class PoissonEvaluator:
 
 
     def eval_loss_grad_adam(self, state, m, v, alpha, omb1, omb2, eps):
-        """eval_loss_grad + the Adam step of the finest level inside the adjoint launch.
-        Returns (..., done=1) or None when this configuration cannot fuse."""
+        """eval_loss_grad + the Adam step of every level inside the launches that form the
+        gradients.  Returns (..., done=nlvl) or None when this configuration cannot fuse."""
         import os
 
         if self.nlvl < 2 or self.one_pass or not int(os.environ.get("ODIL_FUSE_ADAM0", 1)):
             return None
         (field,) = state.fields.values()
         arrays = [t.array for t in field.terms]
-        if not all(a.is_contiguous() for a in arrays) or not (m[0].is_contiguous() and v[0].is_contiguous()):
+        if not all(a.is_contiguous() for a in list(arrays) + list(m) + list(v)):
             return None
-        loss, grads = self.loss_grad_arrays(arrays, adam0=(m[0], v[0], alpha, omb1, omb2, eps))
-        return loss, list(grads), [loss], self.names, [torch.sqrt(loss)], 1
+        loss, grads = self.loss_grad_arrays(arrays, adam=(m, v, alpha, omb1, omb2, eps))
+        return loss, list(grads), [loss], self.names, [torch.sqrt(loss)], self.nlvl
 
 
 def _close(a, b, rtol):

@@ -78,6 +78,18 @@ def interp_adj(gfine, loc, cshape, scale=None, out=None, cut=(False, False)):
     return out if scale is None else (out, scaled)
 
 
+def interp_adj_adam(gfine, loc, cshape, out, x, m, v, alpha, one_minus_b1, one_minus_b2, eps, cut=(False, False)):
+    """out = P^T gfine and the Adam step of (x, m, v) (arrays of out's shape) with that gradient."""
+    cshape = tuple(int(s) for s in cshape)
+    assert tuple(out.shape) == cshape == tuple(x.shape) == tuple(m.shape) == tuple(v.shape)
+    call(
+        "interp_adj_cut_adam", gfine.dtype, ptr(gfine), ptr(out), i64(cshape), c_int(len(cshape)), loc.encode(),
+        c_int(1 if cut[0] else 0), c_int(1 if cut[1] else 0), ptr(x), ptr(m), ptr(v), float(alpha),
+        float(one_minus_b1), float(one_minus_b2), float(eps), stream_ptr(),
+    )
+    return out
+
+
 def restrict_to_coarser(u, loc, depth=1):
     """Full weighting (reference core.py:703-755)."""
     for _ in range(depth):
@@ -129,6 +141,22 @@ def mg_synth_adj(gu, shapes, loc, factors=None, grads=None):
     call(
         "mg_synth_adj", dtype, ptr(gu), ptr_array(grads), fac[1], ptr_array(work), i64(flat), c_int(nlvl),
         c_int(gu.dim()), loc.encode(), stream_ptr(),
+    )
+    return grads
+
+
+def mg_synth_adj_adam(gu, shapes, loc, grads, x, m, v, alpha, one_minus_b1, one_minus_b2, eps):
+    """P^T chain with the Adam update of levels >= 1 inside the launches that form their
+    gradients (factors == 1).  x, m, v: level arrays (entry 0 is left alone)."""
+    nlvl = len(shapes)
+    flat = []
+    for s in shapes:
+        flat += list(s)
+    none0 = lambda arrs: ptr_array([None] + list(arrs[1:]))
+    call(
+        "mg_synth_adj_adam", gu.dtype, ptr(gu), ptr_array(grads), None, ptr_array([None] * nlvl), i64(flat),
+        c_int(nlvl), c_int(gu.dim()), loc.encode(), none0(x), none0(m), none0(v), float(alpha), float(one_minus_b1),
+        float(one_minus_b2), float(eps), stream_ptr(),
     )
     return grads
 

@@ -124,7 +124,8 @@ class AdamNativeOptimizer(Optimizer):
                 copy_into(gf, gviews, grads)
                 g = gf
             n0 = sum(int(a.numel()) for a in x[:done])
-            ops.adam_step(xf[n0:], mf[n0:], vf[n0:], g[n0:], alpha, 1 - beta_1, 1 - beta_2, epsilon)
+            if n0 < xf.numel():
+                ops.adam_step(xf[n0:], mf[n0:], vf[n0:], g[n0:], alpha, 1 - beta_1, 1 - beta_2, epsilon)
             if epoch > 0 and callback is not None:
                 callback(x, epoch, pinfo)
         optinfo = Namespace()

@@ -69,6 +69,8 @@ class PoissonMultigridAdam:
         self.m = torch.zeros(n, dtype=dtype, device=device)
         self.v = torch.zeros(n, dtype=dtype, device=device)
         self.w = [t.view(s) for t, s in zip(self.x.split(self.sizes), self.shapes)]
+        self.mw = [t.view(s) for t, s in zip(self.m.split(self.sizes), self.shapes)]
+        self.vw = [t.view(s) for t, s in zip(self.v.split(self.sizes), self.shapes)]
         # rhs = discrete Laplacian of the reference solution (poisson.py:71-86): same kernel, rhs = 0
         ref_u = hat_reference(cshape, dtype, device)
         self.ref_u = ref_u
@@ -92,22 +94,17 @@ class PoissonMultigridAdam:
         t = self.npdt(self.t)
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)  # optimizer.py:313-315
         omb1, omb2 = 1 - self.b1, 1 - self.b2
-        n0 = self.sizes[0]
-        fuse0 = self.fuse_adam0 and not self.ev.one_pass and self.nlvl > 1
-        if fuse0:
-            # the finest level is updated by the lane that forms its gradient (adjoint launch);
-            # the optimizer launch below covers only the coarser levels
-            m0, v0 = self.m[:n0].view(self.shapes[0]), self.v[:n0].view(self.shapes[0])
-            self.ev.loss_grad_arrays(self.w, timers, adam0=(m0, v0, alpha, omb1, omb2, self.eps))
-        else:
-            self.loss_grad(timers)
+        fuse = self.fuse_adam0 and not self.ev.one_pass and self.nlvl > 1
+        if fuse:
+            # every level is updated by the lane that forms its gradient (adjoint launch for the
+            # finest level, P^T chain for the others): no optimizer launch at all
+            self.ev.loss_grad_arrays(self.w, timers, adam=(self.mw, self.vw, alpha, omb1, omb2, self.eps))
+            return
+        self.loss_grad(timers)
         if timers is not None:
             a, b = timers.section("adam")
             a.record()
-        if fuse0:
-            ops.adam_step(self.x[n0:], self.m[n0:], self.v[n0:], self.g[n0:], alpha, omb1, omb2, self.eps)
-        else:
-            ops.adam_step(self.x, self.m, self.v, self.g, alpha, omb1, omb2, self.eps)
+        ops.adam_step(self.x, self.m, self.v, self.g, alpha, omb1, omb2, self.eps)
         if timers is not None:
             b.record()
 

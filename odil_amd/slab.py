@@ -98,6 +98,7 @@ class SlabPoissonAdam:
         self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
         split = lambda f: [t.view(lv.shape) for t, lv in zip(f.split(sizes), self.levels)]
         self.w, self.gw = split(self.x), split(self.g)
+        self.mw, self.vw = split(self.m), split(self.v)
         l0 = self.levels[0]
         self.u = torch.zeros(l0.shape, dtype=dtype, device=device)
         self.fu = torch.zeros(l0.shape, dtype=dtype, device=device)
@@ -196,9 +197,16 @@ class SlabPoissonAdam:
             toc(b)
             b = tic("mg_synth_adj")
             cview = lv[l].inner(self.gw[l])
-            ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview,
-                           cut=(self.rank > 0, self.rank < self.world - 1))
+            cut = (self.rank > 0, self.rank < self.world - 1)
+            if fuse0 and hasattr(ops, "interp_adj_adam"):
+                ops.interp_adj_adam(self.gw[l - 1], "ccc", tuple(cview.shape), cview, lv[l].inner(self.w[l]),
+                                    lv[l].inner(self.mw[l]), lv[l].inner(self.vw[l]), alpha, omb1, omb2, self.eps,
+                                    cut=cut)
+            else:
+                ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview, cut=cut)
             toc(b)
+        if fuse0 and hasattr(ops, "interp_adj_adam"):
+            return  # every level was updated inside the launch that formed its gradient
         b = tic("adam")
         if fuse0:
             ops.adam_step(self.x[n0:], self.m[n0:], self.v[n0:], self.g[n0:], alpha, omb1, omb2, self.eps)
