@@ -75,6 +75,12 @@ class ModRocm:
             if x.device != self.device:
                 x = x.to(self.device)
             return x if dtype is None or x.dtype == dtype else x.to(dtype)
+        if isinstance(x, (bool, int, float, np.bool_, np.integer, np.floating)):
+            # a device fill, not a host->device copy: legal inside hipGraph capture (ODIL_JIT=1)
+            if dtype is None:
+                dtype = (torch.bool if isinstance(x, (bool, np.bool_)) else torch.int64 if isinstance(x, (int, np.integer))
+                         else torch_dtype(np.asarray(x).dtype))
+            return torch.full((), x, dtype=dtype, device=self.device)
         return torch.as_tensor(np.asarray(x), device=self.device).to(dtype) if dtype is not None else torch.as_tensor(
             np.asarray(x), device=self.device
         )
