@@ -84,6 +84,19 @@ def cpu_baseline(ndim, N, budget_s=20.0):
     }
 
 
+def measured_traffic(kernel, ndim, N, dtype):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (collected separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied);
+    None when no profile of this kernel / workload is on record."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except OSError:
+        return None
+    if rec.get("kernel") == kernel and (ndim, N, dtype) == (3, 512, "f64"):
+        return rec["traffic_bytes_per_launch"]
+    return None
+
+
 class Timers:
     """HIP-event pairs per kernel family, recorded on the stream the kernels run on."""
 
@@ -209,7 +222,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(dom_name.format("double" if wordsize == 8 else "float"), ndim, N, args.dtype),
                 "algorithmic_bytes_per_launch": adam_bytes,
                 "avg_launch_ms": adam_ms,
             },
