@@ -28,11 +28,7 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
-// Canonical 4-D view (leading axes padded with size 1 / loc '.').
-struct Dims4 {
-  int64_t n[4];
-};
-
+// Arrays are handled in a canonical 4-D view: leading axes padded with size 1 / loc '.'.
 enum Loc : int { kNone = 0, kCell = 1, kNode = 2 };
 
 inline int parse_loc(const char* loc, int ndim, int out[4]) {

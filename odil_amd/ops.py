@@ -35,10 +35,6 @@ def coarse_shape(fshape, loc):
     return tuple((s - 2) // 2 + 1 if l == "c" else (s - 1) // 2 + 1 for s, l in zip(fshape, loc))
 
 
-def _real(dtype, v):
-    return float(v)
-
-
 def interp_add(coarse, loc, add=None, coarse_scale=1.0, add_scale=1.0, out=None):
     """out = add_scale*add + P(coarse_scale*coarse)  (reference core.py:606-700, :258-262)."""
     fshape = fine_shape(coarse.shape, loc)
