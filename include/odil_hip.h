@@ -203,6 +203,12 @@ int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64
                   double* out, void* stream);
 int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,
                   void* stream);
+/* out[j*nvec + k] = <a_k, b_j>, j < 3 (b1, b2 may be NULL -> zeros), in one pass over the a_k.
+ * `partials`: odil_dots_workspace_bytes(3 * nvec) scratch; `out`: 3 * nvec values. */
+int odil_dots3_f64(const double* a, int64_t lda, int nvec, const double* b0, const double* b1, const double* b2,
+                   int64_t n, double* partials, double* out, void* stream);
+int odil_dots3_f32(const float* a, int64_t lda, int nvec, const float* b0, const float* b1, const float* b2, int64_t n,
+                   double* partials, float* out, void* stream);
 /* y = beta * y + sum_k coef[k] * a[k*lda + :]  (coef on DEVICE, length nvec). */
 int odil_lincomb_f64(double* y, double beta, const double* a, int64_t lda, int nvec, const double* coef, int64_t n,
                      void* stream);

@@ -183,6 +183,48 @@ static int dots(const T* a, int64_t lda, int nvec, const T* b, int64_t n, double
   return launch_final_reduce<T>(partials, grid, kDotPartials, nvec, 1.0, out, (hipStream_t)stream);
 }
 
+// out[j][k] = <a_k, b_j> for up to three right-hand vectors in ONE pass over the a_k (the L-BFGS
+// history is by far the largest operand: S^T y, S^T s and S^T g cost one read of S instead of three).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dots3(const T* __restrict__ a, int64_t lda, const T* __restrict__ b0,
+                                                 const T* __restrict__ b1, const T* __restrict__ b2, int64_t n,
+                                                 int nvec, double* __restrict__ partials) {
+  const T* ak = a + (int64_t)blockIdx.y * lda;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  int64_t hi = lo + per;
+  if (hi > n) hi = n;
+  double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const double av = (double)ak[i];
+    l0 += av * (double)b0[i];
+    if (b1) l1 += av * (double)b1[i];
+    if (b2) l2 += av * (double)b2[i];
+  }
+  const double t0 = block_sum(l0), t1 = block_sum(l1), t2 = block_sum(l2);
+  if (threadIdx.x == 0) {
+    const int64_t base = (int64_t)blockIdx.y * kDotPartials + blockIdx.x;
+    partials[base] = t0;
+    partials[(int64_t)nvec * kDotPartials + base] = t1;
+    partials[(int64_t)2 * nvec * kDotPartials + base] = t2;
+  }
+}
+
+template <typename T>
+static int dots3(const T* a, int64_t lda, int nvec, const T* b0, const T* b1, const T* b2, int64_t n, double* partials,
+                 T* out, void* stream) {
+  if (!a || !b0 || !partials || !out || n < 1 || nvec < 1 || nvec > 65535) {
+    set_error("dots3: null pointer, n < 1 or nvec=%d out of range", nvec);
+    return ODIL_E_INVAL;
+  }
+  int grid = grid_for(n, kBlock * 8);
+  if (grid > kDotPartials) grid = kDotPartials;
+  hipLaunchKernelGGL(k_dots3<T>, dim3(grid, nvec), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b0, b1, b2, n, nvec,
+                     partials);
+  if (int e = check_launch("k_dots3")) return e;
+  return launch_final_reduce<T>(partials, grid, kDotPartials, 3 * nvec, 1.0, out, (hipStream_t)stream);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_lincomb(T* __restrict__ y, T beta, const T* __restrict__ a, int64_t lda,
                                                    int nvec, const T* __restrict__ coef, int64_t n) {
@@ -244,6 +286,14 @@ int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64
 int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,
                   void* stream) {
   return dots<float>(a, lda, nvec, b, n, partials, out, stream);
+}
+int odil_dots3_f64(const double* a, int64_t lda, int nvec, const double* b0, const double* b1, const double* b2,
+                   int64_t n, double* partials, double* out, void* stream) {
+  return dots3<double>(a, lda, nvec, b0, b1, b2, n, partials, out, stream);
+}
+int odil_dots3_f32(const float* a, int64_t lda, int nvec, const float* b0, const float* b1, const float* b2, int64_t n,
+                   double* partials, float* out, void* stream) {
+  return dots3<float>(a, lda, nvec, b0, b1, b2, n, partials, out, stream);
 }
 int odil_lincomb_f64(double* y, double beta, const double* a, int64_t lda, int nvec, const double* coef, int64_t n,
                      void* stream) {

@@ -336,6 +336,22 @@ def dots(a, b, out=None):
     return out
 
 
+def dots3(a, bs, out=None):
+    """out[j, k] = <a[k], bs[j]> for up to three vectors bs, reading a once."""
+    if a.dim() == 1:
+        a = a[None]
+    nvec, n = a.shape
+    bs = list(bs) + [None] * (3 - len(bs))
+    assert a.stride(1) == 1 and all(b is None or b.numel() == n for b in bs)
+    if out is None:
+        out = torch.empty((3, nvec), dtype=a.dtype, device=a.device)
+    call(
+        "dots3", a.dtype, ptr_strided(a), c_int64(a.stride(0)), c_int(nvec), ptr(bs[0]), ptr(bs[1]), ptr(bs[2]),
+        c_int64(n), ptr(dots_workspace(a.device, 3 * nvec)), ptr(out), stream_ptr(),
+    )
+    return out
+
+
 def ptr_strided(a):
     import ctypes
 

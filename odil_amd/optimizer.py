@@ -345,6 +345,12 @@ class LbfgsVectors:
             return np.zeros(0)
         return ops.dots(mat[:nrows], b).cpu().numpy()
 
+    def dots3(self, mat, nrows, bs):
+        """[[<mat[k], b>] for b in bs] (len(bs) <= 3) in one pass over mat, host float64."""
+        if nrows == 0:
+            return np.zeros((len(bs), 0))
+        return ops.dots3(mat[:nrows], bs).cpu().numpy()[: len(bs)]
+
     def max_abs(self, a):
         return float(a.abs().max())
 
@@ -397,6 +403,7 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
     d = vec.new()
     g = vec.new()
 
+    pending = None  # (Y^T g, S^T g) for the next direction, when already known
     f, gnew = fg(x)
     vec.copy(g, gnew)
     nfev += 1
@@ -411,8 +418,12 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             vec.scale_into(d, g, -1.0 / theta)
         else:
             order = slots  # logical -> physical
-            p1 = vec.dots(wy, len(order), g)
-            p2 = vec.dots(ws, len(order), g)
+            if pending is not None:
+                p1, p2 = pending  # Y^T g, S^T g came out of the pass that formed the update rows
+            else:
+                p1 = vec.dots(wy, len(order), g)
+                p2 = vec.dots(ws, len(order), g)
+            pending = None
             # physical -> logical order
             yg = np.array([p1[k] for k in order])
             sg = np.array([p2[k] for k in order]) * theta
@@ -474,6 +485,7 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
                 return dict(task="ABNORMAL_TERMINATION_IN_LNSRCH", warnflag=2, nit=nit, funcalls=nfev, f=f)
             # refresh the memory and restart with the steepest-descent step
             col, slots, theta = 0, [], 1.0
+            pending = None
             continue
 
         # ---- new iterate ---------------------------------------------------------------------
@@ -504,6 +516,7 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             ddum = -gdold * stp
         if dr <= epsmch * ddum:
             nskip += 1
+            pending = None
             continue
         if col < m:
             slot = col
@@ -520,10 +533,11 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
         theta = rr / dr
         # new row / column of S^T Y, S^T S, Y^T Y
         nphys = len(slots)
-        s_y = vec.dots(ws, nphys, r)  # s_k . y_new
-        y_s = vec.dots(wy, nphys, d)  # y_k . s_new
-        s_s = vec.dots(ws, nphys, d)
-        y_y = vec.dots(wy, nphys, r)
+        # one pass over S and one over Y give the new rows of S^T Y, S^T S, Y^T Y and, for the next
+        # direction, S^T g and Y^T g (the history is the dominant traffic of an iteration)
+        s_y, s_s, s_g = vec.dots3(ws, nphys, [r, d, g])  # s_k . y_new, s_k . s_new, s_k . g
+        y_y, y_s, y_g = vec.dots3(wy, nphys, [r, d, g])
+        pending = (y_g, s_g)
         c = col - 1
         for i, k in enumerate(slots):
             sy[i, c] = s_y[k]

@@ -253,6 +253,12 @@ def test_vector_ops(dev):
     a, b = rng.standard_normal((k, n)), rng.standard_normal(n)
     d = ops.dots(to(a, dev), to(b, dev)).cpu().numpy()
     assert np.max(np.abs(d - a @ b)) < 1e-11
+    b2, b3 = rng.standard_normal(n), rng.standard_normal(n)
+    d3 = ops.dots3(to(a, dev), [to(b, dev), to(b2, dev), to(b3, dev)]).cpu().numpy()
+    assert np.max(np.abs(d3 - np.stack([a @ b, a @ b2, a @ b3]))) < 1e-11
+    assert np.array_equal(d3[0], d)  # same partial-sum order as odil_dots
+    d2 = ops.dots3(to(a, dev), [to(b, dev), to(b2, dev)]).cpu().numpy()
+    assert np.array_equal(d2[:2], d3[:2])
     y = rng.standard_normal(n)
     coef = rng.standard_normal(k)
     ty = to(y, dev)

@@ -32,6 +32,9 @@ class NumpyVectors:
     def dots(self, mat, nrows, b):
         return mat[:nrows] @ b
 
+    def dots3(self, mat, nrows, bs):
+        return np.array([mat[:nrows] @ b for b in bs])
+
     def max_abs(self, a):
         return float(np.max(np.abs(a)))
 
