@@ -126,7 +126,11 @@ def main():
         local_rank = local_rank % max(ngpu, 1)  # (tests may oversubscribe one GPU with gloo)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:  # keep the measurement alive: planes are then staged through the host
+                sys.stderr.write("bench.py: RCCL init failed ({}); falling back to gloo\n".format(e))
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"

@@ -83,6 +83,13 @@ int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape,
 int odil_restrict_f32(const float* fine, float* coarse, const int64_t* fshape, int ndim, const char* loc,
                       void* stream);
 
+/* gfine = R^T gcoarse: the cotangent autodiff routes through `restrict_to_coarser`
+ * (`poisson --mgloss`, examples/poisson/poisson.py:116-122).  `fshape` = fine array shape. */
+int odil_restrict_adj_f64(const double* gcoarse, double* gfine, const int64_t* fshape, int ndim, const char* loc,
+                          void* stream);
+int odil_restrict_adj_f32(const float* gcoarse, float* gfine, const int64_t* fshape, int ndim, const char* loc,
+                          void* stream);
+
 /* u = sum_l P^l (factor_l * w_l): `Domain.multigrid_to_regular` (core.py:245-263).
  * terms / work / grads are HOST arrays of device pointers, factors / shapes HOST arrays.
  * terms[l]: level arrays fine->coarse, shapes[l*ndim..]: their array shapes,

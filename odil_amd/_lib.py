@@ -26,6 +26,7 @@ _SIGNATURES = {
     "interp_adj_cut": [_P, _P, _P, _I64P, c_int, c_char_p, _R, c_int, c_int, _P],
     "interp_adj_cut_adam": [_P, _P, _I64P, c_int, c_char_p, c_int, c_int, _P, _P, _P, _R, _R, _R, _R, _P],
     "restrict": [_P, _P, _I64P, c_int, c_char_p, _P],
+    "restrict_adj": [_P, _P, _I64P, c_int, c_char_p, _P],
     "mg_synth": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
     "mg_synth_adj": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
     "mg_synth_adj_adam": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P, _P, _P, _R, _R, _R, _R, _P],

@@ -12,6 +12,7 @@ names.  What differs is who does the work:
   * loss terms mean(f^2) (core.py:1093)                              -> odil_mean_reduce,
     cotangent -> odil_scale
   * interp_to_finer / restrict_to_coarser (core.py:606-755)          -> odil_interp_add / odil_restrict
+    (cotangents odil_interp_adj / odil_restrict_adj)
   * affine stencil operators (Poisson) are recognised from their Jacobian coefficients and
     evaluated by the fused residual / adjoint kernels (see fused.py)
   * Jacobian rows (core.py:1144-1171) stay on the device as coefficient arrays
@@ -145,6 +146,17 @@ class _InterpFn(torch.autograd.Function):
         return ops.interp_adj(g.contiguous(), ctx.loc, ctx.shape), None
 
 
+class _RestrictFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, loc):
+        ctx.loc, ctx.shape = loc, tuple(u.shape)
+        return ops.restrict_to_coarser(u.contiguous(), loc)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.restrict_adj(g.contiguous(), ctx.loc, ctx.shape), None
+
+
 def _as_tensor(u, mod):
     if isinstance(u, torch.Tensor):
         return u
@@ -185,9 +197,9 @@ def restrict_to_coarser(u, loc=None, method=None, mod=None, depth=1):
     assert_equal(len(loc), u.dim())
     for l in loc:
         assert l in "cn.", "Invalid loc={}".format(loc)
-    if u.requires_grad:
-        raise NotImplementedError("restrict_to_coarser is not differentiable yet (poisson --mgloss); see DESIGN.md")
-    return ops.restrict_to_coarser(u.contiguous(), loc, depth=depth)
+    for _ in range(depth):
+        u = _RestrictFn.apply(u, loc)
+    return u
 
 
 def check_multigrid_cshapes(cshapes, axes=None):

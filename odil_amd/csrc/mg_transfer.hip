@@ -186,6 +186,101 @@ __global__ __launch_bounds__(kBlock) void k_restrict(const T* __restrict__ fine,
   }
 }
 
+// ------------------------------------------------------------------------------------
+// R^T (cotangent of the restriction; `poisson --mgloss` differentiates through R).  Gather
+// form per FINE element K: per axis the coarse taps (j, w) with 2j + t (- 1 on 'n' axes) = q for
+// q in C(K) / R(K), the clamp / reflect pre-images of K under the joint ghost rule on 'n' axes.
+// ------------------------------------------------------------------------------------
+struct RAdjTaps {
+  int cnt;
+  int64_t j[4];
+  float wc[4], wr[4];
+  bool special;
+};
+
+__device__ inline void radj_add(RAdjTaps& t, int64_t q, int64_t nout, bool in_c, bool in_r) {
+  for (int k = 0; k < 3; ++k) {
+    const int64_t num = q + 1 - k;
+    if (num & 1) continue;
+    const int64_t j = num / 2;
+    if (num < 0 || j >= nout) continue;
+    const float w = k == 1 ? 0.5f : 0.25f;
+    int slot = -1;
+    for (int i = 0; i < t.cnt; ++i)
+      if (t.j[i] == j) slot = i;
+    if (slot < 0) {
+      slot = t.cnt++;
+      t.j[slot] = j;
+      t.wc[slot] = t.wr[slot] = 0.f;
+    }
+    if (in_c) t.wc[slot] += w;
+    if (in_r) t.wr[slot] += w;
+  }
+}
+
+__device__ inline RAdjTaps make_radj_taps(int loc, int64_t K, int64_t n, int64_t nout) {
+  RAdjTaps t;
+  t.cnt = 0;
+  t.special = false;
+  for (int i = 0; i < 4; ++i) {
+    t.j[i] = 0;
+    t.wc[i] = t.wr[i] = 0.f;
+  }
+  if (loc == kCell) {
+    const int64_t j = K >> 1;
+    if (j < nout) {
+      t.cnt = 1;
+      t.j[0] = j;
+      t.wc[0] = t.wr[0] = 0.5f;
+    }
+  } else if (loc == kNone) {
+    if ((K & 1) == 0 && K / 2 < nout) {
+      t.cnt = 1;
+      t.j[0] = K / 2;
+      t.wc[0] = t.wr[0] = 1.f;
+    }
+  } else {
+    t.special = K == 0 || K == 1 || K == n - 1 || K == n - 2;
+    radj_add(t, K, nout, true, true);
+    if (K == 0) radj_add(t, -1, nout, true, false);
+    if (K == n - 1) radj_add(t, n, nout, true, false);
+    if (K == 1) radj_add(t, -1, nout, false, true);
+    if (K == n - 2) radj_add(t, n, nout, false, true);
+  }
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_restrict_adj(const T* __restrict__ gcoarse, T* __restrict__ gfine,
+                                                         InterpArgs a) {
+  const int64_t cs2 = a.cn[3], cs1 = a.cn[2] * cs2, cs0 = a.cn[1] * cs1;
+  const int64_t total = a.fn[0] * a.fn[1] * a.fn[2] * a.fn[3];
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += nthreads) {
+    int64_t rem = i;
+    int64_t K[4];
+    for (int d = 3; d >= 0; --d) {
+      K[d] = rem % a.fn[d];
+      rem /= a.fn[d];
+    }
+    const RAdjTaps t0 = make_radj_taps(a.loc[0], K[0], a.fn[0], a.cn[0]);
+    const RAdjTaps t1 = make_radj_taps(a.loc[1], K[1], a.fn[1], a.cn[1]);
+    const RAdjTaps t2 = make_radj_taps(a.loc[2], K[2], a.fn[2], a.cn[2]);
+    const RAdjTaps t3 = make_radj_taps(a.loc[3], K[3], a.fn[3], a.cn[3]);
+    const bool special = t0.special || t1.special || t2.special || t3.special;
+    T sc = T(0), sr = T(0);
+    for (int i0 = 0; i0 < t0.cnt; ++i0)
+      for (int i1 = 0; i1 < t1.cnt; ++i1)
+        for (int i2 = 0; i2 < t2.cnt; ++i2)
+          for (int i3 = 0; i3 < t3.cnt; ++i3) {
+            const T g = gcoarse[t0.j[i0] * cs0 + t1.j[i1] * cs1 + t2.j[i2] * cs2 + t3.j[i3]];
+            sc = sc + T(t0.wc[i0] * t1.wc[i1] * t2.wc[i2] * t3.wc[i3]) * g;
+            sr = sr + T(t0.wr[i0] * t1.wr[i1] * t2.wr[i2] * t3.wr[i3]) * g;
+          }
+    gfine[i] = special ? T(2) * sc - sr : sc;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scale_copy(const T* __restrict__ x, T* __restrict__ y, int64_t n, T a) {
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
@@ -286,6 +381,33 @@ static int restrict_(const T* fine, T* coarse, const int64_t* fshape, int ndim, 
   a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_restrict<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, fine, coarse, a);
   return check_launch("k_restrict");
+}
+
+template <typename T>
+static int restrict_adj(const T* gcoarse, T* gfine, const int64_t* fshape, int ndim, const char* loc, void* stream) {
+  InterpArgs a;
+  if (ndim < 1 || ndim > ODIL_MAX_NDIM || parse_loc(loc, ndim, a.loc)) {
+    set_error("restrict_adj: invalid ndim=%d / loc", ndim);
+    return ODIL_E_INVAL;
+  }
+  canon_shape(fshape, ndim, a.fn);
+  a.cut_axis = -1;
+  a.cut_lo = a.cut_hi = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t n = a.fn[i];
+    a.cn[i] = a.loc[i] == kCell ? (n - 2) / 2 + 1 : (n - 1) / 2 + 1;
+    if (a.loc[i] == kCell && n < 2) {
+      set_error("restrict_adj: extent %lld too small", (long long)n);
+      return ODIL_E_INVAL;
+    }
+  }
+  if (!gcoarse || !gfine) {
+    set_error("restrict_adj: null pointer");
+    return ODIL_E_INVAL;
+  }
+  hipLaunchKernelGGL(k_restrict_adj<T>, dim3(grid_for(prod4(a.fn), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     gcoarse, gfine, a);
+  return check_launch("k_restrict_adj");
 }
 
 static int check_levels(const int64_t* shapes, int nlvl, int ndim, const char* loc) {
@@ -441,6 +563,14 @@ int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape,
 int odil_restrict_f32(const float* fine, float* coarse, const int64_t* fshape, int ndim, const char* loc,
                       void* stream) {
   return restrict_<float>(fine, coarse, fshape, ndim, loc, stream);
+}
+int odil_restrict_adj_f64(const double* gcoarse, double* gfine, const int64_t* fshape, int ndim, const char* loc,
+                          void* stream) {
+  return restrict_adj<double>(gcoarse, gfine, fshape, ndim, loc, stream);
+}
+int odil_restrict_adj_f32(const float* gcoarse, float* gfine, const int64_t* fshape, int ndim, const char* loc,
+                          void* stream) {
+  return restrict_adj<float>(gcoarse, gfine, fshape, ndim, loc, stream);
 }
 int odil_mg_synth_f64(const double* const* terms, const double* factors, double* const* work, double* u,
                       const int64_t* shapes, int nlvl, int ndim, const char* loc, void* stream) {

@@ -95,6 +95,16 @@ def restrict_to_coarser(u, loc, depth=1):
     return u
 
 
+def restrict_adj(gcoarse, loc, fshape):
+    """R^T gcoarse (cotangent of restrict_to_coarser) for a fine array of shape `fshape`."""
+    fshape = tuple(int(s) for s in fshape)
+    assert tuple(gcoarse.shape) == coarse_shape(fshape, loc), (gcoarse.shape, fshape, loc)
+    out = torch.empty(fshape, dtype=gcoarse.dtype, device=gcoarse.device)
+    call("restrict_adj", gcoarse.dtype, ptr(gcoarse), ptr(out), i64(fshape), c_int(len(fshape)), loc.encode(),
+         stream_ptr())
+    return out
+
+
 def _shapes_flat(tensors):
     flat = []
     for t in tensors:

@@ -218,6 +218,29 @@ def restrict_to_coarser(u, loc, depth=1):
     return restrict_to_coarser(res, loc, depth - 1)
 
 
+def restrict_to_coarser_adj(gcoarse, loc, fine_shape_):
+    """R^T: cotangent of restrict_to_coarser (needed by `poisson --mgloss`, poisson.py:116-122)."""
+    gcoarse = np.asarray(gcoarse)
+    pshape = tuple(n + 2 if l == "n" else n for n, l in zip(fine_shape_, loc))
+    wloc = {"n": np.array([1, 2, 1]) * 0.25, "c": np.array([1, 1]) * 0.5, ".": np.array([1.0])}
+    # transpose of the separable strided correlation, axis by axis (last applied first)
+    g = gcoarse
+    for ax in reversed(range(len(loc))):
+        w = wloc[loc[ax]].astype(gcoarse.dtype)
+        nout = g.shape[ax]
+        shape = list(g.shape)
+        shape[ax] = pshape[ax]
+        up = np.zeros(shape, dtype=gcoarse.dtype)
+        for j in range(len(w)):
+            sl = [slice(None)] * g.ndim
+            sl[ax] = slice(j, j + 2 * (nout - 1) + 1, 2)
+            up[tuple(sl)] += w[j] * g
+        g = up
+    # transpose of upad = 2 * symmetric - reflect on the 'n' axes
+    nloc = "".join("c" if l == "n" else "." for l in loc)  # _fold_pad folds the axes marked 'c'
+    return 2 * _fold_pad(g, fine_shape_, nloc, "symmetric") - _fold_pad(g, fine_shape_, nloc, "reflect")
+
+
 # --------------------------------------------------------------------------
 # Multigrid synthesis u = sum_l P^l (f_l w_l) and its adjoint (core.py:245-263)
 # --------------------------------------------------------------------------

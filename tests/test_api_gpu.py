@@ -292,3 +292,32 @@ def test_newton_multigrid_matches_direct_small(mod):
     state.fields["u"].array = mod.array(g["u0"])
     odil.util.optimize_newton(args, problem, state)
     assert rel(state.fields["u"].array, g["u1"]) < 1e-9
+
+
+def test_poisson_mgloss_gradient(mod, monkeypatch):
+    """`--mgloss 2` (reference poisson.py:116-122): extra loss terms on restricted residuals; their
+    gradient flows through R^T.  Checked against the oracle composition."""
+    poisson, args = poisson_args(2, 16, mgloss=2)
+    problem, state = poisson.make_problem(args)
+    rng = np.random.default_rng(4)
+    arrays = [mod.array(rng.standard_normal(tuple(a.shape)) * 0.1) for a in problem.domain.arrays_from_state(state)]
+    problem.domain.arrays_to_state(arrays, state)
+    loss, grads, terms, names, norms = problem.eval_loss_grad(state)
+    assert len(terms) == 3 and problem._fused is None
+    # oracle: same composition in NumPy
+    cshape = (16, 16)
+    dw = onp.step(cshape)
+    w = [a.cpu().numpy() for a in arrays]
+    rhs = problem.extra.rhs.cpu().numpy()
+    u = onp.multigrid_to_regular(w, "cc")
+    f0 = onp.poisson_residual(u, rhs, dw)
+    f1 = onp.restrict_to_coarser(f0, "cc")
+    f2 = onp.restrict_to_coarser(f1, "cc")
+    want = sum(np.mean(f**2) for f in (f0, f1, f2))
+    assert abs(float(loss) - want) <= 1e-12 * want
+    g2 = 2 * f2 / f2.size
+    g1 = 2 * f1 / f1.size + onp.restrict_to_coarser_adj(g2, "cc", f1.shape)
+    g0 = 2 * f0 / f0.size + onp.restrict_to_coarser_adj(g1, "cc", f0.shape)
+    gw = onp.multigrid_to_regular_adj(onp.poisson_adjoint(g0, dw), [a.shape for a in w], "cc")
+    for a, b in zip(grads, gw):
+        assert rel(a, b) < 1e-11

@@ -411,3 +411,15 @@ def test_device_resident_adam_driver_vs_golden(dev, fuse, monkeypatch):
     if 0 in res and 1 in res:
         for a, b in zip(res[0], res[1]):
             assert torch.equal(a, b)
+
+
+def test_restrict_adjoint_vs_oracle(dev):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(21)
+    for loc, shape in [("c", (8,)), ("n", (9,)), ("cc", (6, 8)), ("nn", (7, 9)), ("cn", (6, 9)), ("c.n", (4, 5, 7)),
+                       ("ccc", (4, 6, 8)), ("nnn", (5, 7, 9)), ("nccc", (5, 4, 6, 4))]:
+        cshape = ops.coarse_shape(shape, loc)
+        y = rng.standard_normal(cshape)
+        got = ops.restrict_adj(to(y, dev), loc, shape)
+        assert rel(got, onp.restrict_to_coarser_adj(y, loc, shape)) < 1e-14, loc

@@ -204,3 +204,16 @@ def test_lbfgsb_trajectory():
     rel = np.abs(np.array(iter_losses[:n]) - ref[:n]) / ref[:n]
     if str(g["scipy_version"]) == scipy.__version__:
         assert rel[:10].max() < 1e-6, rel
+
+
+def test_restrict_adjoint_is_the_transpose():
+    """<R x, y> == <x, R^T y> for the oracle pair (R itself is pinned by the exactness test above)."""
+    rng = np.random.default_rng(9)
+    for loc, shape in [("c", (8,)), ("n", (9,)), ("cc", (6, 8)), ("nn", (7, 9)), ("cn", (6, 9)), ("c.n", (4, 5, 7)),
+                       ("ccc", (4, 6, 8)), ("nnn", (5, 7, 9))]:
+        x = rng.standard_normal(shape)
+        rx = onp.restrict_to_coarser(x, loc)
+        y = rng.standard_normal(rx.shape)
+        lhs = np.sum(rx * y)
+        rhs = np.sum(x * onp.restrict_to_coarser_adj(y, loc, shape))
+        assert abs(lhs - rhs) <= 1e-13 * max(1.0, abs(lhs)), (loc, lhs, rhs)
