@@ -843,6 +843,7 @@ class Problem:
         self._names = None
         self._fused = None  # fused evaluator (fused.py) once the operator has been recognised
         self._fused_checked = False
+        self._traced = None  # generated per-operator kernels (stencil_jit.py)
         if not isinstance(domain.mod, ModRocm):
             raise NotImplementedError("Unsupported mod={:}".format(domain.mod))
 
@@ -889,8 +890,14 @@ class Problem:
 
             if runtime.enable_fuse:
                 self._fused = fused.detect(self, state)
+            if self._fused is None and runtime.enable_trace:
+                from . import stencil_jit
+
+                self._traced = stencil_jit.trace(self, state)
         if self._fused is not None:
             return self._fused.eval_loss_grad(state)
+        if self._traced is not None:
+            return self._traced.eval_loss_grad(state)
         if self.jit:
             return self._eval_loss_grad_graph(state)
         return self._eval_loss_grad_generic(state)

@@ -9,6 +9,9 @@
   ODIL_FUSE     1 (default): recognise affine stencil operators and route them to the
                 fused HIP kernels (core.Problem); 0: always use the generic path
 
+TRACE    1 (default): trace every other operator once and run it as one generated HIP
+                kernel (stencil_jit.py); 0: generic autograd path
+
 `tf` and `jax` are None (reference examples test them to pick code paths).
 """
 
@@ -26,6 +29,7 @@ if backend_name not in ("rocm", "hip"):
 
 enable_jit = bool(int(os.environ.get("ODIL_JIT", 0)))
 enable_fuse = bool(int(os.environ.get("ODIL_FUSE", 1)))
+enable_trace = bool(int(os.environ.get("ODIL_TRACE", 1)))
 tf = None
 jax = None
 

@@ -1,0 +1,64 @@
+"""Host side of the operator tracer (odil_amd/stencil_jit.py): the example operators trace on CPU
+tensors, the generated HIP source cross-compiles for gfx950 and exports its launchers; what the
+tracer cannot express is refused (and the problem then keeps the generic path).  No launches."""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+from conftest import ROOT
+
+import odil_amd as odil
+from odil_amd import stencil_jit
+
+for sub in ("poisson", "heat", "velocity_from_tracer"):
+    sys.path.insert(0, os.path.join(ROOT, "examples", sub))
+
+
+@pytest.fixture()
+def cpu_mod(monkeypatch):
+    mod = odil.ModRocm(device="cpu")
+    monkeypatch.setattr(odil.runtime, "_mod", mod)
+    return mod
+
+
+def test_examples_trace_and_compile(cpu_mod):
+    import heat
+    import veltracer
+
+    problem, state = veltracer.make_problem(veltracer.parse_args(["--Nx", "16", "--Nt", "8"]))
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert sorted(tro.cg.gathers) == ["u", "vx", "vy"] and len(tro.cg.cots) == 18
+    assert hasattr(tro.lib, "jit_fwd") and hasattr(tro.lib, "jit_gather")
+    assert "k_gat_2" in tro.source and "k_final" in tro.source
+
+    args = heat.parse_args(["--Nx", "16", "--Nt", "8", "--infer_k", "1", "--imposed", "stripe", "--kxreg", "0.1",
+                            "--kxregdecay", "100"])
+    problem, state = heat.make_problem(args)
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert tro.cg.nets == [("k_net", (1, 5, 5, 1))] and len(tro.cg.pg_decl) == 46
+    assert len(tro.cg.hs) == 1  # the annealed weight: a host scalar recomputed from the epoch tracer
+    problem.tracers["epoch"] = 200
+    assert tro._host_value(tro.cg.hs[0], dict()) == pytest.approx(0.1 * 0.5 ** 2)
+
+
+def test_untraceable_operators_are_refused(cpu_mod):
+    domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
+    state = odil.State()
+    state.fields["u"] = odil.Field(None, loc="cc")
+    state.fields["p"] = odil.Array(np.zeros(3))
+    state = domain.init_state(state)
+    cases = {
+        "slicing": lambda ctx: [ctx.field("u")[1:]],
+        "reduction": lambda ctx: [ctx.field("u") - ctx.mod.mean(ctx.field("u"))],
+        "control flow": lambda ctx: [ctx.field("u") if ctx.field("u") > 0 else ctx.field("u", 1, 0)],
+        "array unknown": lambda ctx: [ctx.field("u") * ctx.field("p")[0]],
+        "state bypass": lambda ctx: [ctx.field("u") * 0 + ctx.state.fields["u"].array],
+        "scalar output": lambda ctx: [ctx.field("u"), ctx.tracers["epoch"] * 2.0],
+    }
+    for name, op in cases.items():
+        with pytest.raises(stencil_jit.TraceUnsupported):
+            stencil_jit.TracedOperator(odil.Problem(op, domain), state)
+        assert stencil_jit.trace(odil.Problem(op, domain), state) is None, name
