@@ -946,9 +946,11 @@ class _Codegen:
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
         S.append('extern "C" __global__ __launch_bounds__(NB) void k_fwd(const Args a) {')
         S.append("  __shared__ T sm[NB / 64];")
-        S.append("  const int lin = blockIdx.x * NB + threadIdx.x;")
-        S.append("  const bool act = lin < {};".format(self.total))
-        S.append("  const int l = act ? lin : 0;")
+        for k in range(nout):
+            S.append("  T s_{} = (T)0;".format(k))
+        for name in self.pg_decl:
+            S.append("  T {} = (T)0;".format(name))
+        S.append("  for (int l = blockIdx.x * NB + threadIdx.x; l < {}; l += a.nblocks * NB) {{".format(self.total))
         rem = "l"
         for d in reversed(range(self.ndim)):
             if d == 0:
@@ -957,38 +959,38 @@ class _Codegen:
                 S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
                 S.append("  const int r{} = {} / {};".format(d, rem, self.G[d]))
                 rem = "r{}".format(d)
-        for name in self.pg_decl:
-            S.append("  T {} = (T)0;".format(name))
         S.extend(fwd)
         S.extend(rev)
-        S.append("  if (act) {")
         for slot, n in enumerate(self.cots):
-            S.append("    __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
-        S.append("  }")
+            S.append("  __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
         for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
-            e = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
-            S.append("  {{ const T s = block_sum(act ? {} : (T)0, sm); if (threadIdx.x == 0) a.part[{} * a.nblocks + blockIdx.x] = s; }}".format(e, k))
+            S.append("  s_{0} = s_{0} + {1};".format(k, self.r(o_) if raw else "{0} * {0}".format(self.r(o_))))
+        S.append("  }")
+        for k in range(nout):
+            S.append("  {{ const T s = block_sum(s_{0}, sm); if (threadIdx.x == 0) a.part[{0} * a.nblocks + blockIdx.x] = s; }}".format(k))
         for k, name in enumerate(self.pg_decl):
-            S.append("  {{ const T s = block_sum(act ? {} : (T)0, sm); if (threadIdx.x == 0) a.ppart[{} * a.nblocks + blockIdx.x] = s; }}".format(name, k))
+            S.append("  {{ const T s = block_sum({}, sm); if (threadIdx.x == 0) a.ppart[{} * a.nblocks + blockIdx.x] = s; }}".format(name, k))
         S.append("}")
-        # final reduction: out = [loss, terms..., norms...], pgrad = parameter gradients
+        # final reduction, one workgroup per row of partials: out = [loss, terms..., norms...] and
+        # the parameter gradients; the loss is summed in output order by k_loss
         S.append('extern "C" __global__ __launch_bounds__(NB) void k_final(const Args a) {')
         S.append("  __shared__ T sm[NB / 64];")
+        S.append("  const int k = blockIdx.x;")
+        S.append("  const T* row = k < {0} ? a.part + k * a.nblocks : a.ppart + (k - {0}) * a.nblocks;".format(nout))
+        S.append("  T s = (T)0;")
+        S.append("  for (int j = threadIdx.x; j < a.nblocks; j += NB) s = s + row[j];")
+        S.append("  s = block_sum(s, sm);")
+        S.append("  if (threadIdx.x != 0) return;")
+        S.append("  if (k >= {0}) {{ a.pgrad[k - {0}] = s; return; }}".format(nout))
+        S.append("  s = s / (T){};".format(float(self.total)))
+        S.append("  a.out[1 + k] = s;")
+        S.append("  const bool raw[{}] = {{{}}};".format(nout, ", ".join("true" if r else "false" for r in self.raw)))
+        S.append("  a.out[1 + {} + k] = raw[k] ? s : FN(sqrt)(s);".format(nout))
+        S.append("}")
+        S.append('extern "C" __global__ void k_loss(const Args a) {')
         S.append("  T loss = (T)0;")
-        S.append("  for (int k = 0; k < {}; ++k) {{".format(nout))
-        S.append("    T s = (T)0;")
-        S.append("    for (int j = threadIdx.x; j < a.nblocks; j += NB) s = s + a.part[k * a.nblocks + j];")
-        S.append("    s = block_sum(s, sm) / (T){};".format(float(self.total)))
-        S.append("    loss = loss + s;")
-        S.append("    if (threadIdx.x == 0) { a.out[1 + k] = s; }")
-        S.append("  }")
-        S.append("  if (threadIdx.x == 0) a.out[0] = loss;")
-        S.append("  for (int k = 0; k < {}; ++k) {{".format(len(self.pg_decl)))
-        S.append("    T s = (T)0;")
-        S.append("    for (int j = threadIdx.x; j < a.nblocks; j += NB) s = s + a.ppart[k * a.nblocks + j];")
-        S.append("    s = block_sum(s, sm);")
-        S.append("    if (threadIdx.x == 0) a.pgrad[k] = s;")
-        S.append("  }")
+        S.append("  for (int k = 0; k < {}; ++k) loss = loss + a.out[1 + k];".format(nout))
+        S.append("  a.out[0] = loss;")
         S.append("}")
         # gathers
         self.gathers = []  # (key, [cot slots]) for fields that need a gather launch
@@ -1043,7 +1045,8 @@ class _Codegen:
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
         S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3(NB), 0, (hipStream_t)stream, *a);")
-        S.append("  hipLaunchKernelGGL(k_final, dim3(1), dim3(NB), 0, (hipStream_t)stream, *a);")
+        S.append("  hipLaunchKernelGGL(k_final, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a);".format(nout + len(self.pg_decl)))
+        S.append("  hipLaunchKernelGGL(k_loss, dim3(1), dim3(1), 0, (hipStream_t)stream, *a);")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
         S.append('extern "C" int jit_gather(int which, const Args* a, void* g, void* stream) {')
@@ -1116,12 +1119,12 @@ class TracedOperator:
         self.tracer_keys = [n.attr for n in tr.nodes if n.op == "tracer"]
         dev, dt = domain.mod.device, tr.torch_dtype
         self.total = cg.total
-        self.nblocks = (self.total + 255) // 256
+        self.nblocks = min((self.total + 255) // 256, 2048)
         nout = len(outs)
         self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in cg.cots]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)
         self.ppart = torch.empty(max(1, len(cg.pg_decl) * self.nblocks), dtype=dt, device=dev)
-        self.out = torch.zeros(1 + nout, dtype=dt, device=dev)
+        self.out = torch.zeros(1 + 2 * nout, dtype=dt, device=dev)
         self.pgrad = torch.zeros(max(1, len(cg.pg_decl)), dtype=dt, device=dev)
         par_arrays = sum(2 * (len(layers) - 1) for _, layers in cg.nets)
 
@@ -1156,6 +1159,36 @@ class TracedOperator:
             self.layout.append((key, kind, pos, n))
             pos += n
         self.signature = self._signature(state)
+        # gradients live in ONE packed buffer in `arrays_from_state` order (what the optimizers
+        # want: no per-array copies); kernels write straight into its views
+        from .optimizer import pack_like
+
+        arrays = domain.arrays_from_state(state)
+        self.gflat, self.gviews = pack_like(arrays)
+        self.gflat.zero_()
+        self.gtmp = dict()  # regular-array gradients that cannot alias level 0 (scaled multigrid terms)
+        self.mg_meta = dict()
+        for key, kind, pos, n in self.layout:
+            field = state.fields[key]
+            alias = kind == "field"
+            if kind == "mg":
+                factors = field.factors or domain.mg_factors or [1] * n
+                trivial = all(float(f) == 1.0 for f in factors)
+                self.mg_meta[key] = (None if trivial else tuple(float(f) for f in factors), domain._mg_loc(field),
+                                     [tuple(a.shape) for a in arrays[pos:pos + n]])
+                alias = trivial
+            if kind not in ("field", "mg"):
+                continue
+            if key in cg.direct:
+                if alias:
+                    self.cot[cg.direct[key]] = self.gviews[pos]
+                    self.args.cot[cg.direct[key]] = self.gviews[pos].data_ptr()
+            elif key in cg.gathers and not alias:
+                self.gtmp[key] = torch.empty(cg._field_shape(key), dtype=dt, device=dev)
+        nets = [(key, pos) for key, kind, pos, n in self.layout if kind == "net" and key in cg.pgrads]
+        self.pgrad_direct = len(nets) == 1 and len(cg.pgrads) == 1
+        if self.pgrad_direct:
+            self.args.pgrad = self.gviews[nets[0][1]].data_ptr()
 
     def _signature(self, state):
         return tuple((k, type(f).__name__, tuple(tuple(a.shape) for a in self.domain.arrays_from_field(f)))
@@ -1209,49 +1242,37 @@ class TracedOperator:
             raise RuntimeError("traced operator launch failed: hip error {}".format(rc))
         return keep
 
-    def _field_grads(self):
-        """Gradient with respect to the regular array of every field that is read."""
-        res = dict()
-        stream = ops.stream_ptr()
-        for key, slot in self.cg.direct.items():
-            res[key] = self.cot[slot]
-        for gi, key in enumerate(self.cg.gathers):
-            fshape = self.cg._field_shape(key)
-            g = torch.empty(fshape, dtype=self.tr.torch_dtype, device=self.domain.mod.device)
-            rc = self.lib.jit_gather(gi, ctypes.byref(self.args), g.data_ptr(), stream)
-            if rc != 0:
-                raise RuntimeError("traced gather launch failed: hip error {}".format(rc))
-            res[key] = g
-        return res
-
     def eval_loss_grad(self, state):
-        domain, cg = self.domain, self.cg
+        """loss, grads (views of one packed buffer, overwritten by the next call), terms, names, norms."""
+        cg = self.cg
         keep = self._launch(state)
-        arrays = domain.arrays_from_state(state)
-        fg = self._field_grads()
-        grads = [None] * len(arrays)
+        stream = ops.stream_ptr()
         for key, kind, pos, n in self.layout:
-            field = state.fields[key]
-            if kind == "field" and key in fg:
-                grads[pos] = fg[key]
-            elif kind == "mg" and key in fg:
-                factors = field.factors or domain.mg_factors or [1] * n
-                factors = None if all(float(f) == 1.0 for f in factors) else tuple(float(f) for f in factors)
-                shapes = [tuple(a.shape) for a in arrays[pos:pos + n]]
-                gl = ops.mg_synth_adj(fg[key], shapes, domain._mg_loc(field), factors=factors)
-                grads[pos:pos + n] = gl
-            elif kind == "net" and key in cg.pgrads:
+            if kind in ("field", "mg"):
+                if key in cg.gathers:
+                    g = self.gtmp.get(key, self.gviews[pos])
+                    rc = self.lib.jit_gather(cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), stream)
+                    if rc != 0:
+                        raise RuntimeError("traced gather launch failed: hip error {}".format(rc))
+                elif key in cg.direct:
+                    g = self.cot[cg.direct[key]]
+                else:
+                    continue
+                if kind == "mg":
+                    factors, loc, shapes = self.mg_meta[key]
+                    ops.mg_synth_adj(g, shapes, loc, factors=factors, grads=self.gviews[pos:pos + n])
+            elif kind == "net" and key in cg.pgrads and not self.pgrad_direct:
                 pofs = cg.pg_offset[key]
                 for j, group in enumerate(cg.pgrads[key]):
-                    grads[pos + j] = self.pgrad[pofs:pofs + len(group)].reshape(arrays[pos + j].shape).clone()
+                    self.gviews[pos + j].copy_(self.pgrad[pofs:pofs + len(group)].view(self.gviews[pos + j].shape))
                     pofs += len(group)
-        grads = [g if g is not None else torch.zeros_like(a) for g, a in zip(grads, arrays)]
         out = self.out.clone()
+        nout = len(self.raw)
         loss = out[0]
-        terms = [out[1 + k] for k in range(len(self.raw))]
-        norms = [t if r else torch.sqrt(t) for t, r in zip(terms, self.raw)]
+        terms = [out[1 + k] for k in range(nout)]
+        norms = [out[1 + nout + k] for k in range(nout)]
         del keep
-        return loss, grads, terms, self.names, norms
+        return loss, list(self.gviews), terms, self.names, norms
 
 
 def trace(problem, state):
