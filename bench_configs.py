@@ -74,7 +74,7 @@ def main():
         nt, nx = sc(256), sc(512)
         args = heat.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--infer_k", "1", "--imposed", "stripe"])
         problem, state = heat.make_problem(args)
-        out[f"3: heat inverse {nt}x{nx} adam f32 mg (generic path)"] = run(problem, state, args, "adam", 50)
+        out[f"3: heat inverse {nt}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 50)
     if "4a" in a.configs:  # Poisson 3-D 512^3 multigrid, Adam (the bench.py workload through the API)
         import poisson
 
@@ -96,7 +96,7 @@ def main():
         nt, nx = sc(128), sc(256)
         args = veltracer.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx)])
         problem, state = veltracer.make_problem(args)
-        out[f"5: veltracer {nt}x{nx}x{nx} adam f32 mg (generic path)"] = run(problem, state, args, "adam", 20)
+        out[f"5: veltracer {nt}x{nx}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 20)
     for k, v in out.items():
         print(json.dumps({"config": k, **v}))
 

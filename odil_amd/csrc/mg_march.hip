@@ -1,4 +1,5 @@
-// z-marching multigrid transfers for the all-cell 3-D layout ('ccc', the Poisson hot path).
+// z-marching multigrid transfers for the 3-D layouts 'ccc' (the Poisson hot path) and 'ncc'
+// (node-centred leading axis: the space-time fields of the tracer workload).
 // Same arithmetic as mg_fast.hip / mg_transfer.hip; what changes is the data movement:
 //
 // P  : a thread owns a coarse column (jy, jx) and walks coarse planes, holding the 3x3x3
@@ -144,6 +145,77 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
         v[0][dy][dx] = v[1][dy][dx];
         v[1][dy][dx] = v[2][dy][dx];
       }
+  }
+}
+
+// Same walk for a NODE-centred leading axis ('ncc': time-like axis of the space-time workloads):
+// fine plane 2jz is coarse plane jz interpolated in (y, x) only, fine plane 2jz+1 the mean of the
+// two neighbouring coarse planes; ghosts exist on the two cell axes only.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restrict__ coarse,
+                                                               const T* __restrict__ add, T* __restrict__ fine,
+                                                               MarchArgs a, T cscale, T ascale) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Tap3 tx = tap3(jx, cnx), ty = tap3(jy, cny);
+  T v[2][3][3];
+  load_plane9<T>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[0]);
+  const T r16 = T(1) / T(16), r32 = T(1) / T(32);
+  for (int jz = z0; jz < z1; ++jz) {
+    const bool odd = jz + 1 < cnz;  // the last coarse plane has no fine plane above it
+    Pack2<T> ad[2][2];
+    const int64_t fbase = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx;
+    if (add) {
+#pragma unroll
+      for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+          if (sz == 0 || odd)
+            ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx));
+    }
+    if (odd) load_plane9<T>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[1]);
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz) {
+      if (sz == 1 && !odd) break;
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy) {
+        T o[2];
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          T s = T(0);
+#pragma unroll
+          for (int rz = 0; rz <= sz; ++rz)
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+              for (int rx = 0; rx < 2; ++rx) {
+                const int w = (sy == ry ? 1 : 3) * (sx == rx ? 1 : 3);
+                s = s + T(w) * v[rz][sy + ry][sx + rx];
+              }
+          o[sx] = s * (sz ? r32 : r16);
+        }
+        if (add) {
+          o[0] = ascale * ad[sz][sy].a + o[0];
+          o[1] = ascale * ad[sz][sy].b + o[1];
+        }
+        Pack2<T> pk;
+        pk.a = o[0];
+        pk.b = o[1];
+        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk);
+      }
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) v[0][dy][dx] = v[1][dy][dx];
   }
 }
 
@@ -305,9 +377,59 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
   }
 }
 
+// P^T with a node-centred leading axis: coarse plane J collects fine plane 2J and half of the
+// fine planes 2J-1 and 2J+1, each reduced over its (y, x) window with the two-cell-axis ghost rule.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_march_n(const T* __restrict__ gfine, T* __restrict__ gcoarse,
+                                                               T* __restrict__ gscaled, MarchArgs a, T scale,
+                                                               AdamArgs<T> ad) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Adj6 ax = adj6(jx, cnx), ay = adj6(jy, cny);
+  const bool xy_special = ax.special || ay.special;
+  T pc, pr;  // plane sums of the odd fine plane below
+  {
+    const int f1[1] = {2 * z0 - 1};
+    T c1[1], r1[1];
+    reduce_dispatch<T, 1>(gfine, f1, fnz, fplane, fny, fnx, jy, jx, ay, ax, c1, r1);
+    pc = c1[0], pr = r1[0];
+  }
+  for (int jz = z0; jz < z1; ++jz) {
+    T c2[2], r2[2];
+    const int f2[2] = {2 * jz, 2 * jz + 1};
+    reduce_dispatch<T, 2>(gfine, f2, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+    const T sc = c2[0] + T(0.5) * (pc + c2[1]);
+    T v = sc;
+    if (xy_special) {
+      const T sr = r2[0] + T(0.5) * (pr + r2[1]);
+      v = T(2) * sc - sr;
+    }
+    pc = c2[1], pr = r2[1];
+    const int64_t ci = (int64_t)jz * cplane + (int64_t)jy * cnx + jx;
+    gcoarse[ci] = v;
+    if (gscaled) gscaled[ci] = scale * v;
+    if (ad.x) {
+      T xv = ad.x[ci], mv = ad.m[ci], vv = ad.v[ci];
+      adam_update<T>(xv, mv, vv, gscaled ? scale * v : v, ad);
+      ad.x[ci] = xv;
+      ad.m[ci] = mv;
+      ad.v[ci] = vv;
+    }
+  }
+}
+
 static bool march_setup(MarchArgs& m, const InterpArgs& a) {
-  // exactly (1 | '.'), 'c', 'c', 'c'
-  if (a.loc[1] != kCell || a.loc[2] != kCell || a.loc[3] != kCell) return false;
+  // exactly (1 | '.'), 'c' or 'n', 'c', 'c'
+  if ((a.loc[1] != kCell && a.loc[1] != kNode) || a.loc[2] != kCell || a.loc[3] != kCell) return false;
+  if (a.loc[1] == kNode && a.cut_axis >= 0) return false;
   if (a.cn[0] != 1 || a.loc[0] != kNone) return false;
   for (int i = 0; i < 3; ++i) {
     if (a.fn[i + 1] >= (1 << 30)) return false;
@@ -333,8 +455,12 @@ int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a
                      hipStream_t stream) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
-  hipLaunchKernelGGL(k_interp_add_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine, m,
-                     cscale, ascale);
+  if (a.loc[1] == kNode)
+    hipLaunchKernelGGL(k_interp_add_march_n<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine,
+                       m, cscale, ascale);
+  else
+    hipLaunchKernelGGL(k_interp_add_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine,
+                       m, cscale, ascale);
   const int e = check_launch("k_interp_add_march");
   return e ? e : 1;
 }
@@ -344,8 +470,12 @@ int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a
                      const AdamArgs<T>& ad) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
-  hipLaunchKernelGGL(k_interp_adj_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
-                     gscaled, m, scale, ad);
+  if (a.loc[1] == kNode)
+    hipLaunchKernelGGL(k_interp_adj_march_n<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
+                       gscaled, m, scale, ad);
+  else
+    hipLaunchKernelGGL(k_interp_adj_march<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
+                       gscaled, m, scale, ad);
   const int e = check_launch("k_interp_adj_march");
   return e ? e : 1;
 }

@@ -1097,8 +1097,16 @@ class TracedOperator:
         # differentiable leaves so that `lift` can refuse them
         leaves = [a.detach().requires_grad_(True) for a in domain.arrays_from_state(state)]
         ctx = TraceContext(tr, problem._shadow_state(state, leaves), problem.extra, problem.tracers)
-        with torch.enable_grad():
-            names, values = Problem._split_outputs(problem.operator(ctx))
+        try:
+            with torch.enable_grad():
+                res = problem.operator(ctx)
+        except TraceUnsupported:
+            raise
+        except Exception as e:
+            # code that is not written against `ctx.mod` (torch / NumPy calls on the symbols, helper
+            # kernels of this package): the eager path runs it, and reports genuine errors
+            raise TraceUnsupported("{} under tracing: {}".format(type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+        names, values = Problem._split_outputs(res)
         self.names = names
         raw = [isinstance(v, Context.Raw) for v in values]
         outs = [tr.lift(v.value if r else v) for v, r in zip(values, raw)]
