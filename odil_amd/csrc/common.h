@@ -15,6 +15,9 @@ constexpr int kNumXcd = 8;
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kMaxPartials = 65536;  // doubles of reduction scratch per reduced quantity
 constexpr int kDotPartials = 1024;   // partial sums per vector in odil_dots
+// arrays above this size are streamed with non-temporal accesses; smaller ones are left to the
+// 256 MB last-level cache, where the consumer kernel of the same epoch finds them
+constexpr int64_t kStreamBytes = (int64_t)128 << 20;
 constexpr int kGridCap = 2048;       // 256 CUs x 8 resident workgroups
 
 void set_error(const char* fmt, ...);

@@ -17,29 +17,34 @@ struct alignas(2 * sizeof(T)) Pack2 {
   T a, b;
 };
 
-// touch-once streams (fine addend in, fine result out) bypass L2 retention
+// touch-once streams (fine addend in, fine result out) bypass cache retention when the fine array is
+// larger than the last-level cache could hand to the next kernel anyway (MarchArgs::nt)
 template <typename T>
-__device__ inline Pack2<T> stream_ld(const Pack2<T>* p) {
+__device__ inline Pack2<T> stream_ld(const Pack2<T>* p, bool nt) {
   typedef T VT __attribute__((ext_vector_type(2)));
-  const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(p));
+  const VT v = nt ? __builtin_nontemporal_load(reinterpret_cast<const VT*>(p)) : *reinterpret_cast<const VT*>(p);
   Pack2<T> r;
   r.a = v[0];
   r.b = v[1];
   return r;
 }
 template <typename T>
-__device__ inline void stream_st(Pack2<T>* p, const Pack2<T>& x) {
+__device__ inline void stream_st(Pack2<T>* p, const Pack2<T>& x, bool nt) {
   typedef T VT __attribute__((ext_vector_type(2)));
   VT v;
   v[0] = x.a;
   v[1] = x.b;
-  __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
+  if (nt)
+    __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
+  else
+    *reinterpret_cast<VT*>(p) = v;
 }
 
 struct MarchArgs {
   int cn[3], fn[3];  // (z, y, x) coarse / fine extents
   int tx, ty;
   int cut_lo, cut_hi;  // z end is an interior slab interface (ghost planes), not a wall
+  int nt;              // stream the fine array past the caches (it exceeds kStreamBytes)
   UnitSched usched;
 };
 
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
       for (int sz = 0; sz < 2; ++sz)
 #pragma unroll
         for (int sy = 0; sy < 2; ++sy)
-          ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx));
+          ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx), a.nt);
     }
     load_plane9<T>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[2]);
 #pragma unroll
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
         Pack2<T> pk;
         pk.a = o[0];
         pk.b = o[1];
-        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk);
+        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk, a.nt);
       }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restri
 #pragma unroll
         for (int sy = 0; sy < 2; ++sy)
           if (sz == 0 || odd)
-            ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx));
+            ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx), a.nt);
     }
     if (odd) load_plane9<T>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[1]);
 #pragma unroll
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restri
         Pack2<T> pk;
         pk.a = o[0];
         pk.b = o[1];
-        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk);
+        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk, a.nt);
       }
     }
 #pragma unroll
@@ -437,6 +442,7 @@ static bool march_setup(MarchArgs& m, const InterpArgs& a) {
     m.fn[i] = (int)a.fn[i + 1];
   }
   if (m.cn[0] < 4) return false;  // tiny levels: the per-plane kernel is as good
+  m.nt = 0;
   m.cut_lo = a.cut_axis == 1 ? a.cut_lo : 0;
   m.cut_hi = a.cut_axis == 1 ? a.cut_hi : 0;
   if (a.cut_axis >= 0 && a.cut_axis != 1) return false;
@@ -455,6 +461,7 @@ int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a
                      hipStream_t stream) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
+  m.nt = (int64_t)m.fn[0] * m.fn[1] * m.fn[2] * (int64_t)sizeof(T) > kStreamBytes;
   if (a.loc[1] == kNode)
     hipLaunchKernelGGL(k_interp_add_march_n<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine,
                        m, cscale, ascale);

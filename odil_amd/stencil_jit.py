@@ -559,6 +559,7 @@ class _Codegen:
         if self.total >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         self.lines = []
+        self.max_blocks = int(os.environ.get("ODIL_JIT_NBLOCKS", 65536))
         # reachable nodes
         live = set()
         stack = list(outputs)
@@ -950,7 +951,11 @@ class _Codegen:
             S.append("  T s_{} = (T)0;".format(k))
         for name in self.pg_decl:
             S.append("  T {} = (T)0;".format(name))
-        S.append("  for (int l = blockIdx.x * NB + threadIdx.x; l < {}; l += a.nblocks * NB) {{".format(self.total))
+        if self.total <= self.max_blocks * 256:  # one grid point per thread
+            S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
+            S.append("  if (l < {}) {{".format(self.total))
+        else:
+            S.append("  for (int l = blockIdx.x * NB + threadIdx.x; l < {}; l += a.nblocks * NB) {{".format(self.total))
         rem = "l"
         for d in reversed(range(self.ndim)):
             if d == 0:
@@ -961,8 +966,13 @@ class _Codegen:
                 rem = "r{}".format(d)
         S.extend(fwd)
         S.extend(rev)
+        esize = 8 if tdt == torch.float64 else 4
+        stream = len(self.cots) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
         for slot, n in enumerate(self.cots):
-            S.append("  __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
+            if stream:
+                S.append("  __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
+            else:
+                S.append("  a.cot[{}][l] = g{};".format(slot, n.idx))
         for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
             S.append("  s_{0} = s_{0} + {1};".format(k, self.r(o_) if raw else "{0} * {0}".format(self.r(o_))))
         S.append("  }")
@@ -1127,7 +1137,7 @@ class TracedOperator:
         self.tracer_keys = [n.attr for n in tr.nodes if n.op == "tracer"]
         dev, dt = domain.mod.device, tr.torch_dtype
         self.total = cg.total
-        self.nblocks = min((self.total + 255) // 256, 2048)
+        self.nblocks = min((self.total + 255) // 256, cg.max_blocks)
         nout = len(outs)
         self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in cg.cots]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)
