@@ -520,6 +520,89 @@ def gen_veltracer():
         save(f"veltracer_{tag}", **data)
 
 
+
+# ---------------------------------------------------------------- wave, heat_tmax, infer_constant
+def _loss_grads(ff, arrays_l):
+    values = [f[1] if isinstance(f, tuple) else f for f in ff]
+    names = [f[0] if isinstance(f, tuple) else "" for f in ff]
+    terms = [mod.mean(mod.square(v)) for v in values]
+    loss = sum(terms)
+    grads = torch.autograd.grad(loss, arrays_l, allow_unused=True)
+    return names, values, terms, loss, grads
+
+
+def _store(data, arrays, names, values, terms, loss, grads):
+    data["loss"] = npy(loss)
+    data["names"] = np.array(names)
+    for i, (a, g) in enumerate(zip(arrays, grads)):
+        data[f"x{i}"] = npy(a)
+        data[f"g{i}"] = npy(g) if g is not None else np.zeros(tuple(a.shape))
+    for i, (v, t) in enumerate(zip(values, terms)):
+        data[f"value/{i}"] = npy(v)
+        data[f"term/{i}"] = npy(t)
+
+
+def gen_examples_f2():
+    """The reference's remaining example operators on random states: three time levels (wave),
+    an `Array` unknown scaling the time step with a scalar output (heat_tmax), three constants
+    and a residual without its first row (infer_constant)."""
+    rng = np.random.default_rng(808)
+    Nt, Nx = 8, 16
+    # wave.py:29-75; boundary data are inputs of the fixture (the reference builds them with TF)
+    wave = load_module("ref_wave", "/root/reference/examples/wave/wave.py")
+    domain = odil.Domain(cshape=(Nt, Nx), dimnames=("t", "x"), lower=(0, -1), upper=(1, 1), multigrid=True,
+                         dtype=np.float64, mod=mod)
+    extra = argparse.Namespace(args=argparse.Namespace(kimp=1.5), left_u=T(rng.standard_normal(Nt)),
+                               right_u=T(rng.standard_normal(Nt)), init_u=T(rng.standard_normal(Nx)),
+                               init_ut=T(rng.standard_normal(Nx)))
+    state = odil.State()
+    state.fields["u"] = np.zeros(domain.cshape)
+    state = domain.init_state(state)
+    arrays = [T(rng.standard_normal(tuple(a.shape)) * 0.3) for a in domain.arrays_from_state(state)]
+    arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+    domain.arrays_to_state(arrays_l, state)
+    ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+    data = dict(Nt=np.array(Nt), Nx=np.array(Nx), kimp=np.array(1.5), nlvl=np.array(domain.mg_nlvl))
+    for k in ("left_u", "right_u", "init_u", "init_ut"):
+        data[k] = npy(getattr(extra, k))
+    _store(data, arrays, *_loss_grads(wave.operator_wave(ctx), arrays_l))
+    save("wave_f64", **data)
+
+    # heat_tmax.py:29-75
+    ht = load_module("ref_heat_tmax", "/root/reference/examples/heat_tmax/heat_tmax.py")
+    domain = odil.Domain(cshape=(Nt, Nx), dimnames=("t", "x"), lower=(0, 0), upper=(1, np.pi), multigrid=True,
+                         dtype=np.float64, mod=mod)
+    extra = argparse.Namespace(args=argparse.Namespace(kimp=2.0), u_init=T(rng.standard_normal(Nx)),
+                               u_final=T(rng.standard_normal(Nx)))
+    state = odil.State(fields={"u": odil.Field(None, loc="nc"), "coeff": odil.Array([1.7])})
+    state = domain.init_state(state)
+    arrays = [T(rng.standard_normal(tuple(a.shape)) * 0.3) if i < domain.mg_nlvl else T(np.array([1.7]))
+              for i, a in enumerate(domain.arrays_from_state(state))]
+    arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+    domain.arrays_to_state(arrays_l, state)
+    ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+    data = dict(Nt=np.array(Nt), Nx=np.array(Nx), kimp=np.array(2.0), nlvl=np.array(domain.mg_nlvl),
+                u_init=npy(extra.u_init), u_final=npy(extra.u_final))
+    _store(data, arrays, *_loss_grads(ht.operator_heat(ctx), arrays_l))
+    save("heat_tmax_f64", **data)
+
+    # infer_constant.py:44-74 (fields in the reference's order: coeff first)
+    ic = load_module("ref_infer_constant", "/root/reference/examples/infer_constant/infer_constant.py")
+    domain = odil.Domain(cshape=(Nt, Nx), dimnames=("t", "x"), lower=(0, -1), upper=(1, 1), multigrid=True,
+                         dtype=np.float64, mod=mod)
+    extra = argparse.Namespace(u_init=T(rng.standard_normal(Nx)), u_final=T(rng.standard_normal(Nx)))
+    state = odil.State(fields={"coeff": odil.Array([0, 0, 0.001]), "u": odil.Field(None, loc="nc")})
+    state = domain.init_state(state)
+    arrays = [T(np.array([0.03, 0.2, -0.4])) if i == 0 else T(rng.standard_normal(tuple(a.shape)) * 0.3)
+              for i, a in enumerate(domain.arrays_from_state(state))]
+    arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+    domain.arrays_to_state(arrays_l, state)
+    ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+    data = dict(Nt=np.array(Nt), Nx=np.array(Nx), nlvl=np.array(domain.mg_nlvl), u_init=npy(extra.u_init),
+                u_final=npy(extra.u_final))
+    _store(data, arrays, *_loss_grads(ic.operator_adv(ctx), arrays_l))
+    save("infer_constant_f64", **data)
+
 # ---------------------------------------------------------------- reference tests as known-answer checks
 def check_reference_tests():
     """tests/test_mg_interp.py:11-32 on the shim: exact on linear functions."""
@@ -553,3 +636,4 @@ if __name__ == "__main__":
     gen_test_newton()
     gen_heat()
     gen_veltracer()
+    gen_examples_f2()
