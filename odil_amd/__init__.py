@@ -10,7 +10,7 @@ include/odil_hip.h; there is no CPU fallback.
     import odil_amd as odil        # user operators written for `odil` run unchanged
 """
 
-from . import _lib, backend, core, linsolver, optimizer, util  # noqa: F401
+from . import _lib, backend, core, history, io, linsolver, optimizer, util  # noqa: F401
 from .backend import ModBase, ModNumpy, ModRocm  # noqa: F401
 from .core import (  # noqa: F401
     Array,
@@ -24,6 +24,8 @@ from .core import (  # noqa: F401
     interp_to_finer,
     restrict_to_coarser,
 )
+from .history import History  # noqa: F401
+from .io import parse_raw_xmf, read_raw, read_raw_with_xmf, write_raw_with_xmf, write_raw_xmf  # noqa: F401
 from .optimizer import EarlyStopError  # noqa: F401
 from .util import make_callback, optimize, printlog, set_log_file, setup_outdir  # noqa: F401
 

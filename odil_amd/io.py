@@ -1,0 +1,109 @@
+"""Field dumps in the reference's on-disk format: a flat binary `.raw` file plus an XDMF 2
+description (reference src/odil/io.py:7-167; `tests/test_io.py`).  Arrays are written as
+(Nz, Ny, Nx) in C order; the XDMF lists sizes in that order and origin / spacing reversed
+(z first), as ParaView expects for `ORIGIN_DXDYDZ`.  Device tensors are copied to the host once."""
+
+import os
+import re
+
+import numpy as np
+
+
+def _host(u):
+    return u.detach().cpu().numpy() if hasattr(u, "detach") else np.asarray(u)
+
+
+def write_raw_xmf(xmfpath, rawpath, count, spacing=(1, 1, 1), name=None, precision=8, cell=True):
+    """XDMF 2 metadata for the binary file `rawpath` holding a scalar of shape count = (Nz, Ny, Nx)."""
+    name = name or "data"
+    count = [int(c) for c in count]
+    sizes = " ".join(str(c) for c in count)
+    nodes = " ".join(str(c + 1 if cell else c) for c in count)
+    rev = lambda v: " ".join(str(x) for x in reversed(list(v)))
+    item = '<DataItem Name="{}" Dimensions="3" NumberType="Float" Precision="8" Format="XML">'
+    lines = [
+        '<?xml version="1.0" ?>',
+        '<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>',
+        '<Xdmf Version="2.0">',
+        " <Domain>",
+        '   <Grid Name="mesh" GridType="Uniform">',
+        '     <Topology TopologyType="3DCORECTMesh" Dimensions="{}"/>'.format(nodes),
+        '     <Geometry GeometryType="ORIGIN_DXDYDZ">',
+        "       " + item.format("Origin"),
+        "         " + rev([0, 0, 0]),
+        "       </DataItem>",
+        "       " + item.format("Spacing"),
+        "         " + rev(spacing),
+        "       </DataItem>",
+        "     </Geometry>",
+        '     <Attribute Name="{}" AttributeType="Scalar" Center="{}">'.format(name, "Cell" if cell else "Node"),
+        '       <DataItem ItemType="HyperSlab" Dimensions="{}" Type="HyperSlab">'.format(sizes),
+        '           <DataItem Dimensions="3 3" Format="XML">',
+        "             " + rev([0, 0, 0]),
+        "             " + rev([1, 1, 1]),
+        "             " + sizes,
+        "           </DataItem>",
+        '           <DataItem Dimensions="{}" Seek="0" Precision="{}" NumberType="{}" Format="Binary">'.format(
+            sizes, precision, "Double" if precision == 8 else "Float"),
+        "             " + rawpath,
+        "           </DataItem>",
+        "       </DataItem>",
+        "     </Attribute>",
+        "   </Grid>",
+        " </Domain>",
+        "</Xdmf>",
+    ]
+    with open(xmfpath, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def write_raw_with_xmf(u, xmfpath, rawpath=None, spacing=(1, 1, 1), cell=True, name=None):
+    """Writes `u` (host array or device tensor; 1-D / 2-D arrays get leading unit axes) as
+    `.raw` + XDMF 2.  spacing = (hx, hy, hz).  Returns xmfpath."""
+    u = np.ascontiguousarray(_host(u))
+    if u.dtype not in (np.float32, np.float64):
+        u = u.astype(np.float64)
+    while u.ndim < 3:
+        u = u[None]
+    if u.ndim != 3:
+        raise ValueError("Expected at most 3 dimensions, got shape {}".format(u.shape))
+    spacing = list(spacing)
+    while len(spacing) < 3:
+        spacing.append(min(spacing))
+    if rawpath is None:
+        rawpath = os.path.splitext(xmfpath)[0] + ".raw"
+    rel = os.path.relpath(rawpath, start=os.path.dirname(xmfpath) or ".")
+    write_raw_xmf(xmfpath, rel, u.shape, spacing, name or "data", 4 if u.dtype == np.float32 else 8, cell)
+    u.tofile(rawpath)
+    return xmfpath
+
+
+def parse_raw_xmf(xmfpath):
+    """Metadata of a file written by write_raw_xmf: rawpath, count (Nz, Ny, Nx), spacing (hx, hy, hz),
+    name, precision (bytes per value), cell."""
+    with open(xmfpath) as f:
+        text = " ".join(f.read().split())
+    binary = re.search(r'<DataItem Dimensions="(\d+) (\d+) (\d+)"[^>]*Precision="(\d+)"[^>]*Format="Binary">\s*(\S+)', text)
+    attr = re.search(r'<Attribute Name="([^"]*)" AttributeType="Scalar" Center="([A-Za-z]*)">', text)
+    spacing = re.search(r'<DataItem Name="Spacing"[^>]*>\s*([^<]*?)\s*<', text)
+    if not (binary and attr and spacing):
+        raise RuntimeError("Not a raw+XDMF2 scalar description: " + xmfpath)
+    if attr.group(2) not in ("Cell", "Node"):
+        raise RuntimeError("Unknown Center='{}'".format(attr.group(2)))
+    return {
+        "rawpath": os.path.join(os.path.dirname(xmfpath), binary.group(5)),
+        "count": tuple(int(binary.group(i)) for i in (1, 2, 3)),
+        "spacing": tuple(float(v) for v in reversed(spacing.group(1).split())),
+        "name": attr.group(1),
+        "precision": int(binary.group(4)),
+        "cell": attr.group(2) == "Cell",
+    }
+
+
+def read_raw_with_xmf(xmfpath):
+    meta = parse_raw_xmf(xmfpath)
+    dtype = {4: np.float32, 8: np.float64}[meta["precision"]]
+    return np.fromfile(meta["rawpath"], dtype).reshape(meta["count"]), meta
+
+
+read_raw = read_raw_with_xmf

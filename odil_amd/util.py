@@ -19,6 +19,7 @@ import time
 import numpy as np
 import torch
 
+from .history import History
 from .optimizer import EarlyStopError, Optimizer, make_optimizer  # noqa: F401
 
 g_log_file = sys.stderr
@@ -150,29 +151,18 @@ def setup_outdir(args, relpath_args=None):
     printlog(" ".join(sys.argv))
 
 
-class _CsvHistory:
-    """Minimal column store -> train.csv (same column names as reference util.py:423-444)."""
+def get_memory_usage_kb():
+    """Peak resident set size of this process (kB), as the reference reports it (util.py:41-55)."""
+    import resource
 
-    def __init__(self, csvpath):
-        self.csvpath = csvpath
-        self.rows = []
-        self.cur = dict()
+    return int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)
 
-    def append(self, key, value):
-        self.cur[key] = float(np.array(value)) if not isinstance(value, str) else value
 
-    def write(self):
-        self.rows.append(self.cur)
-        self.cur = dict()
-        keys = []
-        for r in self.rows:
-            for k in r:
-                if k not in keys:
-                    keys.append(k)
-        with open(self.csvpath, "w") as f:
-            f.write(",".join(keys) + "\n")
-            for r in self.rows:
-                f.write(",".join(str(r.get(k, "")) for k in keys) + "\n")
+def get_gpu_memory_usage_kb():
+    """(allocated, reserved) device memory of the caching allocator in kB."""
+    if not torch.cuda.is_available():
+        return 0, 0
+    return torch.cuda.memory_allocated() // 1024, torch.cuda.memory_reserved() // 1024
 
 
 def make_callback(problem, args=None, epoch_func=None, report_func=None, history_func=None, checkpoint_func=None,
@@ -185,7 +175,7 @@ def make_callback(problem, args=None, epoch_func=None, report_func=None, history
     cbinfo.problem = problem
     cbinfo.args = args
     cbinfo.frame = 0
-    cbinfo.history = _CsvHistory("train.csv") if getattr(args, "history_every", 0) else None
+    cbinfo.history = History(csvpath="train.csv", warmup=1) if getattr(args, "history_every", 0) else None
 
     def callback(state, epoch, pinfo):
         args = cbinfo.args
@@ -221,8 +211,9 @@ def make_callback(problem, args=None, epoch_func=None, report_func=None, history
                 thr = np.prod(domain.cshape) / wte if wte > 0 else 0
             else:
                 wte, thr = 0, 0
-            gpu_used = torch.cuda.memory_allocated() // (1 << 20) if torch.cuda.is_available() else 0
-            printlog("memory: gpu_used: {:} MiB".format(gpu_used))
+            gpu_used, gpu_pool = get_gpu_memory_usage_kb()
+            printlog("memory: {:} MiB, gpu_used: {:} MiB, gpu_pool: {:} MiB".format(
+                get_memory_usage_kb() // 1024, gpu_used // 1024, gpu_pool // 1024))
             printlog("walltime: {:.3f} s, walltime+callback: {:.3f} s, walltime/epoch: {:.3f} ms".format(
                 walltime, walltime + cbinfo.time_callback, wte * 1000))
             printlog("throughput: {:.3f} Mcells/s".format(thr / 1e6))
@@ -233,10 +224,18 @@ def make_callback(problem, args=None, epoch_func=None, report_func=None, history
             h.append("frame", cbinfo.frame)
             if pinfo and "norms" in pinfo:
                 for i, (norm, name) in enumerate(zip(pinfo["norms"], pinfo["names"])):
-                    h.append("norm_{:}".format(name or str(i)), norm)
+                    h.append("norm_{:}".format(name or str(i)), np.array(norm))
             if pinfo and "loss" in pinfo:
-                h.append("loss", pinfo["loss"])
-            h.append("walltime", np.round(walltime, 3))
+                h.append("loss", np.array(pinfo["loss"]))
+            if getattr(args, "linsolver_history", 0) and pinfo and "linsolver" in pinfo:
+                for key, val in pinfo["linsolver"].items():
+                    if isinstance(val, (int, float, str, np.floating)):
+                        h.append("lin_" + key, val)
+            h.append("walltime", float(np.round(walltime, 3)))
+            gpu_used, gpu_pool = get_gpu_memory_usage_kb()
+            h.append("memory", get_memory_usage_kb() // 1024)
+            h.append("gpu_used", gpu_used // 1024)
+            h.append("gpu_pool", gpu_pool // 1024)
             if history_func is not None:
                 history_func(problem, state, epoch, h, cbinfo)
             h.write()
