@@ -211,7 +211,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "3D Poisson 512^3 multigrid (9 levels) Adam epoch, 1xMI355X"
+                "workload": "3D Poisson 512^3 multigrid (9 levels) Adam epoch, {}".format(
+                    "1xMI355X" if world == 1 else "512^3 slab per GPU x {} MI355X".format(world))
                 if (ndim, N) == (3, 512)
                 else "{}D Poisson {}^{} multigrid Adam epoch".format(ndim, N, ndim),
                 "cells_per_gpu": run.local_cells,

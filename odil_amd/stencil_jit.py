@@ -1072,23 +1072,45 @@ class _Codegen:
         return "\n".join(S) + "\n"
 
 
+def _cache_dirs():
+    """In-tree cache first (travels with the checkout); a per-user temp dir if that is read-only."""
+    import getpass
+
+    yield _CACHE_DIR
+    try:
+        user = getpass.getuser()
+    except Exception:
+        user = str(os.getuid())
+    yield os.path.join(tempfile.gettempdir(), "odil_jit_cache_" + user)
+
+
 def _compile(src):
     tag = hashlib.sha256((src + " ".join(_HIPCC_FLAGS)).encode()).hexdigest()[:20]
-    path = os.path.join(_CACHE_DIR, "odil_jit_{}.so".format(tag))
-    if not os.path.exists(path):
-        os.makedirs(_CACHE_DIR, exist_ok=True)
-        hip = os.path.join(_CACHE_DIR, "odil_jit_{}.hip".format(tag))
-        with open(hip, "w") as f:
-            f.write(src)
-        fd, tmp = tempfile.mkstemp(suffix=".so", dir=_CACHE_DIR)
-        os.close(fd)
+    name = "odil_jit_{}.so".format(tag)
+    for d in _cache_dirs():
+        if os.path.exists(os.path.join(d, name)):
+            return ctypes.CDLL(os.path.join(d, name)), os.path.join(d, name)
+    last = None
+    for d in _cache_dirs():
+        try:
+            os.makedirs(d, exist_ok=True)
+            hip = os.path.join(d, "odil_jit_{}.hip".format(tag))
+            with open(hip, "w") as f:
+                f.write(src)
+            fd, tmp = tempfile.mkstemp(suffix=".so", dir=d)
+            os.close(fd)
+        except OSError as e:
+            last = e
+            continue
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         res = subprocess.run([hipcc] + _HIPCC_FLAGS + ["-o", tmp, hip], capture_output=True, text=True)
         if res.returncode != 0:
             os.unlink(tmp)
             raise RuntimeError("hipcc failed for the traced operator ({}):\n{}".format(hip, res.stderr[-4000:]))
-        os.replace(tmp, path)
-    return ctypes.CDLL(path), path
+        path = os.path.join(d, name)
+        os.replace(tmp, path)  # atomic: concurrent ranks compiling the same source do not collide
+        return ctypes.CDLL(path), path
+    raise FileNotFoundError("no writable cache directory for traced operators: {}".format(last))
 
 
 # ======================================================================================
