@@ -50,7 +50,7 @@ def run(problem, state, args, optname, epochs, warmup=2):
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument("--configs", nargs="*", default=["1", "2", "3", "4a", "4b", "5"])
+    p.add_argument("--configs", nargs="*", default=["1", "2", "3", "3b", "4a", "4b", "5", "5b"])
     p.add_argument("--scale", type=float, default=1.0)
     a = p.parse_args()
     sc = lambda n: max(8, int(round(n * a.scale)) // 8 * 8)
@@ -75,6 +75,13 @@ def main():
         args = heat.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--infer_k", "1", "--imposed", "stripe"])
         problem, state = heat.make_problem(args)
         out[f"3: heat inverse {nt}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 50)
+    if "3b" in a.configs:  # heat inverse with two space dimensions: the shape BASELINE names, (t, x, y) = 256 x 512^2
+        import heat2d
+
+        nt, nx = sc(256), sc(512)
+        args = heat2d.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx), "--infer_k", "1", "--imposed", "stripe"])
+        problem, state = heat2d.make_problem(args)
+        out[f"3b: heat inverse {nt}x{nx}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 20)
     if "4a" in a.configs:  # Poisson 3-D 512^3 multigrid, Adam (the bench.py workload through the API)
         import poisson
 
@@ -97,6 +104,13 @@ def main():
         args = veltracer.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx)])
         problem, state = veltracer.make_problem(args)
         out[f"5: veltracer {nt}x{nx}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 20)
+    if "5b" in a.configs:  # tracer with three space dimensions (t, x, y, z), 4 fields 'nccc'; 32 x 256^3 fits one GPU
+        import veltracer3d
+
+        nt, nx = sc(32), sc(256)
+        args = veltracer3d.parse_args(["--Nt", str(nt), "--Nx", str(nx)])
+        problem, state = veltracer3d.make_problem(args)
+        out[f"5b: veltracer3d {nt}x{nx}^3 adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 5, warmup=1)
     for k, v in out.items():
         print(json.dumps({"config": k, **v}))
 

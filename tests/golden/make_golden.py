@@ -603,6 +603,70 @@ def gen_examples_f2():
     _store(data, arrays, *_loss_grads(ic.operator_adv(ctx), arrays_l))
     save("infer_constant_f64", **data)
 
+
+# ---------------------------------------------------------------- generalised workloads at BASELINE's named shapes
+def gen_generalised():
+    """BASELINE.json names heat with two space dimensions and the tracer problem with three; the
+    reference examples have one and two.  examples/heat/heat2d.py and
+    examples/velocity_from_tracer/veltracer3d.py (this repository) generalise the discretisations;
+    here those operators are evaluated by the REFERENCE's framework (its Context.field,
+    multigrid_to_regular, eval_neural_net, on the shim) to pin what odil_amd must reproduce."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    heat2d = load_module("our_heat2d", os.path.join(root, "examples", "heat", "heat2d.py"))
+    vt3 = load_module("our_veltracer3d", os.path.join(root, "examples", "velocity_from_tracer", "veltracer3d.py"))
+    rng = np.random.default_rng(909)
+    for tag, dtype in [("f64", np.float64), ("f32", np.float32)]:
+        Nt, Nx, Ny = 8, 8, 16
+        domain = odil.Domain(cshape=(Nt, Nx, Ny), dimnames=("t", "x", "y"), multigrid=True, dtype=dtype, mod=mod)
+        args = argparse.Namespace(keep_frozen=1, keep_init=1, infer_k=1, kmax=0.1, kimp=2.0, kxreg=0.3, kxregdecay=50.0,
+                                  ktreg=0.2, ktregdecay=0.0)
+        imp_mask = (rng.random((Nt, Nx, Ny)) < 0.2).astype(dtype)
+        extra = argparse.Namespace(args=args, init_u=T(rng.standard_normal((Nx, Ny)).astype(dtype) * 0.5),
+                                   imp_mask=T(imp_mask), imp_size=int(imp_mask.sum()),
+                                   imp_u=T(rng.standard_normal((Nt, Nx, Ny)).astype(dtype)))
+        state = odil.State()
+        state.fields["u"] = np.zeros(domain.cshape, dtype=dtype)
+        layers = [1, 5, 5, 1]
+        weights = [rng.uniform(-1, 1, (no, ni)).astype(dtype) for ni, no in zip(layers[:-1], layers[1:])]
+        biases = [rng.uniform(-0.5, 0.5, (no,)).astype(dtype) for no in layers[1:]]
+        state.fields["k_net"] = odil.NeuralNet([T(w) for w in weights], [T(b) for b in biases])
+        state = domain.init_state(state)
+        arrays = [T((rng.standard_normal(tuple(a.shape)) * 0.3).astype(dtype)) if i < domain.mg_nlvl else a
+                  for i, a in enumerate(domain.arrays_from_state(state))]
+        arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+        domain.arrays_to_state(arrays_l, state)
+        ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 7})
+        data = dict(Nt=np.array(Nt), Nx=np.array(Nx), Ny=np.array(Ny), epoch=np.array(7), nlvl=np.array(domain.mg_nlvl),
+                    init_u=npy(extra.init_u), imp_mask=imp_mask, imp_u=npy(extra.imp_u), imp_size=np.array(extra.imp_size))
+        for k, v in vars(args).items():
+            data[f"args/{k}"] = np.array(v)
+        _store(data, arrays, *_loss_grads(heat2d.operator(ctx), arrays_l))
+        save(f"heat2d_{tag}", **data)
+
+        Nt, Nx = 4, 8
+        domain = odil.Domain(cshape=(Nt, Nx, Nx, Nx), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
+                             upper=(1, 1, 1, 1), dtype=dtype, multigrid=True, mg_interp="stack", mod=mod)
+        args = argparse.Namespace(kxreg=0.01, ktreg=1.0, kimp=10.0)
+        extra = argparse.Namespace(args=args, u_init=T(rng.standard_normal((Nx, Nx, Nx)).astype(dtype)),
+                                   u_final=T(rng.standard_normal((Nx, Nx, Nx)).astype(dtype)))
+        state = odil.State()
+        for key in ("u",) + vt3.VEL:
+            state.fields[key] = odil.Field(None, loc="nccc")
+        state = domain.init_state(state)
+        arrays = [T((rng.standard_normal(tuple(a.shape)) * 0.3).astype(dtype)) for a in domain.arrays_from_state(state)]
+        arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+        domain.arrays_to_state(arrays_l, state)
+        ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+        data = dict(Nt=np.array(Nt), Nx=np.array(Nx), nlvl=np.array(domain.mg_nlvl), u_init=npy(extra.u_init),
+                    u_final=npy(extra.u_final))
+        for k, v in vars(args).items():
+            data[f"args/{k}"] = np.array(v)
+        names, values, terms, loss, grads = _loss_grads(vt3.operator(ctx), arrays_l)
+        _store(data, arrays, names, values[:2], terms, loss, grads)  # values of the first two outputs only (size)
+        for i, t in enumerate(terms):
+            data[f"term/{i}"] = npy(t)
+        save(f"veltracer3d_{tag}", **data)
+
 # ---------------------------------------------------------------- reference tests as known-answer checks
 def check_reference_tests():
     """tests/test_mg_interp.py:11-32 on the shim: exact on linear functions."""
@@ -637,3 +701,4 @@ if __name__ == "__main__":
     gen_heat()
     gen_veltracer()
     gen_examples_f2()
+    gen_generalised()
