@@ -45,6 +45,7 @@ struct MarchArgs {
   int tx, ty;
   int cut_lo, cut_hi;  // z end is an interior slab interface (ghost planes), not a wall
   int nt;              // stream the fine array past the caches (it exceeds kStreamBytes)
+  int lead_loc, lead_cn, lead_fn;  // 4-D layouts: leading axis kind ('.' batch or 'n') and its extents
   UnitSched usched;
 };
 
@@ -150,6 +151,100 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
         v[0][dy][dx] = v[1][dy][dx];
         v[1][dy][dx] = v[2][dy][dx];
       }
+  }
+}
+
+// 4-D layouts ('.ccc' batches and 'nccc': space-time fields with three space dimensions): the walk
+// of k_interp_add_march per FINE leading index f0 (blockIdx.y).  On a node-centred leading axis an
+// odd f0 averages the two neighbouring coarse volumes: both 3x3x3 windows are held and summed in
+// the reference's order (leading tap outermost).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __restrict__ coarse,
+                                                                  const T* __restrict__ add, T* __restrict__ fine,
+                                                                  MarchArgs a, T cscale, T ascale) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)a.fn[0] * fplane;
+  const int f0 = blockIdx.y;
+  const bool node = a.lead_loc == kNode;
+  const int cnt0 = node && (f0 & 1) ? 2 : 1;
+  const int c0 = node ? f0 >> 1 : f0;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Tap3 tx = tap3(jx, cnx), ty = tap3(jy, cny);
+  const T* cb[2] = {coarse + c0 * cvol, coarse + (c0 + cnt0 - 1) * cvol};
+  add = add ? add + f0 * fvol : add;
+  fine += f0 * fvol;
+  T v[2][3][3][3];
+#pragma unroll
+  for (int r0 = 0; r0 < 2; ++r0) {
+    if (r0 >= cnt0) break;
+    load_plane9<T>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0]);
+    load_plane9<T>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1]);
+  }
+  const T rs = T(1) / T(64 * cnt0);
+  for (int jz = z0; jz < z1; ++jz) {
+    Pack2<T> ad[2][2];
+    const int64_t fbase = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx;
+    if (add) {
+#pragma unroll
+      for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+          ad[sz][sy] = stream_ld(reinterpret_cast<const Pack2<T>*>(add + fbase + sz * fplane + (int64_t)sy * fnx), a.nt);
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 2; ++r0) {
+      if (r0 >= cnt0) break;
+      load_plane9<T>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2]);
+    }
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy) {
+        T o[2];
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          T s = T(0);
+#pragma unroll
+          for (int r0 = 0; r0 < 2; ++r0) {
+            if (r0 >= cnt0) break;
+#pragma unroll
+            for (int rz = 0; rz < 2; ++rz)
+#pragma unroll
+              for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+                for (int rx = 0; rx < 2; ++rx) {
+                  const int w = (sz == rz ? 1 : 3) * (sy == ry ? 1 : 3) * (sx == rx ? 1 : 3);
+                  s = s + T(w) * v[r0][sz + rz][sy + ry][sx + rx];
+                }
+          }
+          o[sx] = s * rs;
+        }
+        if (add) {
+          o[0] = ascale * ad[sz][sy].a + o[0];
+          o[1] = ascale * ad[sz][sy].b + o[1];
+        }
+        Pack2<T> pk;
+        pk.a = o[0];
+        pk.b = o[1];
+        stream_st(reinterpret_cast<Pack2<T>*>(fine + fbase + sz * fplane + (int64_t)sy * fnx), pk, a.nt);
+      }
+#pragma unroll
+    for (int r0 = 0; r0 < 2; ++r0)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          v[r0][0][dy][dx] = v[r0][1][dy][dx];
+          v[r0][1][dy][dx] = v[r0][2][dy][dx];
+        }
   }
 }
 
@@ -382,6 +477,106 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
   }
 }
 
+// z-combination of one window of plane sums (the step of k_interp_adj_march).
+template <typename T>
+__device__ inline T combine_z(const T (&wc)[6], const T (&wr)[6], int jz, int cnz, int fnz, bool xy_special,
+                              int cut_lo, int cut_hi) {
+  const bool z_special = ((jz == 0 || jz == 1) && !cut_lo) || ((jz == cnz - 2 || jz == cnz - 1) && !cut_hi);
+  if (!z_special && !xy_special) return (T(0.25) * wc[1] + T(0.75) * wc[2]) + (T(0.75) * wc[3] + T(0.25) * wc[4]);
+  T sc = T(0), sr = T(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int k = 2 * jz - 2 + i;
+    const float w = w_cell(jz, k, fnz), lo = w_cell(-1, k, fnz), hi = w_cell(cnz, k, fnz);
+    const float zc_w = w + (jz == 0 && !cut_lo ? lo : 0.f) + (jz == cnz - 1 && !cut_hi ? hi : 0.f);
+    const float zr_w = w + (jz == 1 && !cut_lo ? lo : 0.f) + (jz == cnz - 2 && !cut_hi ? hi : 0.f);
+    sc = sc + T(zc_w) * wc[i];
+    sr = sr + T(zr_w) * wr[i];
+  }
+  return T(2) * sc - sr;
+}
+
+// P^T for the 4-D layouts: coarse volume J0 (blockIdx.y) collects the fine volumes 2 J0 and, halved,
+// 2 J0 +- 1 on a node-centred leading axis (volume J0 alone on a batch axis); one z-window of plane
+// sums per contributing fine volume.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __restrict__ gfine,
+                                                                  T* __restrict__ gcoarse, T* __restrict__ gscaled,
+                                                                  MarchArgs a, T scale, AdamArgs<T> ad) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)fnz * fplane;
+  const int J0 = blockIdx.y;
+  const bool node = a.lead_loc == kNode;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;
+  const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;
+  const int jy = yt * a.ty + ly, jx = xt * a.tx + lx;
+  if (jy >= cny || jx >= cnx) return;
+  const int z0 = zc * a.usched.ZC;
+  const int z1 = z0 + a.usched.ZC < cnz ? z0 + a.usched.ZC : cnz;
+  const Adj6 ax = adj6(jx, cnx), ay = adj6(jy, cny);
+  const bool xy_special = ax.special || ay.special;
+  // contributing fine volumes: (index, weight); missing ones get weight 0 and a clamped index
+  int fv[3];
+  T wv[3];
+  int ntap = 1;
+  if (node) {
+    ntap = 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int f = 2 * J0 - 1 + t;
+      const bool ok = f >= 0 && f < a.lead_fn;
+      fv[t] = ok ? f : 2 * J0;
+      wv[t] = ok ? (t == 1 ? T(1) : T(0.5)) : T(0);
+    }
+  } else {
+    fv[0] = fv[1] = fv[2] = J0;
+    wv[0] = T(1);
+    wv[1] = wv[2] = T(0);
+  }
+  T wc[3][6], wr[3][6];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (t >= ntap) break;
+    const T* gf = gfine + fv[t] * fvol;
+    T c2[2], r2[2];
+    const int fa[2] = {2 * z0 - 2, 2 * z0 - 1}, fb[2] = {2 * z0, 2 * z0 + 1};
+    reduce_dispatch<T, 2>(gf, fa, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+    wc[t][0] = c2[0], wc[t][1] = c2[1], wr[t][0] = r2[0], wr[t][1] = r2[1];
+    reduce_dispatch<T, 2>(gf, fb, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+    wc[t][2] = c2[0], wc[t][3] = c2[1], wr[t][2] = r2[0], wr[t][3] = r2[1];
+  }
+  for (int jz = z0; jz < z1; ++jz) {
+    T v = T(0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t >= ntap) break;
+      T c2[2], r2[2];
+      const int fn2[2] = {2 * jz + 2, 2 * jz + 3};
+      reduce_dispatch<T, 2>(gfine + fv[t] * fvol, fn2, fnz, fplane, fny, fnx, jy, jx, ay, ax, c2, r2);
+      wc[t][4] = c2[0], wc[t][5] = c2[1], wr[t][4] = r2[0], wr[t][5] = r2[1];
+      v = v + wv[t] * combine_z<T>(wc[t], wr[t], jz, cnz, fnz, xy_special, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wc[t][i] = wc[t][i + 2];
+        wr[t][i] = wr[t][i + 2];
+      }
+    }
+    const int64_t ci = J0 * cvol + (int64_t)jz * cplane + (int64_t)jy * cnx + jx;
+    gcoarse[ci] = v;
+    if (gscaled) gscaled[ci] = scale * v;
+    if (ad.x) {
+      T xv = ad.x[ci], mv = ad.m[ci], vv = ad.v[ci];
+      adam_update<T>(xv, mv, vv, gscaled ? scale * v : v, ad);
+      ad.x[ci] = xv;
+      ad.m[ci] = mv;
+      ad.v[ci] = vv;
+    }
+  }
+}
+
 // P^T with a node-centred leading axis: coarse plane J collects fine plane 2J and half of the
 // fine planes 2J-1 and 2J+1, each reduced over its (y, x) window with the two-cell-axis ghost rule.
 template <typename T>
@@ -435,7 +630,11 @@ static bool march_setup(MarchArgs& m, const InterpArgs& a) {
   // exactly (1 | '.'), 'c' or 'n', 'c', 'c'
   if ((a.loc[1] != kCell && a.loc[1] != kNode) || a.loc[2] != kCell || a.loc[3] != kCell) return false;
   if (a.loc[1] == kNode && a.cut_axis >= 0) return false;
-  if (a.cn[0] != 1 || a.loc[0] != kNone) return false;
+  const bool lead = a.fn[0] != 1;  // a real leading axis: '.ccc' batch or 'nccc'
+  if (a.loc[0] == kCell || (lead && (a.loc[1] != kCell || a.cut_axis >= 0 || a.fn[0] > 65535))) return false;
+  m.lead_loc = lead ? a.loc[0] : 0;
+  m.lead_cn = (int)a.cn[0];
+  m.lead_fn = (int)a.fn[0];
   for (int i = 0; i < 3; ++i) {
     if (a.fn[i + 1] >= (1 << 30)) return false;
     m.cn[i] = (int)a.cn[i + 1];
@@ -461,8 +660,11 @@ int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a
                      hipStream_t stream) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
-  m.nt = (int64_t)m.fn[0] * m.fn[1] * m.fn[2] * (int64_t)sizeof(T) > kStreamBytes;
-  if (a.loc[1] == kNode)
+  m.nt = (int64_t)m.lead_fn * m.fn[0] * m.fn[1] * m.fn[2] * (int64_t)sizeof(T) > kStreamBytes;
+  if (m.lead_fn != 1)
+    hipLaunchKernelGGL(k_interp_add_march_lead<T>, dim3(unit_grid(m.usched), m.lead_fn), dim3(kBlock), 0, stream,
+                       coarse, add, fine, m, cscale, ascale);
+  else if (a.loc[1] == kNode)
     hipLaunchKernelGGL(k_interp_add_march_n<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, coarse, add, fine,
                        m, cscale, ascale);
   else
@@ -477,7 +679,10 @@ int interp_adj_march(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a
                      const AdamArgs<T>& ad) {
   MarchArgs m;
   if (!march_setup(m, a)) return 0;
-  if (a.loc[1] == kNode)
+  if (m.lead_fn != 1)
+    hipLaunchKernelGGL(k_interp_adj_march_lead<T>, dim3(unit_grid(m.usched), m.lead_cn), dim3(kBlock), 0, stream,
+                       gfine, gcoarse, gscaled, m, scale, ad);
+  else if (a.loc[1] == kNode)
     hipLaunchKernelGGL(k_interp_adj_march_n<T>, dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
                        gscaled, m, scale, ad);
   else

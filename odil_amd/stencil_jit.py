@@ -927,7 +927,7 @@ class _Codegen:
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; double hs[{}]; "
-                 "T* part; T* ppart; T* out; T* pgrad; int nblocks; }};".format(
+                 "T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks; }};".format(
                      max(1, len(self.src_keys)), max(1, len(self.tr.tensors)), max(1, len(self.cots)),
                      max(1, par_arrays), max(1, len(self.hs))))
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
@@ -981,23 +981,33 @@ class _Codegen:
         for k, name in enumerate(self.pg_decl):
             S.append("  {{ const T s = block_sum({}, sm); if (threadIdx.x == 0) a.ppart[{} * a.nblocks + blockIdx.x] = s; }}".format(name, k))
         S.append("}")
-        # final reduction, one workgroup per row of partials: out = [loss, terms..., norms...] and
-        # the parameter gradients; the loss is summed in output order by k_loss
+        # final reduction in two deterministic stages: k_final sums SEG segments of every row of
+        # partials (one workgroup each), k_loss combines them in order: out = [loss, terms..., norms...]
+        # and the parameter gradients
+        nrows = nout + len(self.pg_decl)
+        S.append("#define SEG 16")
         S.append('extern "C" __global__ __launch_bounds__(NB) void k_final(const Args a) {')
         S.append("  __shared__ T sm[NB / 64];")
-        S.append("  const int k = blockIdx.x;")
+        S.append("  const int k = blockIdx.x, seg = blockIdx.y;")
         S.append("  const T* row = k < {0} ? a.part + k * a.nblocks : a.ppart + (k - {0}) * a.nblocks;".format(nout))
+        S.append("  const int len = (a.nblocks + SEG - 1) / SEG, j0 = seg * len, j1 = min(j0 + len, a.nblocks);")
         S.append("  T s = (T)0;")
-        S.append("  for (int j = threadIdx.x; j < a.nblocks; j += NB) s = s + row[j];")
+        S.append("  for (int j = j0 + threadIdx.x; j < j1; j += NB) s = s + row[j];")
         S.append("  s = block_sum(s, sm);")
-        S.append("  if (threadIdx.x != 0) return;")
-        S.append("  if (k >= {0}) {{ a.pgrad[k - {0}] = s; return; }}".format(nout))
-        S.append("  s = s / (T){};".format(float(self.total)))
-        S.append("  a.out[1 + k] = s;")
-        S.append("  const bool raw[{}] = {{{}}};".format(nout, ", ".join("true" if r else "false" for r in self.raw)))
-        S.append("  a.out[1 + {} + k] = raw[k] ? s : FN(sqrt)(s);".format(nout))
+        S.append("  if (threadIdx.x == 0) a.part2[k * SEG + seg] = s;")
         S.append("}")
-        S.append('extern "C" __global__ void k_loss(const Args a) {')
+        S.append('extern "C" __global__ __launch_bounds__(64) void k_loss(const Args a) {')
+        S.append("  const bool raw[{}] = {{{}}};".format(nout, ", ".join("true" if r else "false" for r in self.raw)))
+        S.append("  for (int k = threadIdx.x; k < {}; k += 64) {{".format(nrows))
+        S.append("    T s = (T)0;")
+        S.append("    for (int seg = 0; seg < SEG; ++seg) s = s + a.part2[k * SEG + seg];")
+        S.append("    if (k >= {0}) {{ a.pgrad[k - {0}] = s; continue; }}".format(nout))
+        S.append("    s = s / (T){};".format(float(self.total)))
+        S.append("    a.out[1 + k] = s;")
+        S.append("    a.out[1 + {} + k] = raw[k] ? s : FN(sqrt)(s);".format(nout))
+        S.append("  }")
+        S.append("  __syncthreads();")
+        S.append("  if (threadIdx.x != 0) return;")
         S.append("  T loss = (T)0;")
         S.append("  for (int k = 0; k < {}; ++k) loss = loss + a.out[1 + k];".format(nout))
         S.append("  a.out[0] = loss;")
@@ -1055,8 +1065,8 @@ class _Codegen:
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
         S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3(NB), 0, (hipStream_t)stream, *a);")
-        S.append("  hipLaunchKernelGGL(k_final, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a);".format(nout + len(self.pg_decl)))
-        S.append("  hipLaunchKernelGGL(k_loss, dim3(1), dim3(1), 0, (hipStream_t)stream, *a);")
+        S.append("  hipLaunchKernelGGL(k_final, dim3({}, SEG), dim3(NB), 0, (hipStream_t)stream, *a);".format(nout + len(self.pg_decl)))
+        S.append("  hipLaunchKernelGGL(k_loss, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
         S.append('extern "C" int jit_gather(int which, const Args* a, void* g, void* stream) {')
@@ -1175,7 +1185,7 @@ class TracedOperator:
                 ("cot", ctypes.c_void_p * max(1, len(cg.cots))),
                 ("par", ctypes.c_void_p * max(1, par_arrays)),
                 ("hs", ctypes.c_double * max(1, len(cg.hs))),
-                ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
             ]
 
@@ -1184,7 +1194,9 @@ class TracedOperator:
             self.args.ten[i] = t.data_ptr()
         for i, t in enumerate(self.cot):
             self.args.cot[i] = t.data_ptr()
+        self.part2 = torch.zeros(16 * (nout + len(cg.pg_decl)), dtype=dt, device=dev)
         self.args.part, self.args.ppart = self.part.data_ptr(), self.ppart.data_ptr()
+        self.args.part2 = self.part2.data_ptr()
         self.args.out, self.args.pgrad = self.out.data_ptr(), self.pgrad.data_ptr()
         self.args.nblocks = self.nblocks
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

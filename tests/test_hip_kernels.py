@@ -49,7 +49,8 @@ def test_interp_and_adjoint_vs_golden(dev, loc):
 
 @pytest.mark.parametrize(
     "loc,shape", [("ccc", (5, 6, 7)), ("ncc", (5, 4, 6)), ("cc", (33, 130)), ("c", (700,)), ("cn", (9, 300)),
-                  ("ncc", (9, 16, 20)), ("ncc", (67, 8, 12)), ("ncc", (3, 6, 4)), ("ncc", (4, 2, 2))]
+                  ("ncc", (9, 16, 20)), ("ncc", (67, 8, 12)), ("ncc", (3, 6, 4)), ("ncc", (4, 2, 2)),
+                  ("nccc", (3, 4, 6, 8)), ("nccc", (6, 9, 4, 6)), (".ccc", (3, 5, 4, 6)), ("nccc", (2, 4, 2, 2))]
 )
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_interp_random_vs_oracle(dev, loc, shape, dtype):
