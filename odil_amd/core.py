@@ -789,6 +789,26 @@ class LinearizedOperator:
                                   out=dk.reshape(field.array.shape))
         return d
 
+    def to_dense(self):
+        """M as a dense device matrix (rows x unknowns) for the small-system direct solve: stencil
+        blocks are scattered with the column map of `Context.field` (padded entries, which read the
+        constant 0, are dropped -- the same matrix `matvec` applies)."""
+        dense = torch.zeros((self.nrows, self.ncols), dtype=self.dtype, device=self.device)
+        for row0, nrows, kind, key, payload in self.blocks:
+            off = self.key_to_offset[key]
+            if kind == "dense":
+                dense[row0 : row0 + nrows, off : off + payload.shape[1]] += payload
+            else:
+                coeff, shift, loc, vshape = payload
+                field = self.key_to_field[key]
+                size = self.key_to_size[key]
+                cols = (torch.arange(size, dtype=torch.float64, device=self.device) + 1).reshape(field.array.shape)
+                cols = ops.field_gather(cols.contiguous(), field.loc, shift, loc).reshape(-1).to(torch.int64)
+                rows = torch.arange(nrows, device=self.device) + row0
+                keep = cols > 0
+                dense.index_put_((rows[keep], cols[keep] - 1 + off), coeff.reshape(-1)[keep], accumulate=True)
+        return dense
+
     def to_scipy(self, modsp=None):
         """The CSR matrix of reference core.py:1170-1214 (host, for inspection / parity)."""
         import scipy.sparse as sp

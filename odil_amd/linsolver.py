@@ -6,9 +6,12 @@ scipy.sparse and factorises A with SuperLU (`direct`, linsolver.py:17-26) or han
 iterative routine.  Here M stays a `core.LinearizedOperator` (per-shift coefficient
 arrays + dense blocks), A is applied as M^T (M x) with the HIP stencil kernels and the
 system is solved by Jacobi-preconditioned conjugate gradients with deterministic dot
-products (odil_dots).  `direct` therefore means "CG to round-off" (tol 1e-14 relative,
-bounded by `--linsolver_maxiter` if given, else 20 n), which reproduces the reference's
-Newton iterate to solver tolerance; `cg` / `bicgstab` / `multigrid` use `--linsolver_tol`.
+products (odil_dots) and no host synchronisation inside the iteration.  `direct` is a dense
+Cholesky of A = M^T M up to 16384 unknowns (one f64 GEMM + rocSOLVER, `dense_normal`), geometric
+multigrid for the recognised Poisson stencil above 2e5 unknowns (gmg.py), and otherwise "CG to
+round-off" (tol 1e-14 relative, bounded by `--linsolver_maxiter` if given, else 20 n), which
+reproduces the reference's Newton iterate to solver tolerance; `cg` / `bicgstab` / `multigrid`
+use `--linsolver_tol`.
 cupy / sparseqr / pyamg variants of the reference are optional third-party paths and are
 not provided.
 """
@@ -23,8 +26,12 @@ def _dot(a, b):
     return ops.dots(a[None], b)[0]
 
 
-def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=None, x0=None):
-    """Solves (M^T M + damp^2 I + dampdiag^2 diag(M^T M)) x = M^T rhs by preconditioned CG."""
+def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=None, x0=None, check_every=25):
+    """Solves (M^T M + damp^2 I + dampdiag^2 diag(M^T M)) x = M^T rhs by Jacobi-preconditioned CG.
+
+    The iteration runs without host synchronisation: the scalars <r, z>, <p, A p>, alpha and beta
+    stay 0-d device tensors (deterministic odil_dots; updates through odil_lincomb with device
+    coefficients) and the residual norm is read back only every `check_every` iterations."""
     n = op.shape[1]
     dtype, device = op.dtype, op.device
     b = op.rmatvec(rhs)
@@ -48,33 +55,77 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     r = b.clone()
     if x0 is not None:
         ops.axpy(r, apply_a(x), -1.0)
-    z = torch.empty_like(r)
+    # rows (p, z, p'): the next direction p' = beta p + z is formed from two adjacent rows into the
+    # third, and the roles of rows 0 and 2 alternate (no aliasing inside odil_lincomb)
+    buf = torch.empty((3, n), dtype=dtype, device=device)
+    p, z, flip = buf[0], buf[1], False
     ops.addcmul(z, minv, r, accumulate=False)
-    p = z.clone()
-    rz = float(_dot(r, z))
+    p.copy_(z)
+    rz = _dot(r, z)
     bnorm = float(_dot(b, b)) ** 0.5
     maxiter = maxiter or 20 * n
     niter = 0
     res = float(_dot(r, r)) ** 0.5
-    while niter < maxiter and res > tol * max(bnorm, 1e-300):
-        ap = apply_a(p)
-        pap = float(_dot(p, ap))
-        if pap <= 0:
-            break
-        alpha = rz / pap
-        ops.axpy(x, p, alpha)
-        ops.axpy(r, ap, -alpha)
-        ops.addcmul(z, minv, r, accumulate=False)
-        rz_new = float(_dot(r, z))
-        beta = rz_new / rz
-        rz = rz_new
-        ops.scale(p, beta, out=p)
-        ops.axpy(p, z, 1.0)
-        niter += 1
+    coef = torch.ones(3, dtype=dtype, device=device)  # (beta, 1) on rows 0:2, or (1, beta) on rows 1:3
+    ok = res > tol * max(bnorm, 1e-300)
+    while ok and niter < maxiter:
+        for _ in range(min(check_every, maxiter - niter)):
+            ap = apply_a(p)
+            pap = _dot(p, ap)
+            alpha = (rz / pap).reshape(1)
+            ops.lincomb(x, 1.0, p[None], alpha)
+            ops.lincomb(r, 1.0, ap[None], -alpha)
+            ops.addcmul(z, minv, r, accumulate=False)
+            rz_new = _dot(r, z)
+            beta = rz_new / rz
+            rz = rz_new
+            if not flip:
+                coef[0:1], coef[1:2] = beta, 1.0
+                ops.lincomb(buf[2], 0.0, buf[0:2], coef[0:2])
+                p = buf[2]
+            else:
+                coef[1:2], coef[2:3] = 1.0, beta
+                ops.lincomb(buf[0], 0.0, buf[1:3], coef[1:3])
+                p = buf[0]
+            flip = not flip
+            niter += 1
         res = float(_dot(r, r)) ** 0.5
+        ok = res > tol * max(bnorm, 1e-300) and float(pap) > 0 and res == res
     if status is not None:
         status["residual"] = res
         status["niter"] = niter
+    return x
+
+
+DENSE_MAX_UNKNOWNS = 16384  # up to here `direct` factorises the dense normal matrix (2 GB in f64)
+
+
+def dense_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
+    """`direct` for small systems, as the reference's SuperLU solve of A = M^T M (linsolver.py:17-26):
+    M is scattered into a dense device matrix, A = M^T M is one f64 GEMM (rocBLAS, the only
+    GEMM-shaped work of this path) and A x = M^T rhs is solved by Cholesky (rocSOLVER), LU when A
+    is not numerically positive definite.  Returns None when the factorisation fails."""
+    m = op.to_dense()
+    a = m.t() @ m
+    b = m.t() @ rhs
+    if damp or dampdiag:
+        d = a.diagonal().clone()
+        a.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * d)
+    chol, info = torch.linalg.cholesky_ex(a)
+    if int(info) == 0:
+        x = torch.cholesky_solve(b[:, None], chol)[:, 0]
+        method = "dense-cholesky"
+    else:
+        lu, piv, info = torch.linalg.lu_factor_ex(a)
+        if int(info) != 0:
+            return None
+        x = torch.linalg.lu_solve(lu, piv, b[:, None])[:, 0]
+        method = "dense-lu"
+    if status is not None:
+        r = a @ x - b
+        status["residual"] = float(_dot(r.contiguous(), r.contiguous())) ** 0.5
+        status["niter"] = 1
+        status["method"] = method
     return x
 
 
@@ -112,6 +163,10 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
     if linsolver in ("direct", "directsq"):
+        if matr.ncols <= DENSE_MAX_UNKNOWNS and matr.nrows * matr.ncols <= (1 << 29):
+            x = dense_normal(matr, rhs, damp, dampdiag, status=status)
+            if x is not None and bool(torch.isfinite(x).all()):
+                return x
         return cg_normal(matr, rhs, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=status)
     else:
         return cg_normal(matr, rhs, damp, dampdiag, tol=tol, maxiter=maxiter or 1000, status=status)

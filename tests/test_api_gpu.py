@@ -183,7 +183,23 @@ def test_newton_linearize_and_step_vs_golden(mod):
     assert rel(op.matvec(mod.array(x)), g["matrix"] @ x) < 1e-13
     assert rel(op.rmatvec(mod.array(y)), g["matrix"].T @ y) < 1e-13
     assert rel(op.normal_diagonal(), np.sum(g["matrix"] ** 2, axis=0)) < 1e-13
-    # one Newton step through optimize_newton (normal equations, CG to round-off)
+    # the three ways the normal equations are solved agree: dense Cholesky (`direct`, small systems),
+    # the dense matrix is the assembled one, CG without host synchronisation
+    assert rel(op.to_dense(), g["matrix"]) < 1e-13
+    rhs = mod.array(y)
+    status = dict()
+    x_dense = odil.linsolver.dense_normal(op, rhs, status=status)
+    assert status["method"] == "dense-cholesky" and status["residual"] < 1e-10
+    status = dict()
+    x_cg = odil.linsolver.cg_normal(op, rhs, tol=1e-14, status=status, check_every=7)
+    assert status["niter"] % 7 == 0 and status["niter"] > 0
+    want = np.linalg.solve(g["matrix"].T @ g["matrix"], g["matrix"].T @ y)
+    assert rel(x_dense, want) < 1e-9 and rel(x_cg, want) < 1e-8
+    damped = odil.linsolver.dense_normal(op, rhs, damp=0.3, dampdiag=0.2)
+    a = g["matrix"].T @ g["matrix"]
+    assert rel(damped, np.linalg.solve(a + 0.09 * np.eye(len(a)) + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)) < 1e-9
+    assert rel(odil.linsolver.cg_normal(op, rhs, damp=0.3, dampdiag=0.2, tol=1e-14), damped.cpu().numpy()) < 1e-8
+    # one Newton step through optimize_newton
     args = argparse.Namespace(epoch_start=0, epochs=1, linsolver="direct", linsolver_maxiter=None, linsolver_damp=0,
                               linsolver_dampdiag=0, linsolver_tol=1e-10, linsolver_verbose=0)
     odil.util.optimize_newton(args, problem, state)
