@@ -917,7 +917,12 @@ class Problem:
         if self._fused is not None:
             return self._fused.eval_loss_grad(state)
         if self._traced is not None:
-            return self._traced.eval_loss_grad(state)
+            if not self._traced.matches(state):  # the state was restructured (e.g. another multigrid depth): trace again
+                from . import stencil_jit
+
+                self._traced = stencil_jit.trace(self, state)
+            if self._traced is not None:
+                return self._traced.eval_loss_grad(state)
         if self.jit:
             return self._eval_loss_grad_graph(state)
         return self._eval_loss_grad_generic(state)

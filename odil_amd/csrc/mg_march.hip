@@ -14,86 +14,9 @@
 // (256^3 -> 512^3: 3.0 -> 4.0 TB/s).  P^T stays at CX = 1: its register footprint (two windows of
 // plane sums, three weight tables) halves the occupancy at CX = 2 and loses more than the wide
 // loads gain (measured).
-#include "mg_transfer.h"
+#include "mg_march.h"
 
 namespace odil {
-
-template <typename T, int NV>
-struct alignas(NV * sizeof(T)) PackN {
-  T e[NV];
-};
-
-// touch-once streams (fine addend in, fine result out) bypass cache retention when the fine array is
-// larger than the last-level cache could hand to the next kernel anyway (MarchArgs::nt)
-template <typename T, int NV>
-__device__ inline PackN<T, NV> stream_ld(const T* p, bool nt) {
-  typedef T VT __attribute__((ext_vector_type(NV)));
-  const VT v = nt ? __builtin_nontemporal_load(reinterpret_cast<const VT*>(p)) : *reinterpret_cast<const VT*>(p);
-  PackN<T, NV> r;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) r.e[k] = v[k];
-  return r;
-}
-template <typename T, int NV>
-__device__ inline void stream_st(T* p, const PackN<T, NV>& x, bool nt) {
-  typedef T VT __attribute__((ext_vector_type(NV)));
-  VT v;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = x.e[k];
-  if (nt)
-    __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p));
-  else
-    *reinterpret_cast<VT*>(p) = v;
-}
-
-struct MarchArgs {
-  int cn[3], fn[3];  // (z, y, x) coarse / fine extents
-  int tx, ty;        // thread tile: tx column groups along x, ty rows along y
-  int cut_lo, cut_hi;  // z end is an interior slab interface (ghost planes), not a wall
-  int nt;              // stream the fine array past the caches (it exceeds kStreamBytes)
-  int lead_loc, lead_cn, lead_fn;  // 4-D layouts: leading axis kind ('.' batch or 'n') and its extents
-  UnitSched usched;
-};
-
-// Clamp / reflect indices of the N coarse positions j0-1 .. j0+N-2 on a 'c' axis of n cells.
-template <int N>
-struct TapN {
-  int cl[N], rf[N];
-  bool out[N];
-};
-
-template <int N>
-__device__ inline TapN<N> tapn(int j0, int n) {
-  TapN<N> t;
-#pragma unroll
-  for (int d = 0; d < N; ++d) {
-    const int q = j0 + d - 1;
-    t.out[d] = q < 0 || q >= n;
-    t.cl[d] = q < 0 ? 0 : (q >= n ? n - 1 : q);
-    t.rf[d] = q < 0 ? 1 : (q >= n ? n - 2 : q);
-  }
-  return t;
-}
-
-// Coarse values of (padded) plane q in [-1, n] around the owned columns: ghosts by the joint rule
-// (core.py:640-643).
-template <typename T, int CX>
-__device__ inline void load_plane(const T* __restrict__ coarse, int q, int cnz, int64_t cplane, int cnx,
-                                  const TapN<3>& ty, const TapN<CX + 2>& tx, T cscale, T (&v)[3][CX + 2]) {
-  const bool oz = q < 0 || q >= cnz;
-  const int zcl = q < 0 ? 0 : (q >= cnz ? cnz - 1 : q);
-  const int zrf = q < 0 ? 1 : (q >= cnz ? cnz - 2 : q);
-  const T* ccl = coarse + zcl * cplane;
-  const T* crf = coarse + zrf * cplane;
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < CX + 2; ++dx) {
-      T val = cscale * ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[dx]];
-      if (oz || ty.out[dy] || tx.out[dx]) val = T(2) * val - cscale * crf[(int64_t)ty.rf[dy] * cnx + tx.rf[dx]];
-      v[dy][dx] = val;
-    }
-}
 
 // s[sy][sx] += wz * sum_{ry, rx} wy wx v[sy+ry][...]: one z (or leading) tap of the 2 x 2CX fine
 // outputs of a plane, in the reference's order (ry, rx), rx fastest; per axis the weight is

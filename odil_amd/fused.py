@@ -40,7 +40,7 @@ class PoissonEvaluator:
         n = sum(self.sizes)
         self.g = torch.zeros(n, dtype=dtype, device=device)
         self.gw = [t.view(s) for t, s in zip(self.g.split(self.sizes), self.shapes)]
-        self.u = torch.empty(self.cshape, dtype=dtype, device=device) if self.nlvl > 1 else None
+        self._u = None  # synthesised field, allocated on first use (the fused residual does not need it)
         self.fu = torch.empty(self.cshape, dtype=dtype, device=device)
         self.loss = torch.zeros((), dtype=dtype, device=device)
         self.work = ([None] + [torch.empty(s, dtype=dtype, device=device) for s in self.shapes[1:-1]] + [None])[
@@ -50,6 +50,17 @@ class PoissonEvaluator:
         import os
 
         self.one_pass = ops.poisson_loss_grad_supported(self.cshape) and bool(int(os.environ.get("ODIL_ONE_PASS", 0)))
+        # last prolongation fused into the residual (u never stored): 3-D, even extents, >= 2 levels
+        self.synth_residual = (
+            self.ndim == 3 and self.nlvl >= 2 and not self.one_pass and all(s % 2 == 0 and s >= 4 for s in self.cshape)
+            and tuple(self.shapes[1]) == tuple(s // 2 for s in self.cshape)
+            and bool(int(os.environ.get("ODIL_SYNTH_RESIDUAL", 1))))
+
+    @property
+    def u(self):
+        if self._u is None and self.nlvl > 1:
+            self._u = torch.empty(self.cshape, dtype=self.dtype, device=self.device)
+        return self._u
 
     def loss_grad_arrays(self, arrays, timers=None, adam=None):
         """arrays: level arrays fine -> coarse.  Returns (loss 0-d tensor, grads views of one buffer).
@@ -68,13 +79,33 @@ class PoissonEvaluator:
             if b is not None:
                 b.record()
 
-        if self.nlvl > 1:
+        if self.synth_residual:
+            b = tic("mg_synth")
+            if self.nlvl > 2:
+                coarse = ops.mg_synth(arrays[1:], self.loc, work=[None] + self.work[2:], out=self.work[1])
+            else:
+                coarse = arrays[1]
+            toc(b)
+            u = None
+        elif self.nlvl > 1:
             b = tic("mg_synth")
             u = ops.mg_synth(arrays, self.loc, work=self.work, out=self.u)
             toc(b)
         else:
             u = arrays[0]
-        if self.one_pass:
+        if self.synth_residual:
+            b = tic("residual")
+            ops.poisson_residual_synth(coarse, arrays[0], self.rhs, self.h2, fu=self.fu, loss=self.loss)
+            toc(b)
+            b = tic("adjoint")
+            if adam is not None:
+                ml, vl, alpha, omb1, omb2, eps = adam
+                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], ml[0], vl[0], alpha,
+                                         omb1, omb2, eps)
+            else:
+                ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+            toc(b)
+        elif self.one_pass:
             b = tic("loss_grad")
             ops.poisson_loss_grad(u, self.rhs, self.h2, out=self.gw[0], loss=self.loss)
             toc(b)

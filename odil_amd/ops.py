@@ -237,6 +237,23 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
     return fu, loss
 
 
+def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None):
+    """fu = Lap(w0 + P coarse) - rhs, loss = mean(fu**2): the residual with the last prolongation of
+    the multigrid synthesis fused in (u is never stored).  3-D cell-centred arrays, w0.shape == 2 * coarse.shape."""
+    assert coarse.dim() == 3 and tuple(w0.shape) == tuple(2 * s for s in coarse.shape) and w0.shape == rhs.shape
+    assert coarse.is_contiguous() and w0.is_contiguous() and rhs.is_contiguous()
+    if fu is None:
+        fu = torch.empty_like(w0)
+    if loss is None:
+        loss = torch.empty((), dtype=w0.dtype, device=w0.device)
+    h2a, h2p = host_reals(h2, w0.dtype)
+    call(
+        "poisson_residual_synth", w0.dtype, ptr(coarse), ptr(w0), ptr(rhs), ptr(fu), i64(coarse.shape), h2p,
+        ptr(reduce_workspace(w0.device)), ptr(loss), stream_ptr(),
+    )
+    return fu, loss
+
+
 def poisson_loss_grad_supported(shape):
     return bool(_lib.load().odil_poisson_loss_grad_supported(i64(shape), c_int(len(shape))))
 

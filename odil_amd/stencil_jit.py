@@ -1246,6 +1246,9 @@ class TracedOperator:
         return tuple((k, type(f).__name__, tuple(tuple(a.shape) for a in self.domain.arrays_from_field(f)))
                      for k, f in state.fields.items())
 
+    def matches(self, state):
+        return self._signature(state) == self.signature
+
     # ---- host scalars -----------------------------------------------------------------------
     def _host_value(self, n, memo):
         if n.idx in memo:

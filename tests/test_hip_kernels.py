@@ -425,3 +425,27 @@ def test_restrict_adjoint_vs_oracle(dev):
         y = rng.standard_normal(cshape)
         got = ops.restrict_adj(to(y, dev), loc, shape)
         assert rel(got, onp.restrict_to_coarser_adj(y, loc, shape)) < 1e-14, loc
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cshape", [(4, 6, 10), (2, 2, 2), (9, 5, 7), (32, 40, 64), (5, 130, 3)])
+def test_poisson_residual_with_fused_prolongation_is_bit_identical(dev, dtype, cshape):
+    """odil_poisson_residual_synth: u = w0 + P coarse formed in registers; fu must equal, bit for bit,
+    odil_interp_add followed by odil_poisson_residual (same arithmetic, same order), the loss to round-off."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(12)
+    fshape = tuple(2 * s for s in cshape)
+    coarse = to(rng.standard_normal(cshape).astype(dtype), dev)
+    w0 = to(rng.standard_normal(fshape).astype(dtype), dev)
+    rhs = to(rng.standard_normal(fshape).astype(dtype), dev)
+    for h2 in ([0.25**2, 0.125**2, 0.5**2], [0.1**2, 0.3**2, 0.07**2]):  # power-of-two steps multiply, others divide
+        h2 = [dtype(v) for v in h2]
+        u = ops.interp_add(coarse, "ccc", add=w0)
+        fu_ref, loss_ref = ops.poisson_residual(u, rhs, h2)
+        fu, loss = ops.poisson_residual_synth(coarse, w0, rhs, h2)
+        assert torch.equal(fu, fu_ref)
+        assert abs(float(loss) - float(loss_ref)) <= (1e-13 if dtype == np.float64 else 1e-5) * float(loss_ref)
+        want = onp.poisson_residual(u.cpu().numpy().astype(np.float64), rhs.cpu().numpy().astype(np.float64),
+                                    [float(np.sqrt(v)) for v in h2])
+        assert rel(fu, want) < (1e-12 if dtype == np.float64 else 1e-4)
