@@ -114,9 +114,12 @@ struct UnitSched {
   int per_xcd;      // units per XCD (grid = 8 * per_xcd), or total units when axis < 0
 };
 
-inline UnitSched make_unit_sched(int64_t Z, int64_t Y, int64_t XS) {
+// `target_units`: how many workgroups the launch should at least be cut into.  Kernels that prime a
+// window of planes before their first step (P^T: two extra fine-plane reductions per chunk) ask for
+// fewer, longer chunks.
+inline UnitSched make_unit_sched(int64_t Z, int64_t Y, int64_t XS, int64_t target_units = 2 * kGridCap) {
   UnitSched s;
-  int64_t zc = (Z * Y * XS) / (2 * kGridCap);
+  int64_t zc = (Z * Y * XS) / target_units;
   if (zc < 1) zc = 1;
   if (zc > 64) zc = 64;
   if (zc > Z) zc = Z;
