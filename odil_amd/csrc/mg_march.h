@@ -64,7 +64,11 @@ __device__ inline TapN<N> tapn(int j0, int n) {
 }
 
 // Coarse values of (padded) plane q in [-1, n] around the owned columns: ghosts by the joint rule
-// (core.py:640-643).
+// (core.py:640-643), 2 u[clamp] - u[reflect].  Branch-free: the clamp AND the reflect value of every
+// position are loaded (the same address away from the walls, so the second load is a cache hit) and
+// the ghost is selected afterwards -- a branch around the second load makes the compiler drain all
+// outstanding loads (s_waitcnt vmcnt(0)) nine times per plane, serialising the HBM streams of the
+// step behind these cache hits.
 template <typename T, int CX>
 __device__ inline void load_plane(const T* __restrict__ coarse, int q, int cnz, int64_t cplane, int cnx,
                                   const TapN<3>& ty, const TapN<CX + 2>& tx, T cscale, T (&v)[3][CX + 2]) {
@@ -73,13 +77,21 @@ __device__ inline void load_plane(const T* __restrict__ coarse, int q, int cnz, 
   const int zrf = q < 0 ? 1 : (q >= cnz ? cnz - 2 : q);
   const T* ccl = coarse + zcl * cplane;
   const T* crf = coarse + zrf * cplane;
+  T cl[3][CX + 2], rf[3][CX + 2];
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
     for (int dx = 0; dx < CX + 2; ++dx) {
-      T val = cscale * ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[dx]];
-      if (oz || ty.out[dy] || tx.out[dx]) val = T(2) * val - cscale * crf[(int64_t)ty.rf[dy] * cnx + tx.rf[dx]];
-      v[dy][dx] = val;
+      cl[dy][dx] = ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[dx]];
+      rf[dy][dx] = crf[(int64_t)ty.rf[dy] * cnx + tx.rf[dx]];
+    }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < CX + 2; ++dx) {
+      const T val = cscale * cl[dy][dx];
+      const T ghost = T(2) * val - cscale * rf[dy][dx];
+      v[dy][dx] = (oz || ty.out[dy] || tx.out[dx]) ? ghost : val;
     }
 }
 
