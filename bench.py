@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=40)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--N", type=int, default=512)
     p.add_argument("--ndim", type=int, default=3)
     p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])
