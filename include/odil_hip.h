@@ -159,13 +159,14 @@ int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, 
  * (reference core.py:245-263, last step) is formed in registers and never stored.  `coarse`: the
  * synthesised level-1 array of shape cshape (3-D, all axes cell-centred), w0 / rhs / fu: the fine
  * arrays of shape 2 * cshape, h2: squared FINE steps.  fu is bit-identical to
- * odil_interp_add + odil_poisson_residual. */
+ * odil_interp_add + odil_poisson_residual.  Loss = sum over the fine planes z0 <= z < z1 (z1 < 0:
+ * all) of fu^2 / denom (denom <= 0: the array size), as odil_poisson_residual_slab. */
 int odil_poisson_residual_synth_f64(const double* coarse, const double* w0, const double* rhs, double* fu,
-                                    const int64_t* cshape, const double* h2, double* partials, double* loss,
-                                    void* stream);
+                                    const int64_t* cshape, const double* h2, int64_t z0, int64_t z1, double denom,
+                                    double* partials, double* loss, void* stream);
 int odil_poisson_residual_synth_f32(const float* coarse, const float* w0, const float* rhs, float* fu,
-                                    const int64_t* cshape, const float* h2, double* partials, float* loss,
-                                    void* stream);
+                                    const int64_t* cshape, const float* h2, int64_t z0, int64_t z1, double denom,
+                                    double* partials, float* loss, void* stream);
 
 /* gu = J^T (scale * fu): cotangent of the operator above; scale = 2/size gives
  * d mean(fu^2)/du (core.py:1093-1101). */

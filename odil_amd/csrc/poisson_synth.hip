@@ -201,7 +201,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
 
 template <typename T>
 static int poisson_residual_synth(const T* coarse, const T* w0, const T* rhs, T* fu, const int64_t* cshape,
-                                  const T* h2, double* partials, T* loss, void* stream) {
+                                  const T* h2, int64_t z0, int64_t z1, double denom, double* partials, T* loss,
+                                  void* stream) {
   if (!coarse || !w0 || !rhs || !partials || !loss) {
     set_error("poisson_residual_synth: null pointer");
     return ODIL_E_INVAL;
@@ -241,13 +242,13 @@ static int poisson_residual_synth(const T* coarse, const T* w0, const T* rhs, T*
     set_error("poisson_residual_synth: %d workgroups exceed the reduction workspace", grid);
     return ODIL_E_INVAL;
   }
-  sa.loss_z0 = 0;
-  sa.loss_z1 = m.fn[0];
+  sa.loss_z0 = z0;
+  sa.loss_z1 = z1 < 0 ? m.fn[0] : z1;
   T hh[3] = {h2[0], h2[1], h2[2]};
   hipLaunchKernelGGL(k_poisson_residual_synth<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, coarse, w0, rhs, fu,
                      sa, make_h2<T>(hh), partials);
   if (int e = check_launch("k_poisson_residual_synth")) return e;
-  const double size = (double)m.fn[0] * m.fn[1] * m.fn[2];
+  const double size = denom > 0.0 ? denom : (double)m.fn[0] * m.fn[1] * m.fn[2];
   return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
 }
 
@@ -257,13 +258,13 @@ using namespace odil;
 
 extern "C" {
 int odil_poisson_residual_synth_f64(const double* coarse, const double* w0, const double* rhs, double* fu,
-                                    const int64_t* cshape, const double* h2, double* partials, double* loss,
-                                    void* stream) {
-  return poisson_residual_synth<double>(coarse, w0, rhs, fu, cshape, h2, partials, loss, stream);
+                                    const int64_t* cshape, const double* h2, int64_t z0, int64_t z1, double denom,
+                                    double* partials, double* loss, void* stream) {
+  return poisson_residual_synth<double>(coarse, w0, rhs, fu, cshape, h2, z0, z1, denom, partials, loss, stream);
 }
 int odil_poisson_residual_synth_f32(const float* coarse, const float* w0, const float* rhs, float* fu,
-                                    const int64_t* cshape, const float* h2, double* partials, float* loss,
-                                    void* stream) {
-  return poisson_residual_synth<float>(coarse, w0, rhs, fu, cshape, h2, partials, loss, stream);
+                                    const int64_t* cshape, const float* h2, int64_t z0, int64_t z1, double denom,
+                                    double* partials, float* loss, void* stream) {
+  return poisson_residual_synth<float>(coarse, w0, rhs, fu, cshape, h2, z0, z1, denom, partials, loss, stream);
 }
 }  // extern "C"

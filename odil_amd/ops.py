@@ -237,9 +237,12 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
     return fu, loss
 
 
-def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None):
+def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None, zrange=None, denom=None):
     """fu = Lap(w0 + P coarse) - rhs, loss = mean(fu**2): the residual with the last prolongation of
-    the multigrid synthesis fused in (u is never stored).  3-D cell-centred arrays, w0.shape == 2 * coarse.shape."""
+    the multigrid synthesis fused in (u is never stored).  3-D cell-centred arrays, w0.shape == 2 * coarse.shape.
+    zrange=(z0, z1) / denom: slab variant, loss = sum over fine planes z0 <= z < z1 of fu^2 / denom."""
+    from ctypes import c_double
+
     assert coarse.dim() == 3 and tuple(w0.shape) == tuple(2 * s for s in coarse.shape) and w0.shape == rhs.shape
     assert coarse.is_contiguous() and w0.is_contiguous() and rhs.is_contiguous()
     if fu is None:
@@ -249,6 +252,7 @@ def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None):
     h2a, h2p = host_reals(h2, w0.dtype)
     call(
         "poisson_residual_synth", w0.dtype, ptr(coarse), ptr(w0), ptr(rhs), ptr(fu), i64(coarse.shape), h2p,
+        c_int64(zrange[0] if zrange else 0), c_int64(zrange[1] if zrange else -1), c_double(float(denom or 0.0)),
         ptr(reduce_workspace(w0.device)), ptr(loss), stream_ptr(),
     )
     return fu, loss

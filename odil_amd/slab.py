@@ -100,7 +100,7 @@ class SlabPoissonAdam:
         self.w, self.gw = split(self.x), split(self.g)
         self.mw, self.vw = split(self.m), split(self.v)
         l0 = self.levels[0]
-        self.u = torch.zeros(l0.shape, dtype=dtype, device=device)
+        self._u = None  # synthesised field of the two-kernel path (the fused residual never stores it)
         self.fu = torch.zeros(l0.shape, dtype=dtype, device=device)
         self.work = [None] + [torch.zeros(lv.shape, dtype=dtype, device=device) for lv in self.levels[1:-1]] + [None]
         self.loss_part = torch.zeros((), dtype=dtype, device=device)
@@ -113,6 +113,12 @@ class SlabPoissonAdam:
         self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
         self.t = 0
         self.scale = self.npdt(2) / self.npdt(self.global_cells)
+
+    @property
+    def u(self):
+        if self._u is None:
+            self._u = torch.zeros(self.levels[0].shape, dtype=self.dtype, device=self.device)
+        return self._u
 
     # ---- plane packing -----------------------------------------------------------------
     def _pack(self, arrays, levels, side):
@@ -161,17 +167,24 @@ class SlabPoissonAdam:
         yield from self._exchange(self.w, lv)
         toc(b)
         # u = w_0 + P(w_1 + P(...)): coarse operand with one ghost plane -> fine with two
+        # the last prolongation is fused into the residual when the kernel set has it (u never stored)
+        fused_last = hasattr(ops, "poisson_residual_synth") and L >= 2
         b = tic("mg_synth")
         coarse = lv[L - 1].inner(self.w[L - 1])
-        for l in range(L - 2, -1, -1):
+        for l in range(L - 2, 0 if fused_last else -1, -1):
             out = self.u if l == 0 else self.work[l]
             ops.interp_add(coarse.contiguous(), "ccc", add=self.w[l], out=out)
             coarse = lv[l].inner(out)
         toc(b)
         b = tic("residual")
         l0 = lv[0]
-        ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
-                             zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
+        if fused_last:
+            ops.poisson_residual_synth(coarse.contiguous(), self.w[0], self.rhs, self.h2, fu=self.fu,
+                                       loss=self.loss_part, zrange=(l0.g_lo, l0.g_lo + l0.nz),
+                                       denom=self.global_cells)
+        else:
+            ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
+                                 zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
         toc(b)
         b = tic("halo")
         yield from self._exchange([self.fu], [l0])
