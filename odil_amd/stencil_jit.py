@@ -61,11 +61,13 @@ class Sym:
     """A node of the traced expression DAG; behaves like a device array in user code."""
 
     __array_ufunc__ = None  # NumPy operands defer to the reflected methods below
-    __slots__ = ("tr", "op", "args", "attr", "shape", "kind", "idx", "host")
+    # win: None, or (lens, squeezed) -- the value is a sub-box of the grid anchored at the origin
+    # (`u[1:]`, `u[-1, k]` after the offsets were pushed into the reads); `shape` is what user code sees
+    __slots__ = ("tr", "op", "args", "attr", "shape", "kind", "idx", "host", "win")
 
-    def __init__(self, tr, op, args, attr, shape, kind, host):
+    def __init__(self, tr, op, args, attr, shape, kind, host, win=None):
         self.tr, self.op, self.args, self.attr = tr, op, args, attr
-        self.shape, self.kind, self.host = tuple(shape), kind, host
+        self.shape, self.kind, self.host, self.win = tuple(shape), kind, host, win
         self.idx = len(tr.nodes)
         tr.nodes.append(self)
 
@@ -85,7 +87,7 @@ class Sym:
         raise TraceUnsupported("host control flow on a device value")
 
     def __getitem__(self, item):
-        raise TraceUnsupported("indexing a symbolic array")
+        return self.tr.getitem(self, item)
 
     def __len__(self):
         raise TraceUnsupported("len() of a symbolic array")
@@ -190,15 +192,15 @@ class Tracer:
         self.tensors = []  # concrete device tensors referenced by 'tensor' leaves
 
     # ---- node construction ---------------------------------------------------------------
-    def node(self, op, args=(), attr=None, shape=(), kind=_R, host=False):
-        key = (op, tuple(a.idx for a in args), attr, tuple(shape), kind)
+    def node(self, op, args=(), attr=None, shape=(), kind=_R, host=False, win=None):
+        key = (op, tuple(a.idx for a in args), attr, tuple(shape), kind, win)
         try:
             hit = self.cse.get(key)
         except TypeError:
             key, hit = None, None
         if hit is not None:
             return hit
-        n = Sym(self, op, tuple(args), attr, shape, kind, host)
+        n = Sym(self, op, tuple(args), attr, shape, kind, host, win)
         if key is not None:
             self.cse[key] = n
         return n
@@ -249,6 +251,186 @@ class Tracer:
         except ValueError as e:
             raise TraceUnsupported(str(e))
 
+    def _combine(self, nodes):
+        """(args, shape, win) of an elementwise operation: windowed operands must agree, tensors that
+        meet a window with squeezed axes are re-aligned to the full grid rank."""
+        wins = {n.win for n in nodes if n.win is not None}
+        if len(wins) > 1:
+            raise TraceUnsupported("operands cover different parts of the grid")
+        win = wins.pop() if wins else None
+        if win is not None and any(win[1]):
+            fixed = []
+            for n in nodes:
+                if n.win is None and n.shape != ():
+                    if n.op != "tensor":
+                        raise TraceUnsupported("array expression combined with an indexed field value")
+                    n = self._realign(n, win)
+                fixed.append(n)
+            nodes = fixed
+            shape = tuple(l for l, q in zip(*win) if not q)
+            for n in nodes:
+                if n.win is None and n.op != "tensor":
+                    self._bshape(shape, n.shape)
+        else:
+            shape = self._bshape(*[n.shape for n in nodes])
+            if win is not None and shape != tuple(win[0]):
+                raise TraceUnsupported("broadcast of a sliced field value to {}".format(shape))
+        return nodes, shape, win
+
+    def _realign(self, n, win):
+        """Tensor leaf of the user-visible shape -> unit axes inserted where the window is squeezed."""
+        t = self.tensors[n.attr]
+        lens, sq = win
+        vis = [d for d in range(len(lens)) if not sq[d]]
+        if t.dim() > len(vis):
+            raise TraceUnsupported("tensor of rank {} with an indexed field value".format(t.dim()))
+        full = [1] * len(lens)
+        for k, size in enumerate(t.shape):
+            full[vis[len(vis) - t.dim() + k]] = int(size)
+        return self.tensor(t.reshape(full))
+
+    # ---- views: slices and picks become rolls pushed into the leaves + a window ---------------
+    def grid_shape(self):
+        for n in self.nodes:
+            if n.op == "read":
+                return n.shape
+        raise TraceUnsupported("indexing before any field was read")
+
+    def getitem(self, x, item):
+        if x.host or (x.win is None and x.shape != self.grid_shape()):
+            raise TraceUnsupported("indexing a value that is not a grid array")
+        G = self.grid_shape()
+        lens, sq = x.win if x.win is not None else (tuple(G), (False,) * len(G))
+        vis = [d for d in range(len(G)) if not sq[d]]
+        items = list(item) if isinstance(item, tuple) else [item]
+        if any(i is None for i in items):
+            raise TraceUnsupported("newaxis on a symbolic array")
+        if Ellipsis in items:
+            k = items.index(Ellipsis)
+            items = items[:k] + [slice(None)] * (len(vis) - len(items) + 1) + items[k + 1:]
+        items += [slice(None)] * (len(vis) - len(items))
+        if len(items) != len(vis):
+            raise TraceUnsupported("too many indices")
+        shifts, lens, sq = [0] * len(G), list(lens), list(sq)
+        for d, it in zip(vis, items):
+            n = lens[d]
+            if isinstance(it, slice):
+                if it.step not in (None, 1):
+                    raise TraceUnsupported("strided slice")
+                a, b, _ = it.indices(n)
+                if b <= a:
+                    raise TraceUnsupported("empty slice")
+                shifts[d], lens[d] = -a, b - a
+            elif isinstance(it, (int, np.integer)):
+                k = int(it) + (n if it < 0 else 0)
+                if not 0 <= k < n:
+                    raise IndexError("index {} out of range for axis of size {}".format(int(it), n))
+                shifts[d], lens[d], sq[d] = -k, 1, True
+            else:
+                raise TraceUnsupported("index of type {}".format(type(it).__name__))
+        return self.view(self.roll(x, tuple(shifts)), tuple(lens), tuple(sq))
+
+    def view(self, x, lens, sq):
+        G = self.grid_shape()
+        win = None if tuple(lens) == tuple(G) and not any(sq) else (tuple(lens), tuple(sq))
+        shape = tuple(l for l, q in zip(lens, sq) if not q)
+        return self.node("win", (x,), shape=shape, kind=x.kind, win=win)
+
+    def roll(self, n, shifts):
+        """The grid function i -> n(i - shifts) (periodic, numpy.roll convention), built by pushing
+        the shift into the leaves: reads change their stencil offset, index leaves wrap, tensors are
+        rolled once on the device; everything else is pointwise."""
+        if not any(shifts) or n.host:
+            return n
+        memo = self.__dict__.setdefault("_roll_memo", dict())
+        key = (n.idx, shifts)
+        if key in memo:
+            return memo[key]
+        G = self.grid_shape()
+        if n.op == "read":
+            k, s, loc, frozen = n.attr
+            if loc != self.domain_loc(k):
+                raise TraceUnsupported("roll of a field read at another location")
+            res = self.node("read", attr=(k, tuple(a - b for a, b in zip(s, shifts)), loc, frozen), shape=n.shape)
+        elif n.op == "index":
+            d = n.attr[0]
+            r, size = shifts[d] % G[d], G[d]
+            if r == 0:
+                res = n
+            else:  # (i - r) mod size
+                moved = self.binary("sub", n, r)
+                res = self.where(self.binary("lt", moved, 0), self.binary("add", moved, size), moved)
+        elif n.op == "tensor":
+            t = self.tensors[n.attr]
+            dims, amounts = [], []
+            for d, r in enumerate(shifts):
+                td = d - (len(G) - t.dim())
+                if r and td >= 0 and t.shape[td] > 1:
+                    dims.append(td)
+                    amounts.append(int(r))
+            res = self.tensor(torch.roll(t, amounts, dims)) if dims else n
+        elif n.op == "aparam":
+            res = n
+        else:
+            args = tuple(self.roll(a, shifts) for a in n.args)
+            res = self.node(n.op, args, attr=n.attr, shape=n.shape, kind=n.kind, host=n.host, win=n.win)
+        memo[key] = res
+        return res
+
+    def domain_loc(self, key):
+        return self.state_locs[key]
+
+    def concatenate(self, pieces, axis):
+        """numpy.concatenate of grid values and concrete arrays along one axis (rows imposed exactly:
+        `concatenate([u_init[None], u[1:]])`): every piece is moved to its offset and selected by index."""
+        G = self.grid_shape()
+        ndim = len(G)
+        pieces = [self.lift(p) if isinstance(p, Sym) else p for p in pieces]
+        syms = [p for p in pieces if isinstance(p, Sym)]
+        if not syms or any(p.win is not None and any(p.win[1]) for p in syms):
+            raise TraceUnsupported("concatenate of indexed values")
+        axis = axis % ndim
+        lens0 = [list(p.win[0]) if p.win is not None else list(G) for p in syms]
+        other = lens0[0][:axis] + lens0[0][axis + 1:]
+        sizes, offs, total = [], [], 0
+        for p in pieces:
+            shape = tuple(p.shape)
+            if len(shape) != ndim or list(shape[:axis] + shape[axis + 1:]) != other:
+                raise TraceUnsupported("concatenate of shapes that do not match")
+            sizes.append(shape[axis])
+            offs.append(total)
+            total += shape[axis]
+        lens = list(lens0[0])
+        lens[axis] = total
+        if total > G[axis]:
+            raise TraceUnsupported("concatenate longer than the grid")
+        win = None if lens == list(G) else (tuple(lens), (False,) * ndim)
+        shape = tuple(lens)
+        placed = []
+        for p, o, size in zip(pieces, offs, sizes):
+            if isinstance(p, Sym):
+                sh = [0] * ndim
+                sh[axis] = o
+                placed.append(self.roll(p, tuple(sh)))
+            else:  # concrete: embed at its offset in an array of the full length
+                t = self.real_mod.array(p) if not isinstance(p, torch.Tensor) else p
+                if t.requires_grad:
+                    raise TraceUnsupported("differentiable tensor outside ctx.field / ctx.neural_net")
+                full = list(t.shape)
+                full[axis] = total
+                buf = torch.zeros(full, dtype=t.dtype, device=self.real_mod.device)
+                buf.narrow(axis, o, size).copy_(t)
+                placed.append(self.tensor(buf))
+        idx = self.node("index", attr=(axis, None), shape=tuple(G), kind=_I)
+        res = placed[-1]
+        for p, o, size in reversed(list(zip(placed[:-1], offs[:-1], sizes[:-1]))):
+            cond = self.node("lt", (idx, self.const(o + size)), shape=tuple(G), kind=_B)
+            kind = _promote(p.kind, res.kind)
+            res = self.node("where", (cond, p, res), shape=shape, kind=kind, win=win)
+        if res.win != win:
+            res = self.node("win", (res,), shape=shape, kind=res.kind, win=win)
+        return res
+
     def unary(self, op, a):
         a = self.lift(a)
         if a.op == "const" and op in _HOST_UNARY:
@@ -256,7 +438,7 @@ class Tracer:
         kind = _B if op == "not" else (a.kind if op in ("neg", "abs", "stopgrad", "relu") and a.kind != _B else _R)
         if op == "floor" and a.kind != _R:
             return a
-        return self.node(op, (a,), shape=a.shape, kind=kind, host=a.host and op in _HOST_UNARY)
+        return self.node(op, (a,), shape=a.shape, kind=kind, host=a.host and op in _HOST_UNARY, win=a.win)
 
     def binary(self, op, a, b):
         a, b = self.lift(a), self.lift(b)
@@ -270,15 +452,16 @@ class Tracer:
             kind = _promote(a.kind, b.kind)
             if kind == _B:
                 kind = _I
-        return self.node(op, (a, b), shape=self._bshape(a.shape, b.shape), kind=kind, host=a.host and b.host)
+        (a, b), shape, win = self._combine([a, b])
+        return self.node(op, (a, b), shape=shape, kind=kind, host=a.host and b.host, win=win)
 
     def where(self, c, a, b):
         c, a, b = self.lift(c), self.lift(a), self.lift(b)
         if c.op == "const":
             return a if c.attr else b
         kind = _promote(a.kind, b.kind)
-        return self.node("where", (c, a, b), shape=self._bshape(c.shape, a.shape, b.shape), kind=kind,
-                         host=c.host and a.host and b.host)
+        (c, a, b), shape, win = self._combine([c, a, b])
+        return self.node("where", (c, a, b), shape=shape, kind=kind, host=c.host and a.host and b.host, win=win)
 
 
 def _has_sym(x):
@@ -398,10 +581,58 @@ class ModTrace:
     def arctan2(self, a, b):
         return self._b("atan2", a, b)
 
+    def roll(self, x, shift, axis=None):
+        if not isinstance(x, Sym):
+            return self._real.roll(x, shift, axis)
+        if x.win is not None or axis is None:
+            raise TraceUnsupported("roll of a sliced or flattened symbolic array")
+        ndim = len(x.shape)
+        axes = [int(axis)] if isinstance(axis, (int, np.integer)) else [int(a) for a in axis]
+        amounts = [int(v) for v in np.broadcast_to(np.asarray(shift), (len(axes),))]
+        shifts = [0] * ndim
+        for a, r in zip(axes, amounts):
+            shifts[a % ndim] += r
+        return self._tr.roll(x, tuple(shifts))
+
+    def concatenate(self, xs, axis=0):
+        if not _has_sym(xs):
+            return self._real.concatenate(xs, axis)
+        return self._tr.concatenate(list(xs), int(axis))
+
     def clip(self, x, a, b):
         if _has_sym((x, a, b)):
             return self._tr.binary("min", self._tr.binary("max", x, a), b)
         return self._real.clip(x, a, b)
+
+
+class ParamArray:
+    """An `Array` unknown (a few scalars, e.g. the constants of infer_constant) seen by a traced
+    operator: indexing gives device scalars whose gradients are reduced over the grid."""
+
+    def __init__(self, tr, key, shape, frozen):
+        self.tr, self.key, self.shape, self.frozen = tr, key, tuple(shape), frozen
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, item):
+        if isinstance(item, tuple) and len(item) == 1:
+            item = item[0]
+        if len(self.shape) != 1 or not isinstance(item, (int, np.integer)):
+            raise TraceUnsupported("Array unknowns support a[k] only")
+        k = int(item) + (self.shape[0] if item < 0 else 0)
+        if not 0 <= k < self.shape[0]:
+            raise IndexError("index {} out of range".format(int(item)))
+        return self.tr.node("aparam", attr=(self.key, k, self.frozen), kind=_R)
+
+    def __iter__(self):
+        return (self[k] for k in range(self.shape[0]))
+
+    def _no(self, *a, **k):
+        raise TraceUnsupported("arithmetic on a whole Array unknown (index it: a[k])")
+
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __neg__ = _no
+    __array_ufunc__ = None
 
 
 class TraceContext:
@@ -433,6 +664,9 @@ class TraceContext:
                 self._tracers[k] = v
         self.tracers_accessed = False
         self.nets = dict()
+        from .core import Field as _Field, MultigridField as _MgField
+
+        tr.state_locs = {k: f.loc for k, f in state.fields.items() if isinstance(f, (_Field, _MgField))}
 
     @property
     def tracers(self):
@@ -474,7 +708,9 @@ class TraceContext:
         domain = self.domain
         field = self.state.fields[key]
         if isinstance(field, Array):
-            raise TraceUnsupported("Array unknown '{}'".format(key))
+            if len(shift):
+                raise RuntimeError("Array requires an empty shift")
+            return ParamArray(self._tr, key, tuple(field.array.shape), bool(frozen))
         if not isinstance(field, (Field, MultigridField)):
             raise TypeError(
                 "Expected Field or MultigridField, got type {} for key='{}'".format(type(field).__name__, key))
@@ -593,13 +829,20 @@ class _Codegen:
         self.cots = []  # live read nodes that receive a cotangent
         self.nets = []  # (key, layers) with parameter pointers
         self.net_slot = dict()
+        self.arrays = []  # (key, numel) of `Array` unknowns read through a[k]
+        self.array_slot = dict()
         self.need = self._needs_grad()
+        # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
+        self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
+        self.out_count = [int(np.prod(l)) if l is not None else self.total for l in self.out_lens]
 
     def _needs_grad(self):
         need = dict()
         for n in self.order:
             if n.op == "read":
                 need[n.idx] = not n.attr[3]
+            elif n.op == "aparam":
+                need[n.idx] = not n.attr[2]
             elif n.op == "stopgrad" or n.kind != _R or n.host:
                 need[n.idx] = False
             elif n.op == "mlp":
@@ -728,6 +971,14 @@ class _Codegen:
                 self._emit_tensor(n)
             elif op == "index":
                 self.emit(v + "(long)i{};".format(n.attr[0]))
+            elif op == "win":
+                self.emit(v + "{};".format(self.typed(A[0], n.kind)))
+            elif op == "aparam":
+                key, k, _ = n.attr
+                if key not in self.array_slot:
+                    self.array_slot[key] = len(self.arrays)
+                    self.arrays.append((key, int(np.prod(self.state.fields[key].array.shape))))
+                self.emit(v + "AP({}, {});".format(self.array_slot[key], k))
             elif op == "mlp":
                 self._emit_mlp(n)
             elif op == "mlp_out":
@@ -787,12 +1038,13 @@ class _Codegen:
                 self.emit("T g{} = {};".format(arg.idx, expr))
                 defined.add(arg.idx)
 
-        # seeds
+        # seeds: d loss / d output = 2 f / n (or 1 / n for a Raw output) inside the output's window
         for k, (o, raw) in enumerate(zip(self.outputs, self.raw)):
-            if raw:
-                acc(o, "((T){!r})".format(1.0 / self.total))
-            else:
-                acc(o, "{} * ((T){!r})".format(self.r(o), 2.0 / self.total))
+            seed = "((T){!r})".format(1.0 / self.out_count[k]) if raw else "{} * ((T){!r})".format(
+                self.r(o), 2.0 / self.out_count[k])
+            if self.out_lens[k] is not None:
+                seed = "(inbox{} ? {} : (T)0)".format(k, seed)
+            acc(o, seed)
         self.pgrads = dict()  # net key -> list of per-array lists of accumulator names
         for n in reversed(self.order):
             op, A = n.op, n.args
@@ -804,6 +1056,18 @@ class _Codegen:
             g, v = "g{}".format(n.idx), "v{}".format(n.idx)
             if op == "read":
                 self.cots.append(n)
+            elif op == "win":
+                acc(A[0], g)
+            elif op == "aparam":
+                key, k, _ = n.attr
+                if key not in self.pgrads:
+                    numel = dict(self.arrays)[key]
+                    names = ["pa_{}_{}".format(self.array_slot[key], i) for i in range(numel)]
+                    self.pgrads[key] = [names]
+                    self.pg_offset[key] = len(self.pg_decl)
+                    self.pg_decl.extend(names)
+                name = self.pgrads[key][0][k]
+                self.emit("{0} = {0} + {1};".format(name, g))
             elif op == "add":
                 acc(A[0], g)
                 acc(A[1], g)
@@ -922,7 +1186,8 @@ class _Codegen:
         rev, self.lines = self.lines, []
         nout = len(self.outputs)
         self.npar = sum(len(g) for names in self.pgrads.values() for g in names)
-        par_arrays = sum(2 * (len(layers) - 1) for _, layers in self.nets)
+        par_arrays = sum(2 * (len(layers) - 1) for _, layers in self.nets) + len(self.arrays)
+        self.par_arrays = par_arrays
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
@@ -939,6 +1204,7 @@ class _Codegen:
                 bofs[(s, l)] = o + nl + l
             o += 2 * nl
         self.par_layout = [(key, layers) for key, layers in self.nets]
+        S.append("#define AP(s, k) a.par[{} + s][k]".format(o))  # Array unknowns follow the net arrays
         S.append("#define W(s, l, k) a.par[WOFS_##s##_##l][k]")
         S.append("#define Bv(s, l, k) a.par[BOFS_##s##_##l][k]")
         for (s, l), v in wofs.items():
@@ -964,6 +1230,10 @@ class _Codegen:
                 S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
                 S.append("  const int r{} = {} / {};".format(d, rem, self.G[d]))
                 rem = "r{}".format(d)
+        for k, lens in enumerate(self.out_lens):
+            if lens is not None:
+                conds = ["i{} < {}".format(d, lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
+                S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
         S.extend(fwd)
         S.extend(rev)
         esize = 8 if tdt == torch.float64 else 4
@@ -974,7 +1244,10 @@ class _Codegen:
             else:
                 S.append("  a.cot[{}][l] = g{};".format(slot, n.idx))
         for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
-            S.append("  s_{0} = s_{0} + {1};".format(k, self.r(o_) if raw else "{0} * {0}".format(self.r(o_))))
+            term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
+            if self.out_lens[k] is not None:
+                term = "(inbox{} ? {} : (T)0)".format(k, term)
+            S.append("  s_{0} = s_{0} + {1};".format(k, term))
         S.append("  }")
         for k in range(nout):
             S.append("  {{ const T s = block_sum(s_{0}, sm); if (threadIdx.x == 0) a.part[{0} * a.nblocks + blockIdx.x] = s; }}".format(k))
@@ -1002,7 +1275,8 @@ class _Codegen:
         S.append("    T s = (T)0;")
         S.append("    for (int seg = 0; seg < SEG; ++seg) s = s + a.part2[k * SEG + seg];")
         S.append("    if (k >= {0}) {{ a.pgrad[k - {0}] = s; continue; }}".format(nout))
-        S.append("    s = s / (T){};".format(float(self.total)))
+        S.append("    const T count[{}] = {{{}}};".format(nout, ", ".join("(T){!r}".format(float(c)) for c in self.out_count)))
+        S.append("    s = s / count[k];")
         S.append("    a.out[1 + k] = s;")
         S.append("    a.out[1 + {} + k] = raw[k] ? s : FN(sqrt)(s);".format(nout))
         S.append("  }")
@@ -1152,16 +1426,14 @@ class TracedOperator:
         self.names = names
         raw = [isinstance(v, Context.Raw) for v in values]
         outs = [tr.lift(v.value if r else v) for v, r in zip(values, raw)]
-        shapes = {o.shape for o in outs}
-        if len(shapes) != 1:
-            raise TraceUnsupported("outputs of different shapes {}".format(shapes))
-        (G,) = shapes
-        if len(G) != domain.ndim:
-            raise TraceUnsupported("output shape {}".format(G))
-        outs = [o if o.kind == _R else tr.unary("cast", o) for o in outs]
-        self.G, self.raw = tuple(G), raw
         if not any(n.op == "read" for n in tr.nodes):
             raise TraceUnsupported("operator reads no field")
+        G = tuple(tr.grid_shape())
+        for o in outs:  # every output lives on the grid of the reads, all of it or a window of it
+            if o.host or (o.win is None and tuple(o.shape) != G):
+                raise TraceUnsupported("output of shape {} on grid {}".format(tuple(o.shape), G))
+        outs = [o if o.kind == _R else tr.unary("cast", o) for o in outs]
+        self.G, self.raw = G, raw
         cg = _Codegen(tr, outs, raw, G, state)
         self.source = cg.source()
         self.lib, self.lib_path = _compile(self.source)
@@ -1176,7 +1448,7 @@ class TracedOperator:
         self.ppart = torch.empty(max(1, len(cg.pg_decl) * self.nblocks), dtype=dt, device=dev)
         self.out = torch.zeros(1 + 2 * nout, dtype=dt, device=dev)
         self.pgrad = torch.zeros(max(1, len(cg.pg_decl)), dtype=dt, device=dev)
-        par_arrays = sum(2 * (len(layers) - 1) for _, layers in cg.nets)
+        par_arrays = cg.par_arrays
 
         class Args(ctypes.Structure):
             _fields_ = [
@@ -1207,7 +1479,7 @@ class TracedOperator:
         for key, field in state.fields.items():
             n = len(domain.arrays_from_field(field))
             kind = ("field" if isinstance(field, Field) else "mg" if isinstance(field, MultigridField)
-                    else "net" if isinstance(field, NeuralNet) else "other")
+                    else "net")  # NeuralNet or Array: a few parameters, gradients reduced over the grid
             self.layout.append((key, kind, pos, n))
             pos += n
         self.signature = self._signature(state)
@@ -1291,6 +1563,12 @@ class TracedOperator:
                     raise RuntimeError("neural net arrays must be contiguous")
                 self.args.par[i] = arr.data_ptr()
                 i += 1
+        for key, _ in cg.arrays:
+            arr = state.fields[key].array
+            if not arr.is_contiguous() or arr.dtype != self.tr.torch_dtype:
+                raise RuntimeError("Array unknown '{}' must be a contiguous {} tensor".format(key, self.tr.torch_dtype))
+            self.args.par[i] = arr.data_ptr()
+            i += 1
         stream = ops.stream_ptr()
         rc = self.lib.jit_fwd(ctypes.byref(self.args), stream)
         if rc != 0:

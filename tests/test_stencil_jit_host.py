@@ -44,6 +44,27 @@ def test_examples_trace_and_compile(cpu_mod):
     assert tro._host_value(tro.cg.hs[0], dict()) == pytest.approx(0.1 * 0.5 ** 2)
 
 
+def test_slices_rolls_and_array_unknowns_trace(cpu_mod):
+    """examples/heat_tmax and examples/infer_constant: rows imposed by concatenate, mod.roll of the
+    unknown, an `Array` of constants inside the stencil, a residual without its first row and a
+    single-point output -- slices become stencil offsets of the reads plus a window of the grid."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", "heat_tmax"))
+    sys.path.insert(0, os.path.join(ROOT, "examples", "infer_constant"))
+    import heat_tmax
+    import infer_constant
+
+    problem, state = infer_constant.make_problem(infer_constant.parse_args(["--Nt", "8", "--Nx", "16"]))
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert tro.cg.out_lens == [(8, 16)] and tro.cg.out_count == [128]  # fu[1:] of the (9, 16) grid
+    assert tro.cg.arrays == [("coeff", 3)] and len(tro.cg.pg_decl) == 3
+    shifts = sorted(n.attr[1] for n in tro.cg.cots)
+    assert shifts == [(0, -1), (0, 0), (0, 1), (1, -1), (1, 0), (1, 1)]  # roll by -(s) then [1:]: offsets s + (1, 0)
+    problem, state = heat_tmax.make_problem(heat_tmax.parse_args(["--Nt", "8", "--Nx", "16"]))
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert tro.cg.out_lens == [None, (1, 1)] and tro.cg.out_count == [9 * 16, 1]
+    assert "inbox1" in tro.source and "AP(0, 0)" in tro.source
+
+
 def test_untraceable_operators_are_refused(cpu_mod):
     domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
     state = odil.State()
@@ -51,10 +72,11 @@ def test_untraceable_operators_are_refused(cpu_mod):
     state.fields["p"] = odil.Array(np.zeros(3))
     state = domain.init_state(state)
     cases = {
-        "slicing": lambda ctx: [ctx.field("u")[1:]],
+        "strided slice": lambda ctx: [ctx.field("u")[::2]],
+        "mixed windows": lambda ctx: [ctx.field("u")[1:] + ctx.field("u")],
         "reduction": lambda ctx: [ctx.field("u") - ctx.mod.mean(ctx.field("u"))],
         "control flow": lambda ctx: [ctx.field("u") if ctx.field("u") > 0 else ctx.field("u", 1, 0)],
-        "array unknown": lambda ctx: [ctx.field("u") * ctx.field("p")[0]],
+        "whole Array arithmetic": lambda ctx: [ctx.field("u") * ctx.field("p")],
         "state bypass": lambda ctx: [ctx.field("u") * 0 + ctx.state.fields["u"].array],
         "scalar output": lambda ctx: [ctx.field("u"), ctx.tracers["epoch"] * 2.0],
     }
