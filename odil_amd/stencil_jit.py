@@ -262,15 +262,10 @@ class Tracer:
             fixed = []
             for n in nodes:
                 if n.win is None and n.shape != ():
-                    if n.op != "tensor":
-                        raise TraceUnsupported("array expression combined with an indexed field value")
                     n = self._realign(n, win)
                 fixed.append(n)
             nodes = fixed
             shape = tuple(l for l, q in zip(*win) if not q)
-            for n in nodes:
-                if n.win is None and n.op != "tensor":
-                    self._bshape(shape, n.shape)
         else:
             shape = self._bshape(*[n.shape for n in nodes])
             if win is not None and shape != tuple(win[0]):
@@ -278,7 +273,16 @@ class Tracer:
         return nodes, shape, win
 
     def _realign(self, n, win):
-        """Tensor leaf of the user-visible shape -> unit axes inserted where the window is squeezed."""
+        """Array expression of the user-visible shape (constant arrays, possibly scaled by scalars) ->
+        the same expression with unit axes inserted where the window is squeezed."""
+        if n.shape == () or n.host:
+            return n
+        if n.op != "tensor":
+            if n.op in ("read", "index", "mlp", "mlp_out", "win") or n.win is not None:
+                raise TraceUnsupported("grid value of another shape combined with an indexed field value")
+            args = tuple(self._realign(a, win) for a in n.args)
+            return self.node(n.op, args, attr=n.attr, shape=self._bshape(*[a.shape for a in args]), kind=n.kind,
+                             host=n.host)
         t = self.tensors[n.attr]
         lens, sq = win
         vis = [d for d in range(len(lens)) if not sq[d]]
@@ -923,12 +927,14 @@ class _Codegen:
     def _emit_tensor(self, n):
         t = self.tr.tensors[n.attr]
         shape = (1,) * (self.ndim - t.dim()) + tuple(t.shape)
-        if len(shape) != self.ndim or any(s not in (1, g) for s, g in zip(shape, self.G)):
+        if len(shape) != self.ndim or any(s > g for s, g in zip(shape, self.G)):
             raise TraceUnsupported("tensor of shape {} on grid {}".format(tuple(t.shape), self.G))
         terms, stride = [], 1
         for d in reversed(range(self.ndim)):
             if shape[d] != 1:
-                terms.append("i{} * {}".format(d, stride) if stride != 1 else "i{}".format(d))
+                # shorter than the grid: an operand of a windowed value; clamped outside its window
+                i = "i{}".format(d) if shape[d] == self.G[d] else "min(i{}, {})".format(d, shape[d] - 1)
+                terms.append("{} * {}".format(i, stride) if stride != 1 else i)
                 stride *= shape[d]
         ctype = {torch.float32: "float", torch.float64: "double", torch.int32: "int", torch.int64: "long",
                  torch.bool: "unsigned char"}[t.dtype]
