@@ -72,10 +72,12 @@ int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, 
  * odil_mg_synth_adj_adam. */
 int odil_interp_adj_cut_adam_f64(const double* gfine, double* gcoarse, const int64_t* cshape, int ndim, const char* loc,
                                  int cut_lo, int cut_hi, double* x, double* m, double* v, double alpha,
-                                 double one_minus_b1, double one_minus_b2, double eps, void* stream);
+                                 double one_minus_b1, double one_minus_b2, double eps, const double* alpha_dev,
+                                 void* stream);
 int odil_interp_adj_cut_adam_f32(const float* gfine, float* gcoarse, const int64_t* cshape, int ndim, const char* loc,
                                  int cut_lo, int cut_hi, float* x, float* m, float* v, float alpha,
-                                 float one_minus_b1, float one_minus_b2, float eps, void* stream);
+                                 float one_minus_b1, float one_minus_b2, float eps, const float* alpha_dev,
+                                 void* stream);
 /* coarse = R(fine): full weighting `restrict_to_coarser(method="conv")`
  * (core.py:703-755, backend.py:112-126).  `fshape` = fine array shape. */
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
@@ -114,11 +116,11 @@ int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* fac
 int odil_mg_synth_adj_adam_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
                                const int64_t* shapes, int nlvl, int ndim, const char* loc, double* const* x,
                                double* const* m, double* const* v, double alpha, double one_minus_b1,
-                               double one_minus_b2, double eps, void* stream);
+                               double one_minus_b2, double eps, const double* alpha_dev, void* stream);
 int odil_mg_synth_adj_adam_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
                                const int64_t* shapes, int nlvl, int ndim, const char* loc, float* const* x,
                                float* const* m, float* const* v, float alpha, float one_minus_b1, float one_minus_b2,
-                               float eps, void* stream);
+                               float eps, const float* alpha_dev, void* stream);
 
 /* ---- stencil access: Context.field (reference core.py:910-975) ---------------- */
 /* out = trim(roll(pad(src), -shift)): 'c'->'n' zero-pad at the low end, periodic roll,
@@ -179,10 +181,10 @@ int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, i
  * gu is still written (the P^T chain reads it); x, m, v are updated in place. */
 int odil_poisson_adjoint_adam_f64(const double* fu, double* gu, double* x, double* m, double* v, const int64_t* shape,
                                   int ndim, const double* h2, double scale, double alpha, double one_minus_b1,
-                                  double one_minus_b2, double eps, void* stream);
+                                  double one_minus_b2, double eps, const double* alpha_dev, void* stream);
 int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m, float* v, const int64_t* shape,
                                   int ndim, const float* h2, float scale, float alpha, float one_minus_b1,
-                                  float one_minus_b2, float eps, void* stream);
+                                  float one_minus_b2, float eps, const float* alpha_dev, void* stream);
 /* Fused: gu = (2/size) J^T (J u - rhs) and loss[0] = mean((J u - rhs)^2) in ONE pass over u and
  * rhs; fu is never materialised (3 words per cell instead of 5).  3-D, last extent <= 512,
  * every extent >= 4: `odil_poisson_loss_grad_supported` tells; otherwise use residual + adjoint. */
@@ -200,11 +202,14 @@ int odil_poisson_jac_coeffs_f32(float* coeffs, const int64_t* shape, int ndim, c
 
 /* ---- optimizers (reference optimizer.py:256-341) ------------------------------ */
 /* AdamNativeOptimizer._step (optimizer.py:311-319) on a flat vector:
- *   m += (g-m)*one_minus_b1; v += (g^2-v)*one_minus_b2; x -= (m*alpha)/(sqrt(v)+eps). */
+ *   m += (g-m)*one_minus_b1; v += (g^2-v)*one_minus_b2; x -= (m*alpha)/(sqrt(v)+eps).
+ * In this and every *_adam entry point `alpha_dev`, when non-NULL, is a device scalar that replaces
+ * `alpha`: the bias-corrected step size changes every epoch, and an epoch captured into a hipGraph
+ * must read it from memory (odil_amd/optimizer.py: graph replay of launch-bound epochs). */
 int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t n, double alpha,
-                       double one_minus_b1, double one_minus_b2, double eps, void* stream);
+                       double one_minus_b1, double one_minus_b2, double eps, const double* alpha_dev, void* stream);
 int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
-                       float one_minus_b2, float eps, void* stream);
+                       float one_minus_b2, float eps, const float* alpha_dev, void* stream);
 /* y += a * x  (GdOptimizer: x -= lr*g, optimizer.py:270; Newton update util.py:177). */
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream);
 int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);

@@ -24,12 +24,12 @@ _SIGNATURES = {
     "interp_add": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _R, _P],
     "interp_adj": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _P],
     "interp_adj_cut": [_P, _P, _P, _I64P, c_int, c_char_p, _R, c_int, c_int, _P],
-    "interp_adj_cut_adam": [_P, _P, _I64P, c_int, c_char_p, c_int, c_int, _P, _P, _P, _R, _R, _R, _R, _P],
+    "interp_adj_cut_adam": [_P, _P, _I64P, c_int, c_char_p, c_int, c_int, _P, _P, _P, _R, _R, _R, _R, _P, _P],
     "restrict": [_P, _P, _I64P, c_int, c_char_p, _P],
     "restrict_adj": [_P, _P, _I64P, c_int, c_char_p, _P],
     "mg_synth": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
     "mg_synth_adj": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
-    "mg_synth_adj_adam": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P, _P, _P, _R, _R, _R, _R, _P],
+    "mg_synth_adj_adam": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P, _P, _P, _R, _R, _R, _R, _P, _P],
     "field_gather": [_P, _P, _I64P, c_int, c_char_p, c_char_p, _I64P, _P],
     "field_scatter": [_P, _P, _I64P, c_int, c_char_p, c_char_p, _I64P, c_int, _P],
     "mean_reduce": [_P, c_int64, c_int, _P, _P, _P],
@@ -38,9 +38,9 @@ _SIGNATURES = {
     "poisson_residual_slab": [_P, _P, _P, _I64P, c_int, _P, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_loss_grad": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
-    "poisson_adjoint_adam": [_P, _P, _P, _P, _P, _I64P, c_int, _P, _R, _R, _R, _R, _R, _P],
+    "poisson_adjoint_adam": [_P, _P, _P, _P, _P, _I64P, c_int, _P, _R, _R, _R, _R, _R, _P, _P],
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
-    "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P],
+    "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P, _P],
     "axpy": [_P, _P, c_int64, _R, _P],
     "scale": [_P, _P, c_int64, _R, _P, _P],
     "addcmul": [_P, _P, _P, c_int64, c_int, _P],

@@ -223,6 +223,7 @@ struct AdamArgs {
   T* m;
   T* v;
   T alpha, omb1, omb2, eps;
+  const T* alpha_dev;  // optional: step size read from device memory (hipGraph replay of an epoch)
 };
 
 #ifdef __HIPCC__
@@ -231,13 +232,15 @@ __device__ inline void adam_update(T& x, T& m, T& v, T g, const AdamArgs<T>& a) 
   // reference optimizer.py:316-318
   m = m + (g - m) * a.omb1;
   v = v + (g * g - v) * a.omb2;
-  x = x - (m * a.alpha) / (sqrt(v) + a.eps);
+  const T alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
+  x = x - (m * alpha) / (sqrt(v) + a.eps);
 }
 #endif
 
 // Plain Adam launch on a flat range (optim.hip), for paths that cannot fuse it.
 template <typename T>
-int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream);
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream,
+                const T* alpha_dev = nullptr);
 
 // Final stage of every reduction: out[q] = scale * sum(partials[q*stride .. +count)).
 template <typename T>

@@ -353,7 +353,7 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
   if (int e = check_launch("k_interp_adj")) return e;
   if (ad.x)  // the generic kernel does not fuse the update: plain launch on this level
     return adam_launch<T>(ad.x, ad.m, ad.v, gscaled ? gscaled : gcoarse, prod4(a.cn), ad.alpha, ad.omb1, ad.omb2, ad.eps,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, ad.alpha_dev);
   return 0;
 }
 
@@ -472,7 +472,7 @@ template <typename T>
 static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const* work, const int64_t* shapes,
                         int nlvl, int ndim, const char* loc, void* stream, T* const* ax = nullptr,
                         T* const* am = nullptr, T* const* av = nullptr, T alpha = T(0), T omb1 = T(0), T omb2 = T(0),
-                        T eps = T(0)) {
+                        T eps = T(0), const T* alpha_dev = nullptr) {
   if (int e = check_levels(shapes, nlvl, ndim, loc)) return e;
   if (!gu || !grads) {
     set_error("mg_synth_adj: null pointer");
@@ -502,7 +502,7 @@ static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const
       unscaled = work[l];
       scaled = grads[l];
     }
-    AdamArgs<T> ad{nullptr, nullptr, nullptr, alpha, omb1, omb2, eps};
+    AdamArgs<T> ad{nullptr, nullptr, nullptr, alpha, omb1, omb2, eps, alpha_dev};
     if (ax && ax[l]) {
       ad.x = ax[l];
       ad.m = am[l];
@@ -546,15 +546,15 @@ int odil_interp_adj_cut_f32(const float* gfine, float* gcoarse, float* gscaled, 
 }
 int odil_interp_adj_cut_adam_f64(const double* gfine, double* gcoarse, const int64_t* cshape, int ndim, const char* loc,
                                  int cut_lo, int cut_hi, double* x, double* m, double* v, double alpha,
-                                 double one_minus_b1, double one_minus_b2, double eps, void* stream) {
+                                 double one_minus_b1, double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
   return interp_adj<double>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0, stream, cut_lo, cut_hi,
-                            AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+                            AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev});
 }
 int odil_interp_adj_cut_adam_f32(const float* gfine, float* gcoarse, const int64_t* cshape, int ndim, const char* loc,
                                  int cut_lo, int cut_hi, float* x, float* m, float* v, float alpha,
-                                 float one_minus_b1, float one_minus_b2, float eps, void* stream) {
+                                 float one_minus_b1, float one_minus_b2, float eps, const float* alpha_dev, void* stream) {
   return interp_adj<float>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0f, stream, cut_lo, cut_hi,
-                           AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+                           AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev});
 }
 int odil_restrict_f64(const double* fine, double* coarse, const int64_t* fshape, int ndim, const char* loc,
                       void* stream) {
@@ -591,16 +591,16 @@ int odil_mg_synth_adj_f32(const float* gu, float* const* grads, const float* fac
 int odil_mg_synth_adj_adam_f64(const double* gu, double* const* grads, const double* factors, double* const* work,
                                const int64_t* shapes, int nlvl, int ndim, const char* loc, double* const* x,
                                double* const* m, double* const* v, double alpha, double one_minus_b1,
-                               double one_minus_b2, double eps, void* stream) {
+                               double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
   return mg_synth_adj<double>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream, x, m, v, alpha, one_minus_b1,
-                              one_minus_b2, eps);
+                              one_minus_b2, eps, alpha_dev);
 }
 int odil_mg_synth_adj_adam_f32(const float* gu, float* const* grads, const float* factors, float* const* work,
                                const int64_t* shapes, int nlvl, int ndim, const char* loc, float* const* x,
                                float* const* m, float* const* v, float alpha, float one_minus_b1, float one_minus_b2,
-                               float eps, void* stream) {
+                               float eps, const float* alpha_dev, void* stream) {
   return mg_synth_adj<float>(gu, grads, factors, work, shapes, nlvl, ndim, loc, stream, x, m, v, alpha, one_minus_b1,
-                             one_minus_b2, eps);
+                             one_minus_b2, eps, alpha_dev);
 }
 
 }  // extern "C"

@@ -29,7 +29,8 @@ __device__ inline void adam_one(T& x, T& m, T& v, T g, T alpha, T omb1, T omb2, 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restrict__ m, T* __restrict__ v,
                                                 const T* __restrict__ g, int64_t n, T alpha, T omb1, T omb2, T eps,
-                                                int vec_ok) {
+                                                int vec_ok, const T* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha = *alpha_dev;
   constexpr int V = Vec16<T>::N;
   typedef typename Vec16<T>::type VT;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -71,15 +72,18 @@ __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restric
 static inline int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
-int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream);
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream,
+                const T* alpha_dev);
 
 template <typename T>
-static int adam_step(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, void* stream) {
-  return adam_launch<T>(x, m, v, g, n, alpha, omb1, omb2, eps, (hipStream_t)stream);
+static int adam_step(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, const T* alpha_dev,
+                     void* stream) {
+  return adam_launch<T>(x, m, v, g, n, alpha, omb1, omb2, eps, (hipStream_t)stream, alpha_dev);
 }
 
 template <typename T>
-int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream) {
+int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2, T eps, hipStream_t stream,
+                const T* alpha_dev) {
   if (!x || !m || !v || !g || n < 0) {
     set_error("adam_step: null pointer or n < 0");
     return ODIL_E_INVAL;
@@ -87,13 +91,13 @@ int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2
   if (n == 0) return 0;
   const int vec_ok = aligned16(x) && aligned16(m) && aligned16(v) && aligned16(g);
   hipLaunchKernelGGL(k_adam<T>, dim3(grid_for(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, stream, x, m, v, g, n, alpha,
-                     omb1, omb2, eps, vec_ok);
+                     omb1, omb2, eps, vec_ok, alpha_dev);
   return check_launch("k_adam");
 }
 template int adam_launch<double>(double*, double*, double*, const double*, int64_t, double, double, double, double,
-                                 hipStream_t);
+                                 hipStream_t, const double*);
 template int adam_launch<float>(float*, float*, float*, const float*, int64_t, float, float, float, float,
-                                hipStream_t);
+                                hipStream_t, const float*);
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_axpy(T* __restrict__ y, const T* __restrict__ x, int64_t n, T a) {
@@ -254,12 +258,12 @@ using namespace odil;
 
 extern "C" {
 int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t n, double alpha,
-                       double one_minus_b1, double one_minus_b2, double eps, void* stream) {
-  return adam_step<double>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, stream);
+                       double one_minus_b1, double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
+  return adam_step<double>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev, stream);
 }
 int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
-                       float one_minus_b2, float eps, void* stream) {
-  return adam_step<float>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, stream);
+                       float one_minus_b2, float eps, const float* alpha_dev, void* stream) {
+  return adam_step<float>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev, stream);
 }
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream) {
   return axpy<double>(y, x, n, a, stream);

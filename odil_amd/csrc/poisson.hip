@@ -260,7 +260,7 @@ static int poisson_residual(const T* u, const T* rhs, T* fu, const int64_t* shap
 
 template <typename T>
 static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, const T* h2, T scale, void* stream,
-                           AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0)}) {
+                           AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0), nullptr}) {
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
@@ -325,23 +325,23 @@ int odil_poisson_adjoint_f32(const float* fu, float* gu, const int64_t* shape, i
 }
 int odil_poisson_adjoint_adam_f64(const double* fu, double* gu, double* x, double* m, double* v, const int64_t* shape,
                                   int ndim, const double* h2, double scale, double alpha, double one_minus_b1,
-                                  double one_minus_b2, double eps, void* stream) {
+                                  double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
   if (!x || !m || !v) {
     set_error("poisson_adjoint_adam: null pointer");
     return ODIL_E_INVAL;
   }
   return poisson_adjoint<double>(fu, gu, shape, ndim, h2, scale, stream,
-                                 AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+                                 AdamArgs<double>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev});
 }
 int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m, float* v, const int64_t* shape,
                                   int ndim, const float* h2, float scale, float alpha, float one_minus_b1,
-                                  float one_minus_b2, float eps, void* stream) {
+                                  float one_minus_b2, float eps, const float* alpha_dev, void* stream) {
   if (!x || !m || !v) {
     set_error("poisson_adjoint_adam: null pointer");
     return ODIL_E_INVAL;
   }
   return poisson_adjoint<float>(fu, gu, shape, ndim, h2, scale, stream,
-                                AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps});
+                                AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev});
 }
 int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream) {
   return poisson_jac<double>(coeffs, shape, ndim, h2, stream);

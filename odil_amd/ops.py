@@ -74,14 +74,24 @@ def interp_adj(gfine, loc, cshape, scale=None, out=None, cut=(False, False)):
     return out if scale is None else (out, scaled)
 
 
+def _step_size(alpha, dtype):
+    """(host value, device pointer or None): `alpha` may be a one-element device tensor -- the step size
+    is then read from memory by the kernel (an epoch captured into a hipGraph replays with new values)."""
+    if isinstance(alpha, torch.Tensor):
+        assert alpha.numel() == 1 and alpha.dtype == dtype
+        return 0.0, ptr(alpha)
+    return float(alpha), None
+
+
 def interp_adj_adam(gfine, loc, cshape, out, x, m, v, alpha, one_minus_b1, one_minus_b2, eps, cut=(False, False)):
     """out = P^T gfine and the Adam step of (x, m, v) (arrays of out's shape) with that gradient."""
     cshape = tuple(int(s) for s in cshape)
     assert tuple(out.shape) == cshape == tuple(x.shape) == tuple(m.shape) == tuple(v.shape)
+    a, adev = _step_size(alpha, gfine.dtype)
     call(
         "interp_adj_cut_adam", gfine.dtype, ptr(gfine), ptr(out), i64(cshape), c_int(len(cshape)), loc.encode(),
-        c_int(1 if cut[0] else 0), c_int(1 if cut[1] else 0), ptr(x), ptr(m), ptr(v), float(alpha),
-        float(one_minus_b1), float(one_minus_b2), float(eps), stream_ptr(),
+        c_int(1 if cut[0] else 0), c_int(1 if cut[1] else 0), ptr(x), ptr(m), ptr(v), a,
+        float(one_minus_b1), float(one_minus_b2), float(eps), adev, stream_ptr(),
     )
     return out
 
@@ -159,10 +169,11 @@ def mg_synth_adj_adam(gu, shapes, loc, grads, x, m, v, alpha, one_minus_b1, one_
     for s in shapes:
         flat += list(s)
     none0 = lambda arrs: ptr_array([None] + list(arrs[1:]))
+    a, adev = _step_size(alpha, gu.dtype)
     call(
         "mg_synth_adj_adam", gu.dtype, ptr(gu), ptr_array(grads), None, ptr_array([None] * nlvl), i64(flat),
-        c_int(nlvl), c_int(gu.dim()), loc.encode(), none0(x), none0(m), none0(v), float(alpha), float(one_minus_b1),
-        float(one_minus_b2), float(eps), stream_ptr(),
+        c_int(nlvl), c_int(gu.dim()), loc.encode(), none0(x), none0(m), none0(v), a, float(one_minus_b1),
+        float(one_minus_b2), float(eps), adev, stream_ptr(),
     )
     return grads
 
@@ -291,9 +302,10 @@ def poisson_adjoint_adam(fu, h2, scale, out, x, m, v, alpha, one_minus_b1, one_m
     in the same launch (x, m, v: arrays of fu's shape, updated in place)."""
     assert x.shape == fu.shape and m.numel() == v.numel() == fu.numel()
     h2a, h2p = host_reals(h2, fu.dtype)
+    a, adev = _step_size(alpha, fu.dtype)
     call(
         "poisson_adjoint_adam", fu.dtype, ptr(fu), ptr(out), ptr(x), ptr(m), ptr(v), i64(fu.shape), c_int(fu.dim()),
-        h2p, float(scale), float(alpha), float(one_minus_b1), float(one_minus_b2), float(eps), stream_ptr(),
+        h2p, float(scale), a, float(one_minus_b1), float(one_minus_b2), float(eps), adev, stream_ptr(),
     )
     return out
 
@@ -310,9 +322,10 @@ def poisson_jac_coeffs(shape, h2, dtype, device):
 def adam_step(x, m, v, g, alpha, one_minus_b1, one_minus_b2, eps):
     """In-place AdamNativeOptimizer._step on flat vectors (reference optimizer.py:311-319)."""
     assert x.numel() == m.numel() == v.numel() == g.numel()
+    a, adev = _step_size(alpha, x.dtype)
     call(
-        "adam_step", x.dtype, ptr(x), ptr(m), ptr(v), ptr(g), c_int64(x.numel()), float(alpha), float(one_minus_b1),
-        float(one_minus_b2), float(eps), stream_ptr(),
+        "adam_step", x.dtype, ptr(x), ptr(m), ptr(v), ptr(g), c_int64(x.numel()), a, float(one_minus_b1),
+        float(one_minus_b2), float(eps), adev, stream_ptr(),
     )
 
 

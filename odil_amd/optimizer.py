@@ -15,6 +15,7 @@
 """
 
 import math
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -85,6 +86,62 @@ def copy_into(flat, views, arrays):
         v.copy_(a)
 
 
+def _graph_wanted(numel, loss_grad):
+    """ODIL_GRAPH=1 / 0 forces graph replay of Adam epochs on / off; the default replays problems of at
+    most 4 M unknowns whose evaluator is one of the kernel paths (fused Poisson, traced operator)."""
+    mode = os.environ.get("ODIL_GRAPH", "auto")
+    if mode in ("0", "1"):
+        return mode == "1" and torch.cuda.is_available()
+    safe = getattr(loss_grad, "graph_safe", None)
+    return torch.cuda.is_available() and numel <= (1 << 22) and safe is not None and safe()
+
+
+class _EpochGraph:
+    """One optimizer epoch captured into a hipGraph.  The per-epoch step sizes are computed on the host
+    exactly as in the eager loop and kept in a device table; a captured index_select moves the current
+    one into the scalar the kernels read, a captured increment advances the index."""
+
+    def __init__(self, step, step_sizes, dtype, device, refresh):
+        self.step, self.refresh = step, refresh
+        self.table = torch.tensor(np.array(step_sizes, dtype=np.float64), dtype=dtype, device=device)
+        self.index = torch.zeros(1, dtype=torch.int64, device=device)
+        self.alpha = torch.zeros(1, dtype=dtype, device=device)
+        self.graph, self.pinfo = None, None
+
+    def _body(self):
+        torch.index_select(self.table, 0, self.index, out=self.alpha)
+        self.index.add_(1)
+        return self.step(self.alpha)
+
+    def capture(self):
+        from .util import printlog
+
+        try:
+            graph = torch.cuda.CUDAGraph()
+            if self.refresh is not None:
+                self.refresh()
+            with torch.cuda.graph(graph):
+                pinfo = self._body()
+            # the report of an epoch is a dict of DEVICE scalars that a lazy wrapper converts (and
+            # caches) on first read: keep the raw tensors, hand out a fresh wrapper per replay
+            self.pinfo_type = type(pinfo) if isinstance(pinfo, dict) else None
+            self.pinfo = {k: dict.__getitem__(pinfo, k) for k in dict.keys(pinfo)} if self.pinfo_type else pinfo
+        except Exception as e:  # capture is an optimisation: never a reason to fail
+            printlog("odil_amd: hipGraph capture of the Adam epoch failed ({}: {}); running eagerly".format(
+                type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+            torch.cuda.synchronize()
+            self.index.zero_()
+            return False
+        self.graph = graph
+        return True
+
+    def replay(self):
+        if self.refresh is not None:
+            self.refresh()
+        self.graph.replay()
+        return self.pinfo_type(**self.pinfo) if self.pinfo_type else self.pinfo
+
+
 class AdamNativeOptimizer(Optimizer):
     def __init__(self, dtype=None, mod=None, **kwargs):
         super().__init__(name="adamn", displayname="AdamNative", dtype=dtype)
@@ -100,13 +157,12 @@ class AdamNativeOptimizer(Optimizer):
         copy_into(xf, x, x0)
         mf = torch.zeros_like(xf)
         vf = torch.zeros_like(xf)
-        gf, gviews = None, None
         mviews = [t.view(a.shape) for t, a in zip(mf.split([a.numel() for a in x]), x)]
         vviews = [t.view(a.shape) for t, a in zip(vf.split([a.numel() for a in x]), x)]
-        for epoch in range(epoch_start + 1, epoch_start + epochs + 1):
-            self.evals += 1
-            t = npdt(epoch - epoch_start)
-            alpha = lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
+        scratch = dict(gf=None, gviews=None)
+
+        def step(alpha):
+            """One epoch: loss + gradient, update.  `alpha`: host number or one-element device tensor."""
             # A recognised problem may apply the update of its leading arrays inside its own
             # gradient launch (core.Problem / fused.py): it then tells how many were done.
             fused = getattr(loss_grad, "fused_adam", None)
@@ -119,15 +175,43 @@ class AdamNativeOptimizer(Optimizer):
                 loss, grads, pinfo = loss_grad(x)
             g = flat_base(grads)
             if g is None or g.dtype != tdtype or g.numel() != xf.numel():
-                if gf is None:
-                    gf, gviews = pack_like(x)
-                copy_into(gf, gviews, grads)
-                g = gf
+                if scratch["gf"] is None:
+                    scratch["gf"], scratch["gviews"] = pack_like(x)
+                copy_into(scratch["gf"], scratch["gviews"], grads)
+                g = scratch["gf"]
             n0 = sum(int(a.numel()) for a in x[:done])
             if n0 < xf.numel():
                 ops.adam_step(xf[n0:], mf[n0:], vf[n0:], g[n0:], alpha, 1 - beta_1, 1 - beta_2, epsilon)
+            return pinfo
+
+        def step_size(epoch):
+            t = npdt(epoch - epoch_start)
+            return lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
+
+        first, last = epoch_start + 1, epoch_start + epochs
+        epoch = first
+        # Launch-bound problems (a few million unknowns or fewer: dozens of launches of a few
+        # microseconds each) replay the epoch as ONE hipGraph: the first two epochs run eagerly (lazy
+        # initialisation, allocator warm-up), the third is captured with the step size read from
+        # device memory (`alpha_dev` of the *_adam kernels), the rest are replays.
+        graph = None
+        if epochs > 4 and _graph_wanted(xf.numel(), loss_grad):
+            while epoch < first + 2:
+                self.evals += 1
+                pinfo = step(step_size(epoch))
+                if callback is not None:
+                    callback(x, epoch, pinfo)
+                epoch += 1
+            graph = _EpochGraph(step, [step_size(e) for e in range(epoch, last + 1)], tdtype, xf.device,
+                                getattr(loss_grad, "refresh", None))
+            if not graph.capture():
+                graph = None
+        while epoch <= last:
+            self.evals += 1
+            pinfo = graph.replay() if graph is not None else step(step_size(epoch))
             if epoch > 0 and callback is not None:
                 callback(x, epoch, pinfo)
+            epoch += 1
         optinfo = Namespace()
         optinfo.epochs = epochs
         optinfo.evals = self.evals

@@ -1197,10 +1197,10 @@ class _Codegen:
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
-        S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; double hs[{}]; "
+        S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
                  "T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks; }};".format(
                      max(1, len(self.src_keys)), max(1, len(self.tr.tensors)), max(1, len(self.cots)),
-                     max(1, par_arrays), max(1, len(self.hs))))
+                     max(1, par_arrays)))
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
         wofs, bofs, o = dict(), dict(), 0
         for s, (key, layers) in enumerate(self.nets):
@@ -1462,7 +1462,7 @@ class TracedOperator:
                 ("ten", ctypes.c_void_p * max(1, len(tr.tensors))),
                 ("cot", ctypes.c_void_p * max(1, len(cg.cots))),
                 ("par", ctypes.c_void_p * max(1, par_arrays)),
-                ("hs", ctypes.c_double * max(1, len(cg.hs))),
+                ("hs", ctypes.c_void_p),
                 ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
             ]
@@ -1477,6 +1477,11 @@ class TracedOperator:
         self.args.part2 = self.part2.data_ptr()
         self.args.out, self.args.pgrad = self.out.data_ptr(), self.pgrad.data_ptr()
         self.args.nblocks = self.nblocks
+        nhs = max(1, len(cg.hs))
+        self.hs_host = torch.zeros(nhs, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else torch.zeros(nhs, dtype=torch.float64)
+        self.hs_dev = torch.zeros(nhs, dtype=torch.float64, device=dev)
+        self._hs_last = None
+        self.args.hs = self.hs_dev.data_ptr()
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         # structure of the state: which arrays belong to which field
@@ -1545,6 +1550,20 @@ class TracedOperator:
         memo[n.idx] = v
         return v
 
+    def refresh_host_scalars(self):
+        """Host scalars of the trace (functions of `problem.tracers`, evaluated in Python double as the
+        operator itself would) -> pinned buffer -> device.  The copy is issued on the current stream
+        when a value changed; captured into a hipGraph it re-reads the pinned buffer at every replay,
+        so a replayed epoch only needs this method's host part to be called first."""
+        if not self.cg.hs:
+            return
+        memo = dict()
+        vals = [float(self._host_value(n, memo)) for n in self.cg.hs]
+        if vals != self._hs_last or torch.cuda.is_current_stream_capturing():
+            self.hs_host.copy_(torch.tensor(vals, dtype=torch.float64))
+            self._hs_last = vals
+            self.hs_dev.copy_(self.hs_host, non_blocking=True)
+
     # ---- evaluation ---------------------------------------------------------------------------
     def _launch(self, state):
         from .core import MultigridField
@@ -1552,9 +1571,7 @@ class TracedOperator:
         domain, cg = self.domain, self.cg
         if self._signature(state) != self.signature:
             raise RuntimeError("state structure changed since the operator was traced")
-        memo = dict()
-        for i, n in enumerate(cg.hs):
-            self.args.hs[i] = float(self._host_value(n, memo))
+        self.refresh_host_scalars()
         keep = []
         with torch.no_grad():
             for i, key in enumerate(cg.src_keys):

@@ -324,6 +324,16 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
         return loss, grads, _pinfo(loss, terms, names, norms), done
 
     loss_grad.fused_adam = fused_adam
+    # hipGraph replay of whole Adam epochs (optimizer._EpochGraph): possible when the evaluation is
+    # made of this package's kernels only -- the generic path has its own graph (Problem(jit=True))
+    loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or getattr(problem, "_traced", None) is not None
+
+    def refresh():
+        traced = getattr(problem, "_traced", None)
+        if traced is not None:
+            traced.refresh_host_scalars()
+
+    loss_grad.refresh = refresh
 
     def callback_wrap(arrays, epoch, pinfo):
         domain.arrays_to_state(arrays, state)
