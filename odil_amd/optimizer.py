@@ -206,11 +206,14 @@ class AdamNativeOptimizer(Optimizer):
                                 getattr(loss_grad, "refresh", None))
             if not graph.capture():
                 graph = None
+        captured = [a.data_ptr() for a in x]
         while epoch <= last:
             self.evals += 1
             pinfo = graph.replay() if graph is not None else step(step_size(epoch))
             if epoch > 0 and callback is not None:
                 callback(x, epoch, pinfo)
+                if graph is not None and [a.data_ptr() for a in x] != captured:
+                    graph = None  # the callback swapped arrays (callback_update_state): replays would miss them
             epoch += 1
         optinfo = Namespace()
         optinfo.epochs = epochs
