@@ -192,25 +192,122 @@ static int dots(const T* a, int64_t lda, int nvec, const T* b, int64_t n, double
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dots3(const T* __restrict__ a, int64_t lda, const T* __restrict__ b0,
                                                  const T* __restrict__ b1, const T* __restrict__ b2, int64_t n,
-                                                 int nvec, double* __restrict__ partials) {
+                                                 int nvec, double* __restrict__ partials, int vec_ok) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type VT;
   const T* ak = a + (int64_t)blockIdx.y * lda;
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  // chunk boundaries on multiples of V so that every block reads whole 16 B packs
+  const int64_t per = (((n + gridDim.x - 1) / gridDim.x) + V - 1) / V * V;
   const int64_t lo = (int64_t)blockIdx.x * per;
   int64_t hi = lo + per;
   if (hi > n) hi = n;
   double l0 = 0.0, l1 = 0.0, l2 = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+  int64_t i = lo;
+  if (vec_ok) {
+    // 16 B per lane and two packs in flight per stream: the history is read once at HBM speed, the
+    // right-hand vectors come from the last-level cache
+    const int64_t nv = lo < hi ? (hi - lo) / V : 0;
+    for (int64_t p = threadIdx.x; p < nv; p += kBlock) {
+      const VT av = *reinterpret_cast<const VT*>(ak + lo + p * V);
+      const VT x0 = *reinterpret_cast<const VT*>(b0 + lo + p * V);
+      VT x1 = x0, x2 = x0;
+      if (b1) x1 = *reinterpret_cast<const VT*>(b1 + lo + p * V);
+      if (b2) x2 = *reinterpret_cast<const VT*>(b2 + lo + p * V);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const double ad = (double)av[k];
+        l0 += ad * (double)x0[k];
+        l1 += ad * (double)x1[k];
+        l2 += ad * (double)x2[k];
+      }
+    }
+    i = lo + nv * V;
+  }
+  for (i += threadIdx.x; i < hi; i += kBlock) {
     const double av = (double)ak[i];
     l0 += av * (double)b0[i];
     if (b1) l1 += av * (double)b1[i];
     if (b2) l2 += av * (double)b2[i];
   }
+  if (!b1) l1 = 0.0;
+  if (!b2) l2 = 0.0;
   const double t0 = block_sum(l0), t1 = block_sum(l1), t2 = block_sum(l2);
   if (threadIdx.x == 0) {
     const int64_t base = (int64_t)blockIdx.y * kDotPartials + blockIdx.x;
     partials[base] = t0;
     partials[(int64_t)nvec * kDotPartials + base] = t1;
     partials[(int64_t)2 * nvec * kDotPartials + base] = t2;
+  }
+}
+
+// The same products with the right-hand vectors read ONCE: a workgroup owns a chunk of elements for
+// all history vectors, keeps its part of b0 / b1 / b2 in registers and walks the history; per vector
+// the three wave sums go to that wave's slot of an LDS table (fixed order, no atomics).  The kernel
+// above re-reads b0 / b1 / b2 for every a_k -- four streams per history element, of which three come
+// from the last-level cache: 2.2 TB/s on the history of L-BFGS (m = 50, 1.4 M unknowns).
+constexpr int kDots3MaxVec = 64;
+template <typename T, int E>
+__global__ __launch_bounds__(kBlock) void k_dots3_once(const T* __restrict__ a, int64_t lda, const T* __restrict__ b0,
+                                                      const T* __restrict__ b1, const T* __restrict__ b2, int64_t n,
+                                                      int nvec, double* __restrict__ partials) {
+  constexpr int V = Vec16<T>::N;
+  constexpr int NP = E / V;  // 16 B packs per thread and chunk
+  typedef typename Vec16<T>::type VT;
+  __shared__ double acc[3][kBlock / 64][kDots3MaxVec];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = threadIdx.x; q < 3 * (kBlock / 64) * kDots3MaxVec; q += kBlock) (&acc[0][0][0])[q] = 0.0;
+  __syncthreads();
+  const int64_t chunk = (int64_t)kBlock * E;
+  for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
+    VT x0[NP], x1[NP], x2[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int64_t i = base + ((int64_t)p * kBlock + threadIdx.x) * V;
+      ok[p] = i + V <= n;  // n is a multiple of V on this path
+      const int64_t j = ok[p] ? i : 0;
+      x0[p] = *reinterpret_cast<const VT*>(b0 + j);
+      x1[p] = b1 ? *reinterpret_cast<const VT*>(b1 + j) : x0[p];
+      x2[p] = b2 ? *reinterpret_cast<const VT*>(b2 + j) : x0[p];
+    }
+    for (int k = 0; k < nvec; ++k) {
+      const T* ak = a + (int64_t)k * lda;
+      VT av[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int64_t i = base + ((int64_t)p * kBlock + threadIdx.x) * V;
+        av[p] = *reinterpret_cast<const VT*>(ak + (ok[p] ? i : 0));
+      }
+      double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const double ad = ok[p] ? (double)av[p][e] : 0.0;
+          l0 += ad * (double)x0[p][e];
+          l1 += ad * (double)x1[p][e];
+          l2 += ad * (double)x2[p][e];
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        l0 += __shfl_down(l0, off, 64);
+        l1 += __shfl_down(l1, off, 64);
+        l2 += __shfl_down(l2, off, 64);
+      }
+      if (lane == 0) {
+        acc[0][wave][k] += l0;
+        acc[1][wave][k] += l1;
+        acc[2][wave][k] += l2;
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 3 * nvec; q += kBlock) {
+    const int j = q / nvec, k = q - j * nvec;
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) t += acc[j][w][k];
+    if ((j == 1 && !b1) || (j == 2 && !b2)) t = 0.0;
+    partials[(int64_t)q * kDotPartials + blockIdx.x] = t;
   }
 }
 
@@ -221,10 +318,22 @@ static int dots3(const T* a, int64_t lda, int nvec, const T* b0, const T* b1, co
     set_error("dots3: null pointer, n < 1 or nvec=%d out of range", nvec);
     return ODIL_E_INVAL;
   }
-  int grid = grid_for(n, kBlock * 8);
+  // every block ends with three block reductions: give it enough elements (64 per thread) to hide them
+  int grid = grid_for(n, kBlock * 64);
   if (grid > kDotPartials) grid = kDotPartials;
+  const int vec_ok = aligned16(a) && aligned16(b0) && (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)) &&
+                     (lda * (int64_t)sizeof(T)) % 16 == 0;
+  if (vec_ok && nvec <= kDots3MaxVec && n % Vec16<T>::N == 0 && n >= (int64_t)kBlock * 64) {
+    constexpr int E = 4 * Vec16<T>::N;  // four 16 B packs per thread, stream and chunk
+    int chunks = grid_for(n, kBlock * E);
+    if (chunks > kDotPartials) chunks = kDotPartials;
+    hipLaunchKernelGGL((k_dots3_once<T, E>), dim3(chunks), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b0, b1, b2, n,
+                       nvec, partials);
+    if (int e = check_launch("k_dots3_once")) return e;
+    return launch_final_reduce<T>(partials, chunks, kDotPartials, 3 * nvec, 1.0, out, (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(k_dots3<T>, dim3(grid, nvec), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b0, b1, b2, n, nvec,
-                     partials);
+                     partials, vec_ok);
   if (int e = check_launch("k_dots3")) return e;
   return launch_final_reduce<T>(partials, grid, kDotPartials, 3 * nvec, 1.0, out, (hipStream_t)stream);
 }

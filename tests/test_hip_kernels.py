@@ -258,9 +258,20 @@ def test_vector_ops(dev):
     b2, b3 = rng.standard_normal(n), rng.standard_normal(n)
     d3 = ops.dots3(to(a, dev), [to(b, dev), to(b2, dev), to(b3, dev)]).cpu().numpy()
     assert np.max(np.abs(d3 - np.stack([a @ b, a @ b2, a @ b3]))) < 1e-11
-    assert np.array_equal(d3[0], d)  # same partial-sum order as odil_dots
     d2 = ops.dots3(to(a, dev), [to(b, dev), to(b2, dev)]).cpu().numpy()
     assert np.array_equal(d2[:2], d3[:2])
+    # long vectors, L-BFGS sized history: the variant that reads the right-hand vectors once
+    for dtype, tol in [(np.float64, 1e-10), (np.float32, 1e-3)]:
+        n2, k2 = 70004, 50
+        big = rng.standard_normal((k2, n2)).astype(dtype)
+        rhs = [rng.standard_normal(n2).astype(dtype) for _ in range(3)]
+        got = ops.dots3(to(big, dev), [to(v, dev) for v in rhs]).cpu().numpy()
+        want = np.stack([big.astype(np.float64) @ v.astype(np.float64) for v in rhs])
+        assert np.max(np.abs(got - want)) < tol * np.sqrt(n2)
+        got2 = ops.dots3(to(big, dev), [to(rhs[0], dev), to(rhs[1], dev)]).cpu().numpy()
+        assert np.array_equal(got2[:2], got[:2]) and np.all(got2[2] == 0)
+        again = ops.dots3(to(big, dev), [to(v, dev) for v in rhs]).cpu().numpy()
+        assert np.array_equal(again, got)  # deterministic
     y = rng.standard_normal(n)
     coef = rng.standard_normal(k)
     ty = to(y, dev)
