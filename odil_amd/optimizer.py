@@ -434,6 +434,11 @@ class LbfgsVectors:
     def dot(self, a, b):
         return float(ops.dots(a[None], b)[0])
 
+    def dot2(self, a, b, c):
+        """(<a, b>, <a, c>) with one kernel and one host read."""
+        out = ops.dots3(a[None], [b, c]).cpu().numpy()
+        return float(out[0, 0]), float(out[1, 0])
+
     def dots(self, mat, nrows, b):
         """[<mat[k], b>] for k < nrows, as a host float64 array."""
         if nrows == 0:
@@ -540,14 +545,16 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             vec.lincomb(d, 1.0, ws, len(order), c2)
 
         # ---- line search (lnsrlb) ------------------------------------------------------------
-        dtd = vec.dot(d, d)
+        if hasattr(vec, "dot2"):
+            dtd, gd = vec.dot2(d, d, g)  # one launch, one host read
+        else:
+            dtd, gd = vec.dot(d, d), vec.dot(g, d)
         dnorm = math.sqrt(dtd)
         stpmx = big
         stp = min(1.0 / dnorm, stpmx) if (nit == 0) else 1.0
         vec.copy(t, x)
         vec.copy(r, g)
         fold = f
-        gd = vec.dot(g, d)
         gdold = gd
         ls_failed = False
         if gd >= 0.0:
@@ -601,7 +608,6 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
 
         # ---- BFGS update (matupd) ----------------------------------------------------------------
         vec.sub_into(r, g, r)  # y = g_new - g_old
-        rr = vec.dot(r, r)
         if stp == 1.0:
             dr = gd - gdold
             ddum = -gdold
@@ -625,7 +631,6 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             yy[:-1, :-1] = yy[1:, 1:]
         vec.copy(ws[slot], d)
         vec.copy(wy[slot], r)
-        theta = rr / dr
         # new row / column of S^T Y, S^T S, Y^T Y
         nphys = len(slots)
         # one pass over S and one over Y give the new rows of S^T Y, S^T S, Y^T Y and, for the next
@@ -633,6 +638,8 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
         s_y, s_s, s_g = vec.dots3(ws, nphys, [r, d, g])  # s_k . y_new, s_k . s_new, s_k . g
         y_y, y_s, y_g = vec.dots3(wy, nphys, [r, d, g])
         pending = (y_g, s_g)
+        rr = float(y_y[slot])  # y_new . y_new is one of the products of that pass: no separate reduction
+        theta = rr / dr
         c = col - 1
         for i, k in enumerate(slots):
             sy[i, c] = s_y[k]
