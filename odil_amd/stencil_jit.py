@@ -1564,6 +1564,19 @@ class TracedOperator:
             self._hs_last = vals
             self.hs_dev.copy_(self.hs_host, non_blocking=True)
 
+    def _side_streams(self, nfields):
+        """Streams for per-field chains; none for a single field, for fields beyond 64 MB (their kernels
+        fill the GPU on their own and concurrent streams only fight for HBM and allocator pools:
+        veltracer3d 83 -> 134 ms) or when ODIL_TRACE_STREAMS=0.  Measured gain where it applies: 5 %."""
+        esize = 8 if self.tr.torch_dtype == torch.float64 else 4
+        if (nfields < 2 or self.total * esize > (64 << 20) or not torch.cuda.is_available()
+                or not int(os.environ.get("ODIL_TRACE_STREAMS", 1))):
+            return []
+        pool = self.__dict__.setdefault("_streams", [])
+        while len(pool) < min(nfields, 4):
+            pool.append(torch.cuda.Stream())
+        return pool[: min(nfields, 4)]
+
     # ---- evaluation ---------------------------------------------------------------------------
     def _launch(self, state):
         from .core import MultigridField
@@ -1573,11 +1586,25 @@ class TracedOperator:
             raise RuntimeError("state structure changed since the operator was traced")
         self.refresh_host_scalars()
         keep = []
+        # the multigrid syntheses of different fields are independent chains of mostly small launches:
+        # each runs on its own stream, the forward kernel waits for all of them
+        cur = torch.cuda.current_stream()
+        side = self._side_streams(len(cg.src_keys))
         with torch.no_grad():
             for i, key in enumerate(cg.src_keys):
-                u = domain.get_regular_array(state.fields[key]).contiguous()
+                field = state.fields[key]
+                if side and isinstance(field, MultigridField):
+                    s_ = side[i % len(side)]
+                    s_.wait_stream(cur)
+                    with torch.cuda.stream(s_):
+                        u = domain.get_regular_array(field).contiguous()
+                    u.record_stream(cur)
+                else:
+                    u = domain.get_regular_array(field).contiguous()
                 keep.append(u)
                 self.args.src[i] = u.data_ptr()
+        for s_ in side:
+            cur.wait_stream(s_)
         i = 0
         for key, layers in cg.nets:
             net = state.fields[key]
@@ -1602,22 +1629,28 @@ class TracedOperator:
         """loss, grads (views of one packed buffer, overwritten by the next call), terms, names, norms."""
         cg = self.cg
         keep = self._launch(state)
-        stream = ops.stream_ptr()
-        for key, kind, pos, n in self.layout:
-            if kind in ("field", "mg"):
+        cur = torch.cuda.current_stream()
+        chains = [item for item in self.layout if item[1] in ("field", "mg") and (item[0] in cg.gathers or item[0] in cg.direct)]
+        side = self._side_streams(len(chains))
+        for i, (key, kind, pos, n) in enumerate(chains):
+            s_ = side[i % len(side)] if side else cur
+            if side:
+                s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
                 if key in cg.gathers:
                     g = self.gtmp.get(key, self.gviews[pos])
-                    rc = self.lib.jit_gather(cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), stream)
+                    rc = self.lib.jit_gather(cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), ops.stream_ptr())
                     if rc != 0:
                         raise RuntimeError("traced gather launch failed: hip error {}".format(rc))
-                elif key in cg.direct:
-                    g = self.cot[cg.direct[key]]
                 else:
-                    continue
+                    g = self.cot[cg.direct[key]]
                 if kind == "mg":
                     factors, loc, shapes = self.mg_meta[key]
                     ops.mg_synth_adj(g, shapes, loc, factors=factors, grads=self.gviews[pos:pos + n])
-            elif kind == "net" and key in cg.pgrads and not self.pgrad_direct:
+        for s_ in side:
+            cur.wait_stream(s_)
+        for key, kind, pos, n in self.layout:
+            if kind == "net" and key in cg.pgrads and not self.pgrad_direct:
                 pofs = cg.pg_offset[key]
                 for j, group in enumerate(cg.pgrads[key]):
                     self.gviews[pos + j].copy_(self.pgrad[pofs:pofs + len(group)].view(self.gviews[pos + j].shape))
