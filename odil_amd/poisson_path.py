@@ -27,7 +27,13 @@ def mg_cshapes(cshape, mg_axes=None, mg_nlvl=None):
     mg_axes = mg_axes or [True] * ndim
     nlvl_max = min(int(round(math.log2(n))) if ax else max(cshape) for n, ax in zip(cshape, mg_axes))
     nlvl = nlvl_max if mg_nlvl is None else min(mg_nlvl, nlvl_max)
-    return [tuple(n >> lvl if ax else n for n, ax in zip(cshape, mg_axes)) for lvl in range(nlvl)]
+    shapes = [tuple(n >> lvl if ax else n for n, ax in zip(cshape, mg_axes)) for lvl in range(nlvl)]
+    for fine, coarse in zip(shapes[:-1], shapes[1:]):  # same requirement as the reference (core.py:75-90)
+        for f, c, ax in zip(fine, coarse, mg_axes):
+            if ax and f != 2 * c:
+                raise ValueError("Expected equal '{}' and '{}' with cshapes={}: every extent must be divisible by 2^{}"
+                                 .format(f, 2 * c, shapes, nlvl - 1))
+    return shapes
 
 
 def hat_reference(cshape, dtype, device):
