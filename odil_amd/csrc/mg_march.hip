@@ -650,7 +650,11 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
 #ifndef ODIL_ADJ_UNITS
 #define ODIL_ADJ_UNITS kGridCap  // measured at 512^3: chain 0.80 / 0.69 / 0.72 ms for 1024 / 2048 / 4096
 #endif
-  if (!march_setup(m, a, CX, ODIL_ADJ_UNITS)) return 0;
+#ifndef ODIL_ADJ_UNITS_SMALL
+#define ODIL_ADJ_UNITS_SMALL (kGridCap / 4)  // levels of <= 4 M coarse points: chain 0.690 -> 0.675 ms
+#endif
+  const bool small_level = a.cn[0] * a.cn[1] * a.cn[2] * a.cn[3] <= ((int64_t)1 << 22);
+  if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
   if (m.lead_fn != 1)
     hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m,
