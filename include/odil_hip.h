@@ -157,6 +157,14 @@ int odil_poisson_residual_slab_f64(const double* u, const double* rhs, double* f
 int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
                                    const float* h2, int64_t z0, int64_t z1, double denom, double* partials,
                                    float* loss, void* stream);
+/* One damped-Jacobi sweep of that operator: uout = u - omega (A u - rhs) / diag(A), uout != u.  The
+ * smoother of the geometric multigrid that solves the Newton system of the Poisson stencil
+ * (reference linsolver.py:61-72 hands that system to pyamg). */
+int odil_poisson_jacobi_f64(const double* u, const double* rhs, double* uout, const int64_t* shape, int ndim,
+                            const double* h2, double omega, void* stream);
+int odil_poisson_jacobi_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
+                            const float* h2, float omega, void* stream);
+
 /* The same residual with the LAST prolongation of the multigrid synthesis fused in: u = w0 + P coarse
  * (reference core.py:245-263, last step) is formed in registers and never stored.  `coarse`: the
  * synthesised level-1 array of shape cshape (3-D, all axes cell-centred), w0 / rhs / fu: the fine

@@ -98,6 +98,74 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
+// One damped-Jacobi sweep of the same operator, x_out = x - omega (A x - b) / diag(A), in ONE pass
+// (the smoother of the geometric multigrid that solves the Newton system, odil_amd/gmg.py): the walk
+// of k_poisson_residual, with the diagonal -- sum over the active axes of (-2 - 2 [low wall] -
+// 2 [high wall]) / h^2, see adj_axis -- formed from the indices instead of read from memory.
+// Reads x and b, writes x_out (3 words per cell; residual + update as two kernels move 7).
+template <typename T, bool FULL>
+__global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__ u, const T* __restrict__ rhs,
+                                                          T* __restrict__ uout, StencilArgs a, H2<T> h, T omega) {
+  constexpr int V = VecOf<T>::N;
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
+  int zc, yi, xs;
+  if (!unit_decode(a.usched, zc, yi, xs)) return;
+  const int64_t x0 = ((int64_t)xs * kBlock + threadIdx.x) * V;
+  if (x0 >= X) return;
+  const int64_t y = yi;
+  const int64_t valid = X - x0 < V ? X - x0 : V;
+  const int64_t z0 = (int64_t)zc * a.usched.ZC;
+  const int64_t z1 = z0 + a.usched.ZC < Z ? z0 + a.usched.ZC : Z;
+  const int64_t ym_off = (y == 0 ? Y - 1 : y - 1) * sy + x0, yp_off = (y == Y - 1 ? 0 : y + 1) * sy + x0;
+  const int64_t c_off = y * sy + x0;
+  const int64_t xl = y * sy + (x0 == 0 ? X - 1 : x0 - 1);
+  const int64_t xr = y * sy + (x0 + valid >= X ? 0 : x0 + valid);
+  // diagonal terms per axis: interior -2 / h^2, one more -2 / h^2 per wall touched
+  T dterm[3];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) dterm[ax] = a.active[ax] ? div_h2<T>(T(-2), h, ax) : T(0);
+  const T dy = a.active[1] ? dterm[1] * T(1 + (y == 0) + (y == Y - 1)) : T(0);
+  T um[V], uc[V], up[V];
+  if (a.active[0]) load_vec<T, V, FULL>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
+  load_vec<T, V, FULL>(u + z0 * sz + c_off, valid, uc);
+  for (int64_t z = z0; z < z1; ++z) {
+    const int64_t pz = z * sz;
+    if (a.active[0]) load_vec<T, V, FULL>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
+    T r[V], ym[V], yp[V], out[V];
+    load_vec<T, V, FULL, true>(rhs + pz + c_off, valid, r);
+    if (a.active[1]) {
+      load_vec<T, V, FULL>(u + pz + ym_off, valid, ym);
+      load_vec<T, V, FULL>(u + pz + yp_off, valid, yp);
+    }
+    const T left = u[pz + xl];
+    const T right = u[pz + xr];
+    const T dz = a.active[0] ? dterm[0] * T(1 + (z == 0) + (z == Z - 1)) : T(0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      if (i >= valid) break;
+      const int64_t x = x0 + i;
+      const T q = uc[i];
+      T acc = T(0);
+      if (a.active[0]) acc = axis_term<T>(q, um[i], up[i], z == 0, z == Z - 1, h, 0);
+      if (a.active[1]) acc = acc + axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h, 1);
+      {
+        const T xm = i == 0 ? left : uc[i - 1];
+        const T xp = (i == valid - 1) ? right : uc[i + 1 < V ? i + 1 : i];
+        acc = acc + axis_term<T>(q, xm, xp, x == 0, x == X - 1, h, 2);
+      }
+      const T diag = (dz + dy) + dterm[2] * T(1 + (x == 0) + (x == X - 1));
+      out[i] = q - omega * (acc - r[i]) / diag;
+    }
+    store_vec<T, V, FULL, true>(uout + pz + c_off, valid, out);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      um[i] = uc[i];
+      uc[i] = up[i];
+    }
+  }
+}
+
 template <typename T, bool FULL>
 __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict__ fu, T* __restrict__ gu,
                                                            StencilArgs a, H2<T> h, T scale, AdamArgs<T> ad) {
@@ -278,6 +346,27 @@ static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, c
 }
 
 template <typename T>
+static int poisson_jacobi(const T* u, const T* rhs, T* uout, const int64_t* shape, int ndim, const T* h2, T omega,
+                          void* stream) {
+  StencilArgs a;
+  T h[3];
+  if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  if (!u || !rhs || !uout || u == uout) {
+    set_error("poisson_jacobi: null pointer, or the sweep in place (x_out must differ from x)");
+    return ODIL_E_INVAL;
+  }
+  a.loss_z0 = 0;
+  a.loss_z1 = 0;
+  if (a.n[2] % VecOf<T>::N == 0)
+    hipLaunchKernelGGL((k_poisson_jacobi<T, true>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream, u,
+                       rhs, uout, a, make_h2<T>(h), omega);
+  else
+    hipLaunchKernelGGL((k_poisson_jacobi<T, false>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream,
+                       u, rhs, uout, a, make_h2<T>(h), omega);
+  return check_launch("k_poisson_jacobi");
+}
+
+template <typename T>
 static int poisson_jac(T* coeffs, const int64_t* shape, int ndim, const T* h2, void* stream) {
   StencilArgs a;
   T h[3];
@@ -342,6 +431,14 @@ int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m
   }
   return poisson_adjoint<float>(fu, gu, shape, ndim, h2, scale, stream,
                                 AdamArgs<float>{x, m, v, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev});
+}
+int odil_poisson_jacobi_f64(const double* u, const double* rhs, double* uout, const int64_t* shape, int ndim,
+                            const double* h2, double omega, void* stream) {
+  return poisson_jacobi<double>(u, rhs, uout, shape, ndim, h2, omega, stream);
+}
+int odil_poisson_jacobi_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
+                            const float* h2, float omega, void* stream) {
+  return poisson_jacobi<float>(u, rhs, uout, shape, ndim, h2, omega, stream);
 }
 int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream) {
   return poisson_jac<double>(coeffs, shape, ndim, h2, stream);

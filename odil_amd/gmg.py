@@ -8,7 +8,7 @@ scales to the 1.3e8 unknowns of the 512^3 configuration.  When the linearised op
 arrays, as in fused.py -- `M^T M d = -M^T r` and `M d = -r` have the same solution, and the
 latter is solved here by V-cycles built only from the HIP kernels of the hot path:
 
-  smoother      damped Jacobi: x += (-omega / diag) * (A x - b)   odil_poisson_residual + odil_addcmul
+  smoother      damped Jacobi: x' = x - omega (A x - b) / diag    odil_poisson_jacobi (one pass, 3 words per cell)
   restriction   cell-centred full weighting (mean of 2^d cells)    odil_restrict
   prolongation  x += P(x_c), the multigrid-decomposition P         odil_interp_add
   coarse grids  the same stencil re-discretised with h_l = 2^l h   odil_poisson_jac_coeffs (diag)
@@ -38,17 +38,11 @@ class PoissonGMG:
             self.h2s.append([v * npdt(4) for v in self.h2s[-1]])
         self.nlvl = len(self.shapes)
         mk = lambda s: torch.zeros(s, dtype=dtype, device=device)
-        self.zero = [mk(s) for s in self.shapes]
-        self.x = [None] + [mk(s) for s in self.shapes[1:]]
-        self.b = [None] + [mk(s) for s in self.shapes[1:]]
-        self.r = [mk(s) for s in self.shapes]
-        self.tmp = [mk(s) for s in self.shapes[:-1]] + [None]
+        self.x = [None] + [mk(s) for s in self.shapes[1:]]   # coarse corrections
+        self.b = [None] + [mk(s) for s in self.shapes[1:]]   # coarse right-hand sides
+        self.r = [mk(s) for s in self.shapes]                # residuals
+        self.spare = [mk(s) for s in self.shapes]            # the buffer a sweep / a prolongation writes into
         self.loss = mk(())
-        # -omega / diag(A) per level (the diagonal is position dependent at the walls)
-        self.mwd = []
-        for s, h in zip(self.shapes, self.h2s):
-            diag = ops.poisson_jac_coeffs(s, h, dtype, device)[0]
-            self.mwd.append((-self.omega) / diag)
 
     def residual(self, lvl, x, b, out):
         """out = A x - b."""
@@ -56,44 +50,52 @@ class PoissonGMG:
         return out
 
     def smooth(self, lvl, x, b, n):
+        """n damped-Jacobi sweeps, each ONE kernel (odil_poisson_jacobi: x' = x - omega (A x - b) / diag);
+        the iterate ping-pongs between `x` and the level's spare buffer.  Returns the tensor holding it."""
         for _ in range(n):
-            self.residual(lvl, x, b, self.r[lvl])
-            ops.addcmul(x.view(-1), self.mwd[lvl].view(-1), self.r[lvl].view(-1))
+            y = self.spare[lvl]
+            ops.poisson_jacobi(x, b, self.h2s[lvl], self.omega, out=y)
+            self.spare[lvl] = x
+            x = y
+        return x
 
     def vcycle(self, lvl, x, b):
+        """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate."""
         if lvl == self.nlvl - 1:
-            self.smooth(lvl, x, b, 40)
-            return
-        self.smooth(lvl, x, b, self.nu1)
+            return self.smooth(lvl, x, b, 40)
+        x = self.smooth(lvl, x, b, self.nu1)
         r = self.residual(lvl, x, b, self.r[lvl])
         # coarse right-hand side = R (b - A x)
         bc = ops.restrict_to_coarser(r, self.loc)
         ops.scale(bc, -1.0, out=self.b[lvl + 1])
         xc = self.x[lvl + 1]
         xc.zero_()
-        self.vcycle(lvl + 1, xc, self.b[lvl + 1])
-        ops.interp_add(xc, self.loc, add=x, out=self.tmp[lvl])  # x + P x_c
-        x.copy_(self.tmp[lvl])
-        self.smooth(lvl, x, b, self.nu2)
+        xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1])
+        if xc_new is not xc:  # keep the zeroed-per-cycle buffer distinct from the level's spare
+            self.x[lvl + 1] = xc_new
+        out = self.spare[lvl]
+        ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
+        self.spare[lvl] = x
+        return self.smooth(lvl, out, b, self.nu2)
 
     def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None):
         """Solves A x = b to ||A x - b|| <= tol * ||b||."""
         x = torch.zeros_like(b) if x0 is None else x0.clone()
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
-        r = torch.empty_like(b)
+        r = self.r[0]
         while it < maxiter:
             self.residual(0, x, b, r)
             res = float(ops.dots(r.view(1, -1), r.view(-1))[0]) ** 0.5
             if res <= tol * max(bn, 1e-300):
                 break
-            self.vcycle(0, x, b)
+            x = self.vcycle(0, x, b)
             it += 1
         if status is not None:
             status["residual"] = res
             status["niter"] = it
             status["method"] = "gmg-vcycle"
-        return x
+        return x.clone()  # the iterate may live in one of this object's work buffers
 
 
 def recognise_poisson(op):

@@ -248,6 +248,15 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
     return fu, loss
 
 
+def poisson_jacobi(u, rhs, h2, omega, out):
+    """out = u - omega (A u - rhs) / diag(A): one damped-Jacobi sweep of the Poisson stencil (out is not u)."""
+    assert u.shape == rhs.shape == out.shape and out.data_ptr() != u.data_ptr()
+    h2a, h2p = host_reals(h2, u.dtype)
+    call("poisson_jacobi", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p, float(omega),
+         stream_ptr())
+    return out
+
+
 def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None, zrange=None, denom=None):
     """fu = Lap(w0 + P coarse) - rhs, loss = mean(fu**2): the residual with the last prolongation of
     the multigrid synthesis fused in (u is never stored).  3-D cell-centred arrays, w0.shape == 2 * coarse.shape.

@@ -460,3 +460,21 @@ def test_poisson_residual_with_fused_prolongation_is_bit_identical(dev, dtype, c
         want = onp.poisson_residual(u.cpu().numpy().astype(np.float64), rhs.cpu().numpy().astype(np.float64),
                                     [float(np.sqrt(v)) for v in h2])
         assert rel(fu, want) < (1e-12 if dtype == np.float64 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(12,), (6, 10), (8, 6, 10), (5, 7, 9)])
+def test_poisson_jacobi_sweep(dev, dtype, shape):
+    """odil_poisson_jacobi == x - omega (A x - b) / diag(A) with A, diag from the residual / Jacobian kernels."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(31)
+    h2 = [dtype(v) for v in [0.25**2, 0.1**2, 0.3**2][: len(shape)]]
+    x = to(rng.standard_normal(shape).astype(dtype), dev)
+    b = to(rng.standard_normal(shape).astype(dtype), dev)
+    omega = 0.8
+    out = ops.poisson_jacobi(x, b, h2, omega, torch.empty_like(x))
+    r, _ = ops.poisson_residual(x, b, h2)
+    diag = ops.poisson_jac_coeffs(shape, h2, x.dtype, dev)[0]
+    want = x - omega * r / diag
+    assert rel(out, want.cpu().numpy()) < (1e-13 if dtype == np.float64 else 1e-5)
