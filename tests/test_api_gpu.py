@@ -337,3 +337,25 @@ def test_poisson_mgloss_gradient(mod, monkeypatch):
     gw = onp.multigrid_to_regular_adj(onp.poisson_adjoint(g0, dw), [a.shape for a in w], "cc")
     for a, b in zip(grads, gw):
         assert rel(a, b) < 1e-11
+
+
+@pytest.mark.parametrize("ndim,N", [(3, 32), (2, 64)])
+def test_newton_poisson_through_geometric_multigrid(mod, ndim, N):
+    """`--linsolver multigrid` on the recognised Poisson operator: the Newton step comes from the fused
+    residual and V-cycles (Chebyshev-weighted Jacobi sweeps, odil_poisson_jacobi) and equals the step
+    of the general route (coefficient arrays -> normal equations) -- one step solves the linear problem."""
+    poisson, args = poisson_args(ndim, N, multigrid=0, epochs=1, linsolver="multigrid", linsolver_maxiter=None)
+    args.linsolver_tol = 1e-12
+    problem, state = poisson.make_problem(args)
+    odil.util.optimize_newton(args, problem, state)
+    assert problem._fused is not None and "_gmg" in problem._fused.__dict__  # the fast route was taken
+    u_fast = state.fields["u"].array.clone()
+    err = u_fast - problem.extra.ref_u
+    assert float(err.abs().max()) < 1e-8
+    # general route on the same problem
+    problem2, state2 = poisson.make_problem(args)
+    vector, matrix = problem2.linearize_device(state2)
+    status = dict()
+    delta = odil.linsolver.solve(matrix, -vector, args, status, "multigrid")
+    assert status["method"] == "gmg-vcycle" and status["niter"] < 25
+    assert float((state2.fields["u"].array.reshape(-1) + delta - u_fast.reshape(-1)).abs().max()) < 1e-9
