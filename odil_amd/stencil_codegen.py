@@ -97,12 +97,14 @@ class _Codegen:
         self.src_keys = []
         self.loads = dict()  # (key, shift, loc) -> variable
         self.cots = []  # live read nodes that receive a cotangent
+        self.cut_nodes = []  # affine sub-expressions whose adjoint is stored instead of their reads' cotangents
         self.nets = []  # (key, layers) with parameter pointers
         self.net_slot = dict()
         self.arrays = []  # (key, numel) of `Array` unknowns read through a[k]
         self.array_slot = dict()
         self.need = self._needs_grad()
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
+        self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
         self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
         self.out_count = [int(np.prod(l)) if l is not None else self.total for l in self.out_lens]
 
@@ -120,6 +122,91 @@ class _Codegen:
             else:
                 need[n.idx] = any(need[a.idx] for a in n.args)
         return need
+
+    # ---- cotangents cut at linear sub-expressions ---------------------------------------------
+    def _affine(self, n, memo):
+        """{read idx: coefficient expression} when `n` is a linear combination of live reads with
+        coefficients that are scalars known to every kernel (literals, host scalars); {} for values
+        that do not depend on live reads; None otherwise."""
+        if n.idx in memo:
+            return memo[n.idx]
+        res = None
+        if not self.need.get(n.idx, False):
+            res = dict()
+        elif n.op == "read":
+            res = {n.idx: "(T)1"}
+        elif n.op in ("win", "cast"):
+            res = self._affine(n.args[0], memo)
+        elif n.op == "neg":
+            a = self._affine(n.args[0], memo)
+            res = None if a is None else {k: "-({})".format(c) for k, c in a.items()}
+        elif n.op in ("add", "sub"):
+            a, b = self._affine(n.args[0], memo), self._affine(n.args[1], memo)
+            if a is not None and b is not None:
+                res = dict(a)
+                for k, c in b.items():
+                    c = c if n.op == "add" else "-({})".format(c)
+                    res[k] = "({} + {})".format(res[k], c) if k in res else c
+        elif n.op == "mul":
+            for x, y in (n.args, n.args[::-1]):
+                a = self._affine(y, memo)
+                if x.host and x.kind != _B and a is not None:
+                    res = {k: "({} * {})".format(c, self.r(x)) for k, c in a.items()}
+                    break
+        elif n.op == "div":
+            a = self._affine(n.args[0], memo)
+            if n.args[1].host and a is not None:
+                res = {k: "({} / {})".format(c, self.r(n.args[1])) for k, c in a.items()}
+        memo[n.idx] = res
+        return res
+
+    def _choose_cuts(self):
+        """Nodes whose adjoint is stored as ONE array for all the reads below them: a regulariser
+        `lap = (q+ - 2 q + q-) / h^2 + ...` needs one array, not one per stencil point.  A node is cut when
+        it is linear in at least two live reads and somebody non-linear (or the loss) consumes it."""
+        memo, consumers = dict(), dict()
+        for n in self.order:
+            for a in n.args:
+                consumers.setdefault(a.idx, []).append(n)
+        outputs = {o.idx for o in self.outputs}
+        cuts = dict()
+        for n in self.order:
+            form = self._affine(n, memo)
+            if n.op == "read" or not form or len(form) < 2 or n.kind != _R:
+                continue
+            outside = n.idx in outputs or any(self._affine(c, memo) is None for c in consumers.get(n.idx, []))
+            if outside:
+                cuts[n.idx] = form
+        # a cut only pays when it makes read cotangents disappear: drop cuts greedily while that lowers
+        # the number of stored arrays (ties: fewer cuts)
+        best = self._stored_arrays(cuts)
+        improved = True
+        while cuts and improved:
+            improved = False
+            for idx in list(cuts):
+                trial = {k: v for k, v in cuts.items() if k != idx}
+                count = self._stored_arrays(trial)
+                if count <= best:
+                    cuts, best, improved = trial, count, True
+                    break
+        return cuts
+
+    def _stored_arrays(self, cuts):
+        """How many cotangent arrays the reverse pass stores for a given set of cut nodes."""
+        reached = {o.idx for o in self.outputs if self.need.get(o.idx, False)}
+        stored = 0
+        for n in reversed(self.order):
+            if n.idx not in reached:
+                continue
+            if n.idx in cuts or n.op == "read":
+                stored += 1
+                continue
+            if n.op in ("stopgrad", "floor", "tensor", "index", "aparam"):
+                continue
+            for a in n.args:
+                if self.need.get(a.idx, False):
+                    reached.add(a.idx)
+        return stored
 
     # ---- expressions ----------------------------------------------------------------------
     def ex(self, n):
@@ -326,6 +413,9 @@ class _Codegen:
             if n.idx not in defined:
                 continue
             g, v = "g{}".format(n.idx), "v{}".format(n.idx)
+            if n.idx in self.cut_set:
+                self.cut_nodes.append(n)  # its adjoint is stored; the gathers expand it onto the reads
+                continue
             if op == "read":
                 self.cots.append(n)
             elif op == "win":
@@ -401,6 +491,7 @@ class _Codegen:
             else:
                 raise TraceUnsupported("derivative of " + op)
         self.cots.reverse()
+        self.cut_nodes.reverse()
 
     def _reverse_mlp(self, n, defined, acc):
         if not self.need[n.idx]:
@@ -465,7 +556,7 @@ class _Codegen:
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
                  "T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks; }};".format(
-                     max(1, len(self.src_keys)), max(1, len(self.tr.tensors)), max(1, len(self.cots)),
+                     max(1, len(self.src_keys)), max(1, len(self.tr.tensors)), max(1, len(self.cots) + len(self.cut_nodes)),
                      max(1, par_arrays)))
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
         wofs, bofs, o = dict(), dict(), 0
@@ -509,8 +600,10 @@ class _Codegen:
         S.extend(fwd)
         S.extend(rev)
         esize = 8 if tdt == torch.float64 else 4
-        stream = len(self.cots) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
-        for slot, n in enumerate(self.cots):
+        stored = list(self.cots) + list(self.cut_nodes)  # cut arrays follow the read cotangents
+        self.ncot = len(stored)
+        stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
+        for slot, n in enumerate(stored):
             if stream:
                 S.append("  __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
             else:
@@ -561,13 +654,17 @@ class _Codegen:
         # gathers
         self.gathers = []  # (key, [cot slots]) for fields that need a gather launch
         self.direct = dict()  # key -> cot slot that already IS the gradient
-        by_key = dict()
+        by_key = dict()  # key -> [(slot, read attr, coefficient expression or None)]
         for slot, n in enumerate(self.cots):
-            by_key.setdefault(n.attr[0], []).append((slot, n))
+            by_key.setdefault(n.attr[0], []).append((slot, n.attr, None))
+        for k, n in enumerate(self.cut_nodes):
+            for ridx, coeff in self.cut_set[n.idx].items():
+                attr = self.tr.nodes[ridx].attr
+                by_key.setdefault(attr[0], []).append((len(self.cots) + k, attr, coeff))
         for key, reads in by_key.items():
             floc = self.state.fields[key].loc
             fshape = self._field_shape(key)
-            if len(reads) == 1 and not any(reads[0][1].attr[1]) and reads[0][1].attr[2] == floc:
+            if len(reads) == 1 and reads[0][2] is None and not any(reads[0][1][1]) and reads[0][1][2] == floc:
                 self.direct[key] = reads[0][0]
                 continue
             gi = len(self.gathers)
@@ -585,24 +682,26 @@ class _Codegen:
                     S.append("  const int q{} = {} / {};".format(d, rem, fshape[d]))
                     rem = "q{}".format(d)
             S.append("  T acc = (T)0;")
-            for slot, n in reads:
-                _, shift, loc, _ = n.attr
+            for entry, (slot, attr, coeff) in enumerate(reads):
+                _, shift, loc, _ = attr
                 idx, valid = [], []
                 for d in range(self.ndim):
                     ns, nr = fshape[d], self.G[d]
                     ext = max(ns, nr)
-                    s = shift[d] % ext
-                    if s > ext // 2:
-                        s -= ext
+                    s_ = shift[d] % ext
+                    if s_ > ext // 2:
+                        s_ -= ext
                     pos = "j{}".format(d) if not (floc[d] == "c" and loc[d] == "n") else "(j{} + 1)".format(d)
-                    e = pos if s == 0 else "wrap({} - ({}), {})".format(pos, s, ext)
+                    e = pos if s_ == 0 else "wrap({} - ({}), {})".format(pos, s_, ext)
                     if floc[d] == "n" and loc[d] == "c":  # trimmed: the last padded position was dropped
-                        name = "t{}_{}".format(slot, d)
+                        name = "t{}_{}".format(entry, d)
                         S.append("  const int {} = {};".format(name, e))
                         valid.append("{} < {}".format(name, nr))
                         e = name
                     idx.append(e)
                 load = "a.cot[{}][{}]".format(slot, self._offset(idx, self.G))
+                if coeff is not None:  # a cut array: the stored adjoint times d(node) / d(read)
+                    load = "({}) * {}".format(coeff, load)
                 if valid:
                     load = "(({}) ? {} : (T)0)".format(" && ".join(valid), load)
                 S.append("  acc = acc + {};".format(load))

@@ -90,7 +90,7 @@ class TracedOperator:
         self.total = cg.total
         self.nblocks = min((self.total + 255) // 256, cg.max_blocks)
         nout = len(outs)
-        self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in cg.cots]
+        self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in range(cg.ncot)]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)
         self.ppart = torch.empty(max(1, len(cg.pg_decl) * self.nblocks), dtype=dt, device=dev)
         self.out = torch.zeros(1 + 2 * nout, dtype=dt, device=dev)
@@ -101,7 +101,7 @@ class TracedOperator:
             _fields_ = [
                 ("src", ctypes.c_void_p * max(1, len(cg.src_keys))),
                 ("ten", ctypes.c_void_p * max(1, len(tr.tensors))),
-                ("cot", ctypes.c_void_p * max(1, len(cg.cots))),
+                ("cot", ctypes.c_void_p * max(1, cg.ncot)),
                 ("par", ctypes.c_void_p * max(1, par_arrays)),
                 ("hs", ctypes.c_void_p),
                 ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
