@@ -281,6 +281,27 @@ __global__ __launch_bounds__(kBlock) void k_restrict_adj(const T* __restrict__ g
   }
 }
 
+// P^T when only the LEADING axis is refined and it is node-centred (loc 'n...'): the second half of the
+// two-step transpose of the 4-D space-time layouts (ops.mg_synth_adj), a pure stream:
+// gc[J] = gf[2J] + (gf[2J-1] + gf[2J+1]) / 2 over volumes of `vol` contiguous elements.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_lead_node(const T* __restrict__ gfine, T* __restrict__ gcoarse,
+                                                                T* __restrict__ gscaled, int64_t cn0, int64_t fn0,
+                                                                int64_t vol, T scale) {
+  const int64_t total = cn0 * vol;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += nthreads) {
+    const int64_t J = i / vol, r = i - J * vol;
+    const int64_t k = 2 * J;
+    T sides = T(0);
+    if (k - 1 >= 0) sides = sides + gfine[(k - 1) * vol + r];
+    if (k + 1 < fn0) sides = sides + gfine[(k + 1) * vol + r];
+    const T v = gfine[k * vol + r] + T(0.5) * sides;
+    gcoarse[i] = v;
+    if (gscaled) gscaled[i] = scale * v;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scale_copy(const T* __restrict__ x, T* __restrict__ y, int64_t n, T a) {
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
@@ -344,6 +365,16 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
   if (!gfine || !gcoarse) {
     set_error("interp_adj: null pointer");
     return ODIL_E_INVAL;
+  }
+  if (a.loc[0] == kNode && a.loc[1] == kNone && a.loc[2] == kNone && a.loc[3] == kNone && a.cut_axis < 0) {
+    const int64_t vol = a.cn[1] * a.cn[2] * a.cn[3];
+    hipLaunchKernelGGL(k_interp_adj_lead_node<T>, dim3(grid_for(a.cn[0] * vol, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, gfine, gcoarse, gscaled, a.cn[0], a.fn[0], vol, scale);
+    if (int e = check_launch("k_interp_adj_lead_node")) return e;
+    if (ad.x)
+      return adam_launch<T>(ad.x, ad.m, ad.v, gscaled ? gscaled : gcoarse, prod4(a.cn), ad.alpha, ad.omb1, ad.omb2,
+                            ad.eps, (hipStream_t)stream, ad.alpha_dev);
+    return 0;
   }
   if (int r = interp_adj_march<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;
   if (int r = interp_adj_fast<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;

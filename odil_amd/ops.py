@@ -139,11 +139,31 @@ def mg_synth(terms, loc, factors=None, work=None, out=None):
     return out
 
 
+def _two_step_adjoint(gu, shapes, loc, nontrivial):
+    return (gu.dim() == 4 and loc == "nccc" and len(shapes) >= 2 and not nontrivial
+            and gu.numel() * gu.element_size() >= (64 << 20) and all(s % 2 == 0 for s in gu.shape[1:]))
+
+
 def mg_synth_adj(gu, shapes, loc, factors=None, grads=None):
     """[f_l (P^T)^l gu]  (cotangent of mg_synth)."""
     nlvl = len(shapes)
     dtype, device = gu.dtype, gu.device
     nontrivial = factors is not None and any(float(f) != 1.0 for f in factors)
+    if _two_step_adjoint(gu, shapes, loc, nontrivial):
+        # 4-D space-time layout 'nccc', large: P^T of the first (dominant) level as the product of
+        # its space part (the batched 'ccc' march kernel, every fine value read ONCE) and its time
+        # part (a stream over an array 8x smaller).  The one-kernel version holds three windows of
+        # plane sums per thread and re-reads the odd fine volumes (0.5 TB/s in float); the joint
+        # ghost rule couples cell axes only, so the transpose factorises exactly over the node axis.
+        if grads is None:
+            grads = [gu] + [torch.empty(tuple(s), dtype=dtype, device=device) for s in shapes[1:]]
+        elif grads[0].data_ptr() != gu.data_ptr():
+            grads[0].copy_(gu)
+        space = interp_adj(gu, "." + loc[1:], (gu.shape[0],) + tuple(shapes[1][1:]))
+        interp_adj(space, "n...", tuple(shapes[1]), out=grads[1])
+        if nlvl > 2:
+            mg_synth_adj(grads[1], shapes[1:], loc, grads=grads[1:])
+        return grads
     if grads is None:
         first = torch.empty_like(gu) if (nontrivial and float(factors[0]) != 1.0) else gu
         grads = [first] + [torch.empty(tuple(s), dtype=dtype, device=device) for s in shapes[1:]]

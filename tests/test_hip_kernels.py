@@ -478,3 +478,27 @@ def test_poisson_jacobi_sweep(dev, dtype, shape):
     diag = ops.poisson_jac_coeffs(shape, h2, x.dtype, dev)[0]
     want = x - omega * r / diag
     assert rel(out, want.cpu().numpy()) < (1e-13 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
+    """Large 'nccc' arrays take P^T = (P^T over the node axis) o (P^T over the three cell axes)
+    (ops.mg_synth_adj); it must equal the one-kernel chain."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(17)
+    shapes = [(9, 128, 128, 64), (5, 64, 64, 32), (3, 32, 32, 16)]
+    if dtype == np.float32:
+        shapes = [(17, 128, 128, 64), (9, 64, 64, 32), (5, 32, 32, 16)]
+    g = to(rng.standard_normal(shapes[0]).astype(dtype), dev)
+    assert ops._two_step_adjoint(g, shapes, "nccc", False)
+    two = ops.mg_synth_adj(g, shapes, "nccc")
+    monkeypatch.setattr(ops, "_two_step_adjoint", lambda *a: False)
+    one = ops.mg_synth_adj(g, shapes, "nccc")
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    for a, b in zip(two, one):
+        assert a.shape == b.shape and rel(a, b.cpu().numpy()) < tol
+    # node-axis-only transpose against the oracle
+    y = rng.standard_normal((9, 6, 5, 4))
+    got = ops.interp_adj(to(y, dev), "n...", (5, 6, 5, 4))
+    assert rel(got, onp.interp_to_finer_adj(y, "n...", (5, 6, 5, 4))) < 1e-14
