@@ -184,17 +184,21 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restri
 // axis an odd f0 averages the two neighbouring coarse volumes: both windows are held and summed in
 // the reference's order (leading tap outermost).
 // ------------------------------------------------------------------------------------
-template <typename T, int CX>
+// CNT0 = coarse volumes per fine leading index, a compile-time constant so that the single-volume
+// launches (batches, even fine indices of a node axis) carry one window and keep the occupancy of the
+// 3-D kernel; the fine leading index is f0 = f0_first + f0_step * blockIdx.y.
+template <typename T, int CX, int CNT0>
 __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __restrict__ coarse,
                                                                   const T* __restrict__ add, T* __restrict__ fine,
-                                                                  MarchArgs a, T cscale, T ascale) {
+                                                                  MarchArgs a, T cscale, T ascale, int f0_first,
+                                                                  int f0_step) {
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
   const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)a.fn[0] * fplane;
-  const int f0 = blockIdx.y;
+  const int f0 = f0_first + f0_step * (int)blockIdx.y;
   const bool node = a.lead_loc == kNode;
-  const int cnt0 = node && (f0 & 1) ? 2 : 1;
+  constexpr int cnt0 = CNT0;
   const int c0 = node ? f0 >> 1 : f0;
   int z0, z1, jy, jx0;
   if (!march_decode<CX>(a, z0, z1, jy, jx0)) return;
@@ -203,10 +207,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
   const T* cb[2] = {coarse + c0 * cvol, coarse + (c0 + cnt0 - 1) * cvol};
   add = add ? add + f0 * fvol : add;
   fine += f0 * fvol;
-  T v[2][3][3][CX + 2];
+  T v[CNT0][3][3][CX + 2];
 #pragma unroll
-  for (int r0 = 0; r0 < 2; ++r0) {
-    if (r0 >= cnt0) break;
+  for (int r0 = 0; r0 < CNT0; ++r0) {
     load_plane<T, CX>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0]);
     load_plane<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1]);
   }
@@ -219,24 +222,19 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
       load_add<T, CX>(add, fbase + fplane, fnx, ad[1], a.nt);
     }
 #pragma unroll
-    for (int r0 = 0; r0 < 2; ++r0) {
-      if (r0 >= cnt0) break;
-      load_plane<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2]);
-    }
+    for (int r0 = 0; r0 < CNT0; ++r0) load_plane<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2]);
 #pragma unroll
     for (int sz = 0; sz < 2; ++sz) {
       T s[2][2 * CX];
       zero_plane<T, CX>(s);
 #pragma unroll
-      for (int r0 = 0; r0 < 2; ++r0) {
-        if (r0 >= cnt0) break;
+      for (int r0 = 0; r0 < CNT0; ++r0)
 #pragma unroll
         for (int rz = 0; rz < 2; ++rz) acc_plane<T, CX>(s, v[r0][sz + rz], sz == rz ? 1 : 3);
-      }
       store_plane<T, CX>(fine, fbase + sz * fplane, fnx, s, rs, ad[sz], add != nullptr, ascale, a.nt);
     }
 #pragma unroll
-    for (int r0 = 0; r0 < 2; ++r0) shift_window<T, CX>(v[r0]);
+    for (int r0 = 0; r0 < CNT0; ++r0) shift_window<T, CX>(v[r0]);
   }
 }
 
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_n(const T* __restri
 // P^T for the 4-D layouts: coarse volume J0 (blockIdx.y) collects the fine volumes 2 J0 and, halved,
 // 2 J0 +- 1 on a node-centred leading axis (volume J0 alone on a batch axis); one z-window of plane
 // sums per contributing fine volume.
-template <typename T, int CX>
+template <typename T, int CX, int NTAP>
 __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __restrict__ gfine,
                                                                   T* __restrict__ gcoarse, T* __restrict__ gscaled,
                                                                   MarchArgs a, T scale, AdamArgs<T> ad) {
@@ -528,9 +526,8 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __res
   // contributing fine volumes: (index, weight); missing ones get weight 0 and a valid index
   int fv[3];
   T wv[3];
-  int ntap = 1;
+  // NTAP: 3 contributing fine volumes on a node-centred leading axis, 1 on a batch axis (one window only)
   if (node) {
-    ntap = 3;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int f = 2 * J0 - 1 + t;
@@ -543,10 +540,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __res
     wv[0] = T(1);
     wv[1] = wv[2] = T(0);
   }
-  T wc[3][CX][6], wr[3][CX][6];
+  T wc[NTAP][CX][6], wr[NTAP][CX][6];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    if (t >= ntap) break;
+  for (int t = 0; t < NTAP; ++t) {
     const T* gf = gfine + fv[t] * fvol;
     T c2[2][CX], r2[2][CX];
     const int fa[2] = {2 * z0 - 2, 2 * z0 - 1}, fb[2] = {2 * z0, 2 * z0 + 1};
@@ -560,8 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __res
 #pragma unroll
     for (int c = 0; c < CX; ++c) v[c] = T(0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      if (t >= ntap) break;
+    for (int t = 0; t < NTAP; ++t) {
       T c2[2][CX], r2[2][CX];
       const int fn2[2] = {2 * jz + 2, 2 * jz + 3};
       reduce_pair<T, CX>(gfine + fv[t] * fvol, fn2, fnz, fplane, fny, fnx, jy, jx0, ay, ax, c2, r2);
@@ -629,10 +624,20 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
   if (!march_setup(m, a, CX)) return 0;
   m.nt = (int64_t)m.lead_fn * m.fn[0] * m.fn[1] * m.fn[2] * (int64_t)sizeof(T) > kStreamBytes;
   const dim3 grid(unit_grid(m.usched), m.lead_fn);
-  if (m.lead_fn != 1)
-    hipLaunchKernelGGL((k_interp_add_march_lead<T, CX>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m, cscale,
-                       ascale);
-  else if (a.loc[1] == kNode)
+  if (m.lead_fn != 1) {
+    if (m.lead_loc == kNode) {
+      // even fine indices read one coarse volume, odd ones two: two launches, each with its window count
+      const dim3 even(unit_grid(m.usched), (m.lead_fn + 1) / 2), odd(unit_grid(m.usched), m.lead_fn / 2);
+      hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), even, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                         cscale, ascale, 0, 2);
+      if (odd.y > 0)
+        hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 2>), odd, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                           cscale, ascale, 1, 2);
+    } else {
+      hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                         cscale, ascale, 0, 1);
+    }
+  } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_add_march_n<T, CX>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m, cscale,
                        ascale);
   else
@@ -656,10 +661,14 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   const bool small_level = a.cn[0] * a.cn[1] * a.cn[2] * a.cn[3] <= ((int64_t)1 << 22);
   if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
-  if (m.lead_fn != 1)
-    hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m,
-                       scale, ad);
-  else if (a.loc[1] == kNode)
+  if (m.lead_fn != 1) {
+    if (m.lead_loc == kNode)
+      hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 3>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
+                         m, scale, ad);
+    else
+      hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
+                         m, scale, ad);
+  } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_adj_march_n<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
   else
