@@ -180,19 +180,21 @@ def make_callback(problem, args=None, epoch_func=None, report_func=None, history
     def callback(state, epoch, pinfo):
         args = cbinfo.args
         domain = problem.domain
-        t_in = time.time()
         report = bool(args.report_every) and epoch % args.report_every == 0
         hist = cbinfo.history is not None and (epoch % args.history_every == 0 or epoch < (args.history_full or 0))
         plot = epoch % args.plot_every == 0 and bool(epoch or args.frames)
         checkpoint = bool(args.checkpoint_every) and epoch % args.checkpoint_every == 0
+        if (report or hist or plot or checkpoint) and torch.cuda.is_available():
+            # epochs are enqueued asynchronously (whole epochs as graph replays): wait for the device
+            # BEFORE the callback clock starts, so that device time is attributed to the epochs
+            torch.cuda.synchronize()
+        t_in = time.time()
         cbinfo.task_report, cbinfo.task_history, cbinfo.task_plot, cbinfo.task_checkpoint = report, hist, plot, checkpoint
         cbinfo.pinfo = pinfo
         if isinstance(problem.tracers, dict):
             problem.tracers["epoch"] = epoch
         if epoch_func is not None:
             epoch_func(problem, state, epoch, cbinfo)
-        if report or hist or plot or checkpoint:
-            torch.cuda.synchronize()  # attribute device time to the epochs, not to the callback
         now = time.time()
         cbinfo.time_callback += now - t_in
         t_in = now
