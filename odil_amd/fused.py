@@ -161,7 +161,7 @@ def _close(a, b, rtol):
 
 def detect(problem, state):
     """Returns a fused evaluator for `problem`, or None to keep the generic path."""
-    from .core import Context, Field, MultigridField, State
+    from .core import Field, MultigridField, State
 
     domain = problem.domain
     if len(state.fields) != 1:

@@ -26,7 +26,6 @@ using the generic autograd path.  The source is compiled with hipcc into an in-t
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 from . import ops
@@ -51,7 +50,7 @@ class TracedOperator:
     """loss / gradient of one user operator through its generated kernels."""
 
     def __init__(self, problem, state):
-        from .core import Context, Field, MultigridField, NeuralNet, Problem
+        from .core import Context, Field, MultigridField, Problem
 
         domain = problem.domain
         self.problem, self.domain = problem, domain

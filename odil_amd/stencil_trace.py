@@ -7,7 +7,6 @@ src/odil/core.py:865-990).  Code generation lives in stencil_codegen.py.
 """
 
 import math
-import os
 
 import numpy as np
 import torch
