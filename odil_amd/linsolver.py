@@ -7,7 +7,7 @@ iterative routine.  Here M stays a `core.LinearizedOperator` (per-shift coeffici
 arrays + dense blocks), A is applied as M^T (M x) with the HIP stencil kernels and the
 system is solved by Jacobi-preconditioned conjugate gradients with deterministic dot
 products (odil_dots) and no host synchronisation inside the iteration.  `direct` is a dense
-Cholesky of A = M^T M up to 16384 unknowns (one f64 GEMM + rocSOLVER, `dense_normal`), geometric
+Cholesky of A = M^T M up to 49152 unknowns, memory permitting (one f64 GEMM + rocSOLVER, `dense_normal`), geometric
 multigrid for the recognised Poisson stencil above 2e5 unknowns (gmg.py), and otherwise "CG to
 round-off" (tol 1e-14 relative, bounded by `--linsolver_maxiter` if given, else 20 n), which
 reproduces the reference's Newton iterate to solver tolerance; `cg` / `bicgstab` / `multigrid`
@@ -97,7 +97,18 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     return x
 
 
-DENSE_MAX_UNKNOWNS = 16384  # up to here `direct` factorises the dense normal matrix (2 GB in f64)
+DENSE_MAX_UNKNOWNS = 49152  # `direct` factorises the dense normal matrix up to here, memory permitting
+
+
+def _dense_fits(op):
+    """M (rows x unknowns), A = M^T M and the Cholesky factor as dense matrices must fit comfortably:
+    16384 unknowns take 6 GB in f64, 49152 take 58 GB of the 288 GB of an MI355X."""
+    if op.ncols > DENSE_MAX_UNKNOWNS:
+        return False
+    esize = 8 if op.dtype == torch.float64 else 4
+    need = (op.nrows * op.ncols + 2 * op.ncols * op.ncols) * esize
+    free = torch.cuda.mem_get_info(op.device)[0] if op.device.type == "cuda" else 0
+    return need <= 0.5 * free
 
 
 def dense_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
@@ -163,7 +174,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
     if linsolver in ("direct", "directsq"):
-        if matr.ncols <= DENSE_MAX_UNKNOWNS and matr.nrows * matr.ncols <= (1 << 29):
+        if _dense_fits(matr):
             x = dense_normal(matr, rhs, damp, dampdiag, status=status)
             if x is not None and bool(torch.isfinite(x).all()):
                 return x
