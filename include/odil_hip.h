@@ -242,6 +242,11 @@ int odil_dots3_f64(const double* a, int64_t lda, int nvec, const double* b0, con
                    int64_t n, double* partials, double* out, void* stream);
 int odil_dots3_f32(const float* a, int64_t lda, int nvec, const float* b0, const float* b1, const float* b2, int64_t n,
                    double* partials, float* out, void* stream);
+/* out[0] = <g, d>, out[1] = <g, g>, out[2] = max_i |g[i]| in one pass: what the L-BFGS-B line search and
+ * stopping test read after an evaluation (reference optimizer.py:95-105 -> SciPy lnsrlb / projgr).
+ * `partials`: odil_dots_workspace_bytes(3) scratch. */
+int odil_lbfgs_probe_f64(const double* g, const double* d, int64_t n, double* partials, double* out, void* stream);
+int odil_lbfgs_probe_f32(const float* g, const float* d, int64_t n, double* partials, float* out, void* stream);
 /* y = beta * y + sum_k coef[k] * a[k*lda + :]  (coef on DEVICE, length nvec). */
 int odil_lincomb_f64(double* y, double beta, const double* a, int64_t lda, int nvec, const double* coef, int64_t n,
                      void* stream);

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "addcmul": [_P, _P, _P, c_int64, c_int, _P],
     "dots": [_P, c_int64, c_int, _P, c_int64, _P, _P, _P],
     "dots3": [_P, c_int64, c_int, _P, _P, _P, c_int64, _P, _P, _P],
+    "lbfgs_probe": [_P, _P, c_int64, _P, _P, _P],
     "lincomb": [_P, _R, _P, c_int64, c_int, _P, c_int64, _P],
     "stencil_apply": [_P, _I64P, c_int, _P, _P, _I64P, c_int, c_int, _P],
     "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_dots3(const T* __restrict__ a, int64
 // the three wave sums go to that wave's slot of an LDS table (fixed order, no atomics).  The kernel
 // above re-reads b0 / b1 / b2 for every a_k -- four streams per history element, of which three come
 // from the last-level cache: 2.2 TB/s on the history of L-BFGS (m = 50, 1.4 M unknowns).
-constexpr int kDots3MaxVec = 64;
+constexpr int kDots3MaxVec = 128;  // S and Y of L-BFGS (m = 50) interleaved in one matrix
 template <typename T, int E>
 __global__ __launch_bounds__(kBlock) void k_dots3_once(const T* __restrict__ a, int64_t lda, const T* __restrict__ b0,
                                                       const T* __restrict__ b1, const T* __restrict__ b2, int64_t n,
@@ -361,6 +361,72 @@ static int lincomb(T* y, T beta, const T* a, int64_t lda, int nvec, const T* coe
   return check_launch("k_lincomb");
 }
 
+// One pass over the new gradient for everything the L-BFGS line search reads on the host after an
+// evaluation: <g, d> (Wolfe test), <g, g> and max |g| (projected-gradient stopping test); fixed
+// summation order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lbfgs_probe(const T* __restrict__ g, const T* __restrict__ d, int64_t n,
+                                                       double* __restrict__ partials) {
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  int64_t hi = lo + per;
+  if (hi > n) hi = n;
+  double gd = 0.0, gg = 0.0, gm = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const double gi = (double)g[i];
+    gd += gi * (double)d[i];
+    gg += gi * gi;
+    gm = fmax(gm, fabs(gi));
+  }
+  const double t0 = block_sum(gd), t1 = block_sum(gg);
+  __shared__ double wave_max[kBlock / 64];
+  for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) gm = fmax(gm, wave_max[w]);
+    partials[blockIdx.x] = t0;
+    partials[kDotPartials + blockIdx.x] = t1;
+    partials[2 * kDotPartials + blockIdx.x] = gm;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lbfgs_probe_final(const double* __restrict__ partials, int count,
+                                                             T* __restrict__ out) {
+  double gd = 0.0, gg = 0.0, gm = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) {
+    gd += partials[i];
+    gg += partials[kDotPartials + i];
+    gm = fmax(gm, partials[2 * kDotPartials + i]);
+  }
+  const double t0 = block_sum(gd), t1 = block_sum(gg);
+  __shared__ double wave_max[kBlock / 64];
+  for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_down(gm, off, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) gm = fmax(gm, wave_max[w]);
+    out[0] = (T)t0;
+    out[1] = (T)t1;
+    out[2] = (T)gm;
+  }
+}
+
+template <typename T>
+static int lbfgs_probe(const T* g, const T* d, int64_t n, double* partials, T* out, void* stream) {
+  if (!g || !d || !partials || !out || n < 1) {
+    set_error("lbfgs_probe: null pointer or n < 1");
+    return ODIL_E_INVAL;
+  }
+  int grid = grid_for(n, kBlock * 8);
+  if (grid > kDotPartials) grid = kDotPartials;
+  hipLaunchKernelGGL(k_lbfgs_probe<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, g, d, n, partials);
+  if (int e = check_launch("k_lbfgs_probe")) return e;
+  hipLaunchKernelGGL(k_lbfgs_probe_final<T>, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, partials, grid, out);
+  return check_launch("k_lbfgs_probe_final");
+}
+
 }  // namespace odil
 
 using namespace odil;
@@ -399,6 +465,12 @@ int odil_dots_f64(const double* a, int64_t lda, int nvec, const double* b, int64
 int odil_dots_f32(const float* a, int64_t lda, int nvec, const float* b, int64_t n, double* partials, float* out,
                   void* stream) {
   return dots<float>(a, lda, nvec, b, n, partials, out, stream);
+}
+int odil_lbfgs_probe_f64(const double* g, const double* d, int64_t n, double* partials, double* out, void* stream) {
+  return lbfgs_probe<double>(g, d, n, partials, out, stream);
+}
+int odil_lbfgs_probe_f32(const float* g, const float* d, int64_t n, double* partials, float* out, void* stream) {
+  return lbfgs_probe<float>(g, d, n, partials, out, stream);
 }
 int odil_dots3_f64(const double* a, int64_t lda, int nvec, const double* b0, const double* b1, const double* b2,
                    int64_t n, double* partials, double* out, void* stream) {

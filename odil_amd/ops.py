@@ -425,6 +425,14 @@ def dots3(a, bs, out=None):
     return out
 
 
+def lbfgs_probe(g, d, out):
+    """out[:3] = (<g, d>, <g, g>, max |g|) in one pass over g."""
+    assert g.numel() == d.numel() and g.dtype == d.dtype == out.dtype and out.numel() >= 3
+    call("lbfgs_probe", g.dtype, ptr(g), ptr(d), c_int64(g.numel()), ptr(dots_workspace(g.device, 3)), ptr(out),
+         stream_ptr())
+    return out
+
+
 def ptr_strided(a):
     import ctypes
 

@@ -418,44 +418,29 @@ class _Dcsrch:
 
 class LbfgsVectors:
     """The n-vector algebra L-BFGS needs, on HIP kernels.  (Tests substitute a NumPy double
-    to exercise the scalar logic on CPU.)"""
+    to exercise the scalar logic on CPU.)
+
+    The history lives in ONE matrix with s_k and y_k interleaved (row 2k = s_k, row 2k + 1 = y_k),
+    so that the products of the whole history with the new vectors are one launch and one host
+    read, and the direction is one linear combination.  Everything the host needs after an
+    evaluation (loss, <g, d>, max |g|, and the <d, d>, <g_old, d> launched before it) sits in one
+    small device buffer that is read with a single copy: two host reads per iteration."""
 
     def __init__(self, n, m, device):
         self.n, self.m, self.device = n, m, device
-        self.ws = torch.zeros((m, n), dtype=torch.float64, device=device)
-        self.wy = torch.zeros((m, n), dtype=torch.float64, device=device)
+        self.w = torch.zeros((2 * m, n), dtype=torch.float64, device=device)
+        self.ws = self.w[0::2]
+        self.wy = self.w[1::2]
+        self.scal = torch.zeros(8, dtype=torch.float64, device=device)  # dtd, gd_old, -, gd, gg, gmax, f
+        self.scal_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+        self.coef_host = torch.zeros(2 * m, dtype=torch.float64).pin_memory()
+        self.coef = torch.zeros(2 * m, dtype=torch.float64, device=device)
 
     def new(self):
         return torch.zeros(self.n, dtype=torch.float64, device=self.device)
 
     def copy(self, dst, src):
         dst.copy_(src)
-
-    def dot(self, a, b):
-        return float(ops.dots(a[None], b)[0])
-
-    def dot2(self, a, b, c):
-        """(<a, b>, <a, c>) with one kernel and one host read."""
-        out = ops.dots3(a[None], [b, c]).cpu().numpy()
-        return float(out[0, 0]), float(out[1, 0])
-
-    def dots(self, mat, nrows, b):
-        """[<mat[k], b>] for k < nrows, as a host float64 array."""
-        if nrows == 0:
-            return np.zeros(0)
-        return ops.dots(mat[:nrows], b).cpu().numpy()
-
-    def dots3(self, mat, nrows, bs):
-        """[[<mat[k], b>] for b in bs] (len(bs) <= 3) in one pass over mat, host float64."""
-        if nrows == 0:
-            return np.zeros((len(bs), 0))
-        return ops.dots3(mat[:nrows], bs).cpu().numpy()[: len(bs)]
-
-    def max_abs(self, a):
-        return float(a.abs().max())
-
-    def axpy(self, y, x, a):
-        ops.axpy(y, x, a)
 
     def set_axpy(self, out, t, d, a):
         """out = t + a * d."""
@@ -464,12 +449,6 @@ class LbfgsVectors:
 
     def scale_into(self, dst, src, a):
         ops.scale(src, a, out=dst)
-
-    def lincomb(self, y, beta, mat, nrows, coef):
-        if nrows:
-            ops.lincomb(y, beta, mat[:nrows], torch.as_tensor(coef, dtype=torch.float64, device=self.device))
-        elif beta != 1.0:
-            ops.scale(y, beta, out=y)
 
     def sub_into(self, dst, a, b):
         """dst = a - b (dst may alias b)."""
@@ -480,14 +459,65 @@ class LbfgsVectors:
             dst.copy_(a)
             ops.axpy(dst, b, -1.0)
 
+    # ---- scalars: launched where their operands are ready, read together ------------------------
+    def probe_direction(self, d, g):
+        """Launches <d, d> and <g, d> for the direction just formed."""
+        ops.dots3(d[None], [d, g], out=self.scal[0:3].view(3, 1))
+
+    def probe_eval(self, f, g, d):
+        """Launches <g, d>, <g, g>, max |g| for a new evaluation and places its loss beside them."""
+        ops.lbfgs_probe(g, d, self.scal[3:6])
+        if torch.is_tensor(f):
+            self.scal[6:7].copy_(f.reshape(1))
+        else:
+            self.scal[6:7].fill_(float(f))
+
+    def read_probes(self):
+        """-> (dtd, gd_direction, gd, gmax, f) with one device-to-host copy."""
+        self.scal_host.copy_(self.scal, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h = self.scal_host
+        return float(h[0]), float(h[1]), float(h[3]), float(h[5]), float(h[6])
+
+    # ---- history ------------------------------------------------------------------------------------
+    def store_pair(self, slot, s, y):
+        self.w[2 * slot].copy_(s)
+        self.w[2 * slot + 1].copy_(y)
+
+    def history_products(self, nphys, bs):
+        """[<s_k, b>], [<y_k, b>] for every b in bs (<= 3 vectors) and every stored pair k < nphys:
+        one pass over the history, one host read.  -> (S-products, Y-products), each (len(bs), nphys)."""
+        if nphys == 0:
+            z = np.zeros((len(bs), 0))
+            return z, z
+        out = ops.dots3(self.w[: 2 * nphys], bs).cpu().numpy()[: len(bs)]
+        return out[:, 0::2], out[:, 1::2]
+
+    def history_lincomb(self, y, nphys, cs, cy):
+        """y += sum_k cs[k] s_k + cy[k] y_k in one pass over the history."""
+        if nphys == 0:
+            return
+        c = self.coef_host.numpy()
+        c[0 : 2 * nphys : 2] = cs
+        c[1 : 2 * nphys : 2] = cy
+        # the pinned staging buffer is rewritten only after the next read_probes(), which waits for this copy
+        self.coef[: 2 * nphys].copy_(self.coef_host[: 2 * nphys], non_blocking=True)
+        ops.lincomb(y, 1.0, self.w[: 2 * nphys], self.coef[: 2 * nphys])
+
 
 def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, maxfun=math.inf, callback=None):
     """L-BFGS-B 3.0 without bounds.  `x`: flat vector (updated in place); `fg(x) -> (f, g)`
-    with g written/returned as a flat vector; `vec`: vector backend.  Returns
-    dict(task, warnflag, nit, funcalls, f)."""
+    with g written/returned as a flat vector (f may stay on the device: it reaches the host through
+    `vec.read_probes`); `vec`: vector backend.  Returns dict(task, warnflag, nit, funcalls, f).
+
+    The host reads device results twice per iteration: once after the evaluation (loss, <g, d>,
+    max |g| together with the <d, d> and <g_old, d> of the direction), once after the pass over the
+    history that forms the new rows of S^T Y, S^T S, Y^T Y.  From the second iteration on the first
+    trial step is 1, so the first evaluation of a line search is launched before <g_old, d> is
+    known; a non-descent direction (never seen with a positive-definite memory) discards it."""
+    from scipy.linalg import solve_triangular
+
     epsmch = np.finfo(np.float64).eps
-    n = vec.n
-    ws, wy = vec.ws, vec.wy
     sy = np.zeros((m, m))  # sy[i, j] = s_i . y_j (logical order, oldest first)
     ss = np.zeros((m, m))
     yy = np.zeros((m, m))
@@ -503,58 +533,63 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
     d = vec.new()
     g = vec.new()
 
+    def evaluate(step):
+        """x = t + step d, evaluation there, probes launched: -> nothing; read with read_probes()."""
+        vec.set_axpy(x, t, d, step)
+        fobj, gnew = fg(x)
+        vec.copy(g, gnew)
+        vec.probe_eval(fobj, g, d)
+
     pending = None  # (Y^T g, S^T g) for the next direction, when already known
-    f, gnew = fg(x)
+    fobj, gnew = fg(x)
     vec.copy(g, gnew)
     nfev += 1
-    sbgnrm = vec.max_abs(g)
-    info = dict(task="START", warnflag=2)
+    vec.probe_eval(fobj, g, g)
+    _, _, _, sbgnrm, f = vec.read_probes()
     if sbgnrm <= pgtol:
         return dict(task="CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL", warnflag=0, nit=0, funcalls=nfev, f=f)
 
     while True:
         # ---- search direction d = -B^{-1} g (compact representation) --------------------
-        if col == 0:
-            vec.scale_into(d, g, -1.0 / theta)
-        else:
-            order = slots  # logical -> physical
+        vec.scale_into(d, g, -1.0 / theta)
+        if col > 0:
+            order = np.asarray(slots)  # logical -> physical
             if pending is not None:
                 p1, p2 = pending  # Y^T g, S^T g came out of the pass that formed the update rows
             else:
-                p1 = vec.dots(wy, len(order), g)
-                p2 = vec.dots(ws, len(order), g)
+                sg_, yg_ = vec.history_products(len(slots), [g])
+                p1, p2 = yg_[0], sg_[0]
             pending = None
-            # physical -> logical order
-            yg = np.array([p1[k] for k in order])
-            sg = np.array([p2[k] for k in order]) * theta
-            D = np.diag(np.diag(sy[:col, :col]))
-            Rbar = np.triu(sy[:col, :col])  # s_i.y_j for i <= j
-            N = np.zeros((2 * col, 2 * col))
-            N[:col, :col] = -D - yy[:col, :col] / theta
-            N[:col, col:] = -Rbar.T
-            N[col:, :col] = -Rbar
-            q = np.linalg.solve(N, np.concatenate([yg, sg]))
+            yg = np.asarray(p1)[order]
+            sg = np.asarray(p2)[order] * theta
+            # [[-D - Y^T Y / theta, -Rbar^T], [-Rbar, 0]] q = [yg, sg] with Rbar = triu(S^T Y): the zero
+            # block makes it two triangular solves
+            rbar = np.triu(sy[:col, :col])  # s_i.y_j for i <= j
+            amat = np.diag(np.diag(sy[:col, :col])) + yy[:col, :col] / theta
+            q1 = -solve_triangular(rbar, sg, lower=False, check_finite=False)
+            q2 = -solve_triangular(rbar, yg + amat @ q1, trans=1, lower=False, check_finite=False)
             # d = -g/theta - (1/theta^2) (Y q1 + theta S q2)
-            vec.scale_into(d, g, -1.0 / theta)
-            c1 = np.zeros(len(order))
-            c2 = np.zeros(len(order))
-            for i, k in enumerate(order):
-                c1[k] = -q[i] / theta**2
-                c2[k] = -q[col + i] / theta
-            vec.lincomb(d, 1.0, wy, len(order), c1)
-            vec.lincomb(d, 1.0, ws, len(order), c2)
+            cy = np.zeros(len(slots))
+            cs = np.zeros(len(slots))
+            cy[order] = -q1 / theta**2
+            cs[order] = -q2 / theta
+            vec.history_lincomb(d, len(slots), cs, cy)
 
         # ---- line search (lnsrlb) ------------------------------------------------------------
-        if hasattr(vec, "dot2"):
-            dtd, gd = vec.dot2(d, d, g)  # one launch, one host read
-        else:
-            dtd, gd = vec.dot(d, d), vec.dot(g, d)
-        dnorm = math.sqrt(dtd)
-        stpmx = big
-        stp = min(1.0 / dnorm, stpmx) if (nit == 0) else 1.0
+        vec.probe_direction(d, g)
         vec.copy(t, x)
         vec.copy(r, g)
         fold = f
+        stpmx = big
+        launched = False
+        if nit == 0:
+            dtd, gd = vec.read_probes()[:2]
+            stp = min(1.0 / math.sqrt(dtd), stpmx)
+        else:
+            stp = 1.0
+            evaluate(stp)  # before <g_old, d> is on the host
+            launched = True
+            dtd, gd, gd_new, gmax_new, f_new = vec.read_probes()
         gdold = gd
         ls_failed = False
         if gd >= 0.0:
@@ -570,10 +605,11 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
                 if iback >= maxls:
                     ls_failed = True
                     break
-                vec.set_axpy(x, t, d, stp)
-                f, gnew = fg(x)
-                vec.copy(g, gnew)
-                gd = vec.dot(g, d)
+                if not launched:
+                    evaluate(stp)
+                    _, _, gd_new, gmax_new, f_new = vec.read_probes()
+                launched = False
+                f, gd, sbgnrm = f_new, gd_new, gmax_new
                 stp, task = search.step(stp, f, gd)
                 if nfev > maxfun:
                     break
@@ -592,7 +628,6 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
 
         # ---- new iterate ---------------------------------------------------------------------
         nit += 1
-        sbgnrm = vec.max_abs(g)
         if callback is not None:
             callback(x)
         if nit >= maxiter:
@@ -629,23 +664,20 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             sy[:-1, :-1] = sy[1:, 1:]
             ss[:-1, :-1] = ss[1:, 1:]
             yy[:-1, :-1] = yy[1:, 1:]
-        vec.copy(ws[slot], d)
-        vec.copy(wy[slot], r)
-        # new row / column of S^T Y, S^T S, Y^T Y
-        nphys = len(slots)
-        # one pass over S and one over Y give the new rows of S^T Y, S^T S, Y^T Y and, for the next
-        # direction, S^T g and Y^T g (the history is the dominant traffic of an iteration)
-        s_y, s_s, s_g = vec.dots3(ws, nphys, [r, d, g])  # s_k . y_new, s_k . s_new, s_k . g
-        y_y, y_s, y_g = vec.dots3(wy, nphys, [r, d, g])
+        vec.store_pair(slot, d, r)
+        # one pass over the history gives the new rows of S^T Y, S^T S, Y^T Y and, for the next direction,
+        # S^T g and Y^T g (the history is the dominant traffic of an iteration)
+        (s_y, s_s, s_g), (y_y, y_s, y_g) = vec.history_products(len(slots), [r, d, g])
         pending = (y_g, s_g)
         rr = float(y_y[slot])  # y_new . y_new is one of the products of that pass: no separate reduction
         theta = rr / dr
         c = col - 1
-        for i, k in enumerate(slots):
-            sy[i, c] = s_y[k]
-            sy[c, i] = y_s[k]
-            ss[i, c] = ss[c, i] = s_s[k]
-            yy[i, c] = yy[c, i] = y_y[k]
+        order = np.asarray(slots)
+        idx = np.arange(col)
+        sy[idx, c] = s_y[order]
+        sy[c, idx] = y_s[order]
+        ss[idx, c] = ss[c, idx] = s_s[order]
+        yy[idx, c] = yy[c, idx] = y_y[order]
         sy[c, c] = dr
         ss[c, c] = stp * stp * dtd if stp != 1.0 else dtd
         yy[c, c] = rr
@@ -682,7 +714,7 @@ class LbfgsbOptimizer(Optimizer):
                 for gv, gi in zip(gviews, grads):
                     gv.copy_(gi)
                 g = gbuf
-            return float(loss), g
+            return loss, g  # the loss reaches the host through vec.read_probes()
 
         def callback_wrap(xflat):
             self.epoch += 1

@@ -272,6 +272,22 @@ def test_vector_ops(dev):
         assert np.array_equal(got2[:2], got[:2]) and np.all(got2[2] == 0)
         again = ops.dots3(to(big, dev), [to(v, dev) for v in rhs]).cpu().numpy()
         assert np.array_equal(again, got)  # deterministic
+        # interleaved S / Y history of L-BFGS (m = 50): 100 strided rows in one launch
+        wide = rng.standard_normal((100, n2)).astype(dtype)
+        tw = to(wide, dev)
+        got = ops.dots3(tw, [to(v, dev) for v in rhs]).cpu().numpy()
+        want = np.stack([wide.astype(np.float64) @ v.astype(np.float64) for v in rhs])
+        assert np.max(np.abs(got - want)) < tol * np.sqrt(n2)
+        odd = ops.dots3(tw[1::2], [to(v, dev) for v in rhs]).cpu().numpy()  # row stride 2 n
+        assert np.max(np.abs(odd - want[:, 1::2])) < tol * np.sqrt(n2)
+        # what the line search reads after an evaluation
+        for nn in [1, 777, n2]:
+            gv, dv = rng.standard_normal(nn).astype(dtype), rng.standard_normal(nn).astype(dtype)
+            out = torch.zeros(3, dtype=to(gv, dev).dtype, device=dev)
+            ops.lbfgs_probe(to(gv, dev), to(dv, dev), out)
+            g64, d64 = gv.astype(np.float64), dv.astype(np.float64)
+            want = np.array([g64 @ d64, g64 @ g64, np.max(np.abs(g64))])
+            assert np.max(np.abs(out.cpu().numpy() - want)) < tol * np.sqrt(nn) and float(out[2]) == want[2]
     y = rng.standard_normal(n)
     coef = rng.standard_normal(k)
     ty = to(y, dev)

@@ -13,12 +13,12 @@ from oracle import odil_np as onp
 
 
 class NumpyVectors:
-    """Test double of optimizer.LbfgsVectors."""
+    """Test double of optimizer.LbfgsVectors (same interface, immediate NumPy arithmetic)."""
 
     def __init__(self, n, m):
         self.n, self.m = n, m
-        self.ws = np.zeros((m, n))
-        self.wy = np.zeros((m, n))
+        self.w = np.zeros((2 * m, n))
+        self.scal = np.zeros(8)
 
     def new(self):
         return np.zeros(self.n)
@@ -26,32 +26,38 @@ class NumpyVectors:
     def copy(self, dst, src):
         dst[...] = src
 
-    def dot(self, a, b):
-        return float(a @ b)
-
-    def dots(self, mat, nrows, b):
-        return mat[:nrows] @ b
-
-    def dots3(self, mat, nrows, bs):
-        return np.array([mat[:nrows] @ b for b in bs])
-
-    def max_abs(self, a):
-        return float(np.max(np.abs(a)))
-
-    def axpy(self, y, x, a):
-        y += a * x
-
     def set_axpy(self, out, t, d, a):
         out[...] = t + a * d
 
     def scale_into(self, dst, src, a):
         dst[...] = a * src
 
-    def lincomb(self, y, beta, mat, nrows, coef):
-        y[...] = beta * y + (np.asarray(coef) @ mat[:nrows] if nrows else 0)
-
     def sub_into(self, dst, a, b):
         dst[...] = a - b
+
+    def probe_direction(self, d, g):
+        self.scal[0:2] = d @ d, g @ d
+
+    def probe_eval(self, f, g, d):
+        self.scal[3:7] = g @ d, g @ g, np.max(np.abs(g)), f
+
+    def read_probes(self):
+        h = self.scal
+        return float(h[0]), float(h[1]), float(h[3]), float(h[5]), float(h[6])
+
+    def store_pair(self, slot, s, y):
+        self.w[2 * slot] = s
+        self.w[2 * slot + 1] = y
+
+    def history_products(self, nphys, bs):
+        out = np.array([self.w[: 2 * nphys] @ b for b in bs]).reshape(len(bs), 2 * nphys)
+        return out[:, 0::2], out[:, 1::2]
+
+    def history_lincomb(self, y, nphys, cs, cy):
+        if nphys:
+            c = np.zeros(2 * nphys)
+            c[0::2], c[1::2] = cs, cy
+            y += c @ self.w[: 2 * nphys]
 
 
 def rosenbrock(x):
