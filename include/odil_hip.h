@@ -157,6 +157,15 @@ int odil_poisson_residual_slab_f64(const double* u, const double* rhs, double* f
 int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, const int64_t* shape, int ndim,
                                    const float* h2, int64_t z0, int64_t z1, double denom, double* partials,
                                    float* loss, void* stream);
+/* Residual restricted to the next coarser grid in one pass (3-D, even extents, shape[2] a multiple of the
+ * 16-byte pack): coarse[K,J,I] = scale * sum over the 2x2x2 fine cells of (A u - rhs), *loss = mean((A u -
+ * rhs)^2).  Replaces odil_poisson_residual + odil_restrict in the V-cycle that solves the Newton system
+ * (reference linsolver.py:61-72 uses pyamg there); `partials`: odil_reduce_workspace_bytes() scratch. */
+int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, double* coarse, const int64_t* shape,
+                                       int ndim, const double* h2, double scale, double* partials, double* loss,
+                                       void* stream);
+int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape, int ndim,
+                                       const float* h2, float scale, double* partials, float* loss, void* stream);
 /* One damped-Jacobi sweep of that operator: uout = u - omega (A u - rhs) / diag(A), uout != u.  The
  * smoother of the geometric multigrid that solves the Newton system of the Poisson stencil
  * (reference linsolver.py:61-72 hands that system to pyamg). */

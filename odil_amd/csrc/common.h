@@ -215,6 +215,28 @@ __device__ inline double block_sum(double v) {
 }
 #endif
 
+#ifdef __HIPCC__
+// Value held by the previous / next lane of the wavefront (wave-wide DPP shift: no LDS, no memory).
+// Undefined for lane 0 / lane 63, which read their x neighbour from memory instead.  The x-1 / x+1
+// neighbours of a lane's pack are the edge values of the adjacent lanes' packs: taking them from
+// registers removes two half-efficiency (one element per lane) loads per plane from kernels whose
+// limit is the number of memory instructions, not HBM.
+__device__ inline int lane_shift_word(int v, bool up) {
+  return up ? __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false)   // wave_shr:1 -> from lane - 1
+            : __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> from lane + 1
+}
+__device__ inline float from_prev_lane(float v) { return __int_as_float(lane_shift_word(__float_as_int(v), true)); }
+__device__ inline float from_next_lane(float v) { return __int_as_float(lane_shift_word(__float_as_int(v), false)); }
+__device__ inline double from_prev_lane(double v) {
+  const int lo = lane_shift_word(__double2loint(v), true), hi = lane_shift_word(__double2hiint(v), true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double from_next_lane(double v) {
+  const int lo = lane_shift_word(__double2loint(v), false), hi = lane_shift_word(__double2hiint(v), false);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
 // Optional Adam update fused into the kernel that FORMS a gradient array (the lane that writes
 // g[i] also owns x[i], m[i], v[i]): saves re-reading g in a separate optimizer launch.
 template <typename T>

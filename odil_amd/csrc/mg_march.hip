@@ -268,7 +268,9 @@ __device__ inline Adj6 adj6(int J, int n) {
 // (addresses clamped into range; out-of-range rows / packs carry zero weights), and only then
 // reduced: the kernel is bound by how many HBM requests a wave keeps in flight, so loads must not
 // sit behind branches.  (Tried: one pack per lane + wave shuffles for the neighbours' values --
-// 3x fewer loads, but the 32-64 ds_bpermute per step made it 15 % slower: profiles/r01 notes.)
+// 3x fewer loads, but the 32-64 ds_bpermute per step made it 15 % slower; the same with wave-wide DPP
+// shifts instead of ds_bpermute and the segment-end lanes reading memory: 197 -> 284 VGPRs (the edge
+// packs stay live across the divergent block), epoch 2.88 -> 3.32 ms; one plane at a time 3.00 ms.)
 template <typename T, int CX, int NR, int NP>
 __device__ inline void reduce_planes(const T* __restrict__ gfine, const int (&f)[NP], int fnz, int64_t fplane, int fny,
                                      int fnx, int jy, int jx0, const Adj6& ay, const Adj6 (&ax)[CX], T (&rc)[NP][CX],

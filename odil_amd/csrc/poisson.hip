@@ -58,8 +58,17 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
       }
       // x neighbours of the pack: periodic like mod.roll (core.py:963); the wrapped values
       // are discarded by the where() masks exactly as in the reference.
-      const T left = u[pz + xl];
-      const T right = u[pz + xr];
+      T left, right;
+      if (FULL) {
+        // x neighbours of the pack from the adjacent lanes' registers; wave edges read memory
+        left = from_prev_lane(uc[V - 1]);
+        right = from_next_lane(uc[0]);
+        if ((threadIdx.x & 63) == 0) left = u[pz + xl];
+        if ((threadIdx.x & 63) == 63 || x0 + V >= X) right = u[pz + xr];
+      } else {
+        left = u[pz + xl];
+        right = u[pz + xr];
+      }
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         if (i >= valid) break;
@@ -126,6 +135,16 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) dterm[ax] = a.active[ax] ? div_h2<T>(T(-2), h, ax) : T(0);
   const T dy = a.active[1] ? dterm[1] * T(1 + (y == 0) + (y == Y - 1)) : T(0);
+  // omega / diag takes four values along a unit's walk (z at a wall or not, x at a wall or not): four
+  // divisions per lane instead of one ~35-instruction f64 divide per cell
+  T wdiag[2][2];
+#pragma unroll
+  for (int zw = 0; zw < 2; ++zw)
+#pragma unroll
+    for (int xw = 0; xw < 2; ++xw) {
+      const T dzv = a.active[0] ? dterm[0] * T(1 + zw) : T(0);
+      wdiag[zw][xw] = omega / ((dzv + dy) + dterm[2] * T(1 + xw));
+    }
   T um[V], uc[V], up[V];
   if (a.active[0]) load_vec<T, V, FULL>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
   load_vec<T, V, FULL>(u + z0 * sz + c_off, valid, uc);
@@ -138,9 +157,20 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__
       load_vec<T, V, FULL>(u + pz + ym_off, valid, ym);
       load_vec<T, V, FULL>(u + pz + yp_off, valid, yp);
     }
-    const T left = u[pz + xl];
-    const T right = u[pz + xr];
-    const T dz = a.active[0] ? dterm[0] * T(1 + (z == 0) + (z == Z - 1)) : T(0);
+    T left, right;
+    if (FULL) {
+      const int lane = threadIdx.x & 63;
+      left = from_prev_lane(uc[V - 1]);
+      right = from_next_lane(uc[0]);
+      if (lane == 0) left = u[pz + xl];
+      if (lane == 63 || x0 + V >= X) right = u[pz + xr];
+    } else {
+      left = u[pz + xl];
+      right = u[pz + xr];
+    }
+    // (a wall on both sides needs an extent of 1, which fill_args rejects)
+    const bool zw = a.active[0] && (z == 0 || z == Z - 1);
+    const T w_in = zw ? wdiag[1][0] : wdiag[0][0], w_wall = zw ? wdiag[1][1] : wdiag[0][1];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       if (i >= valid) break;
@@ -154,8 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__
         const T xp = (i == valid - 1) ? right : uc[i + 1 < V ? i + 1 : i];
         acc = acc + axis_term<T>(q, xm, xp, x == 0, x == X - 1, h, 2);
       }
-      const T diag = (dz + dy) + dterm[2] * T(1 + (x == 0) + (x == X - 1));
-      out[i] = q - omega * (acc - r[i]) / diag;
+      out[i] = q - (acc - r[i]) * ((x == 0 || x == X - 1) ? w_wall : w_in);
     }
     store_vec<T, V, FULL, true>(uout + pz + c_off, valid, out);
 #pragma unroll
@@ -164,6 +193,100 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__
       uc[i] = up[i];
     }
   }
+}
+
+// Residual of the same operator restricted to the next coarser grid in ONE pass, for the geometric
+// multigrid of the Newton step (odil_amd/gmg.py): coarse[K, J, I] = scale * sum over the 2^3 fine cells
+// of (A u - rhs), and mean((A u - rhs)^2) as the convergence measure.  The fine residual never reaches
+// memory (separate residual + restriction kernels: 5 fine-grid words per cell, here 2 + 1/8).
+// A workgroup owns an x-segment of a PAIR of rows (y = 2J, 2J + 1) and walks pairs of planes; row
+// 2J + 1 is the y+1 neighbour of row 2J and vice versa, so the pair costs two y-neighbour loads, not
+// four.  3-D, even extents, X a multiple of the pack width.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_poisson_residual_restrict(const T* __restrict__ u,
+                                                                     const T* __restrict__ rhs,
+                                                                     T* __restrict__ coarse, StencilArgs a, H2<T> h,
+                                                                     T scale, double* __restrict__ partials) {
+  constexpr int V = VecOf<T>::N;
+  constexpr int C = V / 2;  // coarse cells per lane
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
+  const int64_t cX = X / 2, csz = (Y / 2) * cX;
+  double local = 0.0;
+  int zc, jj, xs;
+  const bool have = unit_decode(a.usched, zc, jj, xs);  // units: (chunk of plane pairs, row pair, x-segment)
+  const int64_t x0 = ((int64_t)xs * kBlock + threadIdx.x) * V;
+  if (have && x0 < X) {
+    const int64_t ya = 2 * (int64_t)jj, yb = ya + 1;
+    const int64_t z0 = 2 * (int64_t)zc * a.usched.ZC;
+    const int64_t z1 = z0 + 2 * a.usched.ZC < Z ? z0 + 2 * a.usched.ZC : Z;
+    const int64_t a_off = ya * sy + x0, b_off = yb * sy + x0;
+    const int64_t ym_off = (ya == 0 ? Y - 1 : ya - 1) * sy + x0, yp_off = (yb == Y - 1 ? 0 : yb + 1) * sy + x0;
+    const int64_t xl = x0 == 0 ? X - 1 : x0 - 1, xr = x0 + V >= X ? 0 : x0 + V;
+    T am[V], ac[V], ap[V], bm[V], bc[V], bp[V], acc[C];
+    load_vec<T, V, true>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + a_off, V, am);
+    load_vec<T, V, true>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + b_off, V, bm);
+    load_vec<T, V, true>(u + z0 * sz + a_off, V, ac);
+    load_vec<T, V, true>(u + z0 * sz + b_off, V, bc);
+    for (int64_t z = z0; z < z1; ++z) {
+      const int64_t pz = z * sz, pn = (z == Z - 1 ? 0 : z + 1) * sz;
+      load_vec<T, V, true>(u + pn + a_off, V, ap);
+      load_vec<T, V, true>(u + pn + b_off, V, bp);
+      T ra[V], rb[V], ym[V], yp[V];
+      load_vec<T, V, true, true>(rhs + pz + a_off, V, ra);
+      load_vec<T, V, true, true>(rhs + pz + b_off, V, rb);
+      load_vec<T, V, true>(u + pz + ym_off, V, ym);
+      load_vec<T, V, true>(u + pz + yp_off, V, yp);
+      // x neighbours of the packs: adjacent lanes' registers, memory at the wave edges
+      T wa = from_prev_lane(ac[V - 1]), ea = from_next_lane(ac[0]);
+      T wb = from_prev_lane(bc[V - 1]), eb = from_next_lane(bc[0]);
+      if ((threadIdx.x & 63) == 0) {
+        wa = u[pz + ya * sy + xl];
+        wb = u[pz + yb * sy + xl];
+      }
+      if ((threadIdx.x & 63) == 63 || x0 + V >= X) {
+        ea = u[pz + ya * sy + xr];
+        eb = u[pz + yb * sy + xr];
+      }
+      const bool zlo = z == 0, zhi = z == Z - 1;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int64_t x = x0 + i;
+        const bool xlo = x == 0, xhi = x == X - 1;
+        T fa = axis_term<T>(ac[i], am[i], ap[i], zlo, zhi, h, 0);
+        fa = fa + axis_term<T>(ac[i], ym[i], bc[i], ya == 0, false, h, 1);
+        fa = fa + axis_term<T>(ac[i], i == 0 ? wa : ac[i - 1], i == V - 1 ? ea : ac[i + 1 < V ? i + 1 : i], xlo, xhi,
+                               h, 2);
+        fa = fa - ra[i];
+        T fb = axis_term<T>(bc[i], bm[i], bp[i], zlo, zhi, h, 0);
+        fb = fb + axis_term<T>(bc[i], ac[i], yp[i], false, yb == Y - 1, h, 1);
+        fb = fb + axis_term<T>(bc[i], i == 0 ? wb : bc[i - 1], i == V - 1 ? eb : bc[i + 1 < V ? i + 1 : i], xlo, xhi,
+                               h, 2);
+        fb = fb - rb[i];
+        local += (double)(fa * fa) + (double)(fb * fb);
+        const T pair = fa + fb;
+        if ((i & 1) == 0)
+          acc[i / 2] = ((z & 1) ? acc[i / 2] : T(0)) + pair;
+        else
+          acc[i / 2] = acc[i / 2] + pair;
+      }
+      if (z & 1) {
+        T out[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = scale * acc[c];
+        store_vec<T, C, true>(coarse + (z / 2) * csz + (int64_t)jj * cX + x0 / 2, C, out);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        am[i] = ac[i];
+        ac[i] = ap[i];
+        bm[i] = bc[i];
+        bc[i] = bp[i];
+      }
+    }
+  }
+  const double total = block_sum(local);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
 template <typename T, bool FULL>
@@ -195,8 +318,17 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict_
       load_vec<T, V, FULL>(fu + pz + ym_off, valid, ym);
       load_vec<T, V, FULL>(fu + pz + yp_off, valid, yp);
     }
-    const T left = fu[pz + xl];
-    const T right = fu[pz + xr];
+    T left, right;
+    if (FULL) {
+      // x neighbours of the pack from the adjacent lanes' registers; wave edges read memory
+      left = from_prev_lane(fc[V - 1]);
+      right = from_next_lane(fc[0]);
+      if ((threadIdx.x & 63) == 0) left = fu[pz + xl];
+      if ((threadIdx.x & 63) == 63 || x0 + V >= X) right = fu[pz + xr];
+    } else {
+      left = fu[pz + xl];
+      right = fu[pz + xr];
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       if (i >= valid) break;
@@ -367,6 +499,31 @@ static int poisson_jacobi(const T* u, const T* rhs, T* uout, const int64_t* shap
 }
 
 template <typename T>
+static int poisson_residual_restrict(const T* u, const T* rhs, T* coarse, const int64_t* shape, int ndim, const T* h2,
+                                     T scale, double* partials, T* loss, void* stream) {
+  StencilArgs a;
+  T h[3];
+  if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
+  if (!u || !rhs || !coarse || !partials || !loss) {
+    set_error("poisson_residual_restrict: null pointer");
+    return ODIL_E_INVAL;
+  }
+  if (ndim != 3 || a.n[0] % 2 || a.n[1] % 2 || a.n[2] % VecOf<T>::N) {
+    set_error("poisson_residual_restrict: needs ndim = 3, even extents and n[2] %% %d == 0", VecOf<T>::N);
+    return ODIL_E_INVAL;
+  }
+  a.loss_z0 = 0;
+  a.loss_z1 = a.n[0];
+  const int per = kBlock * VecOf<T>::N;
+  a.usched = make_unit_sched(a.n[0] / 2, a.n[1] / 2, (a.n[2] + per - 1) / per);
+  const int grid = unit_grid(a.usched);
+  hipLaunchKernelGGL((k_poisson_residual_restrict<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, coarse,
+                     a, make_h2<T>(h), scale, partials);
+  if (int e = check_launch("k_poisson_residual_restrict")) return e;
+  return launch_final_reduce<T>(partials, grid, 0, 1, (double)(a.n[0] * a.n[1] * a.n[2]), loss, (hipStream_t)stream);
+}
+
+template <typename T>
 static int poisson_jac(T* coeffs, const int64_t* shape, int ndim, const T* h2, void* stream) {
   StencilArgs a;
   T h[3];
@@ -403,6 +560,15 @@ int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, 
                                    const float* h2, int64_t z0, int64_t z1, double denom, double* partials,
                                    float* loss, void* stream) {
   return poisson_residual<float>(u, rhs, fu, shape, ndim, h2, partials, loss, stream, z0, z1, denom);
+}
+int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, double* coarse, const int64_t* shape,
+                                       int ndim, const double* h2, double scale, double* partials, double* loss,
+                                       void* stream) {
+  return poisson_residual_restrict<double>(u, rhs, coarse, shape, ndim, h2, scale, partials, loss, stream);
+}
+int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape, int ndim,
+                                       const float* h2, float scale, double* partials, float* loss, void* stream) {
+  return poisson_residual_restrict<float>(u, rhs, coarse, shape, ndim, h2, scale, partials, loss, stream);
 }
 int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,
                              double scale, void* stream) {

@@ -40,9 +40,30 @@ class PoissonGMG:
         mk = lambda s: torch.zeros(s, dtype=dtype, device=device)
         self.x = [None] + [mk(s) for s in self.shapes[1:]]   # coarse corrections
         self.b = [None] + [mk(s) for s in self.shapes[1:]]   # coarse right-hand sides
-        self.r = [mk(s) for s in self.shapes]                # residuals
-        self.spare = [mk(s) for s in self.shapes]            # the buffer a sweep / a prolongation writes into
+        self._r = [None] * self.nlvl                         # residuals (only where the fused restriction cannot be used)
+        self.spare = [torch.empty(s, dtype=dtype, device=device) for s in self.shapes]  # target of a sweep / prolongation
         self.loss = mk(())
+        self._coarse_inv = None
+
+    def coarse_inverse(self):
+        """Inverse of the coarsest-grid operator (at most a few dozen unknowns), built once from the
+        residual kernel applied to unit vectors: the coarsest solve is then one product (odil_dots)
+        instead of dozens of launch-bound sweeps."""
+        if self._coarse_inv is None:
+            shape = self.shapes[-1]
+            n = math.prod(shape)
+            eye = torch.eye(n, dtype=self.dtype, device=self.device)
+            zero = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            cols = [ops.poisson_residual(eye[j].view(shape), zero, self.h2s[-1])[0].reshape(-1) for j in range(n)]
+            amat = torch.stack(cols, dim=1).cpu().numpy().astype(np.float64)  # column j = A e_j
+            inv = np.linalg.inv(amat)
+            self._coarse_inv = torch.as_tensor(inv, dtype=self.dtype).to(self.device).contiguous()
+        return self._coarse_inv
+
+    def r(self, lvl):
+        if self._r[lvl] is None:
+            self._r[lvl] = torch.empty(self.shapes[lvl], dtype=self.dtype, device=self.device)
+        return self._r[lvl]
 
     def residual(self, lvl, x, b, out):
         """out = A x - b."""
@@ -69,15 +90,20 @@ class PoissonGMG:
             x = y
         return x
 
-    def vcycle(self, lvl, x, b):
-        """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate."""
-        if lvl == self.nlvl - 1:
-            return self.smooth(lvl, x, b, 40, chebyshev=False)  # coarsest grid (2^d cells): solved by iteration
-        x = self.smooth(lvl, x, b, self.nu1)
-        r = self.residual(lvl, x, b, self.r[lvl])
-        # coarse right-hand side = R (b - A x)
-        bc = ops.restrict_to_coarser(r, self.loc)
-        ops.scale(bc, -1.0, out=self.b[lvl + 1])
+    def coarse_rhs(self, lvl, x, b):
+        """b_{lvl+1} = R (b - A x), and mean((A x - b)^2) in self.loss.  One fused pass in 3-D (the fine
+        residual is never stored); residual, restriction and sign as three launches otherwise."""
+        bc = self.b[lvl + 1]
+        if ops.residual_restrict_supported(self.shapes[lvl], self.dtype):
+            ops.poisson_residual_restrict(x, b, self.h2s[lvl], -1.0 / 2**self.ndim, bc, self.loss)
+        else:
+            r = self.residual(lvl, x, b, self.r(lvl))
+            ops.scale(ops.restrict_to_coarser(r, self.loc), -1.0, out=bc)
+        return bc
+
+    def finish_cycle(self, lvl, x, b):
+        """Second half of a V(nu1, nu2) cycle: `x` is pre-smoothed and b_{lvl+1} holds its restricted
+        residual.  Coarse-grid correction and post-smoothing; returns the tensor holding the new iterate."""
         xc = self.x[lvl + 1]
         xc.zero_()
         xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1])
@@ -88,24 +114,46 @@ class PoissonGMG:
         self.spare[lvl] = x
         return self.smooth(lvl, out, b, self.nu2)
 
-    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None):
-        """Solves A x = b to ||A x - b|| <= tol * ||b||."""
+    def vcycle(self, lvl, x, b):
+        """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate."""
+        if lvl == self.nlvl - 1:
+            if math.prod(self.shapes[lvl]) <= 512:  # coarsest grid: x = A^-1 b
+                out = self.spare[lvl]
+                ops.dots(self.coarse_inverse(), b.reshape(-1), out=out.view(-1))
+                self.spare[lvl] = x
+                return out
+            return self.smooth(lvl, x, b, 40, chebyshev=False)  # cannot coarsen further (odd extent): by iteration
+        x = self.smooth(lvl, x, b, self.nu1)
+        self.coarse_rhs(lvl, x, b)
+        return self.finish_cycle(lvl, x, b)
+
+    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True):
+        """Solves A x = b to ||A x - b|| <= tol * ||b||.  The residual that is tested is the one every cycle
+        forms anyway (after its pre-smoothing sweeps, on its way to the coarse grid): the iterate returned
+        is that pre-smoothed one, so convergence costs no pass of its own."""
+        n = b.numel()
         x = torch.zeros_like(b) if x0 is None else x0.clone()
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
-        r = self.r[0]
-        while it < maxiter:
-            self.residual(0, x, b, r)
-            res = float(ops.dots(r.view(1, -1), r.view(-1))[0]) ** 0.5
-            if res <= tol * max(bn, 1e-300):
-                break
+        if self.nlvl == 1:
             x = self.vcycle(0, x, b)
+            self.residual(0, x, b, self.r(0))
+            res = math.sqrt(max(float(self.loss), 0.0) * n)
+        while self.nlvl > 1:
+            x = self.smooth(0, x, b, self.nu1)
+            self.coarse_rhs(0, x, b)
+            res = math.sqrt(max(float(self.loss), 0.0) * n)
+            if res <= tol * max(bn, 1e-300) or it >= maxiter:
+                break
+            x = self.finish_cycle(0, x, b)
             it += 1
         if status is not None:
             status["residual"] = res
             status["niter"] = it
             status["method"] = "gmg-vcycle"
-        return x.clone()  # the iterate may live in one of this object's work buffers
+        # the iterate may live in one of this object's work buffers: copy=False only for a caller that
+        # consumes it before the next solve
+        return x.clone() if copy else x
 
 
 def recognise_poisson(op):

@@ -268,6 +268,22 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
     return fu, loss
 
 
+def residual_restrict_supported(shape, dtype):
+    pack = 2 if dtype == torch.float64 else 4
+    return len(shape) == 3 and shape[0] % 2 == 0 and shape[1] % 2 == 0 and shape[2] % pack == 0 and min(shape) >= 2
+
+
+def poisson_residual_restrict(u, rhs, h2, scale, out, loss):
+    """out = scale * (sum over 2x2x2 fine cells of (A u - rhs)) on the next coarser grid, loss = mean((A u -
+    rhs)**2), in one pass over u and rhs (3-D; see residual_restrict_supported)."""
+    assert u.shape == rhs.shape and tuple(out.shape) == tuple(n // 2 for n in u.shape)
+    assert residual_restrict_supported(tuple(u.shape), u.dtype) and out.is_contiguous()
+    h2a, h2p = host_reals(h2, u.dtype)
+    call("poisson_residual_restrict", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p, float(scale),
+         ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr())
+    return out, loss
+
+
 def poisson_jacobi(u, rhs, h2, omega, out):
     """out = u - omega (A u - rhs) / diag(A): one damped-Jacobi sweep of the Poisson stencil (out is not u)."""
     assert u.shape == rhs.shape == out.shape and out.data_ptr() != u.data_ptr()

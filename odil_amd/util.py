@@ -293,9 +293,9 @@ def _poisson_newton_step(problem, state, args, status):
     if solver is None:
         solver = ev.__dict__["_gmg"] = gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device)
     tol = 1e-12 if linsolver == "direct" else getattr(args, "linsolver_tol", 1e-10)
-    b = ops.scale(r, -1.0)
-    delta = solver.solve(b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status)
-    return delta.reshape(-1)
+    b = ops.scale(r, -1.0, out=r)  # the evaluator's residual buffer is scratch: negate it in place
+    delta = solver.solve(b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False)
+    return delta.reshape(-1)  # a work buffer of the solver; optimize_newton adds it to the state right away
 
 
 def optimize_newton(args, problem, state, callback=None, **kwargs):
@@ -322,8 +322,15 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
             delta = solve(matrix, -vector, args, linstatus, getattr(args, "linsolver", "direct"))
         if getattr(args, "linsolver_verbose", 0):
             printlog(linstatus)
-        packed = domain.pack_state(state)
-        domain.unpack_state(packed + delta, state)
+        fields = list(state.fields.values())
+        if len(fields) == 1 and type(fields[0]).__name__ == "Field" and torch.is_tensor(fields[0].array) \
+                and fields[0].array.is_contiguous() and fields[0].array.numel() == delta.numel():
+            from . import ops
+
+            ops.axpy(fields[0].array, delta.to(fields[0].array.dtype), 1.0)  # x += delta in place (util.py:176-178)
+        else:
+            packed = domain.pack_state(state)
+            domain.unpack_state(packed + delta, state)
         if callback:
             pinfo = eval_pinfo(state)
             pinfo["linsolver"] = linstatus

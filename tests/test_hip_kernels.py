@@ -497,6 +497,29 @@ def test_poisson_jacobi_sweep(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(4, 6, 8), (8, 12, 16), (64, 32, 520), (2, 2, 4)])
+def test_poisson_residual_restrict(dev, dtype, shape):
+    """odil_poisson_residual_restrict == scale * 2^d * restrict(residual) and the same loss, from the
+    oracle-checked residual and restriction kernels."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(37)
+    h2 = [dtype(v) for v in [0.25**2, 0.1**2, 0.3**2]]
+    x = to(rng.standard_normal(shape).astype(dtype), dev)
+    b = to(rng.standard_normal(shape).astype(dtype), dev)
+    assert ops.residual_restrict_supported(shape, x.dtype)
+    out = torch.full(tuple(n // 2 for n in shape), 7.0, dtype=x.dtype, device=dev)
+    loss = torch.zeros((), dtype=x.dtype, device=dev)
+    ops.poisson_residual_restrict(x, b, h2, -0.125, out, loss)
+    r, want_loss = ops.poisson_residual(x, b, h2)
+    want = -ops.restrict_to_coarser(r, "ccc")
+    tol = 1e-13 if dtype == np.float64 else 1e-5
+    assert rel(out, want.cpu().numpy()) < tol
+    assert abs(float(loss) - float(want_loss)) < tol * float(want_loss)
+    assert not ops.residual_restrict_supported((8, 8), x.dtype) and not ops.residual_restrict_supported((8, 6, 7), x.dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
     """Large 'nccc' arrays take P^T = (P^T over the node axis) o (P^T over the three cell axes)
     (ops.mg_synth_adj); it must equal the one-kernel chain."""
