@@ -262,6 +262,37 @@ __device__ inline Adj6 adj6(int J, int n) {
   return t;
 }
 
+// The arithmetic of the (y, x) reduction on loaded windows g[plane][row][pack] (see reduce_planes).
+template <typename T, int CX, int NR, int NP>
+__device__ inline void reduce_loaded(const PackN<T, 2 * CX> (&g)[NP][NR][3], const int (&f)[NP], int fnz,
+                                     const Adj6& ay, const Adj6 (&ax)[CX], T (&rc)[NP][CX], T (&rr)[NP][CX]) {
+  constexpr int R0 = (6 - NR) / 2;
+  constexpr int NV = 2 * CX;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const bool inside = f[p] >= 0 && f[p] < fnz;
+#pragma unroll
+    for (int c = 0; c < CX; ++c) {
+      T sc = T(0), sr = T(0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        T xc = T(0), xr = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int e = NV - 2 + 2 * c + i;  // compile-time after unrolling
+          const T val = g[p][r][e / NV].e[e % NV];
+          xc = xc + T(ax[c].wc[i]) * val;
+          xr = xr + T(ax[c].wr[i]) * val;
+        }
+        sc = sc + T(ay.wc[R0 + r]) * xc;
+        sr = sr + T(ay.wr[R0 + r]) * xr;
+      }
+      rc[p][c] = inside ? sc : T(0);
+      rr[p][c] = inside ? sr : T(0);
+    }
+  }
+}
+
 // (y, x) reduction of fine planes for the owned coarse columns: rc with the C weights, rr with the
 // R weights.  The window of a row is three 16 B packs starting at fine x = 2 jx0 - 2 CX; column c
 // uses its entries 2 CX - 2 + 2 c + (0..5).  All row loads of a call are issued back to back
@@ -295,29 +326,7 @@ __device__ inline void reduce_planes(const T* __restrict__ gfine, const int (&f)
       }
     }
   }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const bool inside = f[p] >= 0 && f[p] < fnz;
-#pragma unroll
-    for (int c = 0; c < CX; ++c) {
-      T sc = T(0), sr = T(0);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        T xc = T(0), xr = T(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int e = NV - 2 + 2 * c + i;  // compile-time after unrolling
-          const T val = g[p][r][e / NV].e[e % NV];
-          xc = xc + T(ax[c].wc[i]) * val;
-          xr = xr + T(ax[c].wr[i]) * val;
-        }
-        sc = sc + T(ay.wc[R0 + r]) * xc;
-        sr = sr + T(ay.wr[R0 + r]) * xr;
-      }
-      rc[p][c] = inside ? sc : T(0);
-      rr[p][c] = inside ? sr : T(0);
-    }
-  }
+  reduce_loaded<T, CX, NR, NP>(g, f, fnz, ay, ax, rc, rr);
 }
 
 template <typename T, int CX, int NP>
@@ -464,6 +473,177 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
     }
     slide<T, CX>(wc, wr);
   }
+}
+
+// P^T for the large 'ccc' levels with the fine planes staged through LDS.  The register version above
+// loads 12 packs per thread and fine plane for 2 packs of new data: HBM sees every line once, but the
+// L2 serves six times the traffic (512^3 -> 256^3: 2.0 GB of HBM traffic in 0.59 ms).  Here a
+// workgroup owns a tile of kTileY x kTileX coarse columns, reads the (2 kTileY + 4) x (2 kTileX + 4)
+// window of each fine plane once with coalesced 16 B loads (1.33 x the tile's own data, the halo from
+// L2), and every thread takes its 6 x 6 (4 x 6 away from the walls) window from LDS.  Same
+// arithmetic, same order: the results are bit-identical to k_interp_adj_march.
+#ifndef ODIL_ADJ_UNITS
+#define ODIL_ADJ_UNITS kGridCap  // measured at 512^3: chain 0.80 / 0.69 / 0.72 ms for 1024 / 2048 / 4096
+#endif
+#ifndef ODIL_ADJ_UNITS_SMALL
+#define ODIL_ADJ_UNITS_SMALL (kGridCap / 4)  // levels of <= 4 M coarse points: chain 0.690 -> 0.675 ms
+#endif
+#ifndef ODIL_TILE_Y
+#define ODIL_TILE_Y 8
+#define ODIL_TILE_X 32
+#endif
+#ifndef ODIL_TILE_UNITS
+#define ODIL_TILE_UNITS (kGridCap / 2)  // 512^3 -> 256^3: 465 / 450 / 455 us for 2048 / 1024 / 512 units
+#endif
+constexpr int kTileY = ODIL_TILE_Y, kTileX = ODIL_TILE_X;
+constexpr int kTileR = 2 * kTileY + 4, kTileC = 2 * kTileX + 4;       // fine rows / columns staged per plane
+constexpr int kTilePacks = kTileR * (kTileC / 2);                       // packs of two values per plane
+constexpr int kTileLoads = (kTilePacks + kBlock - 1) / kBlock;          // per thread and plane
+static_assert(kTileY * kTileX == kBlock, "one thread per coarse column of the tile");
+
+template <typename T>
+struct TileVec {
+  typedef T type __attribute__((ext_vector_type(2)));
+};
+
+// This thread's packs of the fine planes fz0, fz0 + 1 (clamped into the array: planes beyond it carry
+// zero weights), issued back to back.
+template <typename T>
+__device__ __forceinline__ void tile_fetch(const T* __restrict__ gfine, int fz0, int fnz, int64_t fplane,
+                                           const int64_t (&src)[kTileLoads],
+                                           typename TileVec<T>::type (&pre)[2][kTileLoads]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int fz = fz0 + q;
+    fz = fz < 0 ? 0 : (fz >= fnz ? fnz - 1 : fz);
+    const T* gp = gfine + (int64_t)fz * fplane;
+#pragma unroll
+    for (int i = 0; i < kTileLoads; ++i) pre[q][i] = *reinterpret_cast<const typename TileVec<T>::type*>(gp + src[i]);
+  }
+}
+
+// State of one thread of k_interp_adj_tile that the stages share.
+template <typename T>
+struct TileCtx {
+  const T* gfine;
+  T* gcoarse;
+  T* gscaled;
+  int cnz, cnx, fnz, z0, jy, jx, lx, ly;
+  int cut_lo, cut_hi;
+  int64_t cplane, fplane;
+  bool owner;
+  T scale;
+};
+
+// One pair of fine planes (2 (z0 - 1 + k), + 1): publish the staged packs, refill the staging registers
+// with the pair `ahead` steps later, reduce this pair from LDS, and from k = 2 on emit coarse plane
+// z0 + k - 2.  `live` is false for the padding step of an odd pair count (barriers only).
+template <typename T>
+__device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec<T>::type* __restrict__ tile0,
+                                           typename TileVec<T>::type* __restrict__ tile1, int k, int ahead, bool live,
+                                           const int64_t (&src)[kTileLoads],
+                                           typename TileVec<T>::type (&pre)[2][kTileLoads], const Adj6& ay,
+                                           const Adj6 (&ax)[1], T (&wc)[1][6], T (&wr)[1][6], const AdamArgs<T>& ad) {
+  typedef typename TileVec<T>::type P2;
+  __syncthreads();  // the previous pair has been consumed
+#pragma unroll
+  for (int i = 0; i < kTileLoads; ++i) {
+    tile0[threadIdx.x + i * kBlock] = pre[0][i];
+    tile1[threadIdx.x + i * kBlock] = pre[1][i];
+  }
+  __syncthreads();
+  // (unconditional: past the last pair it re-reads clamped planes, which keeps the staging registers out
+  // of scratch memory)
+  tile_fetch<T>(c.gfine, 2 * (c.z0 - 1 + k + ahead), c.fnz, c.fplane, src, pre);
+  const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
+  T c2[2][1], r2[2][1];
+  // one plane at a time keeps the register count down (boundary rows need the 6-row window)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const P2* tq = q == 0 ? tile0 : tile1;
+    const int f1[1] = {f2[q]};
+    T c1[1][1], r1[1][1];
+    if (ay.special) {
+      PackN<T, 2> g[1][6][3];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const P2 t = tq[(2 * c.ly + r) * (kTileC / 2) + c.lx + w];
+          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
+        }
+      reduce_loaded<T, 1, 6, 1>(g, f1, c.fnz, ay, ax, c1, r1);
+    } else {
+      PackN<T, 2> g[1][4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const P2 t = tq[(2 * c.ly + 1 + r) * (kTileC / 2) + c.lx + w];
+          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
+        }
+      reduce_loaded<T, 1, 4, 1>(g, f1, c.fnz, ay, ax, c1, r1);
+    }
+    c2[q][0] = c1[0][0];
+    r2[q][0] = r1[0][0];
+  }
+  put2<T, 1>(wc, wr, 4, c2, r2);  // always the last two slots (a static position: no register indexing)
+  if (k >= 2 && c.owner && live) {
+    const int jz = c.z0 + k - 2;
+    const T v = combine_z<T>(wc[0], wr[0], jz, c.cnz, c.fnz, ax[0].special || ay.special, c.cut_lo, c.cut_hi);
+    emit_coarse<T>(c.gcoarse, c.gscaled, (int64_t)jz * c.cplane + (int64_t)c.jy * c.cnx + c.jx, v, c.scale, ad);
+  }
+  slide<T, 1>(wc, wr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict__ gfine,
+                                                                             T* __restrict__ gcoarse,
+                                                                             T* __restrict__ gscaled, MarchArgs a,
+                                                                             T scale, AdamArgs<T> ad) {
+  typedef typename TileVec<T>::type P2;  // a native vector type: staged values stay in registers
+  // flat, row-major over (row, pack); padded to a whole number of packs per thread so that loads and
+  // LDS writes need no guards (the surplus packs re-read pack 0 and land behind the tile)
+  __shared__ P2 tile[2][kTileLoads * kBlock];
+  const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
+  TileCtx<T> c;
+  c.gfine = gfine, c.gcoarse = gcoarse, c.gscaled = gscaled;
+  c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
+  c.cut_lo = a.cut_lo, c.cut_hi = a.cut_hi;
+  c.cplane = (int64_t)cny * c.cnx, c.fplane = (int64_t)fny * fnx;
+  c.scale = scale;
+  c.z0 = zc * a.usched.ZC;
+  const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
+  c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
+  c.jy = yt * kTileY + c.ly, c.jx = xt * kTileX + c.lx;
+  c.owner = c.jy < cny && c.jx < c.cnx;
+  // clamped so that the weight tables of idle lanes are well defined
+  Adj6 ax[1];
+  column_taps<1>(c.owner ? c.jx : 0, c.cnx, ax);
+  const Adj6 ay = adj6(c.owner ? c.jy : 0, cny);
+  // this thread's share of a staged plane: packs p = threadIdx.x + k kBlock of the tile, row-major
+  int64_t src[kTileLoads];
+#pragma unroll
+  for (int k = 0; k < kTileLoads; ++k) {
+    const int p = threadIdx.x + k * kBlock;
+    const int r = p < kTilePacks ? p / (kTileC / 2) : 0, cc = p < kTilePacks ? p - r * (kTileC / 2) : 0;
+    int fy = 2 * yt * kTileY - 2 + r, fx = 2 * xt * kTileX - 2 + 2 * cc;
+    fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);
+    fx = fx < 0 ? 0 : (fx >= fnx ? fnx - 2 : fx);
+    src[k] = (int64_t)fy * fnx + fx;
+  }
+  T wc[1][6], wr[1][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) wc[0][i] = wr[0][i] = T(0);
+  // pairs of fine planes 2 (z0 - 1 + k), + 1 for k = 0 .. z1 - z0 + 1 (the first two prime the window); the
+  // next pair is in flight while one is reduced.  (Two pairs ahead in two register sets: 256 VGPRs, no
+  // faster -- 452 vs 448 us; three waves per SIMD spill and take 630 us.)
+  const int npairs = z1 - c.z0 + 2;
+  P2 pre[2][kTileLoads];
+  tile_fetch<T>(gfine, 2 * (c.z0 - 1), c.fnz, c.fplane, src, pre);
+  for (int k = 0; k < npairs; ++k) tile_stage<T>(c, tile[0], tile[1], k, 1, true, src, pre, ay, ax, wc, wr, ad);
 }
 
 // P^T with a node-centred marching axis: coarse plane J collects fine plane 2J and half of the
@@ -649,17 +829,17 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
   return e ? e : 1;
 }
 
+// ODIL_ADJ_TILE=0 keeps the register-window kernel on every level (read per call: the tests compare both)
+static bool adj_tile_enabled() {
+  const char* e = getenv("ODIL_ADJ_TILE");
+  return !e || atoi(e) != 0;
+}
+
 template <typename T, int CX>
 static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& a, T scale, hipStream_t stream,
                       const AdamArgs<T>& ad) {
   MarchArgs m;
   // every chunk primes its window with two extra fine-plane reductions: prefer chunks of >= 8 planes
-#ifndef ODIL_ADJ_UNITS
-#define ODIL_ADJ_UNITS kGridCap  // measured at 512^3: chain 0.80 / 0.69 / 0.72 ms for 1024 / 2048 / 4096
-#endif
-#ifndef ODIL_ADJ_UNITS_SMALL
-#define ODIL_ADJ_UNITS_SMALL (kGridCap / 4)  // levels of <= 4 M coarse points: chain 0.690 -> 0.675 ms
-#endif
   const bool small_level = a.cn[0] * a.cn[1] * a.cn[2] * a.cn[3] <= ((int64_t)1 << 22);
   if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
@@ -673,7 +853,15 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_adj_march_n<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
-  else
+  else if (CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled()) {
+    // large all-cell levels: fine planes staged through LDS
+    const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
+    m.tx = kTileX;
+    m.ty = kTileY;
+    m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_TILE_UNITS);
+    hipLaunchKernelGGL((k_interp_adj_tile<T>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
+                       gscaled, m, scale, ad);
+  } else
     hipLaunchKernelGGL((k_interp_adj_march<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
   const int e = check_launch("k_interp_adj_march");

@@ -520,6 +520,47 @@ def test_poisson_residual_restrict(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fine", [(8, 32, 128), (16, 40, 136), (24, 72, 264)])
+def test_tiled_transpose_is_bit_identical(dev, dtype, fine, monkeypatch):
+    """The LDS-staged P^T of the large 'ccc' levels (k_interp_adj_tile) == the register-window kernel
+    bit for bit (whole and partial tiles, both walls in every axis), == the oracle's transpose to rounding,
+    with and without the Adam update of the coarse level."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(41)
+    shapes = [fine, tuple(n // 2 for n in fine)]
+    g = to(rng.standard_normal(fine).astype(dtype), dev)
+    monkeypatch.setenv("ODIL_ADJ_TILE", "1")
+    tiled = [t.clone() for t in ops.mg_synth_adj(g, shapes, "ccc")]
+    monkeypatch.setenv("ODIL_ADJ_TILE", "0")
+    plain = [t.clone() for t in ops.mg_synth_adj(g, shapes, "ccc")]
+    assert torch.equal(tiled[1], plain[1])
+    want = onp.interp_to_finer_adj(g.cpu().numpy().astype(np.float64), "ccc", shapes[1])
+    assert rel(tiled[1], want) < (1e-13 if dtype == np.float64 else 2e-6)
+    # with Adam of the coarse level inside the launch
+    res = {}
+    for mode in ["1", "0"]:
+        monkeypatch.setenv("ODIL_ADJ_TILE", mode)
+        x = [None, to(rng.standard_normal(shapes[1]).astype(dtype) * 0 + 0.5, dev)]
+        m = [None, torch.zeros_like(x[1])]
+        v = [None, torch.zeros_like(x[1])]
+        grads = [g, torch.empty_like(x[1])]
+        ops.mg_synth_adj_adam(g, shapes, "ccc", grads, x, m, v, 0.01, 0.1, 0.001, 1e-7)
+        res[mode] = (x[1].clone(), m[1].clone(), v[1].clone(), grads[1].clone())
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.equal(a, b)
+    # slab interfaces along the marched axis (multi-GPU path)
+    for cut in [(True, False), (False, True), (True, True)]:
+        out = {}
+        for mode in ["1", "0"]:
+            monkeypatch.setenv("ODIL_ADJ_TILE", mode)
+            out[mode] = ops.interp_adj(g, "ccc", shapes[1], cut=cut).clone()
+        assert torch.equal(out["1"], out["0"])
+        assert rel(out["1"], onp.interp_to_finer_adj(g.cpu().numpy().astype(np.float64), "ccc", shapes[1], cut=cut)) < (
+            1e-13 if dtype == np.float64 else 2e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
     """Large 'nccc' arrays take P^T = (P^T over the node axis) o (P^T over the three cell axes)
     (ops.mg_synth_adj); it must equal the one-kernel chain."""
