@@ -185,7 +185,19 @@ def main():
         abytes, S = algorithmic_bytes_per_update(ndim, run.nlvl, wordsize)
         kt = timers.summary()
         n_unknowns = run.n_unknowns_local
-        if kt.get("adjoint", 0) > kt.get("adam", 0):
+        moved_bytes = None
+        if "adjoint_transpose" in kt:
+            # Dominant kernel: stencil adjoint + first transposed prolongation + the Adam updates of levels 0 and
+            # 1 in one launch.  ALGORITHMIC bytes by the minimum-traffic model of SURVEY.md 8(d) for the work this
+            # launch covers: stencil adjoint 2 words (read r, write g) + first level of the P^T chain 1 + 1/8
+            # (read g, write g1) + Adam 7 words per unknown of levels 0 and 1 (7 + 7/8) = 11 words per fine cell.
+            # The launch itself moves less -- g never reaches memory: read fu; read + write x, m, v of level 0;
+            # write g1 and read + write x, m, v of level 1 = 7 + 7/8 words -- reported beside it.
+            dom_name = "k_poisson_adjoint_tile<{}> (adjoint + first P^T + Adam of levels 0 and 1)"
+            adam_bytes = 11.0 * run.local_cells * wordsize
+            moved_bytes = (7.0 + 7.0 / 8.0) * run.local_cells * wordsize
+            adam_ms = kt["adjoint_transpose"]
+        elif kt.get("adjoint", 0) > kt.get("adam", 0):
             # Dominant kernel: adjoint with the finest-level Adam update fused in:
             # read fu, x, m, v; write gu, x, m, v = 8 words per fine cell.
             dom_name = "k_poisson_adjoint<{}, true> (+Adam of the finest level)"
@@ -230,6 +242,8 @@ def main():
                 "traffic": measured_traffic(dom_name.format("double" if wordsize == 8 else "float"), ndim, N, args.dtype),
                 "algorithmic_bytes_per_launch": adam_bytes,
                 "avg_launch_ms": adam_ms,
+                "compulsory_bytes_per_launch": moved_bytes,
+                "achieved_on_compulsory_bytes": None if moved_bytes is None else moved_bytes / (adam_ms * 1e-3) / 1e9,
             },
             "epoch_roofline": {
                 "algorithmic_bytes_per_update": abytes,

@@ -166,6 +166,20 @@ int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, doubl
                                        void* stream);
 int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape, int ndim,
                                        const float* h2, float scale, double* partials, float* loss, void* stream);
+/* Stencil adjoint and the first transposed prolongation in one pass (3-D, even extents >= 4):
+ * g0 = scale * A^T fu (stored only when g0 != NULL), g1 = P^T g0 on the grid of half the extents, and the Adam
+ * update of the finest level (x0, m0, v0; all NULL: no update, g0 required) and of the next level (x1, m1, v1;
+ * optional) by the lanes that form their gradients.  g0 never makes the round trip through memory that
+ * odil_poisson_adjoint_adam + odil_mg_synth_adj_adam need (reference core.py:1100 / optimizer.py:311-319);
+ * results are bit-identical to that pair. */
+int odil_poisson_adjoint_transpose_adam_f64(const double* fu, double* g0, double* g1, const int64_t* fshape,
+                                            const double* h2, double scale, double* x0, double* m0, double* v0,
+                                            double* x1, double* m1, double* v1, double alpha, double one_minus_b1,
+                                            double one_minus_b2, double eps, const double* alpha_dev, void* stream);
+int odil_poisson_adjoint_transpose_adam_f32(const float* fu, float* g0, float* g1, const int64_t* fshape,
+                                            const float* h2, float scale, float* x0, float* m0, float* v0, float* x1,
+                                            float* m1, float* v1, float alpha, float one_minus_b1, float one_minus_b2,
+                                            float eps, const float* alpha_dev, void* stream);
 /* One damped-Jacobi sweep of that operator: uout = u - omega (A u - rhs) / diag(A), uout != u.  The
  * smoother of the geometric multigrid that solves the Newton system of the Poisson stencil
  * (reference linsolver.py:61-72 hands that system to pyamg). */

@@ -15,6 +15,7 @@
 // plane sums, three weight tables) halves the occupancy at CX = 2 and loses more than the wide
 // loads gain (measured).
 #include "mg_march.h"
+#include "poisson.h"
 
 namespace odil {
 
@@ -528,12 +529,77 @@ struct TileCtx {
   const T* gfine;
   T* gcoarse;
   T* gscaled;
-  int cnz, cnx, fnz, z0, jy, jx, lx, ly;
+  int cnz, cny, cnx, fnz, z0, jy, jx, lx, ly;
+  bool sx, sy;  // the column / row is one of the two next to a wall (special weights)
   int cut_lo, cut_hi;
   int64_t cplane, fplane;
   bool owner;
   T scale;
 };
+
+// Reduce the staged pair of fine planes 2 (z0 - 1 + k), + 1 over this thread's (y, x) window, slide it into
+// the z-window and, from k = 2 on, emit coarse plane z0 + k - 2 (with the optional Adam update of that level).
+// Away from the walls the weights are the constants (1, 3, 3, 1) / 4 per axis and the C and R sums coincide;
+// the weight tables of the two columns / rows next to a wall are formed where they are needed instead of
+// being carried in registers (24 VGPRs in double).  Zero-weight terms are skipped: the sums keep their bits.
+template <typename T>
+__device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c, const typename TileVec<T>::type* __restrict__ tile0,
+                                                 const typename TileVec<T>::type* __restrict__ tile1, int k, bool live,
+                                                 T (&wc)[1][6], T (&wr)[1][6], const AdamArgs<T>& ad) {
+  typedef typename TileVec<T>::type P2;
+  const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
+  T c2[2][1], r2[2][1];
+  const bool xy_special = c.sx || c.sy;
+  if (xy_special) {
+    Adj6 ax[1];
+    column_taps<1>(c.jx, c.cnx, ax);
+    const Adj6 ay = adj6(c.jy, c.cny);
+    // one plane at a time keeps the register count down (the 6-row window)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const P2* tq = q == 0 ? tile0 : tile1;
+      const int f1[1] = {f2[q]};
+      T c1[1][1], r1[1][1];
+      PackN<T, 2> g[1][6][3];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const P2 t = tq[(2 * c.ly + r) * (kTileC / 2) + c.lx + w];
+          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
+        }
+      reduce_loaded<T, 1, 6, 1>(g, f1, c.fnz, ay, ax, c1, r1);
+      c2[q][0] = c1[0][0];
+      r2[q][0] = r1[0][0];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const P2* tq = q == 0 ? tile0 : tile1;
+      T sc = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const P2* row = tq + (2 * c.ly + 1 + r) * (kTileC / 2) + c.lx;
+        const P2 g0 = row[0], g1 = row[1], g2 = row[2];
+        T xc = T(0);
+        xc = xc + T(0.25) * g0[1];
+        xc = xc + T(0.75) * g1[0];
+        xc = xc + T(0.75) * g1[1];
+        xc = xc + T(0.25) * g2[0];
+        sc = sc + T((r == 0 || r == 3) ? 0.25 : 0.75) * xc;
+      }
+      const bool inside = f2[q] >= 0 && f2[q] < c.fnz;
+      c2[q][0] = r2[q][0] = inside ? sc : T(0);
+    }
+  }
+  put2<T, 1>(wc, wr, 4, c2, r2);  // always the last two slots (a static position: no register indexing)
+  if (k >= 2 && c.owner && live) {
+    const int jz = c.z0 + k - 2;
+    const T v = combine_z<T>(wc[0], wr[0], jz, c.cnz, c.fnz, xy_special, c.cut_lo, c.cut_hi);
+    emit_coarse<T>(c.gcoarse, c.gscaled, (int64_t)jz * c.cplane + (int64_t)c.jy * c.cnx + c.jx, v, c.scale, ad);
+  }
+  slide<T, 1>(wc, wr);
+}
 
 // One pair of fine planes (2 (z0 - 1 + k), + 1): publish the staged packs, refill the staging registers
 // with the pair `ahead` steps later, reduce this pair from LDS, and from k = 2 on emit coarse plane
@@ -542,9 +608,8 @@ template <typename T>
 __device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec<T>::type* __restrict__ tile0,
                                            typename TileVec<T>::type* __restrict__ tile1, int k, int ahead, bool live,
                                            const int64_t (&src)[kTileLoads],
-                                           typename TileVec<T>::type (&pre)[2][kTileLoads], const Adj6& ay,
-                                           const Adj6 (&ax)[1], T (&wc)[1][6], T (&wr)[1][6], const AdamArgs<T>& ad) {
-  typedef typename TileVec<T>::type P2;
+                                           typename TileVec<T>::type (&pre)[2][kTileLoads], T (&wc)[1][6],
+                                           T (&wr)[1][6], const AdamArgs<T>& ad) {
   __syncthreads();  // the previous pair has been consumed
 #pragma unroll
   for (int i = 0; i < kTileLoads; ++i) {
@@ -555,45 +620,7 @@ __device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec
   // (unconditional: past the last pair it re-reads clamped planes, which keeps the staging registers out
   // of scratch memory)
   tile_fetch<T>(c.gfine, 2 * (c.z0 - 1 + k + ahead), c.fnz, c.fplane, src, pre);
-  const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
-  T c2[2][1], r2[2][1];
-  // one plane at a time keeps the register count down (boundary rows need the 6-row window)
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const P2* tq = q == 0 ? tile0 : tile1;
-    const int f1[1] = {f2[q]};
-    T c1[1][1], r1[1][1];
-    if (ay.special) {
-      PackN<T, 2> g[1][6][3];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const P2 t = tq[(2 * c.ly + r) * (kTileC / 2) + c.lx + w];
-          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
-        }
-      reduce_loaded<T, 1, 6, 1>(g, f1, c.fnz, ay, ax, c1, r1);
-    } else {
-      PackN<T, 2> g[1][4][3];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const P2 t = tq[(2 * c.ly + 1 + r) * (kTileC / 2) + c.lx + w];
-          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
-        }
-      reduce_loaded<T, 1, 4, 1>(g, f1, c.fnz, ay, ax, c1, r1);
-    }
-    c2[q][0] = c1[0][0];
-    r2[q][0] = r1[0][0];
-  }
-  put2<T, 1>(wc, wr, 4, c2, r2);  // always the last two slots (a static position: no register indexing)
-  if (k >= 2 && c.owner && live) {
-    const int jz = c.z0 + k - 2;
-    const T v = combine_z<T>(wc[0], wr[0], jz, c.cnz, c.fnz, ax[0].special || ay.special, c.cut_lo, c.cut_hi);
-    emit_coarse<T>(c.gcoarse, c.gscaled, (int64_t)jz * c.cplane + (int64_t)c.jy * c.cnx + c.jx, v, c.scale, ad);
-  }
-  slide<T, 1>(wc, wr);
+  tile_reduce_emit<T>(c, tile0, tile1, k, live, wc, wr, ad);
 }
 
 template <typename T>
@@ -619,10 +646,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
   c.jy = yt * kTileY + c.ly, c.jx = xt * kTileX + c.lx;
   c.owner = c.jy < cny && c.jx < c.cnx;
-  // clamped so that the weight tables of idle lanes are well defined
-  Adj6 ax[1];
-  column_taps<1>(c.owner ? c.jx : 0, c.cnx, ax);
-  const Adj6 ay = adj6(c.owner ? c.jy : 0, cny);
+  c.cny = cny;
+  c.sx = c.owner && (c.jx < 2 || c.jx >= c.cnx - 2);
+  c.sy = c.owner && (c.jy < 2 || c.jy >= cny - 2);
   // this thread's share of a staged plane: packs p = threadIdx.x + k kBlock of the tile, row-major
   int64_t src[kTileLoads];
 #pragma unroll
@@ -643,7 +669,196 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   const int npairs = z1 - c.z0 + 2;
   P2 pre[2][kTileLoads];
   tile_fetch<T>(gfine, 2 * (c.z0 - 1), c.fnz, c.fplane, src, pre);
-  for (int k = 0; k < npairs; ++k) tile_stage<T>(c, tile[0], tile[1], k, 1, true, src, pre, ay, ax, wc, wr, ad);
+  for (int k = 0; k < npairs; ++k) tile_stage<T>(c, tile[0], tile[1], k, 1, true, src, pre, wc, wr, ad);
+}
+
+// ------------------------------------------------------------------------------------
+// Stencil adjoint + first P^T in one kernel (Poisson hot path, 3-D): g0 = scale A^T fu is formed on the
+// staged tile straight from fu, consumed by the Adam update of the finest level and by the transpose to
+// the next level, and never written to memory -- the separate kernels write g0 (1 word per fine cell)
+// and read it back.  Same tile as k_interp_adj_tile; fu is staged with one more halo cell per side in a
+// ring of four planes (plane z of g0 needs fu planes z - 1 .. z + 1), g0 of the tile's halo ring is
+// recomputed by each neighbouring workgroup (same expression, same bits).  g0 and g1 are bit-identical
+// to k_poisson_adjoint followed by k_interp_adj_tile.
+// ------------------------------------------------------------------------------------
+constexpr int kFuR = 2 * kTileY + 6;   // fine rows from 2 jy0 - 3
+constexpr int kFuC = kTileX + 4;       // packs of two: fine x from 2 jx0 - 4 (pack aligned)
+constexpr int kFuPacks = kFuR * kFuC;
+constexpr int kFuLoads = (kFuPacks + kBlock - 1) / kBlock;
+constexpr int kGC = kTileC / 2;        // packs per row of the g0 tile
+constexpr int kOwnLoads = 2 * kTileY * kTileX / kBlock;  // own packs per thread and plane
+
+template <typename T>
+__device__ __forceinline__ void fu_fetch(const T* __restrict__ fu, int fz0, int fnz, int64_t fplane,
+                                         const int64_t (&src)[kFuLoads], typename TileVec<T>::type (&pre)[2][kFuLoads]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int fz = fz0 + q;
+    fz = fz < 0 ? 0 : (fz >= fnz ? fnz - 1 : fz);
+    const T* gp = fu + (int64_t)fz * fplane;
+#pragma unroll
+    for (int i = 0; i < kFuLoads; ++i) pre[q][i] = *reinterpret_cast<const typename TileVec<T>::type*>(gp + src[i]);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void fu_publish(typename TileVec<T>::type* __restrict__ ring, int fz0,
+                                           const typename TileVec<T>::type (&pre)[2][kFuLoads]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    typename TileVec<T>::type* slot = ring + ((fz0 + q + 8) & 3) * kFuPacks;
+#pragma unroll
+    for (int i = 0; i < kFuLoads; ++i) {
+      const int p = threadIdx.x + i * kBlock;
+      if (p < kFuPacks) slot[p] = pre[q][i];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __restrict__ fu, T* __restrict__ g0out,
+                                                                 T* __restrict__ gcoarse, MarchArgs a, H2<T> h,
+                                                                 T scale, AdamArgs<T> ad0, AdamArgs<T> ad1) {
+  typedef typename TileVec<T>::type P2;
+  __shared__ P2 ring[4 * kFuPacks];      // fu planes z & 3
+  __shared__ P2 gt[2][kTileR * kGC];     // g0 of the current pair of planes
+  const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
+  TileCtx<T> c;
+  c.gfine = nullptr, c.gcoarse = gcoarse, c.gscaled = nullptr;
+  c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
+  c.cut_lo = 0, c.cut_hi = 0;
+  c.cplane = (int64_t)cny * c.cnx, c.fplane = (int64_t)fny * fnx;
+  c.scale = T(1);
+  c.z0 = zc * a.usched.ZC;
+  const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
+  c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
+  c.jy = yt * kTileY + c.ly, c.jx = xt * kTileX + c.lx;
+  c.owner = c.jy < cny && c.jx < c.cnx;
+  c.cny = cny;
+  c.sx = c.owner && (c.jx < 2 || c.jx >= c.cnx - 2);
+  c.sy = c.owner && (c.jy < 2 || c.jy >= cny - 2);
+  const int fy0 = 2 * yt * kTileY, fx0 = 2 * xt * kTileX;  // first own fine row / column of the tile
+  // this thread's packs of a staged fu plane (row-major over the (kFuR, kFuC) window, clamped into the array)
+  int64_t src[kFuLoads];
+#pragma unroll
+  for (int i = 0; i < kFuLoads; ++i) {
+    int p = threadIdx.x + i * kBlock;
+    p = p < kFuPacks ? p : kFuPacks - 1;
+    const int r = p / kFuC, cc = p - r * kFuC;
+    int fy = fy0 - 3 + r, fx = fx0 - 4 + 2 * cc;
+    fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);
+    fx = fx < 0 ? 0 : (fx >= fnx ? fnx - 2 : fx);
+    src[i] = (int64_t)fy * fnx + fx;
+  }
+  T wc[1][6], wr[1][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) wc[0][i] = wr[0][i] = T(0);
+  // g0 planes of step k: zA = 2 m, zB = 2 m + 1 with m = z0 - 1 + k; they need the fu planes 2 m - 1 .. 2 m + 2,
+  // staged as the pairs (2 m - 1, 2 m) and (2 m + 1, 2 m + 2)
+  const int npairs = z1 - c.z0 + 2;
+  P2 pre[2][kFuLoads];
+  fu_fetch<T>(fu, 2 * (c.z0 - 1) - 1, c.fnz, c.fplane, src, pre);
+  fu_publish<T>(ring, 2 * (c.z0 - 1) - 1, pre);
+  fu_fetch<T>(fu, 2 * (c.z0 - 1) + 1, c.fnz, c.fplane, src, pre);
+  // own cells of the tile (the finest level's arrays): packs o = threadIdx.x + i kBlock, row-major
+  int64_t own_off[kOwnLoads];
+  bool own_ok[kOwnLoads];
+#pragma unroll
+  for (int i = 0; i < kOwnLoads; ++i) {
+    const int o = threadIdx.x + i * kBlock;
+    const int row = o / kTileX, cc = o - row * kTileX;
+    const int y = fy0 + row, x = fx0 + 2 * cc;
+    own_ok[i] = y < fny && x < fnx;
+    own_off[i] = (int64_t)(own_ok[i] ? y : 0) * fnx + (own_ok[i] ? x : 0);
+  }
+  P2 xv[kOwnLoads], mv[kOwnLoads], vv[kOwnLoads];
+#pragma unroll
+  for (int i = 0; i < kOwnLoads; ++i) xv[i] = mv[i] = vv[i] = P2{T(0), T(0)};
+  bool pending = false;  // the previous plane's update is outstanding
+  for (int k = 0; k < npairs; ++k) {
+    const int m = c.z0 - 1 + k, zA = 2 * m;
+    __syncthreads();  // readers of the ring slots and of gt that are rewritten below are done
+    fu_publish<T>(ring, zA + 1, pre);
+    __syncthreads();
+    fu_fetch<T>(fu, zA + 3, c.fnz, c.fplane, src, pre);  // next pair of fu planes in flight
+    // One plane at a time.  The update of the finest level runs one plane behind the plane whose g0 is
+    // being formed: its loads (x, m, v of the own cells) are issued at the end of a step and consumed at
+    // the end of the next one, so they have a whole step to arrive (gt keeps two planes).
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+      const int z = zA + q;
+      const P2* pm = ring + ((z - 1 + 8) & 3) * kFuPacks;
+      const P2* pc = ring + ((z + 8) & 3) * kFuPacks;
+      const P2* pp = ring + ((z + 1 + 8) & 3) * kFuPacks;
+      P2* gq = gt[q];
+#pragma unroll 1
+      for (int i = 0; i < kTileLoads; ++i) {
+        const int p = threadIdx.x + i * kBlock;
+        if (p < kTilePacks) {
+          const int r = p / kGC, cc = p - r * kGC;
+          const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
+          const int at = (r + 1) * kFuC + cc + 1;  // the same cells in the fu window
+          P2 g;
+          g[0] = T(0), g[1] = T(0);
+          if (z >= 0 && z < c.fnz && y >= 0 && y < fny && x >= 0 && x < fnx) {
+            const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
+            const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              // the expression of k_poisson_adjoint, term by term
+              const T fb = scale * fc[e];
+              T acc = T(0);
+              acc = acc + adj_axis<T>(fb, scale * fzm[e], scale * fzp[e], z, c.fnz, h, 0);
+              acc = acc + adj_axis<T>(fb, scale * fym[e], scale * fyp[e], y, fny, h, 1);
+              const T xm = scale * (e == 0 ? fl[1] : fc[0]);
+              const T xp = scale * (e == 0 ? fc[1] : fr[0]);
+              acc = acc + adj_axis<T>(fb, xm, xp, x + e, fnx, h, 2);
+              g[e] = acc;
+            }
+          }
+          gq[p] = g;
+        }
+      }
+      __syncthreads();
+      if (pending) {  // plane z - 1: its g0 is in the other half of gt
+        const P2* gprev = gt[q ^ 1];
+#pragma unroll
+        for (int i = 0; i < kOwnLoads; ++i) {
+          const int o = threadIdx.x + i * kBlock;
+          const int row = o / kTileX, cc = o - row * kTileX;
+          if (!own_ok[i]) continue;
+          const P2 g = gprev[(row + 2) * kGC + cc + 1];
+          const int64_t off = (int64_t)(z - 1) * c.fplane + own_off[i];
+          if (g0out) __builtin_nontemporal_store(g, reinterpret_cast<P2*>(g0out + off));
+          if (ad0.x) {
+            P2 xn = xv[i], mn = mv[i], vn = vv[i];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              T xe = xn[e], me = mn[e], ve = vn[e];
+              adam_update<T>(xe, me, ve, g[e], ad0);
+              xn[e] = xe, mn[e] = me, vn[e] = ve;
+            }
+            __builtin_nontemporal_store(xn, reinterpret_cast<P2*>(ad0.x + off));
+            __builtin_nontemporal_store(mn, reinterpret_cast<P2*>(ad0.m + off));
+            __builtin_nontemporal_store(vn, reinterpret_cast<P2*>(ad0.v + off));
+          }
+        }
+      }
+      pending = z >= 2 * c.z0 && z < 2 * z1;  // planes of this chunk (the others belong to its neighbours)
+      if (pending && ad0.x) {
+#pragma unroll
+        for (int i = 0; i < kOwnLoads; ++i) {
+          const int64_t off = (int64_t)z * c.fplane + own_off[i];
+          xv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.x + off));
+          mv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.m + off));
+          vv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.v + off));
+        }
+      }
+    }
+    tile_reduce_emit<T>(c, gt[0], gt[1], k, true, wc, wr, ad1);
+  }
 }
 
 // P^T with a node-centred marching axis: coarse plane J collects fine plane 2J and half of the
@@ -869,6 +1084,49 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
 }
 
 template <typename T>
+int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, const T* h2, T scale,
+                              const AdamArgs<T>& ad0, const AdamArgs<T>& ad1, hipStream_t stream) {
+  if (!fu || !g1 || !fshape || !h2) {
+    set_error("poisson_adjoint_transpose: null pointer (fu, g1, shape, h2)");
+    return ODIL_E_INVAL;
+  }
+  MarchArgs m;
+  for (int i = 0; i < 3; ++i) {
+    if (fshape[i] < 4 || fshape[i] % 2 || fshape[i] >= (1 << 30)) {
+      set_error("poisson_adjoint_transpose: extent %lld on axis %d must be even, >= 4", (long long)fshape[i], i);
+      return ODIL_E_INVAL;
+    }
+    m.fn[i] = (int)fshape[i];
+    m.cn[i] = (int)(fshape[i] / 2);
+  }
+  const void* ptrs[] = {fu, g0, g1, ad0.x, ad0.m, ad0.v};
+  for (const void* q : ptrs)
+    if (q && !aligned_to(q, 2 * sizeof(T))) {
+      set_error("poisson_adjoint_transpose: arrays must be aligned to %d bytes", (int)(2 * sizeof(T)));
+      return ODIL_E_INVAL;
+    }
+  m.tx = kTileX, m.ty = kTileY;
+  m.cut_lo = m.cut_hi = 0;
+  m.nt = 0;
+  m.lead_loc = 0, m.lead_cn = 1, m.lead_fn = 1;
+  const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
+  if ((int64_t)m.cn[0] * ytiles * xtiles >= ((int64_t)1 << 31)) {
+    set_error("poisson_adjoint_transpose: grid too large for one launch");
+    return ODIL_E_INVAL;
+  }
+  m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, ODIL_TILE_UNITS);
+  T h[3] = {h2[0], h2[1], h2[2]};
+  hipLaunchKernelGGL((k_poisson_adjoint_tile<T>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0, g1, m,
+                     make_h2<T>(h), scale, ad0, ad1);
+  return check_launch("k_poisson_adjoint_tile");
+}
+
+template int poisson_adjoint_transpose<double>(const double*, double*, double*, const int64_t*, const double*, double,
+                                               const AdamArgs<double>&, const AdamArgs<double>&, hipStream_t);
+template int poisson_adjoint_transpose<float>(const float*, float*, float*, const int64_t*, const float*, float,
+                                              const AdamArgs<float>&, const AdamArgs<float>&, hipStream_t);
+
+template <typename T>
 int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a, T cscale, T ascale,
                      hipStream_t stream) {
   const int cx = march_cx<T>(a, fine, add);
@@ -893,3 +1151,24 @@ template int interp_adj_march<float>(const float*, float*, float*, const InterpA
                                      const AdamArgs<float>&);
 
 }  // namespace odil
+
+using namespace odil;
+
+extern "C" {
+int odil_poisson_adjoint_transpose_adam_f64(const double* fu, double* g0, double* g1, const int64_t* fshape,
+                                            const double* h2, double scale, double* x0, double* m0, double* v0,
+                                            double* x1, double* m1, double* v1, double alpha, double one_minus_b1,
+                                            double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
+  const AdamArgs<double> a0{x0, m0, v0, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
+  const AdamArgs<double> a1{x1, m1, v1, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
+  return poisson_adjoint_transpose<double>(fu, g0, g1, fshape, h2, scale, a0, a1, (hipStream_t)stream);
+}
+int odil_poisson_adjoint_transpose_adam_f32(const float* fu, float* g0, float* g1, const int64_t* fshape,
+                                            const float* h2, float scale, float* x0, float* m0, float* v0, float* x1,
+                                            float* m1, float* v1, float alpha, float one_minus_b1, float one_minus_b2,
+                                            float eps, const float* alpha_dev, void* stream) {
+  const AdamArgs<float> a0{x0, m0, v0, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
+  const AdamArgs<float> a1{x1, m1, v1, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
+  return poisson_adjoint_transpose<float>(fu, g0, g1, fshape, h2, scale, a0, a1, (hipStream_t)stream);
+}
+}

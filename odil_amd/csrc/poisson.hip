@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint(const T* __restrict_
       g = g + adj_axis<T>(fb, xm, xp, x, X, h, 2);
       out[i] = g;
     }
-    store_vec<T, V, FULL, true>(gu + pz + c_off, valid, out);
+    if (gu) store_vec<T, V, FULL, true>(gu + pz + c_off, valid, out);
     if (ad.x) {
       // x, m, v are touched exactly once per launch: streaming (non-temporal) accesses keep them
       // from evicting the fu rows / planes the stencil re-reads from L2
@@ -464,7 +464,7 @@ static int poisson_adjoint(const T* fu, T* gu, const int64_t* shape, int ndim, c
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
-  if (!fu || !gu) {
+  if (!fu || (!gu && !ad.x)) {  // with the Adam update fused in, the gradient itself need not be stored
     set_error("poisson_adjoint: null pointer");
     return ODIL_E_INVAL;
   }

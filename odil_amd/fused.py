@@ -55,6 +55,46 @@ class PoissonEvaluator:
             self.ndim == 3 and self.nlvl >= 2 and not self.one_pass and all(s % 2 == 0 and s >= 4 for s in self.cshape)
             and tuple(self.shapes[1]) == tuple(s // 2 for s in self.cshape)
             and bool(int(os.environ.get("ODIL_SYNTH_RESIDUAL", 1))))
+        # stencil adjoint, first transposed prolongation and the Adam updates of both levels in one launch
+        self.fuse_transpose = (
+            self.ndim == 3 and self.nlvl >= 2 and ops.adjoint_transpose_supported(self.cshape)
+            and tuple(self.shapes[1]) == tuple(s // 2 for s in self.cshape)
+            and bool(int(os.environ.get("ODIL_FUSE_TRANSPOSE", 1))))
+
+    def adjoint_and_transposes(self, arrays, adam, tic=lambda name: None, toc=lambda b: None):
+        """grads (and, with `adam`, the update of every level) from the residual in self.fu."""
+        if adam is not None:
+            ml, vl, alpha, omb1, omb2, eps = adam
+        if adam is not None and self.fuse_transpose:
+            # stencil adjoint + first P^T + the updates of both levels in one launch: the finest-level gradient
+            # never goes through memory and is not stored (gw[0] is left as it was).  Without the updates the
+            # separate kernels are faster (the one-pass kernel is bound by its LDS / VALU phases at two
+            # workgroups per CU: 1.6 ms against 0.54 + 0.45 ms at 512^3), so gradients alone keep them.
+            b = tic("adjoint_transpose")
+            ops.poisson_adjoint_transpose(self.fu, self.h2, self.scale, self.gw[1], g0=None,
+                                          adam0=(arrays[0], ml[0], vl[0]), adam1=(arrays[1], ml[1], vl[1]),
+                                          alpha=alpha, one_minus_b1=omb1, one_minus_b2=omb2, eps=eps)
+            toc(b)
+            if self.nlvl > 2:
+                b = tic("mg_synth_adj")
+                ops.mg_synth_adj_adam(self.gw[1], self.shapes[1:], self.loc, self.gw[1:], arrays[1:], ml[1:], vl[1:],
+                                      alpha, omb1, omb2, eps)
+                toc(b)
+            return
+        b = tic("adjoint")
+        if adam is not None:
+            ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], ml[0], vl[0], alpha, omb1,
+                                     omb2, eps)
+        else:
+            ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        toc(b)
+        if self.nlvl > 1:
+            b = tic("mg_synth_adj")
+            if adam is not None:
+                ops.mg_synth_adj_adam(self.gw[0], self.shapes, self.loc, self.gw, arrays, ml, vl, alpha, omb1, omb2, eps)
+            else:
+                ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
+            toc(b)
 
     @property
     def u(self):
@@ -93,42 +133,22 @@ class PoissonEvaluator:
             toc(b)
         else:
             u = arrays[0]
-        if self.synth_residual:
-            b = tic("residual")
-            ops.poisson_residual_synth(coarse, arrays[0], self.rhs, self.h2, fu=self.fu, loss=self.loss)
-            toc(b)
-            b = tic("adjoint")
-            if adam is not None:
-                ml, vl, alpha, omb1, omb2, eps = adam
-                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], ml[0], vl[0], alpha,
-                                         omb1, omb2, eps)
-            else:
-                ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
-            toc(b)
-        elif self.one_pass:
+        if self.one_pass:
             b = tic("loss_grad")
             ops.poisson_loss_grad(u, self.rhs, self.h2, out=self.gw[0], loss=self.loss)
             toc(b)
-        else:
-            b = tic("residual")
-            ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
-            toc(b)
-            b = tic("adjoint")
-            if adam is not None:
-                ml, vl, alpha, omb1, omb2, eps = adam
-                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], arrays[0], ml[0], vl[0], alpha,
-                                         omb1, omb2, eps)
-            else:
-                ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
-            toc(b)
-        if self.nlvl > 1:
-            b = tic("mg_synth_adj")
-            if adam is not None:
-                ops.mg_synth_adj_adam(self.gw[0], self.shapes, self.loc, self.gw, arrays, ml, vl, alpha, omb1, omb2,
-                                      eps)
-            else:
+            if self.nlvl > 1:
+                b = tic("mg_synth_adj")
                 ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
-            toc(b)
+                toc(b)
+            return self.loss, self.gw
+        b = tic("residual")
+        if self.synth_residual:
+            ops.poisson_residual_synth(coarse, arrays[0], self.rhs, self.h2, fu=self.fu, loss=self.loss)
+        else:
+            ops.poisson_residual(u, self.rhs, self.h2, fu=self.fu, loss=self.loss)
+        toc(b)
+        self.adjoint_and_transposes(arrays, adam, tic, toc)
         return self.loss, self.gw
 
     def eval_loss_grad(self, state):

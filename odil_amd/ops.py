@@ -349,10 +349,35 @@ def poisson_adjoint_adam(fu, h2, scale, out, x, m, v, alpha, one_minus_b1, one_m
     h2a, h2p = host_reals(h2, fu.dtype)
     a, adev = _step_size(alpha, fu.dtype)
     call(
+        # (out=None: the gradient is consumed by the update, not stored)
         "poisson_adjoint_adam", fu.dtype, ptr(fu), ptr(out), ptr(x), ptr(m), ptr(v), i64(fu.shape), c_int(fu.dim()),
         h2p, float(scale), a, float(one_minus_b1), float(one_minus_b2), float(eps), adev, stream_ptr(),
     )
     return out
+
+
+def adjoint_transpose_supported(shape):
+    """Sizes at which the one-pass stencil adjoint + first transposed prolongation pays (and is defined)."""
+    return len(shape) == 3 and all(n % 2 == 0 for n in shape) and shape[0] >= 8 and shape[1] >= 32 and shape[2] >= 128
+
+
+def poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=None, adam1=None, alpha=0.0, one_minus_b1=0.0,
+                              one_minus_b2=0.0, eps=0.0):
+    """g0 = J^T (scale * fu) (stored only if `g0` is given), g1 = P^T g0, and the Adam steps of the finest level
+    (adam0 = (x, m, v)) and of the next one (adam1) inside the same launch: g0 never goes through memory."""
+    assert fu.dim() == 3 and tuple(g1.shape) == tuple(n // 2 for n in fu.shape) and fu.is_contiguous()
+    h2a, h2p = host_reals(h2, fu.dtype)
+    a, adev = _step_size(alpha, fu.dtype)
+    a0 = adam0 if adam0 is not None else (None, None, None)
+    a1 = adam1 if adam1 is not None else (None, None, None)
+    for t in list(a0) + list(a1):
+        assert t is None or (t.is_contiguous() and t.dtype == fu.dtype)
+    call(
+        "poisson_adjoint_transpose_adam", fu.dtype, ptr(fu), ptr(g0), ptr(g1), i64(fu.shape), h2p, float(scale),
+        ptr(a0[0]), ptr(a0[1]), ptr(a0[2]), ptr(a1[0]), ptr(a1[1]), ptr(a1[2]), a, float(one_minus_b1),
+        float(one_minus_b2), float(eps), adev, stream_ptr(),
+    )
+    return g1
 
 
 def poisson_jac_coeffs(shape, h2, dtype, device):

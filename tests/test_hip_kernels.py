@@ -561,6 +561,46 @@ def test_tiled_transpose_is_bit_identical(dev, dtype, fine, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fine", [(8, 32, 128), (16, 40, 136), (24, 72, 264)])
+def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine):
+    """odil_poisson_adjoint_transpose_adam == odil_poisson_adjoint(_adam) followed by the first P^T (+Adam of
+    that level), bit for bit: the gradient of the finest level, the coarse gradient, and both updated states."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(43)
+    coarse = tuple(n // 2 for n in fine)
+    shapes = [fine, coarse]
+    h2 = [dtype(v) for v in [0.25**2, 0.1**2, 0.3**2]]
+    scale = dtype(2.0 / np.prod(fine))
+    fu = to(rng.standard_normal(fine).astype(dtype), dev)
+    assert ops.adjoint_transpose_supported(fine)
+    # gradients only
+    g0 = torch.full(fine, 7.0, dtype=fu.dtype, device=dev)
+    g1 = torch.full(coarse, 7.0, dtype=fu.dtype, device=dev)
+    ops.poisson_adjoint_transpose(fu, h2, scale, g1, g0=g0)
+    g0_ref = ops.poisson_adjoint(fu, h2, scale)
+    g1_ref = ops.mg_synth_adj(g0_ref, shapes, "ccc")[1]
+    assert torch.equal(g0, g0_ref) and torch.equal(g1, g1_ref)
+    # with the Adam update of both levels (and without storing g0)
+    def fresh():
+        r = np.random.default_rng(47)
+        mk = lambda s, pos=False: to((np.abs(r.standard_normal(s)) if pos else r.standard_normal(s)).astype(dtype), dev)
+        return [mk(fine), mk(coarse)], [mk(fine), mk(coarse)], [mk(fine, True), mk(coarse, True)]
+
+    x, m, v = fresh()
+    g1 = torch.empty(coarse, dtype=fu.dtype, device=dev)
+    ops.poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=(x[0], m[0], v[0]), adam1=(x[1], m[1], v[1]),
+                                  alpha=0.01, one_minus_b1=0.1, one_minus_b2=0.001, eps=1e-7)
+    xr, mr, vr = fresh()
+    gr = [torch.empty(fine, dtype=fu.dtype, device=dev), torch.empty(coarse, dtype=fu.dtype, device=dev)]
+    ops.poisson_adjoint_adam(fu, h2, scale, gr[0], xr[0], mr[0], vr[0], 0.01, 0.1, 0.001, 1e-7)
+    ops.mg_synth_adj_adam(gr[0], shapes, "ccc", gr, xr, mr, vr, 0.01, 0.1, 0.001, 1e-7)
+    assert torch.equal(g1, gr[1])
+    for a, b in zip(x + m + v, xr + mr + vr):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
     """Large 'nccc' arrays take P^T = (P^T over the node axis) o (P^T over the three cell axes)
     (ops.mg_synth_adj); it must equal the one-kernel chain."""
