@@ -65,7 +65,7 @@ class _Codegen:
         if self.total >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         self.lines = []
-        self.max_blocks = int(os.environ.get("ODIL_JIT_NBLOCKS", 65536))
+        self.max_blocks = int(os.environ.get("ODIL_JIT_NBLOCKS", 0))  # 0: chosen by the operator (stencil_jit)
         # reachable nodes
         live = set()
         stack = list(outputs)
