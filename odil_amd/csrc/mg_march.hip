@@ -636,10 +636,14 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   int zc, yt, xt;
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
   TileCtx<T> c;
-  c.gfine = gfine, c.gcoarse = gcoarse, c.gscaled = gscaled;
   c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
   c.cut_lo = a.cut_lo, c.cut_hi = a.cut_hi;
   c.cplane = (int64_t)cny * c.cnx, c.fplane = (int64_t)fny * fnx;
+  // a leading batch axis ('.ccc': the space part of the 4-D space-time transposes): one volume per blockIdx.y
+  const int64_t cvol = (int64_t)blockIdx.y * c.cnz * c.cplane, fvol = (int64_t)blockIdx.y * c.fnz * c.fplane;
+  gfine += fvol;
+  c.gfine = gfine, c.gcoarse = gcoarse + cvol, c.gscaled = gscaled ? gscaled + cvol : nullptr;
+  if (ad.x) ad.x += cvol, ad.m += cvol, ad.v += cvol;
   c.scale = scale;
   c.z0 = zc * a.usched.ZC;
   const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
@@ -1058,17 +1062,26 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   const bool small_level = a.cn[0] * a.cn[1] * a.cn[2] * a.cn[3] <= ((int64_t)1 << 22);
   if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
+  const bool tile_ok = CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled();
   if (m.lead_fn != 1) {
     if (m.lead_loc == kNode)
       hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 3>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
                          m, scale, ad);
-    else
+    else if (tile_ok) {
+      // batch of large all-cell volumes: the LDS-staged kernel, one volume per blockIdx.y
+      const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
+      m.tx = kTileX;
+      m.ty = kTileY;
+      m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, ODIL_ADJ_UNITS_SMALL);
+      hipLaunchKernelGGL((k_interp_adj_tile<T>), dim3(unit_grid(m.usched), m.lead_cn), dim3(kBlock), 0, stream, gfine,
+                         gcoarse, gscaled, m, scale, ad);
+    } else
       hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
                          m, scale, ad);
   } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_adj_march_n<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
-  else if (CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled()) {
+  else if (tile_ok) {
     // large all-cell levels: fine planes staged through LDS
     const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
     m.tx = kTileX;

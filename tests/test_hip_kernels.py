@@ -549,6 +549,16 @@ def test_tiled_transpose_is_bit_identical(dev, dtype, fine, monkeypatch):
         res[mode] = (x[1].clone(), m[1].clone(), v[1].clone(), grads[1].clone())
     for a, b in zip(res["1"], res["0"]):
         assert torch.equal(a, b)
+    # a leading batch axis: the space part of the 4-D space-time transposes, one volume per grid row
+    g4 = to(rng.standard_normal((3,) + tuple(fine)).astype(dtype), dev)
+    out = {}
+    for mode in ["1", "0"]:
+        monkeypatch.setenv("ODIL_ADJ_TILE", mode)
+        out[mode] = ops.interp_adj(g4, ".ccc", (3,) + tuple(shapes[1])).clone()
+    assert torch.equal(out["1"], out["0"])
+    for b in range(3):
+        monkeypatch.setenv("ODIL_ADJ_TILE", "1")
+        assert torch.equal(out["1"][b], ops.interp_adj(g4[b].contiguous(), "ccc", shapes[1]))
     # slab interfaces along the marched axis (multi-GPU path)
     for cut in [(True, False), (False, True), (True, True)]:
         out = {}
