@@ -74,3 +74,44 @@ def test_fused_epoch_equals_separate_kernels_at_full_size(dev, monkeypatch):
         assert torch.equal(a, b) and torch.equal(a, c)
     # zero initial state: the first loss is mean(rhs^2) of the discrete right-hand side; then it moves
     assert fused[0] > 0 and fused[1] != fused[0] and np.isfinite(fused).all()
+
+
+def test_newton_step_and_lbfgs_at_full_size(dev):
+    """BASELINE configs 4b and 2 through the public API: one Newton step of the 512^3 Poisson problem (no
+    decomposition; geometric multigrid on the device) solves it -- loss drops from O(1e5) to rounding -- and
+    L-BFGS-B on 1024^2 with the multigrid decomposition decreases the loss monotonically over its accepted
+    iterations (Wolfe line search) and reproduces itself run to run."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "poisson"))
+    import odil_amd as odil
+    import poisson
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    args = poisson.parse_args(["--ndim", "3", "--N", str(N), "--multigrid", "0", "--linsolver", "multigrid",
+                               "--linsolver_tol", "1e-10"])
+    problem, state = poisson.make_problem(args)
+    loss0 = float(problem.eval_loss_grad(state)[0])
+    args.epoch_start, args.epochs = 0, 1
+    odil.util.optimize(args, "newton", problem, state, None)
+    loss1 = float(problem.eval_loss_grad(state)[0])
+    assert loss0 > 1.0 and loss1 < 1e-18 * loss0
+    del problem, state
+    torch.cuda.empty_cache()
+
+    def lbfgs_losses():
+        a = poisson.parse_args(["--ndim", "2", "--N", "1024"])
+        prob, st = poisson.make_problem(a)
+        a.epoch_start, a.epochs = 0, 30
+        losses = []
+        try:
+            odil.util.optimize(a, "lbfgsb", prob, st, lambda s, e, p: losses.append(float(np.array(p["loss"]))))
+        except odil.EarlyStopError:
+            pass
+        return losses
+
+    la, lb = lbfgs_losses(), lbfgs_losses()
+    assert la == lb and len(la) >= 30
+    assert all(b < a for a, b in zip(la[1:], la[2:]))  # (entry 0 is the initial evaluation)
