@@ -95,4 +95,75 @@ __device__ inline void load_plane(const T* __restrict__ coarse, int q, int cnz, 
     }
 }
 
+#ifndef ODIL_PLANE_DPP
+#define ODIL_PLANE_DPP 1
+#endif
+
+// The same neighbourhood with ONE load per row and source (clamp / reflect) for the lane's own columns;
+// the columns left and right of them are the own columns of the adjacent lanes (wave-wide DPP shift).
+// load_plane issues 2 x 3 x (CX + 2) one-element loads per plane -- with two coarse volumes per fine
+// volume (node-centred leading axis) 48 of them per step, which bounds the kernel by the number of memory
+// instructions (1.5 TB/s), not by bytes.  Lanes at the ends of a row segment (and at the walls, where the
+// ghost rule picks other columns) read their outer columns from memory as before.  `ntx`: lanes per row
+// segment (MarchArgs::tx), jx0: first own column.  4-D tracer (32 x 256^3, four 'nccc' fields): 60.0 -> 56.5
+// ms / epoch.  Not used by the fused prolongation + residual kernel (poisson_synth.hip): at 225 VGPRs the
+// extra live values cost it 0.66 -> 0.74 ms.
+template <typename T, int CX>
+__device__ inline void load_plane_shared(const T* __restrict__ coarse, int q, int cnz, int64_t cplane, int cnx,
+                                         const TapN<3>& ty, const TapN<CX + 2>& tx, T cscale, T (&v)[3][CX + 2],
+                                         int ntx, int jx0) {
+#if ODIL_PLANE_DPP
+  const bool oz = q < 0 || q >= cnz;
+  const int zcl = q < 0 ? 0 : (q >= cnz ? cnz - 1 : q);
+  const int zrf = q < 0 ? 1 : (q >= cnz ? cnz - 2 : q);
+  const T* ccl = coarse + zcl * cplane;
+  const T* crf = coarse + zrf * cplane;
+  const int lx = threadIdx.x % ntx, lane = threadIdx.x & 63;
+  const bool lo_edge = lx == 0 || lane == 0 || jx0 == 0;
+  const bool hi_edge = lx == ntx - 1 || lane == 63 || jx0 + CX >= cnx;
+  T cl[3][CX + 2], rf[3][CX + 2];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const T* rc = ccl + (int64_t)ty.cl[dy] * cnx + jx0;  // own columns are inside the array: clamp == reflect == jx0 + c
+    const T* rr = crf + (int64_t)ty.rf[dy] * cnx + jx0;
+#pragma unroll
+    for (int c = 0; c < CX; ++c) {
+      cl[dy][1 + c] = rc[c];
+      rf[dy][1 + c] = rr[c];
+    }
+  }
+  if (lo_edge) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      cl[dy][0] = ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[0]];
+      rf[dy][0] = crf[(int64_t)ty.rf[dy] * cnx + tx.rf[0]];
+    }
+  }
+  if (hi_edge) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      cl[dy][CX + 1] = ccl[(int64_t)ty.cl[dy] * cnx + tx.cl[CX + 1]];
+      rf[dy][CX + 1] = crf[(int64_t)ty.rf[dy] * cnx + tx.rf[CX + 1]];
+    }
+  }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const T pc = from_prev_lane(cl[dy][CX]), pr = from_prev_lane(rf[dy][CX]);
+    const T nc = from_next_lane(cl[dy][1]), nr = from_next_lane(rf[dy][1]);
+    if (!lo_edge) cl[dy][0] = pc, rf[dy][0] = pr;
+    if (!hi_edge) cl[dy][CX + 1] = nc, rf[dy][CX + 1] = nr;
+  }
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < CX + 2; ++dx) {
+      const T val = cscale * cl[dy][dx];
+      const T ghost = T(2) * val - cscale * rf[dy][dx];
+      v[dy][dx] = (oz || ty.out[dy] || tx.out[dx]) ? ghost : val;
+    }
+#else
+  load_plane<T, CX>(coarse, q, cnz, cplane, cnx, ty, tx, cscale, v);
+#endif
+}
+
 }  // namespace odil

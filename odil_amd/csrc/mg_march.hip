@@ -110,8 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
   const TapN<CX + 2> tx = tapn<CX + 2>(jx0, cnx);
   const TapN<3> ty = tapn<3>(jy, cny);
   T v[3][3][CX + 2];
-  load_plane<T, CX>(coarse, z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[0]);
-  load_plane<T, CX>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[1]);
+  load_plane_shared<T, CX>(coarse, z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[0], a.tx, jx0);
+  load_plane_shared<T, CX>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[1], a.tx, jx0);
   const T r64 = T(1) / T(64);  // exact: sum of weights 4*4*4
   for (int jz = z0; jz < z1; ++jz) {
     // issue the fine-grid addend loads first: they are the HBM stream of this kernel
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march(const T* __restrict
       load_add<T, CX>(add, fbase, fnx, ad[0], a.nt);
       load_add<T, CX>(add, fbase + fplane, fnx, ad[1], a.nt);
     }
-    load_plane<T, CX>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[2]);
+    load_plane_shared<T, CX>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[2], a.tx, jx0);
 #pragma unroll
     for (int sz = 0; sz < 2; ++sz) {
       T s[2][2 * CX];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restri
   const TapN<CX + 2> tx = tapn<CX + 2>(jx0, cnx);
   const TapN<3> ty = tapn<3>(jy, cny);
   T v[2][3][CX + 2];
-  load_plane<T, CX>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[0]);
+  load_plane_shared<T, CX>(coarse, z0, cnz, cplane, cnx, ty, tx, cscale, v[0], a.tx, jx0);
   const T r16 = T(1) / T(16), r32 = T(1) / T(32);
   for (int jz = z0; jz < z1; ++jz) {
     const bool odd = jz + 1 < cnz;  // the last coarse plane has no fine plane above it
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_n(const T* __restri
       load_add<T, CX>(add, fbase, fnx, ad[0], a.nt);
       if (odd) load_add<T, CX>(add, fbase + fplane, fnx, ad[1], a.nt);
     }
-    if (odd) load_plane<T, CX>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[1]);
+    if (odd) load_plane_shared<T, CX>(coarse, jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[1], a.tx, jx0);
     T s[2][2 * CX];
     zero_plane<T, CX>(s);
     acc_plane<T, CX>(s, v[0], 1);
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
   T v[CNT0][3][3][CX + 2];
 #pragma unroll
   for (int r0 = 0; r0 < CNT0; ++r0) {
-    load_plane<T, CX>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0]);
-    load_plane<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1]);
+    load_plane_shared<T, CX>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0], a.tx, jx0);
+    load_plane_shared<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1], a.tx, jx0);
   }
   const T rs = T(1) / T(64 * cnt0);
   for (int jz = z0; jz < z1; ++jz) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
       load_add<T, CX>(add, fbase + fplane, fnx, ad[1], a.nt);
     }
 #pragma unroll
-    for (int r0 = 0; r0 < CNT0; ++r0) load_plane<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2]);
+    for (int r0 = 0; r0 < CNT0; ++r0) load_plane_shared<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2], a.tx, jx0);
 #pragma unroll
     for (int sz = 0; sz < 2; ++sz) {
       T s[2][2 * CX];
