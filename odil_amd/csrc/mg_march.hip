@@ -502,24 +502,25 @@ constexpr int kTilePacks = kTileR * (kTileC / 2);                       // packs
 constexpr int kTileLoads = (kTilePacks + kBlock - 1) / kBlock;          // per thread and plane
 static_assert(kTileY * kTileX == kBlock, "one thread per coarse column of the tile");
 
-template <typename T>
+template <typename T, int CX = 1>
 struct TileVec {
-  typedef T type __attribute__((ext_vector_type(2)));
+  typedef T type __attribute__((ext_vector_type(2 * CX)));  // the fine cells under CX coarse columns
 };
 
 // This thread's packs of the fine planes fz0, fz0 + 1 (clamped into the array: planes beyond it carry
 // zero weights), issued back to back.
-template <typename T>
+template <typename T, int CX = 1>
 __device__ __forceinline__ void tile_fetch(const T* __restrict__ gfine, int fz0, int fnz, int64_t fplane,
                                            const int64_t (&src)[kTileLoads],
-                                           typename TileVec<T>::type (&pre)[2][kTileLoads]) {
+                                           typename TileVec<T, CX>::type (&pre)[2][kTileLoads]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     int fz = fz0 + q;
     fz = fz < 0 ? 0 : (fz >= fnz ? fnz - 1 : fz);
     const T* gp = gfine + (int64_t)fz * fplane;
 #pragma unroll
-    for (int i = 0; i < kTileLoads; ++i) pre[q][i] = *reinterpret_cast<const typename TileVec<T>::type*>(gp + src[i]);
+    for (int i = 0; i < kTileLoads; ++i)
+      pre[q][i] = *reinterpret_cast<const typename TileVec<T, CX>::type*>(gp + src[i]);
   }
 }
 
@@ -537,79 +538,133 @@ struct TileCtx {
   T scale;
 };
 
+// Weight tables of a thread parked in LDS: entry e of thread t at wt[e * kBlock + t] (conflict-free), order
+// ay.wc, ay.wr, then wc, wr of each column.
+template <int CX>
+__device__ __forceinline__ void tile_tables_store(float* __restrict__ wt, const Adj6& ay, const Adj6 (&ax)[CX]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    wt[i * kBlock + threadIdx.x] = ay.wc[i];
+    wt[(6 + i) * kBlock + threadIdx.x] = ay.wr[i];
+#pragma unroll
+    for (int cc = 0; cc < CX; ++cc) {
+      wt[(12 + 12 * cc + i) * kBlock + threadIdx.x] = ax[cc].wc[i];
+      wt[(18 + 12 * cc + i) * kBlock + threadIdx.x] = ax[cc].wr[i];
+    }
+  }
+}
+template <int CX>
+__device__ __forceinline__ void tile_tables_load(const float* __restrict__ wt, Adj6& ay, Adj6 (&ax)[CX]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    ay.wc[i] = wt[i * kBlock + threadIdx.x];
+    ay.wr[i] = wt[(6 + i) * kBlock + threadIdx.x];
+#pragma unroll
+    for (int cc = 0; cc < CX; ++cc) {
+      ax[cc].wc[i] = wt[(12 + 12 * cc + i) * kBlock + threadIdx.x];
+      ax[cc].wr[i] = wt[(18 + 12 * cc + i) * kBlock + threadIdx.x];
+    }
+  }
+}
+
 // Reduce the staged pair of fine planes 2 (z0 - 1 + k), + 1 over this thread's (y, x) window, slide it into
 // the z-window and, from k = 2 on, emit coarse plane z0 + k - 2 (with the optional Adam update of that level).
 // Away from the walls the weights are the constants (1, 3, 3, 1) / 4 per axis and the C and R sums coincide;
 // the weight tables of the two columns / rows next to a wall are formed where they are needed instead of
 // being carried in registers (24 VGPRs in double).  Zero-weight terms are skipped: the sums keep their bits.
-template <typename T>
-__device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c, const typename TileVec<T>::type* __restrict__ tile0,
-                                                 const typename TileVec<T>::type* __restrict__ tile1, int k, bool live,
-                                                 T (&wc)[1][6], T (&wr)[1][6], const AdamArgs<T>& ad) {
-  typedef typename TileVec<T>::type P2;
+template <typename T, int CX = 1>
+__device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
+                                                 const typename TileVec<T, CX>::type* __restrict__ tile0,
+                                                 const typename TileVec<T, CX>::type* __restrict__ tile1, int k,
+                                                 bool live, T (&wc)[CX][6], T (&wr)[CX][6], const AdamArgs<T>& ad,
+                                                 const float* __restrict__ wt = nullptr) {
+  typedef typename TileVec<T, CX>::type P2;
+  constexpr int NV = 2 * CX;
   const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
-  T c2[2][1], r2[2][1];
+  T c2[2][CX], r2[2][CX];
   const bool xy_special = c.sx || c.sy;
   if (xy_special) {
-    Adj6 ax[1];
-    column_taps<1>(c.jx, c.cnx, ax);
-    const Adj6 ay = adj6(c.jy, c.cny);
+    // weight tables of this thread: from the LDS copy made at kernel start when there is one (tiles with a
+    // wall send every wave through this branch, and forming three tables costs more than the reduction)
+    Adj6 ax[CX], ay;
+    if (wt) {
+      tile_tables_load<CX>(wt, ay, ax);
+      ay.special = c.sy;
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) ax[cc].special = c.jx + cc < 2 || c.jx + cc >= c.cnx - 2;
+    } else {
+      column_taps<CX>(c.jx, c.cnx, ax);
+      ay = adj6(c.jy, c.cny);
+    }
     // one plane at a time keeps the register count down (the 6-row window)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const P2* tq = q == 0 ? tile0 : tile1;
       const int f1[1] = {f2[q]};
-      T c1[1][1], r1[1][1];
-      PackN<T, 2> g[1][6][3];
+      T c1[1][CX], r1[1][CX];
+      PackN<T, NV> g[1][6][3];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
           const P2 t = tq[(2 * c.ly + r) * (kTileC / 2) + c.lx + w];
-          g[0][r][w].e[0] = t[0], g[0][r][w].e[1] = t[1];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) g[0][r][w].e[e] = t[e];
         }
-      reduce_loaded<T, 1, 6, 1>(g, f1, c.fnz, ay, ax, c1, r1);
-      c2[q][0] = c1[0][0];
-      r2[q][0] = r1[0][0];
+      reduce_loaded<T, CX, 6, 1>(g, f1, c.fnz, ay, ax, c1, r1);
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) c2[q][cc] = c1[0][cc], r2[q][cc] = r1[0][cc];
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const P2* tq = q == 0 ? tile0 : tile1;
-      T sc = T(0);
+      const bool inside = f2[q] >= 0 && f2[q] < c.fnz;
+      T sc[CX];
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) sc[cc] = T(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const P2* row = tq + (2 * c.ly + 1 + r) * (kTileC / 2) + c.lx;
-        const P2 g0 = row[0], g1 = row[1], g2 = row[2];
-        T xc = T(0);
-        xc = xc + T(0.25) * g0[1];
-        xc = xc + T(0.75) * g1[0];
-        xc = xc + T(0.75) * g1[1];
-        xc = xc + T(0.25) * g2[0];
-        sc = sc + T((r == 0 || r == 3) ? 0.25 : 0.75) * xc;
+        const P2 g[3] = {row[0], row[1], row[2]};
+#pragma unroll
+        for (int cc = 0; cc < CX; ++cc) {
+          // window entries 2 CX - 2 + 2 cc + (1 .. 4) of the three packs, weights (1, 3, 3, 1) / 4
+          const int e0 = NV - 2 + 2 * cc + 1;
+          T xc = T(0);
+          xc = xc + T(0.25) * g[e0 / NV][e0 % NV];
+          xc = xc + T(0.75) * g[(e0 + 1) / NV][(e0 + 1) % NV];
+          xc = xc + T(0.75) * g[(e0 + 2) / NV][(e0 + 2) % NV];
+          xc = xc + T(0.25) * g[(e0 + 3) / NV][(e0 + 3) % NV];
+          sc[cc] = sc[cc] + T((r == 0 || r == 3) ? 0.25 : 0.75) * xc;
+        }
       }
-      const bool inside = f2[q] >= 0 && f2[q] < c.fnz;
-      c2[q][0] = r2[q][0] = inside ? sc : T(0);
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) c2[q][cc] = r2[q][cc] = inside ? sc[cc] : T(0);
     }
   }
-  put2<T, 1>(wc, wr, 4, c2, r2);  // always the last two slots (a static position: no register indexing)
+  put2<T, CX>(wc, wr, 4, c2, r2);  // always the last two slots (a static position: no register indexing)
   if (k >= 2 && c.owner && live) {
     const int jz = c.z0 + k - 2;
-    const T v = combine_z<T>(wc[0], wr[0], jz, c.cnz, c.fnz, xy_special, c.cut_lo, c.cut_hi);
-    emit_coarse<T>(c.gcoarse, c.gscaled, (int64_t)jz * c.cplane + (int64_t)c.jy * c.cnx + c.jx, v, c.scale, ad);
+    const int64_t ci = (int64_t)jz * c.cplane + (int64_t)c.jy * c.cnx + c.jx;
+#pragma unroll
+    for (int cc = 0; cc < CX; ++cc) {
+      const T v = combine_z<T>(wc[cc], wr[cc], jz, c.cnz, c.fnz, xy_special, c.cut_lo, c.cut_hi);
+      emit_coarse<T>(c.gcoarse, c.gscaled, ci + cc, v, c.scale, ad);
+    }
   }
-  slide<T, 1>(wc, wr);
+  slide<T, CX>(wc, wr);
 }
 
 // One pair of fine planes (2 (z0 - 1 + k), + 1): publish the staged packs, refill the staging registers
 // with the pair `ahead` steps later, reduce this pair from LDS, and from k = 2 on emit coarse plane
 // z0 + k - 2.  `live` is false for the padding step of an odd pair count (barriers only).
-template <typename T>
-__device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec<T>::type* __restrict__ tile0,
-                                           typename TileVec<T>::type* __restrict__ tile1, int k, int ahead, bool live,
-                                           const int64_t (&src)[kTileLoads],
-                                           typename TileVec<T>::type (&pre)[2][kTileLoads], T (&wc)[1][6],
-                                           T (&wr)[1][6], const AdamArgs<T>& ad) {
+template <typename T, int CX = 1>
+__device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec<T, CX>::type* __restrict__ tile0,
+                                           typename TileVec<T, CX>::type* __restrict__ tile1, int k, int ahead,
+                                           bool live, const int64_t (&src)[kTileLoads],
+                                           typename TileVec<T, CX>::type (&pre)[2][kTileLoads], T (&wc)[CX][6],
+                                           T (&wr)[CX][6], const AdamArgs<T>& ad, const float* __restrict__ wt) {
   __syncthreads();  // the previous pair has been consumed
 #pragma unroll
   for (int i = 0; i < kTileLoads; ++i) {
@@ -619,19 +674,22 @@ __device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec
   __syncthreads();
   // (unconditional: past the last pair it re-reads clamped planes, which keeps the staging registers out
   // of scratch memory)
-  tile_fetch<T>(c.gfine, 2 * (c.z0 - 1 + k + ahead), c.fnz, c.fplane, src, pre);
-  tile_reduce_emit<T>(c, tile0, tile1, k, live, wc, wr, ad);
+  tile_fetch<T, CX>(c.gfine, 2 * (c.z0 - 1 + k + ahead), c.fnz, c.fplane, src, pre);
+  tile_reduce_emit<T, CX>(c, tile0, tile1, k, live, wc, wr, ad, wt);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict__ gfine,
-                                                                             T* __restrict__ gcoarse,
-                                                                             T* __restrict__ gscaled, MarchArgs a,
-                                                                             T scale, AdamArgs<T> ad) {
-  typedef typename TileVec<T>::type P2;  // a native vector type: staged values stay in registers
+// CX coarse columns per thread: 1, or 2 for float so that every LDS / global access is 16 B per lane (the
+// float kernel with one column ran at 1.8 TB/s on the space part of the 4-D tracer transposes).
+template <typename T, int CX>
+__global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict__ gfine, T* __restrict__ gcoarse,
+                                                            T* __restrict__ gscaled, MarchArgs a, T scale,
+                                                            AdamArgs<T> ad) {
+  typedef typename TileVec<T, CX>::type P2;  // a native vector type: staged values stay in registers
+  constexpr int NV = 2 * CX;
   // flat, row-major over (row, pack); padded to a whole number of packs per thread so that loads and
   // LDS writes need no guards (the surplus packs re-read pack 0 and land behind the tile)
   __shared__ P2 tile[2][kTileLoads * kBlock];
+  __shared__ float wtab[12 * (CX + 1) * kBlock];  // weight tables of the threads next to a wall
   const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
   int zc, yt, xt;
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
@@ -648,32 +706,40 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   c.z0 = zc * a.usched.ZC;
   const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
   c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
-  c.jy = yt * kTileY + c.ly, c.jx = xt * kTileX + c.lx;
-  c.owner = c.jy < cny && c.jx < c.cnx;
+  c.jy = yt * kTileY + c.ly, c.jx = (xt * kTileX + c.lx) * CX;  // first of this thread's CX columns
+  c.owner = c.jy < cny && c.jx < c.cnx;  // (CX = 2 needs an even cnx: both columns exist or neither)
   c.cny = cny;
-  c.sx = c.owner && (c.jx < 2 || c.jx >= c.cnx - 2);
+  c.sx = c.owner && (c.jx < 2 || c.jx + CX - 1 >= c.cnx - 2);
   c.sy = c.owner && (c.jy < 2 || c.jy >= cny - 2);
-  // this thread's share of a staged plane: packs p = threadIdx.x + k kBlock of the tile, row-major
+  if (c.sx || c.sy) {  // (read back by the same thread only: no barrier needed)
+    Adj6 ax[CX];
+    column_taps<CX>(c.jx, c.cnx, ax);
+    tile_tables_store<CX>(wtab, adj6(c.jy, cny), ax);
+  }
+  // this thread's share of a staged plane: packs p = threadIdx.x + k kBlock of the tile, row-major; the window
+  // of a row starts 2 CX fine cells left of the tile (pack aligned; 2 are needed)
   int64_t src[kTileLoads];
 #pragma unroll
   for (int k = 0; k < kTileLoads; ++k) {
     const int p = threadIdx.x + k * kBlock;
     const int r = p < kTilePacks ? p / (kTileC / 2) : 0, cc = p < kTilePacks ? p - r * (kTileC / 2) : 0;
-    int fy = 2 * yt * kTileY - 2 + r, fx = 2 * xt * kTileX - 2 + 2 * cc;
+    int fy = 2 * yt * kTileY - 2 + r, fx = NV * (xt * kTileX - 1 + cc);
     fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);
-    fx = fx < 0 ? 0 : (fx >= fnx ? fnx - 2 : fx);
+    fx = fx < 0 ? 0 : (fx >= fnx ? fnx - NV : fx);
     src[k] = (int64_t)fy * fnx + fx;
   }
-  T wc[1][6], wr[1][6];
+  T wc[CX][6], wr[CX][6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) wc[0][i] = wr[0][i] = T(0);
+  for (int cc = 0; cc < CX; ++cc)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wc[cc][i] = wr[cc][i] = T(0);
   // pairs of fine planes 2 (z0 - 1 + k), + 1 for k = 0 .. z1 - z0 + 1 (the first two prime the window); the
   // next pair is in flight while one is reduced.  (Two pairs ahead in two register sets: 256 VGPRs, no
   // faster -- 452 vs 448 us; three waves per SIMD spill and take 630 us.)
   const int npairs = z1 - c.z0 + 2;
   P2 pre[2][kTileLoads];
-  tile_fetch<T>(gfine, 2 * (c.z0 - 1), c.fnz, c.fplane, src, pre);
-  for (int k = 0; k < npairs; ++k) tile_stage<T>(c, tile[0], tile[1], k, 1, true, src, pre, wc, wr, ad);
+  tile_fetch<T, CX>(gfine, 2 * (c.z0 - 1), c.fnz, c.fplane, src, pre);
+  for (int k = 0; k < npairs; ++k) tile_stage<T, CX>(c, tile[0], tile[1], k, 1, true, src, pre, wc, wr, ad, wtab);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1049,6 +1115,18 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
 }
 
 // ODIL_ADJ_TILE=0 keeps the register-window kernel on every level (read per call: the tests compare both)
+template <typename T>
+static void launch_adj_tile(dim3 grid, bool wide, hipStream_t stream, const T* gfine, T* gcoarse, T* gscaled,
+                            const MarchArgs& m, T scale, const AdamArgs<T>& ad) {
+  if constexpr (sizeof(T) == 4) {
+    if (wide) {
+      hipLaunchKernelGGL((k_interp_adj_tile<T, 2>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale, ad);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_interp_adj_tile<T, 1>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale, ad);
+}
+
 static bool adj_tile_enabled() {
   const char* e = getenv("ODIL_ADJ_TILE");
   return !e || atoi(e) != 0;
@@ -1063,18 +1141,22 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
   const bool tile_ok = CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled();
+  // float: two coarse columns per thread (16 B per lane everywhere) when the rows allow it
+  const bool tile_wide = sizeof(T) == 4 && m.cn[2] % 2 == 0 && m.cn[2] >= 4 * kTileX && aligned_to(gfine, 16);
+  const int tile_cols = kTileX * (tile_wide ? 2 : 1);
   if (m.lead_fn != 1) {
     if (m.lead_loc == kNode)
       hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 3>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
                          m, scale, ad);
     else if (tile_ok) {
       // batch of large all-cell volumes: the LDS-staged kernel, one volume per blockIdx.y
-      const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
+      const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + tile_cols - 1) / tile_cols;
       m.tx = kTileX;
       m.ty = kTileY;
-      m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, ODIL_ADJ_UNITS_SMALL);
-      hipLaunchKernelGGL((k_interp_adj_tile<T>), dim3(unit_grid(m.usched), m.lead_cn), dim3(kBlock), 0, stream, gfine,
-                         gcoarse, gscaled, m, scale, ad);
+      // the batch supplies the parallelism: long chunks (every chunk primes its window with two extra pairs of planes)
+      const int64_t per_volume = kGridCap / m.lead_cn > 2 * ytiles * xtiles ? kGridCap / m.lead_cn : 2 * ytiles * xtiles;
+      m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, per_volume);
+      launch_adj_tile<T>(dim3(unit_grid(m.usched), m.lead_cn), tile_wide, stream, gfine, gcoarse, gscaled, m, scale, ad);
     } else
       hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
                          m, scale, ad);
@@ -1083,12 +1165,11 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
                        ad);
   else if (tile_ok) {
     // large all-cell levels: fine planes staged through LDS
-    const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
+    const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + tile_cols - 1) / tile_cols;
     m.tx = kTileX;
     m.ty = kTileY;
     m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_TILE_UNITS);
-    hipLaunchKernelGGL((k_interp_adj_tile<T>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, gfine, gcoarse,
-                       gscaled, m, scale, ad);
+    launch_adj_tile<T>(dim3(unit_grid(m.usched)), tile_wide, stream, gfine, gcoarse, gscaled, m, scale, ad);
   } else
     hipLaunchKernelGGL((k_interp_adj_march<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
