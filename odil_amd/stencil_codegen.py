@@ -223,6 +223,18 @@ class _Codegen:
     def i(self, n):
         return self.ex(n) if n.kind == _I else "((long){})".format(self.ex(n))
 
+    def over(self, num, den):
+        """`num / den` -- as a multiplication when `den` is a constant power of two (grid steps of 2^k cells:
+        bit-identical, and a float division is ~10 instructions, twenty of them per point in the tracer
+        operator)."""
+        if den.op == "const" and den.kind == _R:
+            value = float(den.attr)
+            if value != 0.0 and math.isfinite(value):
+                mant, exp = math.frexp(abs(value))
+                if mant == 0.5 and -100 < exp < 100:
+                    return "{} * {}".format(num, _lit(1.0 / value, _R))
+        return "{} / {}".format(num, self.r(den))
+
     def b(self, n):
         return self.ex(n) if n.kind == _B else "({} != 0)".format(self.ex(n))
 
@@ -346,7 +358,7 @@ class _Codegen:
                 sym = {"add": "+", "sub": "-", "mul": "*"}[op]
                 self.emit(v + "{} {} {};".format(self.typed(A[0], n.kind), sym, self.typed(A[1], n.kind)))
             elif op == "div":
-                self.emit(v + "{} / {};".format(self.r(A[0]), self.r(A[1])))
+                self.emit(v + self.over(self.r(A[0]), A[1]) + ";")
             elif op == "pow":
                 if A[1].op == "const" and float(A[1].attr) == 2.0:
                     self.emit(v + "{0} * {0};".format(self.r(A[0])))
@@ -440,8 +452,8 @@ class _Codegen:
                 acc(A[0], "{} * {}".format(g, self.r(A[1])))
                 acc(A[1], "{} * {}".format(g, self.r(A[0])))
             elif op == "div":
-                acc(A[0], "{} / {}".format(g, self.r(A[1])))
-                acc(A[1], "-({} * {}) / {}".format(g, v, self.r(A[1])))
+                acc(A[0], self.over(g, A[1]))
+                acc(A[1], self.over("-({} * {})".format(g, v), A[1]))
             elif op == "pow":
                 x, p = self.r(A[0]), self.r(A[1])
                 if A[1].op == "const" and float(A[1].attr) == 2.0:
