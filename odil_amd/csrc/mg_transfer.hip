@@ -186,6 +186,47 @@ __global__ __launch_bounds__(kBlock) void k_restrict(const T* __restrict__ fine,
   }
 }
 
+// Restriction of all-cell layouts ('c', 'cc', 'ccc', 'cccc'): mean of the 2^d fine cells.  A lane reads
+// its pair of fine x-neighbours as ONE pack per fine row (the generic kernel issues one-element loads at
+// stride 2: 0.7 TB/s at 512^3); the sum runs in the generic kernel's order with its weights, so the
+// results are bit-identical.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_restrict_cells(const T* __restrict__ fine, T* __restrict__ coarse,
+                                                           InterpArgs a) {
+  typedef T P2 __attribute__((ext_vector_type(2)));
+  const int64_t fs2 = a.fn[3], fs1 = a.fn[2] * fs2, fs0 = a.fn[1] * fs1;
+  const int64_t rows = a.cn[0] * a.cn[1] * a.cn[2];
+  const int64_t per_row = (a.cn[3] + kBlock - 1) / kBlock;
+  const int n0 = a.loc[0] == kCell ? 2 : 1, n1 = a.loc[1] == kCell ? 2 : 1, n2 = a.loc[2] == kCell ? 2 : 1;
+  const T w = T((n0 == 2 ? 0.5f : 1.f) * (n1 == 2 ? 0.5f : 1.f) * (n2 == 2 ? 0.5f : 1.f) * 0.5f);
+  for (int64_t u = blockIdx.x; u < rows * per_row; u += gridDim.x) {
+    const int64_t row = u / per_row, c3 = (u - row * per_row) * kBlock + threadIdx.x;
+    if (c3 >= a.cn[3]) continue;
+    const int64_t c2 = row % a.cn[2], r1 = row / a.cn[2], c1 = r1 % a.cn[1], c0 = r1 / a.cn[1];
+    const T* base = fine + (n0 * c0) * fs0 + (n1 * c1) * fs1 + (n2 * c2) * fs2 + 2 * c3;
+    P2 v[2][2][2];
+#pragma unroll
+    for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+      for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          if (i0 < n0 && i1 < n1 && i2 < n2) v[i0][i1][i2] = *reinterpret_cast<const P2*>(base + i0 * fs0 + i1 * fs1 + i2 * fs2);
+    T acc = T(0);
+#pragma unroll
+    for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+      for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          if (i0 < n0 && i1 < n1 && i2 < n2) {
+            acc = acc + w * v[i0][i1][i2][0];
+            acc = acc + w * v[i0][i1][i2][1];
+          }
+    coarse[row * a.cn[3] + c3] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // R^T (cotangent of the restriction; `poisson --mgloss` differentiates through R).  Gather
 // form per FINE element K: per axis the coarse taps (j, w) with 2j + t (- 1 on 'n' axes) = q for
@@ -408,6 +449,14 @@ static int restrict_(const T* fine, T* coarse, const int64_t* fshape, int ndim, 
   if (!fine || !coarse) {
     set_error("restrict: null pointer");
     return ODIL_E_INVAL;
+  }
+  bool cells = a.loc[3] == kCell && a.fn[3] % 2 == 0 && (reinterpret_cast<uintptr_t>(fine) % (2 * sizeof(T))) == 0;
+  for (int i = 0; i < 3; ++i) cells = cells && ((a.loc[i] == kCell && a.fn[i] % 2 == 0) || (a.fn[i] == 1 && a.loc[i] != kNode));
+  if (cells) {
+    const int64_t units = a.cn[0] * a.cn[1] * a.cn[2] * ((a.cn[3] + kBlock - 1) / kBlock);
+    const int grid = (int)(units < 16 * kGridCap ? units : 16 * kGridCap);
+    hipLaunchKernelGGL(k_restrict_cells<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, fine, coarse, a);
+    return check_launch("k_restrict_cells");
   }
   a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_restrict<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, fine, coarse, a);
