@@ -322,10 +322,12 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
             delta = solve(matrix, -vector, args, linstatus, getattr(args, "linsolver", "direct"))
         if getattr(args, "linsolver_verbose", 0):
             printlog(linstatus)
+        from . import ops
+        from .core import Field
+
         fields = list(state.fields.values())
-        if len(fields) == 1 and type(fields[0]).__name__ == "Field" and torch.is_tensor(fields[0].array) \
+        if len(fields) == 1 and type(fields[0]) is Field and torch.is_tensor(fields[0].array) \
                 and fields[0].array.is_contiguous() and fields[0].array.numel() == delta.numel():
-            from . import ops
 
             ops.axpy(fields[0].array, delta.to(fields[0].array.dtype), 1.0)  # x += delta in place (util.py:176-178)
         else:
