@@ -171,15 +171,17 @@ int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* 
  * update of the finest level (x0, m0, v0; all NULL: no update, g0 required) and of the next level (x1, m1, v1;
  * optional) by the lanes that form their gradients.  g0 never makes the round trip through memory that
  * odil_poisson_adjoint_adam + odil_mg_synth_adj_adam need (reference core.py:1100 / optimizer.py:311-319);
- * results are bit-identical to that pair. */
+ * results are bit-identical to that pair.  cut_lo / cut_hi: that end of axis 0 is a slab interface with ghost
+ * planes beyond it (multi-GPU), not a wall, as in odil_interp_adj_cut. */
 int odil_poisson_adjoint_transpose_adam_f64(const double* fu, double* g0, double* g1, const int64_t* fshape,
                                             const double* h2, double scale, double* x0, double* m0, double* v0,
                                             double* x1, double* m1, double* v1, double alpha, double one_minus_b1,
-                                            double one_minus_b2, double eps, const double* alpha_dev, void* stream);
+                                            double one_minus_b2, double eps, const double* alpha_dev, int cut_lo,
+                                            int cut_hi, void* stream);
 int odil_poisson_adjoint_transpose_adam_f32(const float* fu, float* g0, float* g1, const int64_t* fshape,
                                             const float* h2, float scale, float* x0, float* m0, float* v0, float* x1,
                                             float* m1, float* v1, float alpha, float one_minus_b1, float one_minus_b2,
-                                            float eps, const float* alpha_dev, void* stream);
+                                            float eps, const float* alpha_dev, int cut_lo, int cut_hi, void* stream);
 /* One damped-Jacobi sweep of that operator: uout = u - omega (A u - rhs) / diag(A), uout != u.  The
  * smoother of the geometric multigrid that solves the Newton system of the Poisson stencil
  * (reference linsolver.py:61-72 hands that system to pyamg). */

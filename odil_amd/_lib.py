@@ -41,7 +41,8 @@ _SIGNATURES = {
     "poisson_loss_grad": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_adjoint_adam": [_P, _P, _P, _P, _P, _I64P, c_int, _P, _R, _R, _R, _R, _R, _P, _P],
-    "poisson_adjoint_transpose_adam": [_P, _P, _P, _I64P, _P, _R, _P, _P, _P, _P, _P, _P, _R, _R, _R, _R, _P, _P],
+    "poisson_adjoint_transpose_adam": [_P, _P, _P, _I64P, _P, _R, _P, _P, _P, _P, _P, _P, _R, _R, _R, _R, _P, c_int,
+                                       c_int, _P],
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
     "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P, _P],
     "axpy": [_P, _P, c_int64, _R, _P],

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   TileCtx<T> c;
   c.gfine = nullptr, c.gcoarse = gcoarse, c.gscaled = nullptr;
   c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
-  c.cut_lo = 0, c.cut_hi = 0;
+  c.cut_lo = a.cut_lo, c.cut_hi = a.cut_hi;
   c.cplane = (int64_t)cny * c.cnx, c.fplane = (int64_t)fny * fnx;
   c.scale = T(1);
   c.z0 = zc * a.usched.ZC;
@@ -854,44 +854,13 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
     __syncthreads();
     fu_fetch<T>(fu, zA + 3, c.fnz, c.fplane, src, pre);  // next pair of fu planes in flight
     // One plane at a time.  The update of the finest level runs one plane behind the plane whose g0 is
-    // being formed: its loads (x, m, v of the own cells) are issued at the end of a step and consumed at
-    // the end of the next one, so they have a whole step to arrive (gt keeps two planes).
+    // being formed: its loads (x, m, v of the own cells) are issued before g0 of its plane is formed and
+    // consumed at the start of the next step, so they have a whole step to arrive (gt keeps two planes).
 #pragma unroll 1
     for (int q = 0; q < 2; ++q) {
       const int z = zA + q;
-      const P2* pm = ring + ((z - 1 + 8) & 3) * kFuPacks;
-      const P2* pc = ring + ((z + 8) & 3) * kFuPacks;
-      const P2* pp = ring + ((z + 1 + 8) & 3) * kFuPacks;
-      P2* gq = gt[q];
-#pragma unroll 1
-      for (int i = 0; i < kTileLoads; ++i) {
-        const int p = threadIdx.x + i * kBlock;
-        if (p < kTilePacks) {
-          const int r = p / kGC, cc = p - r * kGC;
-          const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
-          const int at = (r + 1) * kFuC + cc + 1;  // the same cells in the fu window
-          P2 g;
-          g[0] = T(0), g[1] = T(0);
-          if (z >= 0 && z < c.fnz && y >= 0 && y < fny && x >= 0 && x < fnx) {
-            const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
-            const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              // the expression of k_poisson_adjoint, term by term
-              const T fb = scale * fc[e];
-              T acc = T(0);
-              acc = acc + adj_axis<T>(fb, scale * fzm[e], scale * fzp[e], z, c.fnz, h, 0);
-              acc = acc + adj_axis<T>(fb, scale * fym[e], scale * fyp[e], y, fny, h, 1);
-              const T xm = scale * (e == 0 ? fl[1] : fc[0]);
-              const T xp = scale * (e == 0 ? fc[1] : fr[0]);
-              acc = acc + adj_axis<T>(fb, xm, xp, x + e, fnx, h, 2);
-              g[e] = acc;
-            }
-          }
-          gq[p] = g;
-        }
-      }
-      __syncthreads();
+      // (the update of plane z - 1 comes BEFORE plane z is formed: its readers of gt are then separated from
+      // the next writer of that half by this step's barrier)
       if (pending) {  // plane z - 1: its g0 is in the other half of gt
         const P2* gprev = gt[q ^ 1];
 #pragma unroll
@@ -926,6 +895,42 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           vv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.v + off));
         }
       }
+      const P2* pm = ring + ((z - 1 + 8) & 3) * kFuPacks;
+      const P2* pc = ring + ((z + 8) & 3) * kFuPacks;
+      const P2* pp = ring + ((z + 1 + 8) & 3) * kFuPacks;
+      P2* gq = gt[q];
+      // slab interfaces (ghost planes beyond them, multi-GPU): the transposed stencil has its interior rows
+      // there -- the wall rows of adj_axis sit two planes inside an end that is a wall
+      const int zj = z + (c.cut_lo ? 2 : 0), zn = c.fnz + (c.cut_lo ? 2 : 0) + (c.cut_hi ? 2 : 0);
+#pragma unroll 1
+      for (int i = 0; i < kTileLoads; ++i) {
+        const int p = threadIdx.x + i * kBlock;
+        if (p < kTilePacks) {
+          const int r = p / kGC, cc = p - r * kGC;
+          const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
+          const int at = (r + 1) * kFuC + cc + 1;  // the same cells in the fu window
+          P2 g;
+          g[0] = T(0), g[1] = T(0);
+          if (z >= 0 && z < c.fnz && y >= 0 && y < fny && x >= 0 && x < fnx) {
+            const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
+            const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              // the expression of k_poisson_adjoint, term by term
+              const T fb = scale * fc[e];
+              T acc = T(0);
+              acc = acc + adj_axis<T>(fb, scale * fzm[e], scale * fzp[e], zj, zn, h, 0);
+              acc = acc + adj_axis<T>(fb, scale * fym[e], scale * fyp[e], y, fny, h, 1);
+              const T xm = scale * (e == 0 ? fl[1] : fc[0]);
+              const T xp = scale * (e == 0 ? fc[1] : fr[0]);
+              acc = acc + adj_axis<T>(fb, xm, xp, x + e, fnx, h, 2);
+              g[e] = acc;
+            }
+          }
+          gq[p] = g;
+        }
+      }
+      __syncthreads();
     }
     tile_reduce_emit<T>(c, gt[0], gt[1], k, true, wc, wr, ad1);
   }
@@ -1179,7 +1184,8 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
 
 template <typename T>
 int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, const T* h2, T scale,
-                              const AdamArgs<T>& ad0, const AdamArgs<T>& ad1, hipStream_t stream) {
+                              const AdamArgs<T>& ad0, const AdamArgs<T>& ad1, int cut_lo, int cut_hi,
+                              hipStream_t stream) {
   if (!fu || !g1 || !fshape || !h2) {
     set_error("poisson_adjoint_transpose: null pointer (fu, g1, shape, h2)");
     return ODIL_E_INVAL;
@@ -1200,7 +1206,7 @@ int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, 
       return ODIL_E_INVAL;
     }
   m.tx = kTileX, m.ty = kTileY;
-  m.cut_lo = m.cut_hi = 0;
+  m.cut_lo = cut_lo, m.cut_hi = cut_hi;
   m.nt = 0;
   m.lead_loc = 0, m.lead_cn = 1, m.lead_fn = 1;
   const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + kTileX - 1) / kTileX;
@@ -1222,9 +1228,9 @@ int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, 
 }
 
 template int poisson_adjoint_transpose<double>(const double*, double*, double*, const int64_t*, const double*, double,
-                                               const AdamArgs<double>&, const AdamArgs<double>&, hipStream_t);
+                                               const AdamArgs<double>&, const AdamArgs<double>&, int, int, hipStream_t);
 template int poisson_adjoint_transpose<float>(const float*, float*, float*, const int64_t*, const float*, float,
-                                              const AdamArgs<float>&, const AdamArgs<float>&, hipStream_t);
+                                              const AdamArgs<float>&, const AdamArgs<float>&, int, int, hipStream_t);
 
 template <typename T>
 int interp_add_march(const T* coarse, const T* add, T* fine, const InterpArgs& a, T cscale, T ascale,
@@ -1258,17 +1264,18 @@ extern "C" {
 int odil_poisson_adjoint_transpose_adam_f64(const double* fu, double* g0, double* g1, const int64_t* fshape,
                                             const double* h2, double scale, double* x0, double* m0, double* v0,
                                             double* x1, double* m1, double* v1, double alpha, double one_minus_b1,
-                                            double one_minus_b2, double eps, const double* alpha_dev, void* stream) {
+                                            double one_minus_b2, double eps, const double* alpha_dev, int cut_lo,
+                                            int cut_hi, void* stream) {
   const AdamArgs<double> a0{x0, m0, v0, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
   const AdamArgs<double> a1{x1, m1, v1, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
-  return poisson_adjoint_transpose<double>(fu, g0, g1, fshape, h2, scale, a0, a1, (hipStream_t)stream);
+  return poisson_adjoint_transpose<double>(fu, g0, g1, fshape, h2, scale, a0, a1, cut_lo, cut_hi, (hipStream_t)stream);
 }
 int odil_poisson_adjoint_transpose_adam_f32(const float* fu, float* g0, float* g1, const int64_t* fshape,
                                             const float* h2, float scale, float* x0, float* m0, float* v0, float* x1,
                                             float* m1, float* v1, float alpha, float one_minus_b1, float one_minus_b2,
-                                            float eps, const float* alpha_dev, void* stream) {
+                                            float eps, const float* alpha_dev, int cut_lo, int cut_hi, void* stream) {
   const AdamArgs<float> a0{x0, m0, v0, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
   const AdamArgs<float> a1{x1, m1, v1, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev};
-  return poisson_adjoint_transpose<float>(fu, g0, g1, fshape, h2, scale, a0, a1, (hipStream_t)stream);
+  return poisson_adjoint_transpose<float>(fu, g0, g1, fshape, h2, scale, a0, a1, cut_lo, cut_hi, (hipStream_t)stream);
 }
 }

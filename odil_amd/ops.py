@@ -362,9 +362,10 @@ def adjoint_transpose_supported(shape):
 
 
 def poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=None, adam1=None, alpha=0.0, one_minus_b1=0.0,
-                              one_minus_b2=0.0, eps=0.0):
+                              one_minus_b2=0.0, eps=0.0, cut=(False, False)):
     """g0 = J^T (scale * fu) (stored only if `g0` is given), g1 = P^T g0, and the Adam steps of the finest level
-    (adam0 = (x, m, v)) and of the next one (adam1) inside the same launch: g0 never goes through memory."""
+    (adam0 = (x, m, v)) and of the next one (adam1) inside the same launch: g0 never goes through memory.
+    cut=(lo, hi): that end of axis 0 is a slab interface (ghost planes), not a wall."""
     assert fu.dim() == 3 and tuple(g1.shape) == tuple(n // 2 for n in fu.shape) and fu.is_contiguous()
     h2a, h2p = host_reals(h2, fu.dtype)
     a, adev = _step_size(alpha, fu.dtype)
@@ -375,7 +376,7 @@ def poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=None, adam1=None
     call(
         "poisson_adjoint_transpose_adam", fu.dtype, ptr(fu), ptr(g0), ptr(g1), i64(fu.shape), h2p, float(scale),
         ptr(a0[0]), ptr(a0[1]), ptr(a0[2]), ptr(a1[0]), ptr(a1[1]), ptr(a1[2]), a, float(one_minus_b1),
-        float(one_minus_b2), float(eps), adev, stream_ptr(),
+        float(one_minus_b2), float(eps), adev, c_int(1 if cut[0] else 0), c_int(1 if cut[1] else 0), stream_ptr(),
     )
     return g1
 

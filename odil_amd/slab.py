@@ -113,6 +113,9 @@ class SlabPoissonAdam:
         self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
         self.t = 0
         self.scale = self.npdt(2) / self.npdt(self.global_cells)
+        import os
+
+        self.fuse_transpose = bool(int(os.environ.get("ODIL_FUSE_TRANSPOSE", 1)))
 
     @property
     def u(self):
@@ -121,31 +124,31 @@ class SlabPoissonAdam:
         return self._u
 
     # ---- plane packing -----------------------------------------------------------------
-    def _pack(self, arrays, levels, side):
-        """First (side 'lo') or last ('hi') OWNED plane of each array, concatenated; None at a wall."""
+    def _pack(self, arrays, levels, side, depth=1):
+        """The first (side 'lo') or last ('hi') `depth` OWNED planes of each array, concatenated; None at a wall."""
         if (side == "lo" and self.rank == 0) or (side == "hi" and self.rank == self.world - 1):
             return None
         parts = []
         for a, lv in zip(arrays, levels):
-            k = lv.g_lo if side == "lo" else lv.g_lo + lv.nz - 1
-            parts.append(a[k].reshape(-1))
+            k = lv.g_lo if side == "lo" else lv.g_lo + lv.nz - depth
+            parts.append(a[k : k + depth].reshape(-1))
         return torch.cat(parts) if len(parts) > 1 else parts[0].clone()
 
-    def _unpack(self, buf, arrays, levels, side):
-        """Received planes -> the INNER ghost plane on `side` of each array."""
+    def _unpack(self, buf, arrays, levels, side, depth=1):
+        """Received planes -> the `depth` ghost planes next to the owned ones on `side` of each array."""
         if buf is None:
             return
         off = 0
         for a, lv in zip(arrays, levels):
-            k = lv.g_lo - 1 if side == "lo" else lv.g_lo + lv.nz
-            a[k].copy_(buf[off : off + lv.plane].view(lv.ny, lv.nx))
-            off += lv.plane
+            k = lv.g_lo - depth if side == "lo" else lv.g_lo + lv.nz
+            a[k : k + depth].copy_(buf[off : off + depth * lv.plane].view(depth, lv.ny, lv.nx))
+            off += depth * lv.plane
 
-    def _exchange(self, arrays, levels):
+    def _exchange(self, arrays, levels, depth=1):
         """Generator step: swap boundary planes of `arrays` with both neighbours."""
-        recv_lo, recv_hi = yield (self._pack(arrays, levels, "lo"), self._pack(arrays, levels, "hi"))
-        self._unpack(recv_lo, arrays, levels, "lo")
-        self._unpack(recv_hi, arrays, levels, "hi")
+        recv_lo, recv_hi = yield (self._pack(arrays, levels, "lo", depth), self._pack(arrays, levels, "hi", depth))
+        self._unpack(recv_lo, arrays, levels, "lo", depth)
+        self._unpack(recv_hi, arrays, levels, "hi", depth)
 
     # ---- one epoch -----------------------------------------------------------------------
     def epoch_gen(self, timers=None):
@@ -186,17 +189,38 @@ class SlabPoissonAdam:
             ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
                                  zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
         toc(b)
+        n0 = lv[0].size
+        fuse0 = hasattr(ops, "poisson_adjoint_adam")
+        # stencil adjoint + first transposed prolongation + Adam of levels 0 and 1 in one launch, as on one GPU
+        # (fused.py): the finest-level gradient is never stored, so its halo exchange disappears; the residual
+        # then needs BOTH ghost planes (g0 of the inner ghost plane reads the outer one).
+        fuse_t = (fuse0 and L >= 2 and self.fuse_transpose and hasattr(ops, "poisson_adjoint_transpose")
+                  and G >= 2 and lv[0].nz >= 2 and ops.adjoint_transpose_supported(tuple(lv[0].shape))
+                  and tuple(lv[1].inner(self.gw[1]).shape) == tuple(n // 2 for n in lv[0].shape))
         b = tic("halo")
-        yield from self._exchange([self.fu], [l0])
+        yield from self._exchange([self.fu], [l0], depth=2 if fuse_t else 1)
         toc(b)
         self.t += 1
         t = self.npdt(self.t)
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
         omb1, omb2 = 1 - self.b1, 1 - self.b2
-        n0 = lv[0].size
-        fuse0 = hasattr(ops, "poisson_adjoint_adam")
-        b = tic("adjoint")
-        if fuse0:
+        cut = (self.rank > 0, self.rank < self.world - 1)
+        first = 1  # first level whose transposed prolongation is still to do
+        if fuse_t:
+            # The interfaces are `cut` ends: interior stencil rows there, and the owned coarse planes only
+            # read fine planes whose g0 is complete (the outermost ghost plane has zero weight).
+            b = tic("adjoint_transpose")
+            ops.poisson_adjoint_transpose(
+                self.fu, self.h2, self.scale, lv[1].inner(self.gw[1]), g0=None,
+                adam0=(self.w[0], self.m[:n0].view(lv[0].shape), self.v[:n0].view(lv[0].shape)),
+                adam1=(lv[1].inner(self.w[1]), lv[1].inner(self.mw[1]), lv[1].inner(self.vw[1])),
+                alpha=alpha, one_minus_b1=omb1, one_minus_b2=omb2, eps=self.eps, cut=cut)
+            toc(b)
+            first = 2
+        b = tic("adjoint") if first == 1 else None
+        if first == 2:
+            pass
+        elif fuse0:
             # Adam of the finest level inside the adjoint launch (as on one GPU, poisson_path.py)
             ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], self.w[0],
                                      self.m[:n0].view(lv[0].shape), self.v[:n0].view(lv[0].shape), alpha, omb1, omb2,
@@ -204,13 +228,12 @@ class SlabPoissonAdam:
         else:
             ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
         toc(b)
-        for l in range(1, L):
+        for l in range(first, L):
             b = tic("halo")
             yield from self._exchange([self.gw[l - 1]], [lv[l - 1]])
             toc(b)
             b = tic("mg_synth_adj")
             cview = lv[l].inner(self.gw[l])
-            cut = (self.rank > 0, self.rank < self.world - 1)
             if fuse0 and hasattr(ops, "interp_adj_adam"):
                 ops.interp_adj_adam(self.gw[l - 1], "ccc", tuple(cview.shape), cview, lv[l].inner(self.w[l]),
                                     lv[l].inner(self.mw[l]), lv[l].inner(self.vw[l]), alpha, omb1, omb2, self.eps,

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,N", [(2, 16), (3, 8), (4, 32)])
+@pytest.mark.parametrize("world,N", [(2, 16), (3, 8), (4, 32), (2, 128), (3, 128)])  # 128: the one-launch adjoint + P^T path
 def test_emulated_ranks_equal_single_domain(world, N):
     from odil_amd import ops
     from odil_amd.fused import PoissonEvaluator
