@@ -610,6 +610,39 @@ def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine):
         assert torch.equal(a, b)
 
 
+def test_adjoint_and_transpose_in_one_launch_is_race_free(dev):
+    """The one-launch kernel hands g0 from the lanes that form it to the lanes that consume it through LDS, one
+    plane behind: a missing barrier shows as run-to-run differences on a grid with many resident workgroups.
+    Twelve runs on (64, 128, 256), slab cut ends included, must all equal the separate kernels bit for bit."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(53)
+    fine = (64, 128, 256)
+    coarse = tuple(n // 2 for n in fine)
+    h2 = [np.float64(v) for v in [0.25**2, 0.1**2, 0.3**2]]
+    scale = np.float64(2.0 / np.prod(fine))
+    fu = to(rng.standard_normal(fine), dev)
+    state0 = [to(rng.standard_normal(s), dev) for s in (fine, coarse)] + [to(rng.standard_normal(s), dev) for s in (fine, coarse)] \
+        + [to(np.abs(rng.standard_normal(s)), dev) for s in (fine, coarse)]
+
+    def clone():
+        x, m, v = [t.clone() for t in state0[0:2]], [t.clone() for t in state0[2:4]], [t.clone() for t in state0[4:6]]
+        return x, m, v
+
+    xr, mr, vr = clone()
+    gr = [torch.empty(fine, dtype=fu.dtype, device=dev), torch.empty(coarse, dtype=fu.dtype, device=dev)]
+    ops.poisson_adjoint_adam(fu, h2, scale, gr[0], xr[0], mr[0], vr[0], 0.01, 0.1, 0.001, 1e-7)
+    ops.mg_synth_adj_adam(gr[0], [fine, coarse], "ccc", gr, xr, mr, vr, 0.01, 0.1, 0.001, 1e-7)
+    for rep in range(12):
+        x, m, v = clone()
+        g1 = torch.empty(coarse, dtype=fu.dtype, device=dev)
+        ops.poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=(x[0], m[0], v[0]), adam1=(x[1], m[1], v[1]),
+                                      alpha=0.01, one_minus_b1=0.1, one_minus_b2=0.001, eps=1e-7)
+        assert torch.equal(g1, gr[1]), rep
+        for a, b in zip(x + m + v, xr + mr + vr):
+            assert torch.equal(a, b), rep
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
     """Large 'nccc' arrays take P^T = (P^T over the node axis) o (P^T over the three cell axes)
