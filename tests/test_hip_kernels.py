@@ -613,7 +613,7 @@ def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine):
 def test_adjoint_and_transpose_in_one_launch_is_race_free(dev):
     """The one-launch kernel hands g0 from the lanes that form it to the lanes that consume it through LDS, one
     plane behind: a missing barrier shows as run-to-run differences on a grid with many resident workgroups.
-    Twelve runs on (64, 128, 256), slab cut ends included, must all equal the separate kernels bit for bit."""
+    Twelve runs on (64, 128, 256) must all equal the separate kernels bit for bit."""
     from odil_amd import ops
 
     rng = np.random.default_rng(53)
