@@ -291,6 +291,36 @@ __device__ inline RAdjTaps make_radj_taps(int loc, int64_t K, int64_t n, int64_t
   return t;
 }
 
+// R^T of all-cell layouts: every fine cell receives 1 / 2^d of its coarse cell.  One coarse value per lane,
+// written as 16 B packs to its 2^(d-1) fine rows (the generic gather kernel: per-element tap tables and
+// 64-bit divisions, 0.17 TB/s at 512^3).  The single product w * g is what the generic sum reduces to.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_restrict_adj_cells(const T* __restrict__ gcoarse, T* __restrict__ gfine,
+                                                               InterpArgs a) {
+  typedef T P2 __attribute__((ext_vector_type(2)));
+  const int64_t fs2 = a.fn[3], fs1 = a.fn[2] * fs2, fs0 = a.fn[1] * fs1;
+  const int64_t rows = a.cn[0] * a.cn[1] * a.cn[2];
+  const int64_t per_row = (a.cn[3] + kBlock - 1) / kBlock;
+  const int n0 = a.loc[0] == kCell ? 2 : 1, n1 = a.loc[1] == kCell ? 2 : 1, n2 = a.loc[2] == kCell ? 2 : 1;
+  const T w = T((n0 == 2 ? 0.5f : 1.f) * (n1 == 2 ? 0.5f : 1.f) * (n2 == 2 ? 0.5f : 1.f) * 0.5f);
+  for (int64_t u = blockIdx.x; u < rows * per_row; u += gridDim.x) {
+    const int64_t row = u / per_row, c3 = (u - row * per_row) * kBlock + threadIdx.x;
+    if (c3 >= a.cn[3]) continue;
+    const int64_t c2 = row % a.cn[2], r1 = row / a.cn[2], c1 = r1 % a.cn[1], c0 = r1 / a.cn[1];
+    const T v = w * gcoarse[row * a.cn[3] + c3];
+    P2 pk;
+    pk[0] = v, pk[1] = v;
+    T* base = gfine + (n0 * c0) * fs0 + (n1 * c1) * fs1 + (n2 * c2) * fs2 + 2 * c3;
+#pragma unroll
+    for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+      for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          if (i0 < n0 && i1 < n1 && i2 < n2) *reinterpret_cast<P2*>(base + i0 * fs0 + i1 * fs1 + i2 * fs2) = pk;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_restrict_adj(const T* __restrict__ gcoarse, T* __restrict__ gfine,
                                                          InterpArgs a) {
@@ -484,6 +514,14 @@ static int restrict_adj(const T* gcoarse, T* gfine, const int64_t* fshape, int n
   if (!gcoarse || !gfine) {
     set_error("restrict_adj: null pointer");
     return ODIL_E_INVAL;
+  }
+  bool cells = a.loc[3] == kCell && a.fn[3] % 2 == 0 && (reinterpret_cast<uintptr_t>(gfine) % (2 * sizeof(T))) == 0;
+  for (int i = 0; i < 3; ++i) cells = cells && ((a.loc[i] == kCell && a.fn[i] % 2 == 0) || (a.fn[i] == 1 && a.loc[i] != kNode));
+  if (cells) {
+    const int64_t units = a.cn[0] * a.cn[1] * a.cn[2] * ((a.cn[3] + kBlock - 1) / kBlock);
+    const int grid = (int)(units < 16 * kGridCap ? units : 16 * kGridCap);
+    hipLaunchKernelGGL(k_restrict_adj_cells<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, gcoarse, gfine, a);
+    return check_launch("k_restrict_adj_cells");
   }
   hipLaunchKernelGGL(k_restrict_adj<T>, dim3(grid_for(prod4(a.fn), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                      gcoarse, gfine, a);
