@@ -13,19 +13,38 @@ struct AccessArgs {
   int64_t shift[4];
 };
 
+// i = (((i0 * n1 + i1) * n2 + i2) * n3 + i3) taken apart; 32-bit divisions whenever the values fit (a 64-bit
+// division is ~40 instructions, and these kernels did twelve per element).
+__device__ inline void split4(int64_t i, const int64_t (&n)[4], int64_t (&id)[4]) {
+  int64_t rem = i;
+#pragma unroll
+  for (int d = 3; d >= 0; --d) {
+    if (n[d] == 1) {
+      id[d] = 0;
+    } else if (rem < (int64_t(1) << 31) && n[d] < (int64_t(1) << 31)) {
+      const uint32_t r = (uint32_t)rem, m = (uint32_t)n[d];
+      id[d] = r % m;
+      rem = r / m;
+    } else {
+      id[d] = rem % n[d];
+      rem /= n[d];
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_field_gather(const T* __restrict__ src, T* __restrict__ out,
                                                         AccessArgs a) {
   const int64_t total = a.on[0] * a.on[1] * a.on[2] * a.on[3];
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += nthreads) {
-    int64_t rem = i, sidx = 0, stride = 1;
+    int64_t sidx = 0, stride = 1, id[4];
     bool zero = false;
+    split4(i, a.on, id);
+#pragma unroll
     for (int d = 3; d >= 0; --d) {
-      const int64_t id = rem % a.on[d];
-      rem /= a.on[d];
-      int64_t p = (id + a.shift[d]) % a.np[d];  // roll by -shift (core.py:963)
-      if (p < 0) p += a.np[d];
+      int64_t p = id[d] + a.shift[d];  // roll by -shift (core.py:963); shift reduced to [0, np) on the host
+      if (p >= a.np[d]) p -= a.np[d];
       const int64_t q = p - a.pad[d];
       if (q < 0) zero = true;
       sidx += (q < 0 ? 0 : q) * stride;
@@ -41,13 +60,14 @@ __global__ __launch_bounds__(kBlock) void k_field_scatter(const T* __restrict__ 
   const int64_t total = a.sn[0] * a.sn[1] * a.sn[2] * a.sn[3];
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += nthreads) {
-    int64_t rem = i, oidx = 0, stride = 1;
+    int64_t oidx = 0, stride = 1, q[4];
     bool none = false;
+    split4(i, a.sn, q);
+#pragma unroll
     for (int d = 3; d >= 0; --d) {
-      const int64_t q = rem % a.sn[d];
-      rem /= a.sn[d];
-      int64_t id = (q + a.pad[d] - a.shift[d]) % a.np[d];
+      int64_t id = q[d] + a.pad[d] - a.shift[d];  // in (-np, np]
       if (id < 0) id += a.np[d];
+      if (id >= a.np[d]) id -= a.np[d];
       if (id >= a.on[d]) none = true;  // trimmed away (core.py:965-969)
       oidx += (id >= a.on[d] ? 0 : id) * stride;
       stride *= a.on[d];
@@ -75,11 +95,12 @@ static int fill_access(AccessArgs& a, const int64_t* sshape, int ndim, const cha
     const int64_t trim = (fl[d] == kNode && tl[d] == kCell) ? 1 : 0;
     a.np[d] = a.sn[d] + a.pad[d];
     a.on[d] = a.np[d] - trim;
-    a.shift[d] = (i >= 0 && shift) ? shift[i] : 0;
     if (a.sn[d] < 1 || a.on[d] < 1) {
       set_error("field access: empty extent on axis %d", d);
       return ODIL_E_INVAL;
     }
+    const int64_t sh = (i >= 0 && shift) ? shift[i] : 0;
+    a.shift[d] = ((sh % a.np[d]) + a.np[d]) % a.np[d];  // periodic roll: reduced to [0, np)
   }
   return 0;
 }
