@@ -104,7 +104,7 @@ inline int sched_grid(const RowSched& s) {
 // workgroup keeps the z-1 / z / z+1 values of its column in registers while it marches, so
 // z re-reads never leave the CU; rows y+-1 belong to workgroups of the SAME XCD (XCD k owns
 // y-chunk k) that march in step, so they are L2 hits.  When Y is too small to split eight
-// ways the z-chunks are split instead; tiny problems fall back to plain order.
+// ways the units are split in their (zc, y, xs) order instead; tiny problems fall back to plain order.
 // ---------------------------------------------------------------------------
 struct UnitSched {
   int ZCH, Y, XS;   // number of z-chunks, rows, x-segments
@@ -132,9 +132,11 @@ inline UnitSched make_unit_sched(int64_t Z, int64_t Y, int64_t XS, int64_t targe
     s.chunk = (int)((Y + kNumXcd - 1) / kNumXcd);
     s.per_xcd = s.ZCH * s.chunk * s.XS;
   } else if (s.ZCH >= kNumXcd) {
+    // contiguous ranges of the (zc, y, xs) order, equal to within one unit: whole z-chunks per XCD left two
+    // XCDs idle when their number was not a multiple of eight (17 chunks -> 3, 3, 3, 3, 3, 2, 0, 0)
     s.axis = 0;
-    s.chunk = (s.ZCH + kNumXcd - 1) / kNumXcd;
-    s.per_xcd = s.chunk * s.Y * s.XS;
+    s.chunk = 0;
+    s.per_xcd = (int)(((int64_t)s.ZCH * s.Y * s.XS + kNumXcd - 1) / kNumXcd);
   } else {
     s.axis = -1;
     s.chunk = 0;
@@ -164,8 +166,12 @@ __device__ inline bool unit_decode(const UnitSched& s, int& zc, int& y, int& xs)
     zc = r / s.chunk;
     return y < s.Y;
   }
-  y = r % s.Y;
-  zc = k * s.chunk + r / s.Y;
+  // axis 0: XCD k owns units [k per_xcd, (k + 1) per_xcd) of the zc-major order
+  const int u = k * s.per_xcd + i;
+  xs = u % s.XS;
+  const int ru = u / s.XS;
+  y = ru % s.Y;
+  zc = ru / s.Y;
   return zc < s.ZCH;
 }
 #endif

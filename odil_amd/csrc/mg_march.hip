@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
 // loads 12 packs per thread and fine plane for 2 packs of new data: HBM sees every line once, but the
 // L2 serves six times the traffic (512^3 -> 256^3: 2.0 GB of HBM traffic in 0.59 ms).  Here a
 // workgroup owns a tile of kTileY x kTileX coarse columns, reads the (2 kTileY + 4) x (2 kTileX + 4)
-// window of each fine plane once with coalesced 16 B loads (1.33 x the tile's own data, the halo from
+// window of each fine plane once with coalesced 16 B loads (1.27 x the tile's own data, the halo from
 // L2), and every thread takes its 6 x 6 (4 x 6 away from the walls) window from LDS.  Same
 // arithmetic, same order: the results are bit-identical to k_interp_adj_march.
 #ifndef ODIL_ADJ_UNITS
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
 #define ODIL_ADJ_UNITS_SMALL (kGridCap / 4)  // levels of <= 4 M coarse points: chain 0.690 -> 0.675 ms
 #endif
 #ifndef ODIL_TILE_Y
-#define ODIL_TILE_Y 8
-#define ODIL_TILE_X 32
+#define ODIL_TILE_Y 16  // 16 x 16 coarse columns per workgroup: 512^3 epoch 2.74 ms, 8 x 32: 2.77
+#define ODIL_TILE_X 16
 #endif
 #ifndef ODIL_TILE_UNITS
 #define ODIL_TILE_UNITS (kGridCap / 2)  // 512^3 -> 256^3: 465 / 450 / 455 us for 2048 / 1024 / 512 units
