@@ -10,7 +10,10 @@ reference solution, discrete rhs, zero initial state; poisson.py:21-24,71-86,264
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--N 512] [--ndim 3]
 
-For N > 1 it is launched by torch.distributed.run, one rank per GPU (RCCL).
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE are then in the environment), or plain
+`python bench.py --gpus N` starts them itself as FRESH child processes before this process has touched
+the GPU, relays rank 0's JSON line and exits with the children's status.
 Prints ONE JSON line on rank 0.
 """
 
@@ -113,8 +116,27 @@ class Timers:
         return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.pairs.items()}
 
 
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` outside a launcher: start N ranks with torch.distributed.run as a child
+    process (this process has not initialised the GPU and never does), pass its output through, return its
+    exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -125,14 +147,15 @@ def main():
         ngpu = torch.cuda.device_count()
         local_rank = local_rank % max(ngpu, 1)  # (tests may oversubscribe one GPU with gloo)
         torch.cuda.set_device(local_rank)
+        # No silent fallback: a rank that cannot initialise RCCL fails the job (gloo, which stages the planes
+        # through the host, only when ODIL_DIST_BACKEND asks for it -- the CPU-side tests do).
         if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:  # keep the measurement alive: planes are then staged through the host
-                sys.stderr.write("bench.py: RCCL init failed ({}); falling back to gloo\n".format(e))
-                dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+        if args.gpus != world:
+            raise SystemExit("bench.py: --gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local_rank)
 
@@ -176,6 +199,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss = run.last_loss(comm) if world > 1 else run.last_loss()
+    dist_world, comm_backend = 1, None
+    if world > 1:
+        dist_world = dist.get_world_size()
+        comm_backend = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -231,6 +258,8 @@ def main():
                 "levels": run.nlvl,
                 "optimizer": "adam lr=0.005",
                 "decomposition": "slab x{}".format(world) if world > 1 else "none",
+                "rccl_ranks": dist_world,
+                "comm_backend": comm_backend,
             },
             "roofline": {
                 "kernel": dom_name.format("double" if wordsize == 8 else "float"),

@@ -107,8 +107,11 @@ class _EpochGraph:
     exactly as in the eager loop and kept in a device table; a captured index_select moves the current
     one into the scalar the kernels read, a captured increment advances the index."""
 
-    def __init__(self, step, step_sizes, dtype, device, refresh):
-        self.step, self.refresh = step, refresh
+    def __init__(self, step, step_sizes, dtype, device, loss_grad):
+        self.step = step
+        self.refresh = getattr(loss_grad, "refresh", None)  # called before every replay
+        self.begin, self.end = getattr(loss_grad, "graph_begin", None), getattr(loss_grad, "graph_end", None)
+        self.nrows = len(step_sizes)
         self.table = torch.tensor(np.array(step_sizes, dtype=np.float64), dtype=dtype, device=device)
         self.index = torch.zeros(1, dtype=torch.int64, device=device)
         self.alpha = torch.zeros(1, dtype=dtype, device=device)
@@ -124,8 +127,8 @@ class _EpochGraph:
 
         try:
             graph = torch.cuda.CUDAGraph()
-            if self.refresh is not None:
-                self.refresh()
+            if self.begin is not None:
+                self.begin(self.nrows)
             with torch.cuda.graph(graph):
                 pinfo = self._body()
             # the report of an epoch is a dict of DEVICE scalars that a lazy wrapper converts (and
@@ -137,11 +140,16 @@ class _EpochGraph:
                 type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
             torch.cuda.synchronize()
             self.index.zero_()
+            self.close()
             return False
         self.graph = graph
         global _graph_runtime_ready
         _graph_runtime_ready = True
         return True
+
+    def close(self):
+        if self.end is not None:
+            self.end()
 
     def replay(self):
         if self.refresh is not None:
@@ -210,8 +218,7 @@ class AdamNativeOptimizer(Optimizer):
                 if callback is not None:
                     callback(x, epoch, pinfo)
                 epoch += 1
-            graph = _EpochGraph(step, [step_size(e) for e in range(epoch, last + 1)], tdtype, xf.device,
-                                getattr(loss_grad, "refresh", None))
+            graph = _EpochGraph(step, [step_size(e) for e in range(epoch, last + 1)], tdtype, xf.device, loss_grad)
             if not graph.capture():
                 graph = None
         captured = [a.data_ptr() for a in x]
@@ -221,8 +228,11 @@ class AdamNativeOptimizer(Optimizer):
             if epoch > 0 and callback is not None:
                 callback(x, epoch, pinfo)
                 if graph is not None and [a.data_ptr() for a in x] != captured:
+                    graph.close()
                     graph = None  # the callback swapped arrays (callback_update_state): replays would miss them
             epoch += 1
+        if graph is not None:
+            graph.close()
         optinfo = Namespace()
         optinfo.epochs = epochs
         optinfo.evals = self.evals

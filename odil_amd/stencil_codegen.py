@@ -58,10 +58,25 @@ def _lit(value, kind):
 
 
 class _Codegen:
-    def __init__(self, tr, outputs, raw, shape, state):
+    def __init__(self, tr, outputs, raw, shape, state, slab=None):
+        """slab = (axis, n): the kernels of ONE RANK of a slab decomposition along grid axis `axis` (n owned
+        cells of it per rank; odil_amd/slab_traced.py).  Threads then cover the owned cells only; the index of
+        that axis seen by index leaves, constant arrays and windows is the GLOBAL one (i + a.off); sources are
+        the rank's ghost-extended arrays (a.lo ghost cells below the owned ones, a.ea cells in all along the
+        axis), reads that leave the global grid come from the wrap planes a.wlo / a.whi (periodic roll of
+        `Context.field`, reference core.py:962-963, across the ends of the decomposition); the gathers write
+        the ghost-extended gradient, ghost cells receiving what belongs to the neighbour."""
         self.tr, self.outputs, self.raw, self.G, self.state = tr, outputs, raw, tuple(shape), state
         self.ndim = len(shape)
-        self.total = int(np.prod(shape))
+        self.slab = slab
+        self.GL = tuple(shape)  # the grid the threads cover
+        if slab is not None:
+            ax, n = slab
+            if shape[ax] % n:
+                raise TraceUnsupported("slab of {} cells on an axis of {}".format(n, shape[ax]))
+            self.GL = tuple(n if d == ax else g for d, g in enumerate(shape))
+            self.halo = 0
+        self.total = int(np.prod(self.GL))
         if self.total >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         self.lines = []
@@ -106,7 +121,7 @@ class _Codegen:
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
         self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
         self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
-        self.out_count = [int(np.prod(l)) if l is not None else self.total for l in self.out_lens]
+        self.out_count = [int(np.prod(l)) if l is not None else int(np.prod(self.G)) for l in self.out_lens]  # GLOBAL counts
 
     def _needs_grad(self):
         need = dict()
@@ -213,7 +228,7 @@ class _Codegen:
         if n.op == "const":
             return _lit(n.attr, n.kind)
         if n.host:
-            e = "a.hs[{}]".format(self.hs_slot[n.idx])
+            e = "HS({})".format(self.hs_slot[n.idx])
             return {"r": "((T){})", "i": "((long){})", "b": "({} != 0.0)"}[n.kind].format(e)
         return "v{}".format(n.idx)
 
@@ -268,6 +283,9 @@ class _Codegen:
         floc = self.state.fields[key].loc
         fshape = self._field_shape(key)
         slot = self._src_slot(key)
+        if self.slab is not None:
+            self._emit_read_slab(n, slot, fshape, floc)
+            return
         idx, zero = [], []
         for d in range(self.ndim):
             ns = fshape[d]
@@ -289,6 +307,62 @@ class _Codegen:
         self.emit("const T v{} = {};".format(n.idx, e))
         self.loads[desc] = "v{}".format(n.idx)
 
+    def _emit_read_slab(self, n, slot, fshape, floc):
+        """A read on one rank's slab: as above on the other axes; along the sharded axis no wrap inside the
+        rank -- owned cell i reads cell i + s of the ghost-extended array, or a wrap plane when i + s falls off
+        the GLOBAL grid (only the first / last rank of the decomposition ever does)."""
+        key, shift, loc, _ = n.attr
+        ax, nloc = self.slab
+        if floc[ax] != "c" or loc[ax] != "c":
+            raise TraceUnsupported("slab axis {} must be cell-centred for field '{}'".format(ax, key))
+        sa = shift[ax] % self.G[ax]
+        if sa > self.G[ax] // 2:
+            sa -= self.G[ax]
+        self.halo = max(self.halo, abs(sa))
+        idx, zero = [], []
+        for d in range(self.ndim):
+            if d == ax:
+                idx.append(None)
+                continue
+            ns = fshape[d]
+            ext = max(ns, self.G[d])
+            s = shift[d] % ext
+            if s > ext // 2:
+                s -= ext
+            j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
+            if floc[d] == "c" and loc[d] == "n":
+                name = "p{}_{}".format(n.idx, d)
+                self.emit("const int {} = {};".format(name, j))
+                zero.append("{} == 0".format(name))
+                j = "({} == 0 ? 0 : {} - 1)".format(name, name)
+            idx.append(j)
+
+        def offset(along, extent):
+            full = [along if d == ax else idx[d] for d in range(self.ndim)]
+            shape = [extent if d == ax else fshape[d] for d in range(self.ndim)]
+            return self._offset(full, shape)
+
+        main = "a.src[{}] + {}".format(slot, offset("(i{} + a.lo + ({}))".format(ax, sa), "a.ea"))
+        if sa == 0:
+            e = "*({})".format(main)
+        else:
+            # the wrap planes hold `halo` cells; their extent is not known before every read was seen: a.hw
+            if sa < 0:
+                cond = "i{}g + ({}) < 0".format(ax, sa)
+                alt = "a.wlo[{}] + {}".format(slot, offset("(i{} + ({}) + a.hw)".format(ax, sa), "a.hw"))
+            else:
+                cond = "i{}g + ({}) >= {}".format(ax, sa, self.G[ax])
+                alt = "a.whi[{}] + {}".format(slot, offset("(i{} + ({}) - {})".format(ax, sa, nloc), "a.hw"))
+            e = "*(({}) ? ({}) : ({}))".format(cond, alt, main)
+        if zero:
+            e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
+        self.emit("const T v{} = {};".format(n.idx, e))
+        self.loads[(key, shift, loc)] = "v{}".format(n.idx)
+
+    def gi(self, d):
+        """Index expression of grid axis d as user code sees it (global on the sharded axis)."""
+        return "i{}g".format(d) if self.slab is not None and d == self.slab[0] else "i{}".format(d)
+
     def _emit_tensor(self, n):
         t = self.tr.tensors[n.attr]
         shape = (1,) * (self.ndim - t.dim()) + tuple(t.shape)
@@ -298,7 +372,7 @@ class _Codegen:
         for d in reversed(range(self.ndim)):
             if shape[d] != 1:
                 # shorter than the grid: an operand of a windowed value; clamped outside its window
-                i = "i{}".format(d) if shape[d] == self.G[d] else "min(i{}, {})".format(d, shape[d] - 1)
+                i = self.gi(d) if shape[d] == self.G[d] else "min({}, {})".format(self.gi(d), shape[d] - 1)
                 terms.append("{} * {}".format(i, stride) if stride != 1 else i)
                 stride *= shape[d]
         ctype = {torch.float32: "float", torch.float64: "double", torch.int32: "int", torch.int64: "long",
@@ -341,7 +415,7 @@ class _Codegen:
             elif op == "tensor":
                 self._emit_tensor(n)
             elif op == "index":
-                self.emit(v + "(long)i{};".format(n.attr[0]))
+                self.emit(v + "(long){};".format(self.gi(n.attr[0])))
             elif op == "win":
                 self.emit(v + "{};".format(self.typed(A[0], n.kind)))
             elif op == "aparam":
@@ -566,10 +640,21 @@ class _Codegen:
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
+        nsrc = max(1, len(self.src_keys))
+        slab_members = ""
+        if self.slab is not None:
+            # off: global index of the first owned cell; lo / ea: ghost cells below the owned ones / extent of the
+            # local arrays along the sharded axis; hw: cells in a wrap plane buffer; wlo / whi: wrap planes of the
+            # sources (read), gwlo / gwhi: of the gradients (written by the gathers where the array has no ghosts)
+            slab_members = " int off, lo, ea, hw; const T* wlo[{0}]; const T* whi[{0}]; T* gwlo[{0}]; T* gwhi[{0}];".format(nsrc)
+        # host scalars (functions of `tracers`): BY VALUE in the argument struct (hsv) -- an eager launch owns its
+        # copy, nothing the host rewrites later is read by a queued kernel; a launch captured into a hipGraph
+        # reads them from device memory instead (hs != NULL: the row of the epoch being replayed)
         S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
-                 "T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks; }};".format(
-                     max(1, len(self.src_keys)), max(1, len(self.tr.tensors)), max(1, len(self.cots) + len(self.cut_nodes)),
-                     max(1, par_arrays)))
+                 "double hsv[{}]; T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks;{} }};".format(
+                     nsrc, max(1, len(self.tr.tensors)), max(1, len(self.cots) + len(self.cut_nodes)),
+                     max(1, par_arrays), max(1, len(self.hs)), slab_members))
+        S.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
         wofs, bofs, o = dict(), dict(), 0
         for s, (key, layers) in enumerate(self.nets):
@@ -602,12 +687,14 @@ class _Codegen:
             if d == 0:
                 S.append("  const int i0 = {};".format(rem))
             else:
-                S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
-                S.append("  const int r{} = {} / {};".format(d, rem, self.G[d]))
+                S.append("  const int i{} = {} % {};".format(d, rem, self.GL[d]))
+                S.append("  const int r{} = {} / {};".format(d, rem, self.GL[d]))
                 rem = "r{}".format(d)
+        if self.slab is not None:
+            S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
         for k, lens in enumerate(self.out_lens):
             if lens is not None:
-                conds = ["i{} < {}".format(d, lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
+                conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
                 S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
         S.extend(fwd)
         S.extend(rev)
@@ -676,11 +763,15 @@ class _Codegen:
         for key, reads in by_key.items():
             floc = self.state.fields[key].loc
             fshape = self._field_shape(key)
-            if len(reads) == 1 and reads[0][2] is None and not any(reads[0][1][1]) and reads[0][1][2] == floc:
+            if (self.slab is None and len(reads) == 1 and reads[0][2] is None and not any(reads[0][1][1])
+                    and reads[0][1][2] == floc):
                 self.direct[key] = reads[0][0]
                 continue
             gi = len(self.gathers)
             self.gathers.append(key)
+            if self.slab is not None:
+                self._gather_slab(S, gi, key, reads, floc, fshape)
+                continue
             tot = int(np.prod(fshape))
             S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g) {{'.format(gi))
             S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
@@ -730,13 +821,85 @@ class _Codegen:
         S.append("  switch (which) {")
         for gi, key in enumerate(self.gathers):
             tot = int(np.prod(self._field_shape(key)))
+            nblk = str((tot + 255) // 256)
+            if self.slab is not None:  # planes -GH .. n + GH of the sharded axis, GH = 2 (slab_traced.G)
+                per = tot // self._field_shape(key)[self.slab[0]]
+                nblk = "(unsigned)(((long){} * ({} + 4) + 255) / 256)".format(per, self.slab[1])
             S.append("    case {}: hipLaunchKernelGGL(k_gat_{}, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, (T*)g); break;".format(
-                gi, gi, (tot + 255) // 256))
+                gi, gi, nblk))
         S.append("    default: return -1;")
         S.append("  }")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
         return "\n".join(S) + "\n"
+
+
+def _gather_slab(self, S, gi, key, reads, floc, fshape):
+    """Gather of one field on one rank's slab.  Threads cover planes -2 .. n + 2 of the sharded axis (owned
+    cells 0 .. n): g = sum_r cot_r[j - shift_r] over the OWNED cells that read j.  Planes that exist in the
+    rank's ghost-extended gradient array are stored there (ghost planes: the part of the neighbour's gradient
+    that this rank's cells produce, sent over and added by slab_traced.py); planes beyond a side WITHOUT ghosts
+    (the ends of the decomposition) that a periodic read reached go to the wrap buffers gwlo / gwhi."""
+    ax, nloc = self.slab
+    slot = self.src_keys.index(key)
+    per = [fshape[d] for d in range(self.ndim)]
+    S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g) {{'.format(gi))
+    S.append("  const long l = (long)blockIdx.x * NB + threadIdx.x;")
+    tot_per = int(np.prod([fshape[d] for d in range(self.ndim) if d != ax]))
+    S.append("  if (l >= (long){} * {}) return;".format(tot_per, nloc + 4))
+    rem = "l"
+    for d in reversed(range(self.ndim)):
+        ext = (nloc + 4) if d == ax else per[d]
+        if d == 0:
+            S.append("  const int j0 = (int){};".format(rem))
+        else:
+            S.append("  const int j{} = (int)({} % {});".format(d, rem, ext))
+            S.append("  const long q{} = {} / {};".format(d, rem, ext))
+            rem = "q{}".format(d)
+    S.append("  const int jo = j{} - 2;".format(ax))  # owned-relative position on the sharded axis
+    S.append("  T acc = (T)0;")
+    for entry, (cslot, attr, coeff) in enumerate(reads):
+        _, shift, loc, _ = attr
+        idx, valid = [], []
+        for d in range(self.ndim):
+            ns, nr = fshape[d], self.G[d]
+            ext = max(ns, nr)
+            s_ = shift[d] % ext
+            if s_ > ext // 2:
+                s_ -= ext
+            if d == ax:
+                name = "c{}".format(entry)
+                S.append("  const int {} = jo - ({});".format(name, s_))
+                valid.append("{0} >= 0 && {0} < {1}".format(name, nloc))
+                idx.append(name)
+                continue
+            pos = "j{}".format(d) if not (floc[d] == "c" and loc[d] == "n") else "(j{} + 1)".format(d)
+            e = pos if s_ == 0 else "wrap({} - ({}), {})".format(pos, s_, ext)
+            if floc[d] == "n" and loc[d] == "c":
+                name = "t{}_{}".format(entry, d)
+                S.append("  const int {} = {};".format(name, e))
+                valid.append("{} < {}".format(name, nr))
+                e = name
+            idx.append(e)
+        load = "a.cot[{}][{}]".format(cslot, self._offset(idx, self.GL))
+        if coeff is not None:
+            load = "({}) * {}".format(coeff, load)
+        load = "(({}) ? {} : (T)0)".format(" && ".join(valid), load)
+        S.append("  acc = acc + {};".format(load))
+
+    def offset(along, extent):
+        full = [along if d == ax else "j{}".format(d) for d in range(self.ndim)]
+        shape = [extent if d == ax else per[d] for d in range(self.ndim)]
+        return self._offset(full, shape)
+
+    S.append("  const int jl = jo + a.lo;")
+    S.append("  if (jl >= 0 && jl < a.ea) g[{}] = acc;".format(offset("jl", "a.ea")))
+    S.append("  else if (jo < 0 && jo >= -a.hw) a.gwlo[{}][{}] = acc;".format(slot, offset("(jo + a.hw)", "a.hw")))
+    S.append("  else if (jo >= {0} && jo < {0} + a.hw) a.gwhi[{1}][{2}] = acc;".format(nloc, slot, offset("(jo - {})".format(nloc), "a.hw")))
+    S.append("}")
+
+
+_Codegen._gather_slab = _gather_slab
 
 
 def _cache_dirs():

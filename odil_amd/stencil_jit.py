@@ -46,39 +46,48 @@ from .stencil_trace import (  # noqa: F401  (re-exported: the public names of th
 # ======================================================================================
 # Traced evaluator
 # ======================================================================================
+def trace_outputs(problem, state):
+    """Runs `problem.operator` once on symbolic values: (tracer, output nodes, raw flags, names, grid shape).
+    Only the STRUCTURE of `state` matters (array shapes; 'meta' tensors do)."""
+    from .core import Context, Problem
+
+    domain = problem.domain
+    tr = Tracer(domain)
+    # unknowns reached around ctx.field / ctx.neural_net would lose their gradient: trace on
+    # differentiable leaves so that `lift` can refuse them
+    leaves = [a.detach().requires_grad_(True) for a in domain.arrays_from_state(state)]
+    ctx = TraceContext(tr, problem._shadow_state(state, leaves), problem.extra, problem.tracers)
+    try:
+        with torch.enable_grad():
+            res = problem.operator(ctx)
+    except TraceUnsupported:
+        raise
+    except Exception as e:
+        # code that is not written against `ctx.mod` (torch / NumPy calls on the symbols, helper
+        # kernels of this package): the eager path runs it, and reports genuine errors
+        raise TraceUnsupported("{} under tracing: {}".format(type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+    names, values = Problem._split_outputs(res)
+    raw = [isinstance(v, Context.Raw) for v in values]
+    outs = [tr.lift(v.value if r else v) for v, r in zip(values, raw)]
+    if not any(n.op == "read" for n in tr.nodes):
+        raise TraceUnsupported("operator reads no field")
+    G = tuple(tr.grid_shape())
+    for o in outs:  # every output lives on the grid of the reads, all of it or a window of it
+        if o.host or (o.win is None and tuple(o.shape) != G):
+            raise TraceUnsupported("output of shape {} on grid {}".format(tuple(o.shape), G))
+    outs = [o if o.kind == _R else tr.unary("cast", o) for o in outs]
+    return tr, outs, raw, names, G
+
+
 class TracedOperator:
     """loss / gradient of one user operator through its generated kernels."""
 
     def __init__(self, problem, state):
-        from .core import Context, Field, MultigridField, Problem
+        from .core import Field, MultigridField
 
         domain = problem.domain
         self.problem, self.domain = problem, domain
-        tr = Tracer(domain)
-        # unknowns reached around ctx.field / ctx.neural_net would lose their gradient: trace on
-        # differentiable leaves so that `lift` can refuse them
-        leaves = [a.detach().requires_grad_(True) for a in domain.arrays_from_state(state)]
-        ctx = TraceContext(tr, problem._shadow_state(state, leaves), problem.extra, problem.tracers)
-        try:
-            with torch.enable_grad():
-                res = problem.operator(ctx)
-        except TraceUnsupported:
-            raise
-        except Exception as e:
-            # code that is not written against `ctx.mod` (torch / NumPy calls on the symbols, helper
-            # kernels of this package): the eager path runs it, and reports genuine errors
-            raise TraceUnsupported("{} under tracing: {}".format(type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
-        names, values = Problem._split_outputs(res)
-        self.names = names
-        raw = [isinstance(v, Context.Raw) for v in values]
-        outs = [tr.lift(v.value if r else v) for v, r in zip(values, raw)]
-        if not any(n.op == "read" for n in tr.nodes):
-            raise TraceUnsupported("operator reads no field")
-        G = tuple(tr.grid_shape())
-        for o in outs:  # every output lives on the grid of the reads, all of it or a window of it
-            if o.host or (o.win is None and tuple(o.shape) != G):
-                raise TraceUnsupported("output of shape {} on grid {}".format(tuple(o.shape), G))
-        outs = [o if o.kind == _R else tr.unary("cast", o) for o in outs]
+        tr, outs, raw, self.names, G = trace_outputs(problem, state)
         self.G, self.raw = G, raw
         cg = _Codegen(tr, outs, raw, G, state)
         self.source = cg.source()
@@ -107,7 +116,7 @@ class TracedOperator:
                 ("ten", ctypes.c_void_p * max(1, len(tr.tensors))),
                 ("cot", ctypes.c_void_p * max(1, cg.ncot)),
                 ("par", ctypes.c_void_p * max(1, par_arrays)),
-                ("hs", ctypes.c_void_p),
+                ("hs", ctypes.c_void_p), ("hsv", ctypes.c_double * max(1, len(cg.hs))),
                 ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
             ]
@@ -122,11 +131,8 @@ class TracedOperator:
         self.args.part2 = self.part2.data_ptr()
         self.args.out, self.args.pgrad = self.out.data_ptr(), self.pgrad.data_ptr()
         self.args.nblocks = self.nblocks
-        nhs = max(1, len(cg.hs))
-        self.hs_host = torch.zeros(nhs, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else torch.zeros(nhs, dtype=torch.float64)
-        self.hs_dev = torch.zeros(nhs, dtype=torch.float64, device=dev)
-        self._hs_last = None
-        self.args.hs = self.hs_dev.data_ptr()
+        self.args.hs = None
+        self._hs_rows = None  # graph replay: (pinned table, device table, device row, device row index)
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         # structure of the state: which arrays belong to which field
@@ -195,19 +201,49 @@ class TracedOperator:
         memo[n.idx] = v
         return v
 
-    def refresh_host_scalars(self):
-        """Host scalars of the trace (functions of `problem.tracers`, evaluated in Python double as the
-        operator itself would) -> pinned buffer -> device.  The copy is issued on the current stream
-        when a value changed; captured into a hipGraph it re-reads the pinned buffer at every replay,
-        so a replayed epoch only needs this method's host part to be called first."""
-        if not self.cg.hs:
-            return
+    def host_scalars(self):
+        """Host scalars of the trace: functions of `problem.tracers`, evaluated in Python double as the
+        operator itself would."""
         memo = dict()
-        vals = [float(self._host_value(n, memo)) for n in self.cg.hs]
-        if vals != self._hs_last or torch.cuda.is_current_stream_capturing():
-            self.hs_host.copy_(torch.tensor(vals, dtype=torch.float64))
-            self._hs_last = vals
-            self.hs_dev.copy_(self.hs_host, non_blocking=True)
+        return [float(self._host_value(n, memo)) for n in self.cg.hs]
+
+    def refresh_host_scalars(self):
+        """Current host scalars -> the argument struct.  Every eager launch copies the struct, so epochs
+        queued behind each other keep their own values however far the host runs ahead."""
+        for i, v in enumerate(self.host_scalars()):
+            self.args.hsv[i] = v
+
+    # Epochs replayed as a hipGraph (optimizer._EpochGraph) cannot take new kernel arguments: the captured
+    # launch reads row k of a device table, k a device counter advanced by the graph itself.  The host fills
+    # row k of a PINNED table of the same shape before replay k and queues its copy; no row is ever rewritten,
+    # so replays queued far ahead of the GPU cannot see each other's values (the single staging buffer this
+    # replaces could).
+    def graph_begin(self, nrows):
+        nhs = len(self.cg.hs)
+        if not nhs:
+            return
+        dev = self.out.device
+        pinned = torch.zeros((nrows, nhs), dtype=torch.float64)
+        if dev.type == "cuda":
+            pinned = pinned.pin_memory()
+        self._hs_rows = dict(pinned=pinned, table=torch.zeros((nrows, nhs), dtype=torch.float64, device=dev),
+                             row=torch.zeros((1, nhs), dtype=torch.float64, device=dev),
+                             index=torch.zeros(1, dtype=torch.int64, device=dev), next=0)
+
+    def graph_upload(self):
+        """Before replay k: this epoch's host scalars -> row k (asynchronous copy on the replay's stream)."""
+        rows = self._hs_rows
+        if rows is None:
+            return
+        k = rows["next"]
+        if k >= rows["pinned"].shape[0]:
+            raise RuntimeError("more graph replays than rows of host scalars")
+        rows["pinned"][k] = torch.tensor(self.host_scalars(), dtype=torch.float64)
+        rows["table"][k].copy_(rows["pinned"][k], non_blocking=True)
+        rows["next"] = k + 1
+
+    def graph_end(self):
+        self._hs_rows = None
 
     def _side_streams(self, nfields):
         """Streams for per-field chains; none for a single field, for fields beyond 64 MB (their kernels
@@ -232,7 +268,14 @@ class TracedOperator:
         from ._lib import ptr
 
         ptr(self.out)  # fails loudly (OdilHipError) when the problem lives on the CPU: there is no CPU path
-        self.refresh_host_scalars()
+        rows = self._hs_rows
+        if rows is not None and torch.cuda.is_current_stream_capturing():
+            torch.index_select(rows["table"], 0, rows["index"], out=rows["row"])
+            rows["index"].add_(1)
+            self.args.hs = rows["row"].data_ptr()
+        else:
+            self.args.hs = None
+            self.refresh_host_scalars()
         keep = []
         # the multigrid syntheses of different fields are independent chains of mostly small launches:
         # each runs on its own stream, the forward kernel waits for all of them

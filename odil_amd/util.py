@@ -372,12 +372,17 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
     # made of this package's kernels only -- the generic path has its own graph (Problem(jit=True))
     loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or getattr(problem, "_traced", None) is not None
 
-    def refresh():
-        traced = getattr(problem, "_traced", None)
-        if traced is not None:
-            traced.refresh_host_scalars()
+    def graph_hook(name):
+        def call(*a):
+            traced = getattr(problem, "_traced", None)
+            if traced is not None:
+                getattr(traced, name)(*a)
 
-    loss_grad.refresh = refresh
+        return call
+
+    # replayed epochs: host scalars of a traced operator travel as rows of a device table (stencil_jit.py)
+    loss_grad.graph_begin, loss_grad.refresh, loss_grad.graph_end = (
+        graph_hook("graph_begin"), graph_hook("graph_upload"), graph_hook("graph_end"))
 
     def callback_wrap(arrays, epoch, pinfo):
         domain.arrays_to_state(arrays, state)

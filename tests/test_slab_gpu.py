@@ -52,11 +52,12 @@ def test_emulated_ranks_equal_single_domain(world, N):
             assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())), (lvl, r)
 
 
-def test_bench_two_ranks_over_torch_distributed_on_one_gpu(tmp_path):
-    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one
-    process per rank), with the gloo backend so that two ranks can share this box's single GPU:
-    exercises init, the TorchDistComm exchanges with real HIP kernels, barrier / max-over-ranks
-    timing and the JSON line."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_over_torch_distributed_on_one_gpu(tmp_path, launcher):
+    """bench.py at N = 2 both ways the driver may start it -- plain `python bench.py --gpus 2` (bench.py starts
+    its ranks itself, as fresh child processes) and under torch.distributed.run -- with the gloo backend so that
+    two ranks can share this box's single GPU: exercises init, the TorchDistComm exchanges with real HIP
+    kernels, barrier / max-over-ranks timing and the JSON line."""
     import json
     import os
     import subprocess
@@ -64,14 +65,20 @@ def test_bench_two_ranks_over_torch_distributed_on_one_gpu(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ODIL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2",
-           "--steps", "3", "--warmup", "1", "--N", "64", "--no_cpu_baseline"]
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--N", "64", "--no_cpu_baseline"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300)] + tail
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["decomposition"] == "slab x2"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["comm_backend"] == "gloo"
     assert d["value"] > 0 and np.isfinite(d["loss_after"])
     # same problem on one rank pair emulated in-process
     from odil_amd.slab import SlabPoissonAdam, run_lockstep
