@@ -77,8 +77,8 @@ class SlabPoissonAdam:
     """One rank of the slab-decomposed Poisson multigrid Adam loop (3-D, all cell-centred)."""
 
     def __init__(self, N, rank, world, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7, ops=None, rhs_global=None):
-        self.ops = ops or hip_ops
+                 epsilon=1e-7, rhs_global=None):
+        self.ops = hip_ops  # the HIP kernels (tests of the exchange logic without a GPU swap this module attribute)
         self.N, self.rank, self.world = N, rank, world
         self.dtype, self.device = dtype, device
         self.npdt = np.float64 if dtype == torch.float64 else np.float32
@@ -165,7 +165,7 @@ class SlabPoissonAdam:
         """Generator step: the boundary planes of all level arrays of the packed state x, one message per
         neighbour (same planes, same order as _exchange(self.w, self.levels))."""
         lo, hi = self._own_idx["lo"], self._own_idx["hi"]
-        recv_lo, recv_hi = yield (None if lo is None else self.x.index_select(0, lo),
+        recv_lo, recv_hi = yield ("halo", None if lo is None else self.x.index_select(0, lo),
                                   None if hi is None else self.x.index_select(0, hi))
         if recv_lo is not None:
             self.x.index_copy_(0, self._ghost_idx["lo"], recv_lo)
@@ -174,7 +174,7 @@ class SlabPoissonAdam:
 
     def _exchange(self, arrays, levels, depth=1):
         """Generator step: swap boundary planes of `arrays` with both neighbours."""
-        recv_lo, recv_hi = yield (self._pack(arrays, levels, "lo", depth), self._pack(arrays, levels, "hi", depth))
+        recv_lo, recv_hi = yield ("halo", self._pack(arrays, levels, "lo", depth), self._pack(arrays, levels, "hi", depth))
         self._unpack(recv_lo, arrays, levels, "lo", depth)
         self._unpack(recv_hi, arrays, levels, "hi", depth)
 
@@ -195,7 +195,7 @@ class SlabPoissonAdam:
                 b.record()
 
         b = tic("halo")
-        yield from (self._exchange_state() if self.x.is_cuda else self._exchange(self.w, lv))
+        yield from self._exchange_state()
         toc(b)
         # u = w_0 + P(w_1 + P(...)): coarse operand with one ghost plane -> fine with two
         # the last prolongation is fused into the residual when the kernel set has it (u never stored)
@@ -291,7 +291,7 @@ class SlabPoissonAdam:
         """Global loss of the last epoch (sum of the ranks' partial means)."""
         part = self.loss_part.clone()
         if comm is not None:
-            part = comm.all_reduce_sum(part)
+            part = comm.exchange("sum", part, None)
         return float(part)
 
     def owned_levels(self):
@@ -299,7 +299,14 @@ class SlabPoissonAdam:
 
 
 class TorchDistComm:
-    """Neighbour exchange over torch.distributed (backend nccl = RCCL on ROCm; gloo in tests)."""
+    """The exchanges of the slab epochs over torch.distributed (backend nccl = RCCL on ROCm; gloo in tests).
+
+    exchange(kind, send_lo, send_hi):
+      "halo"  planes to the lower / upper neighbour (None at an end of the decomposition); returns what the
+              neighbours sent: (recv_lo, recv_hi), same sizes as the sends;
+      "wrap"  the periodic closure: the FIRST rank's send_lo goes to the LAST rank (arriving as its recv_hi),
+              the last rank's send_hi to the first (its recv_lo); other ranks pass (None, None);
+      "sum"   all-reduce of send_lo (a few scalars); returns the tensor."""
 
     def __init__(self, rank, world):
         import torch.distributed as dist
@@ -308,8 +315,24 @@ class TorchDistComm:
         # gloo moves host memory: device planes are staged (tests only; RCCL sends device memory)
         self.stage = dist.get_backend() == "gloo"
 
-    def exchange(self, send_lo, send_hi):
+    def exchange(self, kind, send_lo, send_hi):
         dist = self.dist
+        if kind == "sum":
+            t = send_lo
+            if self.stage and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h)
+                return h.to(t.device)
+            dist.all_reduce(t)
+            return t
+        if kind == "wrap":
+            if self.world == 1:
+                return send_hi, send_lo
+            peer_lo = self.world - 1 if self.rank == 0 else None
+            peer_hi = 0 if self.rank == self.world - 1 else None
+        else:
+            peer_lo = self.rank - 1 if self.rank > 0 else None
+            peer_hi = self.rank + 1 if self.rank < self.world - 1 else None
         dev = None
         if self.stage:
             for t in (send_lo, send_hi):
@@ -319,12 +342,12 @@ class TorchDistComm:
                 send_lo = send_lo.cpu() if send_lo is not None else None
                 send_hi = send_hi.cpu() if send_hi is not None else None
         ops, recv_lo, recv_hi = [], None, None
-        if send_lo is not None:
+        if send_lo is not None and peer_lo is not None:
             recv_lo = torch.empty_like(send_lo)
-            ops += [dist.P2POp(dist.isend, send_lo, self.rank - 1), dist.P2POp(dist.irecv, recv_lo, self.rank - 1)]
-        if send_hi is not None:
+            ops += [dist.P2POp(dist.isend, send_lo, peer_lo), dist.P2POp(dist.irecv, recv_lo, peer_lo)]
+        if send_hi is not None and peer_hi is not None:
             recv_hi = torch.empty_like(send_hi)
-            ops += [dist.P2POp(dist.isend, send_hi, self.rank + 1), dist.P2POp(dist.irecv, recv_hi, self.rank + 1)]
+            ops += [dist.P2POp(dist.isend, send_hi, peer_hi), dist.P2POp(dist.irecv, recv_hi, peer_hi)]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -333,28 +356,31 @@ class TorchDistComm:
             recv_hi = recv_hi.to(dev) if recv_hi is not None else None
         return recv_lo, recv_hi
 
-    def all_reduce_sum(self, t):
-        if self.stage and t.is_cuda:
-            h = t.cpu()
-            self.dist.all_reduce(h)
-            return h.to(t.device)
-        self.dist.all_reduce(t)
-        return t
-
 
 def run_lockstep(ranks, nepochs=1, timers=None):
     """Several ranks emulated in ONE process (one GPU): advances every rank's epoch generator to
-    its next exchange, swaps the planes by device copies, continues."""
+    its next exchange, moves the planes by device copies, continues."""
+    P = len(ranks)
     for _ in range(nepochs):
         gens = [r.epoch_gen(timers if i == 0 else None) for i, r in enumerate(ranks)]
         msgs = [next(g) for g in gens]
         alive = True
         while alive:
-            replies = []
-            for i in range(len(ranks)):
-                from_lo = msgs[i - 1][1].clone() if i > 0 and msgs[i - 1][1] is not None else None
-                from_hi = msgs[i + 1][0].clone() if i + 1 < len(ranks) and msgs[i + 1][0] is not None else None
-                replies.append((from_lo, from_hi))
+            kind = msgs[0][0]
+            assert all(m[0] == kind for m in msgs), "ranks out of step"
+            clone = lambda t: None if t is None else t.clone()
+            if kind == "sum":
+                total = msgs[0][1].clone()
+                for m in msgs[1:]:
+                    total = total + m[1]
+                replies = [total.clone() for _ in range(P)]
+            elif kind == "wrap":
+                replies = [(None, None)] * P
+                replies[0] = (clone(msgs[P - 1][2]), None)
+                replies[P - 1] = (replies[P - 1][0] if P == 1 else None, clone(msgs[0][1]))
+            else:
+                replies = [(clone(msgs[i - 1][2]) if i > 0 else None, clone(msgs[i + 1][1]) if i + 1 < P else None)
+                           for i in range(P)]
             new = []
             for g, rep in zip(gens, replies):
                 try:

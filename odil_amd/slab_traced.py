@@ -1,0 +1,490 @@
+"""Slab decomposition of TRACED operators over the GPUs of one node: any `operator(ctx)` the tracer can
+express (odil_amd/stencil_jit.py) -- the tracer-velocity workload BASELINE.json names for 8 GPUs -- with an
+Adam loop per rank.  No reference counterpart (the reference is single-device).
+
+Layout.  The grid is cut along ONE domain axis `a` on which every grid field is cell-centred (for the
+(t, x, y[, z]) workloads: x; the node-centred time axis stays whole).  Rank r owns n = N_a / P cells of every
+multigrid level (every level keeps >= 2 owned cells per rank).  Level arrays are stored ghost-extended along
+`a` exactly as in the Poisson slab path (odil_amd/slab.py): G = 2 ghost cells at every interior interface,
+none at the two ends of the decomposition, where the prolongation has its wall rule.  All unknowns of a rank
+(level arrays of all fields, then replicated network / Array parameters) live in one packed vector.
+
+Per epoch and rank:
+  1. ("halo") the first / last OWNED plane of every level array of every field -> the neighbours' inner ghost
+     planes, one packed message per neighbour;
+  2. u = w_0 + P(w_1 + P(...)) per field with the unmodified single-GPU transfer kernels run on the extended
+     arrays: a coarse array with one valid ghost plane gives a fine array whose inner ghost plane is exact
+     (the wall formulas only ever reach the outer one, which nobody reads);
+  3. ("wrap") `Context.field` rolls PERIODICALLY (reference core.py:962-963): what owned cells of the first
+     rank read below the grid is the last rank's last plane of u and vice versa -- one plane per field between
+     those two ranks, kept in wrap buffers the generated kernel selects at the ends;
+  4. the generated forward / cotangent kernel on the owned cells (global indices for masks, windows and
+     constant arrays), then the generated gathers, which write the rank's ghost-extended gradient: ghost
+     planes receive what this rank's cells contribute to the NEIGHBOUR's cells, wrap buffers what they
+     contribute across the ends;
+  5. ("wrap") those wrap contributions are added into the owned end planes of the first / last rank;
+  6. P^T down the levels WITHOUT exchanges.  The transpose is linear, so every rank pushes its own partial
+     gradient -- owned planes plus the inner ghost plane of contributions -- through the unmodified whole-
+     array P^T kernel: with the outer ghost planes zero, the wall weights of that kernel multiply zeros, and
+     its result on the coarse owned planes and inner ghost planes is exactly this rank's share;
+  7. ("halo") ONE packed message per neighbour carries the inner ghost planes of the gradients of all
+     levels and fields; the receiver adds them to its owned boundary planes (transpose of step 1);
+  8. ("sum") parameter gradients of networks / Arrays, when there are any; Adam on the packed vector.
+The loss needs one more ("sum") of a few scalars, issued only when a value is read.
+
+The epoch is a generator that yields at exchanges (`(kind, send_lo, send_hi)`), so the same code runs one rank
+per GPU over RCCL (slab.TorchDistComm), over gloo with CPU doubles of the kernels (tests/test_slab_traced_cpu.py)
+and with all ranks emulated in one process on one GPU (slab.run_lockstep, tests/test_slab_gpu.py).
+"""
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import ops as hip_ops
+from .stencil_codegen import _Codegen, _compile
+from .stencil_jit import TracedOperator, trace_outputs
+from .stencil_trace import TraceUnsupported
+
+G = 2  # ghost planes per interior interface (the generated gathers assume 2)
+
+
+class _Level:
+    """One level array of one grid field on one rank."""
+
+    def __init__(self, gshape, axis, rank, world):
+        self.gshape, self.axis = tuple(gshape), axis
+        if gshape[axis] % world:
+            raise ValueError("axis {} of a level of shape {} does not divide over {} ranks".format(axis, gshape, world))
+        self.n = gshape[axis] // world
+        if self.n < 2:
+            raise ValueError("a level of shape {} leaves fewer than 2 planes per rank: lower mg_nlvl".format(gshape))
+        self.g_lo = 0 if rank == 0 else G
+        self.g_hi = 0 if rank == world - 1 else G
+        self.off = rank * self.n
+        self.shape = tuple(self.g_lo + self.n + self.g_hi if d == axis else s for d, s in enumerate(gshape))
+        self.size = math.prod(self.shape)
+        self.plane = self.size // self.shape[axis]
+
+    def planes(self, a, first, count=1):
+        """`count` planes from owned-relative position `first` along the sharded axis."""
+        return a.narrow(self.axis, self.g_lo + first, count)
+
+    def owned(self, a):
+        return a.narrow(self.axis, self.g_lo, self.n)
+
+    def inner(self, a):
+        """View with ONE ghost plane per interior interface: the coarse operand of P, the result of P^T."""
+        lo = self.g_lo - 1 if self.g_lo else 0
+        hi = a.shape[self.axis] - (self.g_hi - 1 if self.g_hi else 0)
+        return a.narrow(self.axis, lo, hi - lo)
+
+    def plane_index(self, start, pos, device):
+        """Flat positions, in the packed vector, of the plane at owned-relative position `pos`."""
+        strides = np.cumprod((1,) + self.shape[::-1])[::-1][1:]
+        idx = torch.full((1,) * len(self.shape), int(start + (self.g_lo + pos) * strides[self.axis]), dtype=torch.int64, device=device)
+        for d, s in enumerate(self.shape):
+            if d == self.axis:
+                continue
+            shape = [1] * len(self.shape)
+            shape[d] = s
+            idx = idx + (torch.arange(s, dtype=torch.int64, device=device) * int(strides[d])).view(shape)
+        return idx.reshape(-1)
+
+
+class HipSlabKernels:
+    """The generated kernels of one rank (stencil_codegen in slab mode) and their buffers."""
+
+    def __init__(self, problem, state, axis, n, device):
+        tr, outs, raw, self.names, Gshape = trace_outputs(problem, state)
+        self.problem, self.tr, self.raw = problem, tr, raw
+        cg = _Codegen(tr, outs, raw, Gshape, state, slab=(axis, n))
+        self.source = cg.source()
+        self.lib, self.lib_path = _compile(self.source)
+        self.cg = cg
+        self.halo = cg.halo
+        dt = tr.torch_dtype
+        self.dtype = dt
+        self.total = cg.total
+        cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
+        self.nblocks = min((self.total + 255) // 256, cap)
+        nout = len(outs)
+        self.nout = nout
+        self.cot = [torch.empty(cg.GL, dtype=dt, device=device) for _ in range(cg.ncot)]
+        self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=device)
+        self.ppart = torch.empty(max(1, len(cg.pg_decl) * self.nblocks), dtype=dt, device=device)
+        self.part2 = torch.zeros(16 * (nout + len(cg.pg_decl)), dtype=dt, device=device)
+        self.out = torch.zeros(1 + 2 * nout, dtype=dt, device=device)
+        self.pgrad = torch.zeros(max(1, len(cg.pg_decl)), dtype=dt, device=device)
+        nsrc = max(1, len(cg.src_keys))
+
+        class Args(ctypes.Structure):
+            _fields_ = [
+                ("src", ctypes.c_void_p * nsrc),
+                ("ten", ctypes.c_void_p * max(1, len(tr.tensors))),
+                ("cot", ctypes.c_void_p * max(1, cg.ncot)),
+                ("par", ctypes.c_void_p * max(1, cg.par_arrays)),
+                ("hs", ctypes.c_void_p), ("hsv", ctypes.c_double * max(1, len(cg.hs))),
+                ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
+                ("off", ctypes.c_int), ("lo", ctypes.c_int), ("ea", ctypes.c_int), ("hw", ctypes.c_int),
+                ("wlo", ctypes.c_void_p * nsrc), ("whi", ctypes.c_void_p * nsrc),
+                ("gwlo", ctypes.c_void_p * nsrc), ("gwhi", ctypes.c_void_p * nsrc),
+            ]
+
+        a = self.args = Args()
+        for i, t in enumerate(tr.tensors):
+            a.ten[i] = t.data_ptr()
+        for i, t in enumerate(self.cot):
+            a.cot[i] = t.data_ptr()
+        a.part, a.ppart, a.part2 = self.part.data_ptr(), self.ppart.data_ptr(), self.part2.data_ptr()
+        a.out, a.pgrad, a.nblocks, a.hs = self.out.data_ptr(), self.pgrad.data_ptr(), self.nblocks, None
+        self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.src_keys, self.gather_keys = list(cg.src_keys), list(cg.gathers)
+        self.param_groups = {key: (cg.pg_offset[key], [len(g) for g in groups]) for key, groups in cg.pgrads.items()}
+
+    _host_value = TracedOperator._host_value  # host scalars (functions of problem.tracers): the single-GPU evaluator
+
+    def set_geometry(self, off, lo, ea):
+        self.args.off, self.args.lo, self.args.ea, self.args.hw = off, lo, ea, self.halo
+
+    def set_params(self, state_arrays_of):
+        """Pointers of network / Array parameters (`state_arrays_of(key)` -> this rank's replicated arrays)."""
+        i = 0
+        for key, _ in self.cg.nets:
+            for arr in state_arrays_of(key):
+                self.args.par[i] = arr.data_ptr()
+                i += 1
+        for key, _ in self.cg.arrays:
+            self.args.par[i] = state_arrays_of(key)[0].data_ptr()
+            i += 1
+
+    def forward(self, srcs, wlo, whi):
+        """Forward + cotangents on the owned cells.  srcs / wlo / whi: src key -> array."""
+        from ._lib import ptr
+
+        ptr(self.out)  # fails loudly on a CPU tensor: there is no CPU path
+        memo = dict()
+        for i, node in enumerate(self.cg.hs):
+            self.args.hsv[i] = float(self._host_value(node, memo))
+        for i, key in enumerate(self.src_keys):
+            self.args.src[i] = srcs[key].data_ptr()
+            self.args.wlo[i], self.args.whi[i] = wlo[key].data_ptr(), whi[key].data_ptr()
+        rc = self.lib.jit_fwd(ctypes.byref(self.args), hip_ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("traced slab kernel launch failed: hip error {}".format(rc))
+
+    def gather(self, key, g, gwlo, gwhi):
+        """Ghost-extended gradient of field `key` (level 0) into g, wrap contributions into gwlo / gwhi."""
+        i = self.src_keys.index(key)
+        self.args.gwlo[i], self.args.gwhi[i] = gwlo.data_ptr(), gwhi.data_ptr()
+        rc = self.lib.jit_gather(self.gather_keys.index(key), ctypes.byref(self.args), g.data_ptr(), hip_ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("traced slab gather launch failed: hip error {}".format(rc))
+
+    def partial_terms(self):
+        """This rank's share of every loss term (sum over owned cells / GLOBAL count)."""
+        return self.out[1:1 + self.nout]
+
+
+class SlabTracedAdam:
+    """One rank of the slab-decomposed Adam loop of a traced operator.
+
+    problem: the GLOBAL problem (global Domain, operator, extra -- constant arrays in `extra` are global, they
+    do not carry the sharded unknowns' time axis); state: the global state's STRUCTURE; its arrays give the
+    initial values when they are real tensors and zeros when they live on the 'meta' device."""
+
+    def __init__(self, problem, state, rank, world, axis=None, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
+                 device=None, kernels=None):
+        from .core import Array, Field, MultigridField, NeuralNet
+
+        domain = problem.domain
+        self.problem, self.domain, self.rank, self.world = problem, domain, rank, world
+        self.device = device if device is not None else domain.mod.device
+        dtype = torch.float64 if np.dtype(domain.dtype) == np.float64 else torch.float32
+        self.dtype = dtype
+        self.npdt = np.float64 if dtype == torch.float64 else np.float32
+        grid = {k: f for k, f in state.fields.items() if isinstance(f, (Field, MultigridField))}
+        if axis is None:
+            ok = [d for d in range(domain.ndim) if all(f.loc[d] == "c" for f in grid.values())]
+            if not ok:
+                raise ValueError("no axis on which every field is cell-centred")
+            axis = ok[0]
+        self.axis = axis
+        N = domain.cshape[axis]
+        if N % world:
+            raise ValueError("{} cells on axis {} over {} ranks".format(N, axis, world))
+        self.n = N // world
+        # ---- layout of the packed vector ---------------------------------------------------------
+        self.entries = []  # (key, kind, [levels] or [shapes])
+        sizes = []
+        for key, f in state.fields.items():
+            if isinstance(f, MultigridField):
+                if not all(float(x) == 1.0 for x in (f.factors or domain.mg_factors or [1])):
+                    raise NotImplementedError("slab decomposition with multigrid factors")
+                mgloc = domain._mg_loc(f)
+                if mgloc[axis] != "c":
+                    raise ValueError("field '{}' is not refined / cell-centred on the sharded axis".format(key))
+                levels = [_Level(tuple(t.array.shape), axis, rank, world) for t in f.terms]
+                init = [t.array for t in f.terms]
+                self.entries.append(dict(key=key, kind="mg", levels=levels, loc=mgloc, init=init))
+                sizes += [lv.size for lv in levels]
+            elif isinstance(f, Field):
+                if f.loc[axis] != "c":
+                    raise ValueError("field '{}' is not cell-centred on the sharded axis".format(key))
+                levels = [_Level(tuple(f.array.shape), axis, rank, world)]
+                self.entries.append(dict(key=key, kind="field", levels=levels, loc=f.loc, init=[f.array]))
+                sizes.append(levels[0].size)
+            elif isinstance(f, (NeuralNet, Array)):
+                arrays = domain.arrays_from_field(f)
+                self.entries.append(dict(key=key, kind="par", shapes=[tuple(a.shape) for a in arrays], init=arrays))
+                sizes += [int(a.numel()) for a in arrays]
+            else:
+                raise TypeError(type(f).__name__)
+        total = sum(sizes)
+        mk = lambda: torch.zeros(total, dtype=dtype, device=self.device)
+        self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
+        pos = 0
+        send_own = dict(lo=[], hi=[])
+        recv_ghost = dict(lo=[], hi=[])
+        for e in self.entries:
+            shapes = [lv.shape for lv in e["levels"]] if "levels" in e else e["shapes"]
+            views = dict(x=[], m=[], v=[], g=[])
+            e["start"] = pos
+            for k, shape in enumerate(shapes):
+                cnt = math.prod(shape)
+                for name, buf in (("x", self.x), ("m", self.m), ("v", self.v), ("g", self.g)):
+                    views[name].append(buf[pos:pos + cnt].view(shape))
+                src = e["init"][k]
+                if src is not None and src.device.type != "meta":
+                    if "levels" in e:
+                        lv = e["levels"][k]
+                        src = src.narrow(axis, lv.off - lv.g_lo, lv.shape[axis])
+                    views["x"][k].copy_(src.to(device=self.device, dtype=dtype))
+                if "levels" in e:
+                    lv = e["levels"][k]
+                    if rank > 0:
+                        send_own["lo"].append(lv.plane_index(pos, 0, self.device))
+                        recv_ghost["lo"].append(lv.plane_index(pos, -1, self.device))
+                    if rank < world - 1:
+                        send_own["hi"].append(lv.plane_index(pos, lv.n - 1, self.device))
+                        recv_ghost["hi"].append(lv.plane_index(pos, lv.n, self.device))
+                pos += cnt
+            e.update(views)
+            del e["init"]
+        cat = lambda parts: torch.cat(parts) if parts else None
+        self._own = {s: cat(send_own[s]) for s in ("lo", "hi")}
+        self._ghost = {s: cat(recv_ghost[s]) for s in ("lo", "hi")}
+        self.by_key = {e["key"]: e for e in self.entries}
+        self.n_unknowns_local = sum(lv.n * lv.plane for e in self.entries if "levels" in e for lv in e["levels"]) + sum(
+            math.prod(s) for e in self.entries if "shapes" in e for s in e["shapes"])
+        self.local_cells = math.prod(domain.cshape) // world
+        self.global_cells = math.prod(domain.cshape)
+        # ---- kernels and their buffers -------------------------------------------------------------
+        self.kern = kernels(problem, state, axis, self.n, self.device) if kernels is not None else HipSlabKernels(
+            problem, state, axis, self.n, self.device)
+        h = self.kern.halo
+        if h > 1:
+            raise TraceUnsupported("reads {} cells away along the sharded axis (the exchange keeps 1 plane)".format(h))
+        self.h = h
+        self.u, self.work, self.wrap = dict(), dict(), dict()
+        for key in self.kern.src_keys:
+            e = self.by_key[key]
+            lv0 = e["levels"][0]
+            wshape = tuple(max(h, 1) if d == axis else s for d, s in enumerate(lv0.shape))
+            z = lambda shape=wshape: torch.zeros(shape, dtype=dtype, device=self.device)
+            self.wrap[key] = dict(lo=z(), hi=z(), glo=z(), ghi=z())
+            if e["kind"] == "mg" and len(e["levels"]) > 1:
+                self.u[key] = torch.zeros(lv0.shape, dtype=dtype, device=self.device)
+                self.work[key] = [None] + [torch.zeros(lv.shape, dtype=dtype, device=self.device)
+                                           for lv in e["levels"][1:-1]] + [None]
+            else:
+                self.u[key] = e["x"][0]
+        lv0 = self.by_key[self.kern.src_keys[0]]["levels"][0]
+        self.kern.set_geometry(lv0.off, lv0.g_lo, lv0.shape[axis])
+        self.kern.set_params(lambda key: self.by_key[key]["x"])
+        self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
+        self.t = 0
+        self.has_params = any(e["kind"] == "par" for e in self.entries) and bool(self.kern.param_groups)
+
+    # ---- pieces of the epoch -------------------------------------------------------------------------
+    def _synthesise(self):
+        for key in self.kern.src_keys:
+            e = self.by_key[key]
+            L = len(e["levels"])
+            if e["kind"] != "mg" or L == 1:
+                continue
+            coarse = e["x"][L - 1]
+            for l in range(L - 2, -1, -1):
+                out = self.u[key] if l == 0 else self.work[key][l]
+                hip_ops.interp_add(e["levels"][l + 1].inner(coarse).contiguous(), e["loc"], add=e["x"][l], out=out)
+                coarse = out
+
+    def _end_planes(self, arrays, side):
+        """The h owned planes at the low ('lo') / high end of each source field's array, packed."""
+        parts = []
+        for key in self.kern.src_keys:
+            lv = self.by_key[key]["levels"][0]
+            a = arrays(key)
+            parts.append(lv.planes(a, 0 if side == "lo" else lv.n - self.h, self.h).reshape(-1))
+        return torch.cat(parts)
+
+    def _split_planes(self, buf):
+        out, off = dict(), 0
+        for key in self.kern.src_keys:
+            shape = self.wrap[key]["lo"].shape
+            cnt = math.prod(shape)
+            out[key] = buf[off:off + cnt].view(shape)
+            off += cnt
+        return out
+
+    def _transpose_chain(self):
+        for key in self.kern.gather_keys:
+            e = self.by_key[key]
+            for l in range(1, len(e["levels"])):
+                lv = e["levels"][l]
+                dst = lv.inner(e["g"][l])
+                dst.copy_(hip_ops.interp_adj(e["g"][l - 1], e["loc"], tuple(dst.shape)))
+
+    # ---- one epoch -------------------------------------------------------------------------------------
+    def epoch_gen(self, timers=None):
+        rank, world, h = self.rank, self.world, self.h
+        first, last = rank == 0, rank == world - 1
+
+        def tic(name):
+            if timers is None:
+                return None
+            a, b = timers.section(name)
+            a.record()
+            return b
+
+        def toc(b):
+            if b is not None:
+                b.record()
+
+        b = tic("halo")
+        lo, hi = self._own["lo"], self._own["hi"]
+        recv_lo, recv_hi = yield ("halo", None if lo is None else self.x.index_select(0, lo),
+                                  None if hi is None else self.x.index_select(0, hi))
+        if recv_lo is not None:
+            self.x.index_copy_(0, self._ghost["lo"], recv_lo)
+        if recv_hi is not None:
+            self.x.index_copy_(0, self._ghost["hi"], recv_hi)
+        toc(b)
+        b = tic("mg_synth")
+        self._synthesise()
+        toc(b)
+        if h:
+            b = tic("halo")
+            ufield = lambda key: self.u[key]
+            recv_lo, recv_hi = yield ("wrap", self._end_planes(ufield, "lo") if first else None,
+                                      self._end_planes(ufield, "hi") if last else None)
+            if recv_lo is not None:
+                for key, t in self._split_planes(recv_lo).items():
+                    self.wrap[key]["lo"].copy_(t)
+            if recv_hi is not None:
+                for key, t in self._split_planes(recv_hi).items():
+                    self.wrap[key]["hi"].copy_(t)
+            toc(b)
+        b = tic("forward")
+        self.kern.forward(self.u, {k: w["lo"] for k, w in self.wrap.items()}, {k: w["hi"] for k, w in self.wrap.items()})
+        toc(b)
+        b = tic("gather")
+        for key in self.kern.gather_keys:
+            w = self.wrap[key]
+            self.kern.gather(key, self.by_key[key]["g"][0], w["glo"], w["ghi"])
+        toc(b)
+        if h and self.kern.gather_keys:
+            b = tic("halo")
+            pack = lambda side: torch.cat([self.wrap[key][side].reshape(-1) for key in self.kern.src_keys])
+            recv_lo, recv_hi = yield ("wrap", pack("glo") if first else None, pack("ghi") if last else None)
+            # what arrives from across the low end belongs to this rank's FIRST owned planes, and vice versa
+            for recv, pos in ((recv_lo, 0), (recv_hi, None)):
+                if recv is None:
+                    continue
+                for key, t in self._split_planes(recv).items():
+                    if key in self.kern.gather_keys:
+                        lv = self.by_key[key]["levels"][0]
+                        lv.planes(self.by_key[key]["g"][0], 0 if pos == 0 else lv.n - h, h).add_(t)
+            toc(b)
+        b = tic("mg_synth_adj")
+        self._transpose_chain()
+        toc(b)
+        b = tic("halo")
+        glo, ghi = self._ghost["lo"], self._ghost["hi"]
+        recv_lo, recv_hi = yield ("halo", None if glo is None else self.g.index_select(0, glo),
+                                  None if ghi is None else self.g.index_select(0, ghi))
+        if recv_lo is not None:
+            self.g.index_add_(0, self._own["lo"], recv_lo)
+        if recv_hi is not None:
+            self.g.index_add_(0, self._own["hi"], recv_hi)
+        toc(b)
+        if self.has_params:
+            total = yield ("sum", self.kern.pgrad.clone(), None)
+            for key, (ofs, lens) in self.kern.param_groups.items():
+                for view, cnt in zip(self.by_key[key]["g"], lens):
+                    view.copy_(total[ofs:ofs + cnt].view(view.shape))
+                    ofs += cnt
+        self.t += 1
+        t = self.npdt(self.t)
+        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
+        b = tic("adam")
+        hip_ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        toc(b)
+
+    def epoch(self, comm, timers=None):
+        gen = self.epoch_gen(timers)
+        try:
+            msg = next(gen)
+            while True:
+                msg = gen.send(comm.exchange(*msg))
+        except StopIteration:
+            pass
+
+    def last_terms(self, comm=None):
+        """Global loss terms of the last evaluation (one small all-reduce)."""
+        part = self.kern.partial_terms().clone()
+        if comm is not None:
+            part = comm.exchange("sum", part, None)
+        return [float(v) for v in part]
+
+    def last_loss(self, comm=None):
+        return float(sum(self.last_terms(comm)))
+
+    def owned_arrays(self):
+        """This rank's part of every unknown array, in `Domain.arrays_from_state` order."""
+        res = []
+        for e in self.entries:
+            if "levels" in e:
+                res += [lv.owned(a) for lv, a in zip(e["levels"], e["x"])]
+            else:
+                res += list(e["x"])
+        return res
+
+
+def shape_state(domain, state):
+    """The structure `Domain.init_state` would give for `state`, with arrays on the 'meta' device (shapes only):
+    what a rank needs of the GLOBAL state when the global arrays would not fit, or need not exist."""
+    from .core import Array, Field, MultigridField, NeuralNet, State
+    from .backend import torch_dtype
+
+    dt = torch_dtype(domain.dtype)
+    meta = lambda shape: torch.empty(tuple(shape), dtype=dt, device="meta")
+    fields = dict()
+    for key, f in state.fields.items():
+        if f is None or isinstance(f, Field):
+            loc = (f.loc if f is not None else None) or "c" * domain.ndim
+            cshape = (f.cshape if f is not None else None) or domain.cshape
+            if domain.multigrid and domain.mg_convert_all:
+                terms = [Field(meta(domain._get_field_shape(cs, loc)), loc=loc, cshape=cs) for cs in domain.mg_cshapes]
+                fields[key] = MultigridField(terms=terms, loc=loc, factors=domain.mg_factors, method=domain.mg_interp)
+            else:
+                fields[key] = Field(meta(domain._get_field_shape(cshape, loc)), loc=loc, cshape=cshape)
+        elif isinstance(f, (NeuralNet, Array, MultigridField)):
+            fields[key] = domain.init_field(f)
+        else:
+            raise TypeError(type(f).__name__)
+    return State(fields=fields, initialized=True)

@@ -41,15 +41,17 @@ def make_rhs(N, world):
 def worker(rank, world, N, epochs, port, out):
     import slab_oracle_ops
 
+    from odil_amd import slab
     from odil_amd.slab import SlabPoissonAdam, TorchDistComm
+
+    slab.hip_ops = slab_oracle_ops  # the exchange logic without a GPU: NumPy-oracle doubles of the kernels
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rhs = torch.from_numpy(make_rhs(N, world))
-        run = SlabPoissonAdam(N, rank, world, dtype=torch.float64, device=torch.device("cpu"), ops=slab_oracle_ops,
-                              rhs_global=rhs)
+        run = SlabPoissonAdam(N, rank, world, dtype=torch.float64, device=torch.device("cpu"), rhs_global=rhs)
         comm = TorchDistComm(rank, world)
         losses = []
         for _ in range(epochs):

@@ -117,3 +117,75 @@ def test_bench_single_gpu_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+# ---- traced operators (odil_amd/slab_traced.py): ranks emulated on one GPU == the undivided HIP path ------------
+def _traced_problem(which, world, dtype_flag):
+    import os
+    import sys
+
+    import odil_amd as odil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub in ("heat", "velocity_from_tracer"):
+        sys.path.insert(0, os.path.join(root, "examples", sub))
+    ex = __import__(which)
+    odil.util.set_log_file(open(os.devnull, "w"))
+    nx = 16 * world
+    if which == "veltracer":
+        argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32"]
+    elif which == "veltracer3d":
+        argv = ["--Nt", "8", "--Nx", str(nx), "--Ny", "16", "--Nz", "24"]
+    else:
+        argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32", "--infer_k", "1", "--imposed", "stripe"]
+    problem, state = ex.make_problem(ex.parse_args(argv + ["--double", str(dtype_flag)]))
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    arrays = problem.domain.arrays_from_state(state)
+    new = [(torch.randn(tuple(a.shape), generator=gen, dtype=torch.float64) * 0.1).to(device=a.device, dtype=a.dtype)
+           for a in arrays]
+    problem.domain.arrays_to_state(new, state)
+    return problem, state
+
+
+@pytest.mark.parametrize("which,world,double", [("veltracer", 2, 1), ("veltracer", 3, 1), ("veltracer3d", 2, 1),
+                                                ("heat2d", 2, 1), ("veltracer", 4, 0)])
+def test_slab_traced_emulated_ranks_equal_single_gpu(which, world, double):
+    """The slab-decomposed Adam loop of a traced operator -- generated kernels in slab mode (global indices,
+    ghost-extended sources, periodic wrap planes, ghost-writing gathers), exchange-free P^T chain, deferred
+    halo-add, summed parameter gradients of the pointwise network -- against the single-GPU traced path of the
+    same problem: loss and every level array after 3 epochs."""
+    import argparse
+
+    import odil_amd as odil
+    from odil_amd.slab import run_lockstep
+    from odil_amd.slab_traced import SlabTracedAdam
+
+    problem, state = _traced_problem(which, world, double)
+    lr, epochs = 0.01, 3
+    # heat2d's fields are cell-centred in t too; x is the axis the workloads shard
+    ranks = [SlabTracedAdam(problem, state, r, world, axis=1, lr=lr) for r in range(world)]
+    assert ranks[0].h == 1
+    run_lockstep(ranks, epochs)
+    run_lockstep(ranks, 1)  # evaluates the loss at the state after `epochs` updates
+    got_loss = sum(r.last_loss() for r in ranks)
+    a = argparse.Namespace(epoch_start=0, epochs=epochs, lr=lr, bfgs_m=None, bfgs_pgtol=None, bfgs_maxls=None,
+                           adam_epsilon=None, adam_beta_1=None, adam_beta_2=None, callback_update_state=0)
+    start = [t.clone() for t in problem.domain.arrays_from_state(state)]
+    odil.util.optimize_grad(a, "adam", problem, state, None)
+    assert problem._traced is not None
+    want_loss = float(problem.eval_loss_grad(state)[0])
+    tol = 1e-10 if double else 2e-4
+    assert abs(got_loss - want_loss) <= tol * abs(want_loss), (got_loss, want_loss)
+    # the ranks have made epochs + 1 updates: the undivided problem again from the start (a new optimizer run
+    # starts with fresh moments)
+    problem.domain.arrays_to_state(start, state)
+    a.epochs = epochs + 1
+    odil.util.optimize_grad(a, "adam", problem, state, None)
+    want = problem.domain.arrays_from_state(state)
+    for r, run in enumerate(ranks):
+        for i, (got, ref) in enumerate(zip(run.owned_arrays(), want)):
+            if got.shape != ref.shape:  # a grid array: this rank's planes of the sharded axis
+                n = ref.shape[1] // world
+                ref = ref[:, r * n:(r + 1) * n]
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= (1e-10 if double else 1e-4) * scale, (r, i)

@@ -1,0 +1,110 @@
+"""Slab decomposition of TRACED operators on CPU, world_size 2 and 3 over gloo: odil_amd/slab_traced.py runs
+unchanged -- its packed exchanges, the periodic wrap planes of `Context.field`, the exchange-free P^T chain with
+one deferred halo-add, partial loss sums -- with CPU doubles for the kernels (tests/slab_traced_double.py for the
+generated ones, tests/slab_oracle_ops.py for the transfers and Adam).  The result must equal the UNDIVIDED
+problem evaluated by the generic oracle (oracle/odil_generic.py, itself pinned against the reference's
+fixtures) under the oracle's Adam: tracer velocity in two and in three space dimensions."""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "examples", "velocity_from_tracer"))
+
+
+def make_problem(which, world):
+    """The GLOBAL problem on CPU tensors (no kernel runs here) with a random state: (problem, state)."""
+    import odil_amd as odil
+
+    odil.runtime._mod = odil.ModRocm(device="cpu")
+    odil.util.set_log_file(open(os.devnull, "w"))
+    ex = __import__(which)
+    nx = 8 * world
+    argv = ["--Nt", "8", "--Nx", str(nx), "--Ny", "8", "--double", "1"] + (["--Nz", "8"] if which == "veltracer3d" else [])
+    args = ex.parse_args(argv)
+    problem, state = ex.make_problem(args)
+    rng = np.random.default_rng(7)
+    arrays = [torch.tensor(rng.standard_normal(tuple(a.shape)) * 0.1) for a in problem.domain.arrays_from_state(state)]
+    problem.domain.arrays_to_state(arrays, state)
+    return problem, state
+
+
+def local_extra(extra, off, n):
+    """u_init / u_final are (x, y[, z]) arrays: the rank's x range."""
+    return argparse.Namespace(args=extra.args, u_init=extra.u_init[off:off + n], u_final=extra.u_final[off:off + n])
+
+
+def worker(rank, world, which, epochs, port, out):
+    import slab_oracle_ops
+    import slab_traced_double
+
+    from odil_amd import slab_traced
+    from odil_amd.slab import TorchDistComm
+
+    slab_traced.hip_ops = slab_oracle_ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        problem, state = make_problem(which, world)
+        run = slab_traced.SlabTracedAdam(problem, state, rank, world, lr=0.01, device=torch.device("cpu"),
+                                         kernels=slab_traced_double.make_kernels(local_extra))
+        assert run.axis == 1
+        comm = TorchDistComm(rank, world)
+        losses = []
+        for _ in range(epochs):
+            run.epoch(comm)
+            losses.append(run.last_loss(comm))
+        torch.save({"losses": losses, "owned": [a.clone().numpy() for a in run.owned_arrays()]},
+                   os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def undivided(which, world, epochs):
+    from oracle import odil_generic as og
+    from oracle import odil_np as onp
+
+    problem, state = make_problem(which, world)
+    domain = problem.domain
+    geom = og.Geometry.of(domain)
+    fields = og.fields_of_state(domain, state)
+    keys = list(fields)
+    nlvl = len(fields[keys[0]]["terms"])
+    x0 = [t for k in keys for t in fields[k]["terms"]]
+
+    def loss_grad(x):
+        for i, k in enumerate(keys):
+            fields[k]["terms"] = x[i * nlvl:(i + 1) * nlvl]
+        loss, grads = og.eval_loss_grad(problem.operator, geom, fields, problem.extra)[:2]
+        return loss, grads
+
+    x, losses = onp.adam_run(x0, loss_grad, epochs, 0.01)
+    return x, losses, domain
+
+
+@pytest.mark.parametrize("which,world", [("veltracer", 2), ("veltracer", 3), ("veltracer3d", 2)])
+def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world):
+    epochs = 3
+    port = 29500 + (os.getpid() * 7 + world + len(which)) % 2000
+    mp.spawn(worker, args=(world, which, epochs, port, str(tmp_path)), nprocs=world, join=True)
+    x_ref, losses_ref, domain = undivided(which, world, epochs)
+    results = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    for r in range(world):
+        assert np.max(np.abs(np.array(results[r]["losses"]) - np.array(losses_ref)) / np.array(losses_ref)) < 1e-12
+    for i, ref in enumerate(x_ref):
+        n = ref.shape[1] // world
+        for r in range(world):
+            got = results[r]["owned"][i]
+            want = ref[:, r * n:(r + 1) * n]
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.max(np.abs(want))), (i, r)
