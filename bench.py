@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-point-updates/s of the ODIL hot path on MI355X.
 
-Workload (BASELINE.json metric): 3-D Poisson 512^3, multigrid decomposition (9 levels),
+Default workload (BASELINE.json metric, config "4a"): 3-D Poisson 512^3, multigrid decomposition (9 levels),
 f64, Adam -- one "step" is one optimizer epoch of the reference's hot loop
 (reference src/odil/optimizer.py:331-336): multigrid synthesis -> residual + loss ->
 adjoint -> P^T chain -> Adam update.  Metric = prod(cshape) * steps / wall
 (reference src/odil/util.py:408-419), inputs resident in HBM, synthetic (`hat`
 reference solution, discrete rhs, zero initial state; poisson.py:21-24,71-86,264-266).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--N 512] [--ndim 3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4a|5|1|2|3|3b|4b|5b] [--N 512] [--ndim 3]
 
-N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run
+N > 1: one rank per GPU over RCCL, weak scaling (every rank owns a 512^3 slab of the (N*512, 512, 512) grid;
+config 5: a (128, 32, 256, 256) slab of the tracer workload's (128, N*32, 256, 256) grid -- at N = 8 the
+256^3 x 128t grid BASELINE.json names).  Either the caller starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE are then in the environment), or plain
-`python bench.py --gpus N` starts them itself as FRESH child processes before this process has touched
-the GPU, relays rank 0's JSON line and exits with the children's status.
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` starts them itself as FRESH child processes before this process has touched the
+GPU, relays rank 0's JSON line and exits with the children's status.
+Prints ONE JSON line on rank 0.  The other --config values run the remaining BASELINE configs through the
+public operator API on one GPU (what bench_configs.py prints, in the driver's JSON contract).
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,11 +41,15 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=40)
     p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--config", type=str, default="4a", choices=["4a", "5", "1", "2", "3", "3b", "4b", "5b"])
     p.add_argument("--N", type=int, default=512)
     p.add_argument("--ndim", type=int, default=3)
     p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_N", type=int, default=128, help="grid size of the CPU-baseline sample")
+    p.add_argument("--cpu_N", type=int, default=256, help="grid size of the 1-core CPU-baseline sample")
+    p.add_argument("--cpu_N_all", type=int, default=128, help="grid size per core of the all-cores CPU-baseline leg")
+    p.add_argument("--cpu_budget", type=float, default=10.0, help="seconds of timed CPU work per leg")
+    p.add_argument("--scale", type=float, default=1.0, help="shrinks the grids of the non-default configs (smoke runs)")
     return p.parse_args()
 
 
@@ -51,53 +59,51 @@ def algorithmic_bytes_per_update(ndim, nlvl, wordsize):
     return (10 * S + 5) * wordsize, S
 
 
-def cpu_baseline(ndim, N, budget_s=20.0):
-    """The oracle (NumPy port of the reference op sequence) timed on this host, 1 thread."""
-    from oracle import odil_np as onp
+def cpu_baseline(ndim, n_one, n_all, budget_s):
+    """The oracle (NumPy port of the reference op sequence, oracle/odil_np.py) timed on this host by
+    oracle/cpu_bench.py workers, outside the timed region and before this process touches the GPU:
+    (i) ONE thread, the reference's default (reference src/odil/runtime.py:8-12); (ii) one worker per host core,
+    concurrently, each on its own grid (what ODIL_MT / one process per core can at best deliver)."""
+    def leg(nproc, n, budget):
+        start = time.time() + 5.0 + 0.02 * nproc
+        cmd = [sys.executable, "-m", "oracle.cpu_bench", str(ndim), str(n), str(budget), str(start)]
+        procs = [subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        if any(p.returncode for p in procs):
+            raise RuntimeError("cpu_bench worker failed")
+        return sum(o["cells"] * o["epochs"] / o["seconds"] for o in outs), outs
 
-    cshape = (N,) * ndim
-    dw = onp.step(cshape)
-    rhs = onp.poisson_discrete_rhs(onp.poisson_ref_u(cshape), dw)
-    x = [np.zeros(s) for s in onp.mg_cshapes(cshape)]
-    m = [np.zeros_like(a) for a in x]
-    v = [np.zeros_like(a) for a in x]
-
-    def epoch(k):
-        nonlocal x, m, v
-        loss, grads, _ = onp.poisson_loss_grad(x, rhs, dw)
-        x, m, v = onp.adam_step(x, m, v, grads, k, 0.005)
-
-    epoch(1)
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        epoch(k + 2)
-        k += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or k >= 50:
-            break
+    v1, o1 = leg(1, n_one, budget_s)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    vall, oall = leg(cores, n_all, budget_s)  # ~0.3 GB per 128^3 worker
     return {
-        "value": N**ndim * k / el,
+        "value": v1,
         "unit": "grid-point-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": "oracle/odil_np.py, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s".format(
-            ndim, N, ndim, k, el
-        ),
+        "sample": "oracle/odil_np.py, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s on one thread".format(
+            ndim, n_one, ndim, o1[0]["epochs"], o1[0]["seconds"]),
+        "all_cores": {
+            "value": vall,
+            "cores": cores,
+            "sample": "{} concurrent single-thread workers, each Poisson {}-D {}^{} f64 multigrid Adam, {:.1f} s".format(
+                cores, ndim, n_all, ndim, max(o["seconds"] for o in oall)),
+        },
     }
 
 
 def measured_traffic(kernel, ndim, N, dtype):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (collected separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied);
-    None when no profile of this kernel / workload is on record."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-    except OSError:
-        return None
-    if rec.get("kernel") == kernel and (ndim, N, dtype) == (3, 512, "f64"):
-        return rec["traffic_bytes_per_launch"]
-    return None
+    (collected separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied), and the
+    file they come from; (None, None) when no profile of this kernel / workload is on record."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        if rec.get("kernel", "").split(" ")[0] == kernel.split(" ")[0] and (ndim, N, dtype) == (3, 512, "f64"):
+            return rec["traffic_bytes_per_launch"], "profiles/" + name + " (rocprofv3 --pmc, 512^3 f64 only)"
+    return None, None
 
 
 class Timers:
@@ -121,7 +127,6 @@ def spawn_ranks(ngpus):
     process (this process has not initialised the GPU and never does), pass its output through, return its
     exit status."""
     import socket
-    import subprocess
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -133,6 +138,158 @@ def spawn_ranks(ngpus):
     return subprocess.call(cmd, env=env)
 
 
+def roofline(kernel, model_bytes, moved_bytes, ms, traffic, traffic_source):
+    """`frac` is PHYSICAL: bytes the launch moves (PMC counters when a profile of this exact launch is on record,
+    else the bytes it must move) / its HIP-event duration / 8 TB/s.  `frac_model` prices the SURVEY 8(d) minimum-
+    traffic model of the work the launch covers -- a fusion credit, it can exceed what any memory system does."""
+    phys = traffic if traffic is not None else moved_bytes
+    achieved = phys / (ms * 1e-3) / 1e9
+    model = model_bytes / (ms * 1e-3) / 1e9
+    return {
+        "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "traffic_source": traffic_source or "none on record for this workload: frac uses compulsory_bytes_per_launch",
+        "avg_launch_ms": ms, "algorithmic_bytes_per_launch": model_bytes, "compulsory_bytes_per_launch": moved_bytes,
+        "achieved_model": model, "frac_model": model / HBM_PEAK_GBS,
+    }
+
+
+class LocalComm:
+    """The exchanges of a slab epoch when there is one rank: the periodic closure is the rank itself."""
+
+    def exchange(self, kind, a, b):
+        if kind == "sum":
+            return a
+        return (b, a) if kind == "wrap" else (None, None)
+
+
+def run_poisson(args, rank, world, dev, comm, barrier):
+    from odil_amd.poisson_path import PoissonMultigridAdam
+    from odil_amd.slab import SlabPoissonAdam
+
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    ndim, N = args.ndim, args.N
+    if world > 1:
+        # weak scaling: every rank owns an N^3 slab of the (world*N, N, N) grid
+        assert ndim == 3, "the slab decomposition is 3-D"
+        run = SlabPoissonAdam(N, rank, world, dtype=dtype, device=dev)
+        step = lambda timers=None: run.epoch(comm, timers)
+    else:
+        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev)
+        step = lambda timers=None: run.epoch(timers)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timers = Timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss = run.last_loss(comm) if world > 1 else run.last_loss()
+    wordsize = 8 if dtype == torch.float64 else 4
+    kt = timers.summary()
+    tname = "double" if wordsize == 8 else "float"
+    if "adjoint_transpose" in kt:
+        # Dominant kernel: stencil adjoint + first transposed prolongation + the Adam updates of levels 0 and
+        # 1 in one launch.  Model bytes (SURVEY.md 8(d)) of the work this launch covers: stencil adjoint 2 words
+        # (read r, write g) + first level of the P^T chain 1 + 1/8 (read g, write g1) + Adam 7 words per unknown
+        # of levels 0 and 1 (7 + 7/8) = 11 words per fine cell.  The launch itself moves less -- g never reaches
+        # memory: read fu; read + write x, m, v of level 0; write g1 and read + write x, m, v of level 1 =
+        # 7 + 7/8 words.
+        kernel = "k_poisson_adjoint_tile<{}> (adjoint + first P^T + Adam of levels 0 and 1)".format(tname)
+        model = 11.0 * run.local_cells * wordsize
+        moved = (7.0 + 7.0 / 8.0) * run.local_cells * wordsize
+        ms = kt["adjoint_transpose"]
+    elif kt.get("adjoint", 0) > kt.get("adam", 0):
+        # adjoint with the finest-level Adam update fused in: read fu, x, m, v; write gu, x, m, v
+        kernel = "k_poisson_adjoint<{}, true> (+Adam of the finest level)".format(tname)
+        model = moved = 8.0 * run.local_cells * wordsize
+        ms = kt["adjoint"]
+    else:
+        kernel = "k_adam<{}>".format(tname)
+        model = moved = 7.0 * run.n_unknowns_local * wordsize
+        ms = kt["adam"]
+    traffic, source = measured_traffic(kernel, ndim, N, args.dtype) if world == 1 else (None, None)
+    abytes, S = algorithmic_bytes_per_update(ndim, run.nlvl, wordsize)
+    return dict(
+        elapsed=elapsed, cells=run.global_cells, loss=loss, kernel_ms=kt,
+        metric="grid-point-updates/s, Poisson {}^{} multigrid".format(N, ndim),
+        workload=("3D Poisson 512^3 multigrid (9 levels) Adam epoch, {}".format(
+            "1xMI355X" if world == 1 else "512^3 slab per GPU x {} MI355X".format(world))
+            if (ndim, N) == (3, 512) else "{}D Poisson {}^{} multigrid Adam epoch".format(ndim, N, ndim)),
+        config=dict(cells_per_gpu=run.local_cells, levels=run.nlvl, optimizer="adam lr=0.005"),
+        roofline=roofline(kernel, model, moved, ms, traffic, source), abytes=abytes, dtype=args.dtype,
+        exchanges_per_epoch=2 if world > 1 else 0)
+
+
+def run_tracer(args, rank, world, dev, comm, barrier):
+    """BASELINE config 5: velocity from tracer with three space dimensions, slab-decomposed along x."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", "velocity_from_tracer"))
+    import odil_amd as odil
+    import veltracer3d
+    from odil_amd.slab_traced import SlabTracedAdam, shape_state
+
+    sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
+    nt, nx_rank, ny = sc(128), sc(32), sc(256)
+    odil.util.set_log_file(open(os.devnull, "w"))
+    nlvl = int(np.log2(nx_rank))  # every level keeps >= 2 cells of x per rank
+    a = veltracer3d.parse_args(["--Nt", str(nt), "--Nx", str(nx_rank * world), "--Ny", str(ny), "--Nz", str(ny),
+                                "--nlvl", str(nlvl)])
+    dtype = np.float32
+    domain = odil.Domain(cshape=(a.Nt, a.Nx, a.Ny, a.Nz), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
+                         upper=(1, 1, 1, 1), dtype=dtype, multigrid=a.multigrid, mg_interp=a.mg_interp, mg_nlvl=a.nlvl)
+    x, y, z = np.meshgrid(*domain.points_1d("x", "y", "z"), indexing="ij")
+    extra = argparse.Namespace(args=a)
+    extra.u_init = domain.mod.cast(veltracer3d.blob(x, y, z, 0), dtype)
+    extra.u_final = domain.mod.cast(veltracer3d.blob(x, y, z, 1), dtype)
+    del x, y, z
+    state = odil.State()
+    for key in ("u",) + veltracer3d.VEL:
+        state.fields[key] = odil.Field(None, loc=veltracer3d.LOC)
+    problem = odil.Problem(veltracer3d.operator, domain, extra)
+    run = SlabTracedAdam(problem, shape_state(domain, state), rank, world, lr=a.lr, device=dev)
+    for _ in range(args.warmup):
+        run.epoch(comm)
+    barrier()
+    timers = Timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.epoch(comm, timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss = run.last_loss(comm)
+    kt = timers.summary()
+    nsrc, ncot = len(run.kern.src_keys), len(run.kern.cot)
+    moved = float(nsrc + ncot) * run.local_cells * 4  # reads each field once (neighbours are cache hits), writes the cotangents
+    return dict(
+        elapsed=elapsed, cells=run.global_cells, loss=loss, kernel_ms=kt,
+        metric="grid-point-updates/s, velocity_from_tracer {}^3 x {}t".format(ny, nt),
+        workload="3D velocity_from_tracer (t,x,y,z) = ({},{},{},{}) slab per GPU x {} MI355X, Adam epoch, f32, {} levels".format(
+            nt, nx_rank, ny, ny, world, nlvl),
+        config=dict(cells_per_gpu=run.local_cells, levels=nlvl, optimizer="adam lr={}".format(a.lr), fields=4),
+        roofline=roofline("k_fwd (generated: residuals + reverse pass, {} fields in, {} cotangent arrays out)".format(nsrc, ncot),
+                          moved, moved, kt["forward"], None, None),
+        abytes=None, dtype="f32", exchanges_per_epoch=4 if world > 1 else 0)
+
+
+def run_api(args, dev):
+    """Configs 1, 2, 3, 3b, 4b, 5b through the public operator API (bench_configs.py) on one GPU."""
+    import bench_configs
+
+    out = bench_configs.run_config(args.config, args.scale, epochs=args.steps, warmup=args.warmup)
+    model = out.get("model_bytes_per_update")
+    ms = out["ms_per_epoch"]
+    rl = None
+    if model:
+        rl = roofline("whole epoch (all launches; SURVEY 8(d) model bytes -- no single dominant launch timed)",
+                      model * out["cells"], model * out["cells"], ms, None, None)
+    return dict(elapsed=out["wall_s"], cells=out["cells"], loss=out["loss"], kernel_ms={},
+                metric="grid-point-updates/s, " + out["name"], workload=out["name"] + ", 1xMI355X, public operator API",
+                config=dict(cells_per_gpu=out["cells"], optimizer=out["optimizer"]), roofline=rl, abytes=model,
+                dtype=out["dtype"], exchanges_per_epoch=0, steps=out["epochs"])
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -140,8 +297,15 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:  # child processes: started before this process initialises the GPU
+        cpu = cpu_baseline(args.ndim if args.config == "4a" else 3, args.cpu_N, args.cpu_N_all, args.cpu_budget)
+    comm = LocalComm()
+    dist = None
     if world > 1:
         import torch.distributed as dist
+
+        from odil_amd.slab import TorchDistComm
 
         backend = os.environ.get("ODIL_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
         ngpu = torch.cuda.device_count()
@@ -156,139 +320,55 @@ def main():
         assert dist.get_world_size() == world
         if args.gpus != world:
             raise SystemExit("bench.py: --gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+        comm = TorchDistComm(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local_rank)
-
-    from odil_amd.poisson_path import PoissonMultigridAdam
-    from odil_amd.slab import SlabPoissonAdam, TorchDistComm
-
-    dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    ndim, N = args.ndim, args.N
-    comm = None
-    if world > 1:
-        # weak scaling: every rank owns an N^3 slab of the (world*N, N, N) grid
-        assert ndim == 3, "the slab decomposition is 3-D"
-        run = SlabPoissonAdam(N, rank, world, dtype=dtype, device=dev)
-        comm = TorchDistComm(rank, world)
-        step = lambda timers=None: run.epoch(comm, timers)
-    else:
-        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev)
-        step = lambda timers=None: run.epoch(timers)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
-
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    timers = Timers()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timers)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if args.config == "4a":
+        res = run_poisson(args, rank, world, dev, comm, barrier)
+    elif args.config == "5":
+        res = run_tracer(args, rank, world, dev, comm, barrier)
+    else:
+        assert world == 1, "config {} is a single-GPU run".format(args.config)
+        res = run_api(args, dev)
+    elapsed = res["elapsed"]
+    dist_world, comm_backend = 1, None
     if world > 1:
-        import torch.distributed as dist
-
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss = run.last_loss(comm) if world > 1 else run.last_loss()
-    dist_world, comm_backend = 1, None
-    if world > 1:
         dist_world = dist.get_world_size()
         comm_backend = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
-
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        cells_total = run.global_cells
-        value = cells_total * args.steps / elapsed
-        wordsize = 8 if dtype == torch.float64 else 4
-        abytes, S = algorithmic_bytes_per_update(ndim, run.nlvl, wordsize)
-        kt = timers.summary()
-        n_unknowns = run.n_unknowns_local
-        moved_bytes = None
-        if "adjoint_transpose" in kt:
-            # Dominant kernel: stencil adjoint + first transposed prolongation + the Adam updates of levels 0 and
-            # 1 in one launch.  ALGORITHMIC bytes by the minimum-traffic model of SURVEY.md 8(d) for the work this
-            # launch covers: stencil adjoint 2 words (read r, write g) + first level of the P^T chain 1 + 1/8
-            # (read g, write g1) + Adam 7 words per unknown of levels 0 and 1 (7 + 7/8) = 11 words per fine cell.
-            # The launch itself moves less -- g never reaches memory: read fu; read + write x, m, v of level 0;
-            # write g1 and read + write x, m, v of level 1 = 7 + 7/8 words -- reported beside it.
-            dom_name = "k_poisson_adjoint_tile<{}> (adjoint + first P^T + Adam of levels 0 and 1)"
-            adam_bytes = 11.0 * run.local_cells * wordsize
-            moved_bytes = (7.0 + 7.0 / 8.0) * run.local_cells * wordsize
-            adam_ms = kt["adjoint_transpose"]
-        elif kt.get("adjoint", 0) > kt.get("adam", 0):
-            # Dominant kernel: adjoint with the finest-level Adam update fused in:
-            # read fu, x, m, v; write gu, x, m, v = 8 words per fine cell.
-            dom_name = "k_poisson_adjoint<{}, true> (+Adam of the finest level)"
-            adam_bytes = 8.0 * run.local_cells * wordsize
-            adam_ms = kt["adjoint"]
-        else:
-            # Dominant kernel: Adam over the packed multigrid state (7 words per unknown).
-            dom_name = "k_adam<{}>"
-            adam_bytes = 7.0 * n_unknowns * wordsize
-            adam_ms = kt["adam"]
-        achieved = adam_bytes / (adam_ms * 1e-3) / 1e9
+        steps = res.get("steps", args.steps)
+        value = res["cells"] * steps / elapsed
+        config = {"workload": res["workload"]}
+        config.update(res["config"])
+        config.update({"decomposition": "slab x{}".format(world) if world > 1 else "none", "rccl_ranks": dist_world,
+                       "comm_backend": comm_backend, "exchanges_per_epoch": res["exchanges_per_epoch"]})
         out = {
-            "metric": "grid-point-updates/s, Poisson {}^{} multigrid".format(N, ndim),
-            "value": value,
-            "unit": "grid-point-updates/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": "3D Poisson 512^3 multigrid (9 levels) Adam epoch, {}".format(
-                    "1xMI355X" if world == 1 else "512^3 slab per GPU x {} MI355X".format(world))
-                if (ndim, N) == (3, 512)
-                else "{}D Poisson {}^{} multigrid Adam epoch".format(ndim, N, ndim),
-                "cells_per_gpu": run.local_cells,
-                "levels": run.nlvl,
-                "optimizer": "adam lr=0.005",
-                "decomposition": "slab x{}".format(world) if world > 1 else "none",
-                "rccl_ranks": dist_world,
-                "comm_backend": comm_backend,
-            },
-            "roofline": {
-                "kernel": dom_name.format("double" if wordsize == 8 else "float"),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(dom_name.format("double" if wordsize == 8 else "float"), ndim, N, args.dtype),
-                "algorithmic_bytes_per_launch": adam_bytes,
-                "avg_launch_ms": adam_ms,
-                "compulsory_bytes_per_launch": moved_bytes,
-                "achieved_on_compulsory_bytes": None if moved_bytes is None else moved_bytes / (adam_ms * 1e-3) / 1e9,
-            },
-            "epoch_roofline": {
-                "algorithmic_bytes_per_update": abytes,
-                "achieved": value * abytes / world / 1e9,
-                "frac": value * abytes / world / 1e9 / HBM_PEAK_GBS,
-                "unit": "GB/s per GPU",
-            },
-            "kernel_ms": kt,
-            "loss_after": loss,
+            "metric": res["metric"], "value": value, "unit": "grid-point-updates/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic", "config": config,
+            "roofline": res["roofline"],
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ndim, args.cpu_N if ndim == 3 else min(N, 2048))
+        if res["abytes"]:
+            out["epoch_roofline"] = {
+                "algorithmic_bytes_per_update": res["abytes"], "achieved": value * res["abytes"] / world / 1e9,
+                "frac": value * res["abytes"] / world / 1e9 / HBM_PEAK_GBS, "unit": "GB/s per GPU (SURVEY 8(d) model bytes)",
+            }
+        out["kernel_ms"] = res["kernel_ms"]
+        out["loss_after"] = res["loss"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
-
         dist.destroy_process_group()
 
 

@@ -51,74 +51,66 @@ def run(problem, state, args, optname, epochs, warmup=2):
                 updates_per_s=cells * epochs / wall, loss=loss, fused=problem._fused is not None)
 
 
+CONFIGS = {
+    # key: (example module, argv builder(sc), optimizer, default epochs, warmup, name)
+    "1": ("poisson", lambda sc: ["--ndim", "1", "--N", "256"], "adam", 400, 2, "poisson 1D N=256 adam f64 mg"),
+    "2": ("poisson", lambda sc: ["--ndim", "2", "--N", str(sc(1024))], "lbfgsb", 100, 1, "poisson 2D {0}^2 lbfgsb f64 mg"),
+    "3": ("heat", lambda sc: ["--Nt", str(sc(256)), "--Nx", str(sc(512)), "--infer_k", "1", "--imposed", "stripe"], "adam", 50, 2,
+          "heat inverse {0}x{1} adam f32 mg (traced operator)"),
+    "3b": ("heat2d", lambda sc: ["--Nt", str(sc(256)), "--Nx", str(sc(512)), "--Ny", str(sc(512)), "--infer_k", "1",
+                                 "--imposed", "stripe"], "adam", 20, 2, "heat inverse {0}x{1}x{1} adam f32 mg (traced operator)"),
+    "4a": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512))], "adam", 20, 2, "poisson 3D {0}^3 adam f64 mg"),
+    "4b": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512)), "--multigrid", "0", "--linsolver", "multigrid",
+                                  "--linsolver_tol", "1e-10"], "newton", 1, 1, "poisson 3D {0}^3 newton + gmg f64 (second step: work buffers exist)"),
+    "5": ("veltracer", lambda sc: ["--Nt", str(sc(128)), "--Nx", str(sc(256)), "--Ny", str(sc(256))], "adam", 20, 2,
+          "veltracer {0}x{1}x{1} adam f32 mg (traced operator)"),
+    "5b": ("veltracer3d", lambda sc: ["--Nt", str(sc(32)), "--Nx", str(sc(256))], "adam", 5, 1,
+           "veltracer3d {0}x{1}^3 adam f32 mg (traced operator)"),
+}
+
+
+def model_bytes_per_update(problem, state, optname, nout):
+    """SURVEY.md 8(d) minimum-traffic model for k multigrid fields and n_out outputs under Adam:
+    synthesis k (S + 1) + residual (k + 1 constant + n_out) + adjoint (n_out + k) + P^T chain k (2 S - 1) + Adam 7 k S
+    = k (10 S + 2) + 2 n_out + 1 words per grid cell; None for the other optimizers."""
+    if optname != "adam":
+        return None
+    domain = problem.domain
+    k = sum(1 for f in state.fields.values() if isinstance(f, (odil.Field, odil.MultigridField)))
+    nl = domain.mg_nlvl if domain.multigrid else 1
+    axes = sum(1 for a in (domain.mg_axes if domain.multigrid else [])) or domain.ndim
+    S = sum(2.0 ** (-axes * l) for l in range(nl))
+    wordsize = np.dtype(domain.dtype).itemsize
+    return (k * (10 * S + 2) + 2 * nout + 1) * wordsize
+
+
+def run_config(key, scale=1.0, epochs=None, warmup=None):
+    """One BASELINE config through the public operator API; returns a dict (see `run`) + name / optimizer / dtype."""
+    import importlib
+
+    sc = lambda n: max(8, int(round(n * scale)) // 8 * 8)
+    modname, argv, optname, nepochs, nwarm, name = CONFIGS[key]
+    ex = importlib.import_module(modname)
+    args = ex.parse_args(argv(sc))
+    problem, state = ex.make_problem(args)
+    res = run(problem, state, args, optname, epochs or nepochs, warmup=nwarm if warmup is None else min(warmup, nwarm))
+    cs = problem.domain.cshape
+    res["name"] = name.format(cs[0], cs[-1])
+    res["optimizer"] = optname
+    res["dtype"] = "f64" if np.dtype(problem.domain.dtype) == np.float64 else "f32"
+    nout = len(problem.eval_loss_grad(state)[2])
+    res["model_bytes_per_update"] = model_bytes_per_update(problem, state, optname, nout)
+    return res
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--configs", nargs="*", default=["1", "2", "3", "3b", "4a", "4b", "5", "5b"])
     p.add_argument("--scale", type=float, default=1.0)
     a = p.parse_args()
-    sc = lambda n: max(8, int(round(n * a.scale)) // 8 * 8)
-    out = {}
-    if "1" in a.configs:  # Poisson 1-D N=256, Adam (launch-bound plumbing case)
-        import poisson
-
-        args = poisson.parse_args(["--ndim", "1", "--N", "256"])
-        problem, state = poisson.make_problem(args)
-        out["1: poisson 1D N=256 adam f64 mg"] = run(problem, state, args, "adam", 400)
-    if "2" in a.configs:  # Poisson 2-D 1024^2, multigrid decomposition, L-BFGS-B (m=50)
-        import poisson
-
-        n = sc(1024)
-        args = poisson.parse_args(["--ndim", "2", "--N", str(n)])
-        problem, state = poisson.make_problem(args)
-        out[f"2: poisson 2D {n}^2 lbfgsb f64 mg"] = run(problem, state, args, "lbfgsb", 100, warmup=1)
-    if "3" in a.configs:  # heat inverse (t, x) = 256 x 512, f32, Adam, infer_k
-        import heat
-
-        nt, nx = sc(256), sc(512)
-        args = heat.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--infer_k", "1", "--imposed", "stripe"])
-        problem, state = heat.make_problem(args)
-        out[f"3: heat inverse {nt}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 50)
-    if "3b" in a.configs:  # heat inverse with two space dimensions: the shape BASELINE names, (t, x, y) = 256 x 512^2
-        import heat2d
-
-        nt, nx = sc(256), sc(512)
-        args = heat2d.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx), "--infer_k", "1", "--imposed", "stripe"])
-        problem, state = heat2d.make_problem(args)
-        out[f"3b: heat inverse {nt}x{nx}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 20)
-    if "4a" in a.configs:  # Poisson 3-D 512^3 multigrid, Adam (the bench.py workload through the API)
-        import poisson
-
-        n = sc(512)
-        args = poisson.parse_args(["--ndim", "3", "--N", str(n)])
-        problem, state = poisson.make_problem(args)
-        out[f"4a: poisson 3D {n}^3 adam f64 mg"] = run(problem, state, args, "adam", 20)
-    if "4b" in a.configs:  # Poisson 3-D 512^3 Newton (no decomposition), sparse Jacobian + multigrid solve
-        import poisson
-
-        n = sc(512)
-        args = poisson.parse_args(["--ndim", "3", "--N", str(n), "--multigrid", "0", "--linsolver", "multigrid",
-                                   "--linsolver_tol", "1e-10"])
-        problem, state = poisson.make_problem(args)
-        out[f"4b: poisson 3D {n}^3 newton + gmg f64"] = run(problem, state, args, "newton", 1, warmup=0)
-        # the same solve (relative tolerance) once the work buffers exist: the first step also pays for
-        # the first-touch device allocations of the solver (several GB)
-        out[f"4b: poisson 3D {n}^3 newton + gmg f64, second step"] = run(problem, state, args, "newton", 1, warmup=0)
-    if "5" in a.configs:  # velocity from tracer (t, x, y) = 128 x 256 x 256, f32, Adam
-        import veltracer
-
-        nt, nx = sc(128), sc(256)
-        args = veltracer.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx)])
-        problem, state = veltracer.make_problem(args)
-        out[f"5: veltracer {nt}x{nx}x{nx} adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 20)
-    if "5b" in a.configs:  # tracer with three space dimensions (t, x, y, z), 4 fields 'nccc'; 32 x 256^3 fits one GPU
-        import veltracer3d
-
-        nt, nx = sc(32), sc(256)
-        args = veltracer3d.parse_args(["--Nt", str(nt), "--Nx", str(nx)])
-        problem, state = veltracer3d.make_problem(args)
-        out[f"5b: veltracer3d {nt}x{nx}^3 adam f32 mg (traced operator)"] = run(problem, state, args, "adam", 5, warmup=1)
-    for k, v in out.items():
-        print(json.dumps({"config": k, **v}))
+    for key in a.configs:
+        res = run_config(key, a.scale)
+        print(json.dumps({"config": key + ": " + res.pop("name"), **res}))
 
 
 if __name__ == "__main__":

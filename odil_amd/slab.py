@@ -5,30 +5,40 @@ Layout.  The global grid (P*Nz, Ny, Nx) is cut along axis 0; rank r owns Nz plan
 every multigrid level (levels halve all axes, and the level count is set by the smallest
 axis, so every level keeps >= 2 planes per rank: no agglomeration is needed).  Each level
 array is stored ghost-extended: G = 2 extra planes at every interior interface, none at a
-wall.  Only the INNER ghost plane ever needs valid data; the outer one exists so that the
-unmodified single-GPU kernels, run on the extended array as if it were a whole domain,
-compute exact values on all owned planes (their wall formulas only ever touch the discarded
-ghost planes, except at true walls where they are the physics).  Two kernels know about
-the cut: P^T drops the wall weights at a cut end (`odil_interp_adj_cut`), and the residual
-restricts its loss sum to the owned planes (`odil_poisson_residual_slab`).
+wall (only the INNER one ever holds valid data; the outer one exists so that a coarse array with
+one ghost plane prolongates to a fine array of the stored shape).  The unmodified single-GPU kernels run on the extended arrays as if they were whole
+domains: their wall formulas only ever reach the outermost ghost planes, which nobody reads,
+except at true walls where they are the physics.  Two kernels know about the cut: P^T and the
+transposed stencil drop the wall rows at a cut end (`cut` flags), and the residual restricts its
+loss sum to the owned planes.
 
-Per epoch each rank exchanges single planes with its two neighbours over RCCL/xGMI
-(point-to-point, one direct link per neighbour pair):
-  1. the first / last owned plane of every level of w, packed in ONE message per neighbour;
-     P then produces u's inner ghost plane by itself (no exchange for u);
-  2. the first / last owned plane of fu (the adjoint reads fu at z +- 1);
-  3. before each level of the P^T chain, the first / last owned plane of that level's
-     cotangent (8 small messages).
-No field-sized collective exists; the loss needs one scalar all-reduce, issued only when a
-loss value is actually asked for.  Adam is local.
+TWO exchanges per epoch and neighbour (RCCL point-to-point over the direct xGMI link) instead of one
+before every kernel that looks across the interface (round 1: nine):
+
+  1. two planes of fu after the residual (the stencil-adjoint launch forms g0 of the inner ghost
+     plane from them, which the first transposed prolongation needs for the owned planes of level 1;
+     u itself is never exchanged: P regenerates its ghost plane from the coarse ghost planes);
+  2. ONE packed message at the end of the epoch.  P^T is linear: below level 1 every rank pushes only
+     ITS OWN contributions down the levels (owned planes of g1, ghost planes zero; a coarse ghost
+     plane then holds what this rank contributes to the neighbour's boundary plane) without waiting
+     for anybody.  The message carries the updated boundary planes of w0 and w1 (their Adam update
+     happened inside the stencil-adjoint launch) and, for every level >= 2, the ghost plane of
+     contributions plus this rank's own boundary plane of the partial gradient.  The receiver
+     completes the gradient of its boundary plane (own + received contribution) AND of its ghost
+     plane (received own part + what it contributed itself: the same two numbers added in the other
+     order, so both ranks hold the same bits); the Adam update of levels >= 2 then runs on owned and
+     ghost planes alike, and the ghost planes of those levels stay equal to the neighbour's planes
+     without ever being sent.
+One scalar all-reduce when a loss value is actually asked for.  Adam is local.
 
 The epoch is written as a generator that yields at every exchange, so the same code runs
 (a) one rank per GPU under torch.distributed (RCCL), (b) over gloo on CPU in the tests with
-an oracle-backed `ops` double, and (c) with several ranks emulated in one process on one
+oracle doubles of the kernels, and (c) with several ranks emulated in one process on one
 GPU (tests), where the HIP kernels themselves are checked against the undivided domain.
 """
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -37,6 +47,7 @@ from . import ops as hip_ops
 from .poisson_path import mg_cshapes
 
 G = 2  # ghost planes per interior interface
+V = 1  # of which valid (kept equal to the neighbour's plane)
 
 
 class SlabLevel:
@@ -52,9 +63,10 @@ class SlabLevel:
         return a[self.g_lo : self.g_lo + self.nz]
 
     def inner(self, a):
-        """View with ONE ghost plane per interior interface (what P takes as its coarse operand)."""
-        lo = self.g_lo - 1 if self.g_lo else 0
-        hi = a.shape[0] - (self.g_hi - 1 if self.g_hi else 0)
+        """View with the V valid ghost planes per interior interface (coarse operand of P, result of P^T):
+        half the fine array's G."""
+        lo = self.g_lo - V if self.g_lo else 0
+        hi = a.shape[0] - (self.g_hi - V if self.g_hi else 0)
         return a[lo:hi]
 
 
@@ -90,6 +102,7 @@ class SlabPoissonAdam:
         self.levels = [SlabLevel(s[0] // world, s[1], s[2], rank, world) for s in shapes_global]
         for lv in self.levels:
             assert lv.nz >= 2, "every level needs >= 2 owned planes per rank"
+        assert self.nlvl >= 2
         self.h2 = [self.npdt(1.0 / N) ** 2] * 3  # box (world, 1, 1): uniform spacing 1/N
         sizes = [lv.size for lv in self.levels]
         n = sum(sizes)
@@ -99,23 +112,8 @@ class SlabPoissonAdam:
         split = lambda f: [t.view(lv.shape) for t, lv in zip(f.split(sizes), self.levels)]
         self.w, self.gw = split(self.x), split(self.g)
         self.mw, self.vw = split(self.m), split(self.v)
-        # positions, in the packed state, of the boundary planes of EVERY level: the start-of-epoch exchange of
-        # all level arrays is then one gather and one scatter per neighbour instead of ~20 slice copies
-        starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-
-        def plane_index(plane_of):
-            parts = []
-            for st, lv in zip(starts, self.levels):
-                k = plane_of(lv)
-                if k is None:
-                    return None
-                parts.append(int(st) + k * lv.plane + np.arange(lv.plane, dtype=np.int64))
-            return torch.as_tensor(np.concatenate(parts), device=device)
-
-        self._own_idx = dict(lo=plane_index(lambda lv: lv.g_lo if rank > 0 else None),
-                             hi=plane_index(lambda lv: lv.g_lo + lv.nz - 1 if rank < world - 1 else None))
-        self._ghost_idx = dict(lo=plane_index(lambda lv: lv.g_lo - 1 if rank > 0 else None),
-                               hi=plane_index(lambda lv: lv.g_lo + lv.nz if rank < world - 1 else None))
+        self.n01 = sizes[0] + sizes[1]  # levels 0 and 1: updated before the exchange; the rest after it
+        self._index_tables(sizes)
         l0 = self.levels[0]
         self._u = None  # synthesised field of the two-kernel path (the fused residual never stores it)
         self.fu = torch.zeros(l0.shape, dtype=dtype, device=device)
@@ -130,9 +128,8 @@ class SlabPoissonAdam:
         self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
         self.t = 0
         self.scale = self.npdt(2) / self.npdt(self.global_cells)
-        import os
-
         self.fuse_transpose = bool(int(os.environ.get("ODIL_FUSE_TRANSPOSE", 1)))
+        self.synced = False  # ghost planes of the initial state
 
     @property
     def u(self):
@@ -140,43 +137,91 @@ class SlabPoissonAdam:
             self._u = torch.zeros(self.levels[0].shape, dtype=self.dtype, device=self.device)
         return self._u
 
-    # ---- plane packing -----------------------------------------------------------------
-    def _pack(self, arrays, levels, side, depth=1):
-        """The first (side 'lo') or last ('hi') `depth` OWNED planes of each array, concatenated; None at a wall."""
-        if (side == "lo" and self.rank == 0) or (side == "hi" and self.rank == self.world - 1):
-            return None
-        parts = []
-        for a, lv in zip(arrays, levels):
-            k = lv.g_lo if side == "lo" else lv.g_lo + lv.nz - depth
-            parts.append(a[k : k + depth].reshape(-1))
-        return torch.cat(parts) if len(parts) > 1 else parts[0].clone()
+    # ---- positions of the exchanged planes in the packed vectors ------------------------------
+    def _index_tables(self, sizes):
+        """Per side ('lo' = towards rank - 1): where the message is read from and where the neighbour's message
+        goes.  Message = [x planes of levels 0 and 1 | g planes that are ADDED | g planes that are COPIED]."""
+        starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        dev = self.device
 
-    def _unpack(self, buf, arrays, levels, side, depth=1):
-        """Received planes -> the `depth` ghost planes next to the owned ones on `side` of each array."""
-        if buf is None:
-            return
-        off = 0
-        for a, lv in zip(arrays, levels):
-            k = lv.g_lo - depth if side == "lo" else lv.g_lo + lv.nz
-            a[k : k + depth].copy_(buf[off : off + depth * lv.plane].view(depth, lv.ny, lv.nx))
-            off += depth * lv.plane
+        def planes(level, rel):
+            """flat positions of the planes at owned-relative z positions `rel` of `level`"""
+            lv = self.levels[level]
+            return np.concatenate([int(starts[level]) + (lv.g_lo + k) * lv.plane + np.arange(lv.plane, dtype=np.int64)
+                                   for k in rel])
 
-    def _exchange_state(self):
-        """Generator step: the boundary planes of all level arrays of the packed state x, one message per
-        neighbour (same planes, same order as _exchange(self.w, self.levels))."""
-        lo, hi = self._own_idx["lo"], self._own_idx["hi"]
-        recv_lo, recv_hi = yield ("halo", None if lo is None else self.x.index_select(0, lo),
-                                  None if hi is None else self.x.index_select(0, hi))
+        self.tab = dict()
+        for side in ("lo", "hi"):
+            if (side == "lo" and self.rank == 0) or (side == "hi" and self.rank == self.world - 1):
+                self.tab[side] = None
+                continue
+            first = lambda lv, k: list(range(k)) if side == "lo" else list(range(lv.nz - 1, lv.nz - 1 - k, -1))
+            ghost = lambda lv, k: [-1 - i for i in range(k)] if side == "lo" else [lv.nz + i for i in range(k)]
+            # order within a message: planes counted AWAY from the interface, so that the sender's k-th owned
+            # plane lands on the receiver's k-th ghost plane
+            depth = [V, V]
+            sx = [planes(l, first(self.levels[l], depth[l])) for l in (0, 1)]
+            rx = [planes(l, ghost(self.levels[l], depth[l])) for l in (0, 1)]
+            deep = range(2, self.nlvl)
+            # added at the receiver: [ghost contribution -> its boundary plane, own plane 0 -> its ghost plane 0]
+            s_add = [planes(l, ghost(self.levels[l], 1) + first(self.levels[l], 1)) for l in deep]
+            r_add = [planes(l, first(self.levels[l], 1) + ghost(self.levels[l], 1)) for l in deep]
+            # copied: nothing (planes further from the interface would be, were more than one ghost plane valid)
+            s_cp, r_cp = [], []
+            cat = lambda parts: torch.as_tensor(np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64), device=dev)
+            t = dict(sx=cat(sx), rx=cat(rx), s_add=cat(s_add), r_add=cat(r_add), s_cp=cat(s_cp), r_cp=cat(r_cp))
+            t["nx"], t["nadd"], t["ncp"] = int(t["sx"].numel()), int(t["s_add"].numel()), int(t["s_cp"].numel())
+            t["send"] = torch.empty(t["nx"] + t["nadd"] + t["ncp"], dtype=self.dtype, device=dev)
+            # the initial state: V (3 on level 0) boundary planes of every level
+            full_s = [planes(l, first(self.levels[l], V)) for l in range(self.nlvl)]
+            full_r = [planes(l, ghost(self.levels[l], V)) for l in range(self.nlvl)]
+            t["full_s"], t["full_r"] = cat(full_s), cat(full_r)
+            self.tab[side] = t
+
+    def _sync_state(self):
+        """Generator step, once: ghost planes of the initial state."""
+        msg = [None if t is None else self.x.index_select(0, t["full_s"]) for t in (self.tab["lo"], self.tab["hi"])]
+        recv = yield ("halo", msg[0], msg[1])
+        for t, r in zip((self.tab["lo"], self.tab["hi"]), recv):
+            if t is not None:
+                self.x.index_copy_(0, t["full_r"], r)
+        self.synced = True
+
+    def _exchange_fu(self, depth):
+        """Generator step: the `depth` boundary planes of fu -> the neighbours' ghost planes."""
+        l0 = self.levels[0]
+        lo = self.fu[l0.g_lo : l0.g_lo + depth] if self.rank > 0 else None
+        hi = self.fu[l0.g_lo + l0.nz - depth : l0.g_lo + l0.nz] if self.rank < self.world - 1 else None
+        recv_lo, recv_hi = yield ("halo", lo, hi)
         if recv_lo is not None:
-            self.x.index_copy_(0, self._ghost_idx["lo"], recv_lo)
+            self.fu[l0.g_lo - depth : l0.g_lo].copy_(recv_lo.view(depth, l0.ny, l0.nx))
         if recv_hi is not None:
-            self.x.index_copy_(0, self._ghost_idx["hi"], recv_hi)
+            self.fu[l0.g_lo + l0.nz : l0.g_lo + l0.nz + depth].copy_(recv_hi.view(depth, l0.ny, l0.nx))
 
-    def _exchange(self, arrays, levels, depth=1):
-        """Generator step: swap boundary planes of `arrays` with both neighbours."""
-        recv_lo, recv_hi = yield ("halo", self._pack(arrays, levels, "lo", depth), self._pack(arrays, levels, "hi", depth))
-        self._unpack(recv_lo, arrays, levels, "lo", depth)
-        self._unpack(recv_hi, arrays, levels, "hi", depth)
+    def _exchange(self):
+        """Generator step: the packed exchange at the end of the epoch (see the module docstring)."""
+        msg = []
+        for t in (self.tab["lo"], self.tab["hi"]):
+            if t is None:
+                msg.append(None)
+                continue
+            buf, nx, na = t["send"], t["nx"], t["nadd"]
+            torch.index_select(self.x, 0, t["sx"], out=buf[:nx])
+            if na:
+                torch.index_select(self.g, 0, t["s_add"], out=buf[nx:nx + na])
+            if t["ncp"]:
+                torch.index_select(self.g, 0, t["s_cp"], out=buf[nx + na:])
+            msg.append(buf)
+        recv = yield ("halo", msg[0], msg[1])
+        for t, r in zip((self.tab["lo"], self.tab["hi"]), recv):
+            if t is None:
+                continue
+            nx, na = t["nx"], t["nadd"]
+            self.x.index_copy_(0, t["rx"], r[:nx])
+            if t["ncp"]:
+                self.g.index_copy_(0, t["r_cp"], r[nx + na:])
+            if na:
+                self.g.index_add_(0, t["r_add"], r[nx:nx + na])
 
     # ---- one epoch -----------------------------------------------------------------------
     def epoch_gen(self, timers=None):
@@ -194,12 +239,11 @@ class SlabPoissonAdam:
             if b is not None:
                 b.record()
 
-        b = tic("halo")
-        yield from self._exchange_state()
-        toc(b)
+        if not self.synced:
+            yield from self._sync_state()
         # u = w_0 + P(w_1 + P(...)): coarse operand with one ghost plane -> fine with two
         # the last prolongation is fused into the residual when the kernel set has it (u never stored)
-        fused_last = hasattr(ops, "poisson_residual_synth") and L >= 2
+        fused_last = hasattr(ops, "poisson_residual_synth")
         b = tic("mg_synth")
         coarse = lv[L - 1].inner(self.w[L - 1])
         for l in range(L - 2, 0 if fused_last else -1, -1):
@@ -208,7 +252,7 @@ class SlabPoissonAdam:
             coarse = lv[l].inner(out)
         toc(b)
         b = tic("residual")
-        l0 = lv[0]
+        l0, l1 = lv[0], lv[1]
         if fused_last:
             ops.poisson_residual_synth(coarse.contiguous(), self.w[0], self.rhs, self.h2, fu=self.fu,
                                        loss=self.loss_part, zrange=(l0.g_lo, l0.g_lo + l0.nz),
@@ -217,66 +261,78 @@ class SlabPoissonAdam:
             ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
                                  zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
         toc(b)
-        n0 = lv[0].size
-        fuse0 = hasattr(ops, "poisson_adjoint_adam")
-        # stencil adjoint + first transposed prolongation + Adam of levels 0 and 1 in one launch, as on one GPU
-        # (fused.py): the finest-level gradient is never stored, so its halo exchange disappears; the residual
-        # then needs BOTH ghost planes (g0 of the inner ghost plane reads the outer one).
-        fuse_t = (fuse0 and L >= 2 and self.fuse_transpose and hasattr(ops, "poisson_adjoint_transpose")
-                  and G >= 2 and lv[0].nz >= 2 and ops.adjoint_transpose_supported(tuple(lv[0].shape))
-                  and tuple(lv[1].inner(self.gw[1]).shape) == tuple(n // 2 for n in lv[0].shape))
-        b = tic("halo")
-        yield from self._exchange([self.fu], [l0], depth=2 if fuse_t else 1)
-        toc(b)
+        n0 = l0.size
         self.t += 1
         t = self.npdt(self.t)
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
         omb1, omb2 = 1 - self.b1, 1 - self.b2
         cut = (self.rank > 0, self.rank < self.world - 1)
-        first = 1  # first level whose transposed prolongation is still to do
-        if fuse_t:
-            # The interfaces are `cut` ends: interior stencil rows there, and the owned coarse planes only
-            # read fine planes whose g0 is complete (the outermost ghost plane has zero weight).
-            b = tic("adjoint_transpose")
-            ops.poisson_adjoint_transpose(
-                self.fu, self.h2, self.scale, lv[1].inner(self.gw[1]), g0=None,
-                adam0=(self.w[0], self.m[:n0].view(lv[0].shape), self.v[:n0].view(lv[0].shape)),
-                adam1=(lv[1].inner(self.w[1]), lv[1].inner(self.mw[1]), lv[1].inner(self.vw[1])),
-                alpha=alpha, one_minus_b1=omb1, one_minus_b2=omb2, eps=self.eps, cut=cut)
-            toc(b)
-            first = 2
-        b = tic("adjoint") if first == 1 else None
-        if first == 2:
-            pass
-        elif fuse0:
-            # Adam of the finest level inside the adjoint launch (as on one GPU, poisson_path.py)
-            ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], self.w[0],
-                                     self.m[:n0].view(lv[0].shape), self.v[:n0].view(lv[0].shape), alpha, omb1, omb2,
-                                     self.eps)
-        else:
-            ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        g1 = l1.inner(self.gw[1])
+        adam1 = (l1.inner(self.w[1]), l1.inner(self.mw[1]), l1.inner(self.vw[1]))
+        m0, v0 = self.m[:n0].view(l0.shape), self.v[:n0].view(l0.shape)
+        # stencil adjoint + first transposed prolongation + Adam of levels 0 and 1 in one launch, as on one GPU
+        # (fused.py): the interfaces are `cut` ends (interior stencil rows there; the owned coarse planes only
+        # read fine planes whose g0 is complete)
+        fuse_t = (self.fuse_transpose and hasattr(ops, "poisson_adjoint_transpose")
+                  and ops.adjoint_transpose_supported(tuple(l0.shape))
+                  and tuple(g1.shape) == tuple(n // 2 for n in l0.shape))
+        # the adjoint reads fu at z +- 1; the one-launch form makes g0 of the inner ghost plane itself and needs both
+        b = tic("halo")
+        yield from self._exchange_fu(2 if fuse_t else 1)
         toc(b)
-        for l in range(first, L):
+        if fuse_t:
+            b = tic("adjoint_transpose")
+            ops.poisson_adjoint_transpose(self.fu, self.h2, self.scale, g1, g0=None, adam0=(self.w[0], m0, v0),
+                                          adam1=adam1, alpha=alpha, one_minus_b1=omb1, one_minus_b2=omb2,
+                                          eps=self.eps, cut=cut)
+            toc(b)
+        else:
+            b = tic("adjoint")
+            if hasattr(ops, "poisson_adjoint_adam"):
+                ops.poisson_adjoint_adam(self.fu, self.h2, self.scale, self.gw[0], self.w[0], m0, v0, alpha, omb1, omb2,
+                                         self.eps)
+            else:
+                ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+                ops.adam_step(self.x[:n0], self.m[:n0], self.v[:n0], self.g[:n0], alpha, omb1, omb2, self.eps)
+            toc(b)
+            # (fallback for shapes the one-launch kernel does not take: g0 is stored, its ghost plane comes
+            # from the neighbour -- one more exchange)
             b = tic("halo")
-            yield from self._exchange([self.gw[l - 1]], [lv[l - 1]])
+            recv_lo, recv_hi = yield ("halo", self.gw[0][l0.g_lo] if cut[0] else None,
+                                      self.gw[0][l0.g_lo + l0.nz - 1] if cut[1] else None)
+            if recv_lo is not None:
+                self.gw[0][l0.g_lo - 1].copy_(recv_lo)
+            if recv_hi is not None:
+                self.gw[0][l0.g_lo + l0.nz].copy_(recv_hi)
             toc(b)
             b = tic("mg_synth_adj")
-            cview = lv[l].inner(self.gw[l])
-            if fuse0 and hasattr(ops, "interp_adj_adam"):
-                ops.interp_adj_adam(self.gw[l - 1], "ccc", tuple(cview.shape), cview, lv[l].inner(self.w[l]),
-                                    lv[l].inner(self.mw[l]), lv[l].inner(self.vw[l]), alpha, omb1, omb2, self.eps,
-                                    cut=cut)
+            if hasattr(ops, "interp_adj_adam"):
+                ops.interp_adj_adam(self.gw[0], "ccc", tuple(g1.shape), g1, *adam1, alpha, omb1, omb2, self.eps, cut=cut)
             else:
-                ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview, cut=cut)
+                ops.interp_adj(self.gw[0], "ccc", tuple(g1.shape), out=g1, cut=cut)
+                n1 = lv[1].size
+                ops.adam_step(self.x[n0:n0 + n1], self.m[n0:n0 + n1], self.v[n0:n0 + n1], self.g[n0:n0 + n1], alpha,
+                              omb1, omb2, self.eps)
             toc(b)
-        if fuse0 and hasattr(ops, "interp_adj_adam"):
-            return  # every level was updated inside the launch that formed its gradient
-        b = tic("adam")
-        if fuse0:
-            ops.adam_step(self.x[n0:], self.m[n0:], self.v[n0:], self.g[n0:], alpha, omb1, omb2, self.eps)
-        else:
-            ops.adam_step(self.x, self.m, self.v, self.g, alpha, omb1, omb2, self.eps)
+        b = tic("mg_synth_adj")
+        # from here down every rank carries only its own contributions: g1 is complete on the owned planes,
+        # so its ghost planes (written above with partial sums nobody needs) count as zero
+        if cut[0]:
+            self.gw[1][: l1.g_lo].zero_()
+        if cut[1]:
+            self.gw[1][l1.g_lo + l1.nz :].zero_()
+        for l in range(2, L):
+            cview = lv[l].inner(self.gw[l])
+            ops.interp_adj(self.gw[l - 1], "ccc", tuple(cview.shape), out=cview, cut=cut)
         toc(b)
+        b = tic("halo")
+        yield from self._exchange()
+        toc(b)
+        if L > 2:
+            b = tic("adam")
+            k = self.n01
+            ops.adam_step(self.x[k:], self.m[k:], self.v[k:], self.g[k:], alpha, omb1, omb2, self.eps)
+            toc(b)
 
     def epoch(self, comm, timers=None):
         gen = self.epoch_gen(timers)
@@ -314,6 +370,16 @@ class TorchDistComm:
         self.dist, self.rank, self.world = dist, rank, world
         # gloo moves host memory: device planes are staged (tests only; RCCL sends device memory)
         self.stage = dist.get_backend() == "gloo"
+        self._recv = dict()  # receive buffers, kept: (side, numel, dtype, device) -> tensor
+
+    def _recv_like(self, side, t):
+        """The receive buffer for a message of t's size from `side` (allocated once; every consumer copies the
+        planes out on the stream the next receive is ordered behind)."""
+        key = (side, t.numel(), t.dtype, t.device)
+        buf = self._recv.get(key)
+        if buf is None:
+            buf = self._recv[key] = torch.empty(t.numel(), dtype=t.dtype, device=t.device)
+        return buf.view(t.shape)
 
     def exchange(self, kind, send_lo, send_hi):
         dist = self.dist
@@ -343,10 +409,12 @@ class TorchDistComm:
                 send_hi = send_hi.cpu() if send_hi is not None else None
         ops, recv_lo, recv_hi = [], None, None
         if send_lo is not None and peer_lo is not None:
-            recv_lo = torch.empty_like(send_lo)
+            send_lo = send_lo.contiguous()
+            recv_lo = self._recv_like("lo", send_lo)
             ops += [dist.P2POp(dist.isend, send_lo, peer_lo), dist.P2POp(dist.irecv, recv_lo, peer_lo)]
         if send_hi is not None and peer_hi is not None:
-            recv_hi = torch.empty_like(send_hi)
+            send_hi = send_hi.contiguous()
+            recv_hi = self._recv_like("hi", send_hi)
             ops += [dist.P2POp(dist.isend, send_hi, peer_hi), dist.P2POp(dist.irecv, recv_hi, peer_hi)]
         if ops:
             for req in dist.batch_isend_irecv(ops):

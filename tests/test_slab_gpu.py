@@ -100,7 +100,7 @@ def test_bench_single_gpu_json_contract():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--N", "64",
-                          "--cpu_N", "16"], capture_output=True, text=True, timeout=900, cwd=root)
+                          "--cpu_N", "16", "--cpu_N_all", "16", "--cpu_budget", "1"], capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -114,9 +114,11 @@ def test_bench_single_gpu_json_contract():
     assert abs(d["value"] - 64**3 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r and r["traffic_source"]
+    assert abs(r["frac_model"] - r["achieved_model"] / r["peak"]) < 1e-12 and r["frac_model"] >= r["frac"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0 and c["all_cores"]["sample"]
 
 
 # ---- traced operators (odil_amd/slab_traced.py): ranks emulated on one GPU == the undivided HIP path ------------
