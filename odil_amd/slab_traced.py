@@ -102,7 +102,7 @@ class HipSlabKernels:
         self.problem, self.tr, self.raw = problem, tr, raw
         cg = _Codegen(tr, outs, raw, Gshape, state, slab=(axis, n))
         self.source = cg.source()
-        self.lib, self.lib_path = _compile(self.source)
+        self.lib, self.lib_path = _compile(self.source, cg.flags)
         self.cg = cg
         self.halo = cg.halo
         dt = tr.torch_dtype

@@ -18,6 +18,10 @@ from .stencil_trace import _B, _CMP, _I, _R, TraceUnsupported, _promote
 
 _CACHE_DIR = os.environ.get("ODIL_JIT_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_jit_cache"))
 _HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "--offload-arch=gfx950"]
+# float kernels (tolerance 2e-5, stated in the tests): contraction to FMA allowed -- the 5 x 5 layers of a pointwise
+# network and their parameter-gradient accumulations become (packed) FMAs instead of multiply + add pairs
+_HIPCC_FLAGS_F32 = [f if f != "-ffp-contract=off" else "-ffp-contract=fast" for f in _HIPCC_FLAGS]
+_FAST_F32 = bool(int(os.environ.get("ODIL_TRACE_FAST_F32", 1)))
 
 
 # ======================================================================================
@@ -41,6 +45,28 @@ __device__ inline T block_sum(T v, T* sm) {
   return r;
 }
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
+// Float transcendentals of the float kernels.  The library tanhf is ~30 instructions with two divergent branches;
+// a traced operator with a pointwise network evaluates it 40 times per grid point (heat with two space dimensions:
+// 1660 VALU instructions per point, 1200 of them tanh -- profiles/r02_v0_heat2d_pmc.txt).  Here tanh(x) =
+// 1 - 2 / (e^2x + 1) through the hardware exp2 / rcp: 5 instructions, ABSOLUTE error <= ~2e-7 (a float rounding of
+// the O(1) sums the activations enter; the relative error grows as |x| -> 0, where a series branch would cost as
+// much again -- the float kernels are held to 2e-5 against the float64 fixtures, stated in the tests).  exp and
+// division likewise through v_exp_f32 / v_rcp_f32 (~2 ulp).
+__device__ inline float odil_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ inline float odil_fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ inline float odil_fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+typedef float T2 __attribute__((ext_vector_type(2)));
+__device__ inline T2 odil_fast_tanh2(T2 x) {  // two lanes: the arithmetic packs, exp2 / rcp are per lane
+  const T2 s = x * 2.88539008177792681472f;
+  T2 e = {__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
+  e = e + 1.0f;
+  const T2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+  return 1.0f - 2.0f * r;
+}
+__device__ inline T2 odil_step2(T2 h) { T2 r = {h.x > 0.0f ? 1.0f : 0.0f, h.y > 0.0f ? 1.0f : 0.0f}; return r; }
 """
 
 
@@ -68,6 +94,8 @@ class _Codegen:
         the ghost-extended gradient, ghost cells receiving what belongs to the neighbour."""
         self.tr, self.outputs, self.raw, self.G, self.state = tr, outputs, raw, tuple(shape), state
         self.ndim = len(shape)
+        self.fast = _FAST_F32 and tr.torch_dtype == torch.float32
+        self.flags = _HIPCC_FLAGS_F32 if self.fast else _HIPCC_FLAGS
         self.slab = slab
         self.GL = tuple(shape)  # the grid the threads cover
         if slab is not None:
@@ -118,6 +146,9 @@ class _Codegen:
         self.arrays = []  # (key, numel) of `Array` unknowns read through a[k]
         self.array_slot = dict()
         self.need = self._needs_grad()
+        self.partner, self.pair_first = dict(), set()
+        if self.fast and int(os.environ.get("ODIL_TRACE_PAIR_MLP", 1)):
+            self._pair_mlps()
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
         self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
         self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
@@ -248,6 +279,10 @@ class _Codegen:
                 mant, exp = math.frexp(abs(value))
                 if mant == 0.5 and -100 < exp < 100:
                     return "{} * {}".format(num, _lit(1.0 / value, _R))
+                if self.fast:
+                    return "{} * {}".format(num, _lit(1.0 / value, _R))
+        if self.fast:
+            return "odil_fast_div({}, {})".format(num, self.r(den))
         return "{} / {}".format(num, self.r(den))
 
     def b(self, n):
@@ -382,26 +417,97 @@ class _Codegen:
         self.emit("const {} v{} = {}((const {}*)a.ten[{}])[{}];".format(
             ktype, n.idx, cast, ctype, n.attr, " + ".join(terms) or "0"))
 
-    def _act(self, kind, x):
+    # ---- pointwise networks: two evaluations of the same network per pair of float lanes ---------------------
+    def _pair_mlps(self):
+        """Float kernels: evaluations of the same network (heat: the conductivity at the four faces of a cell) are
+        emitted two at a time on 2-vectors, so that every multiply-add of the layers, of the reverse pass and of the
+        parameter-gradient sums is ONE packed instruction (v_pk_fma_f32) for two evaluations, with the weights
+        broadcast.  The pair is evaluated where the later of the two would be: the node order is re-sorted
+        (topologically) with the pair as one unit; pairs that would close a cycle stay single."""
+        groups = dict()
+        for n in self.order:
+            if n.op == "mlp":
+                groups.setdefault(n.attr, []).append(n)
+        pairs = [(nodes[k], nodes[k + 1]) for nodes in groups.values() for k in range(0, len(nodes) - 1, 2)]
+        while pairs:
+            order = self._sorted_with_pairs(pairs)
+            if order is not None:
+                self.order = order
+                for a, b in pairs:
+                    self.partner[a.idx], self.partner[b.idx] = b, a
+                    self.pair_first.add(a.idx)
+                return
+            pairs.pop()  # a cycle through some pair: try with fewer
+
+    def _sorted_with_pairs(self, pairs):
+        import heapq
+
+        deps = {n.idx: {a.idx for a in n.args} for n in self.order}
+        second = dict()
+        for a, b in pairs:
+            deps[a.idx] |= {x.idx for x in b.args}
+            deps[b.idx] = deps[b.idx] | {a.idx}
+            second[a.idx] = b
+        by_idx = {n.idx: n for n in self.order}
+        users = {i: [] for i in deps}
+        for i, ds in deps.items():
+            for d in ds:
+                if d in users:
+                    users[d].append(i)
+        left = {i: len([d for d in ds if d in deps]) for i, ds in deps.items()}
+        ready = [i for i, c in left.items() if c == 0]
+        heapq.heapify(ready)
+        out, held = [], set(b.idx for _, b in pairs)
+
+        def emit(i):
+            out.append(by_idx[i])
+            for u in users[i]:
+                left[u] -= 1
+                if left[u] == 0 and u not in held:
+                    heapq.heappush(ready, u)
+
+        while ready:
+            i = heapq.heappop(ready)
+            emit(i)
+            if i in second:  # its partner follows immediately (its dependencies are a subset of this node's)
+                j = second[i].idx
+                if left[j] != 0:
+                    return None
+                emit(j)
+        return out if len(out) == len(self.order) else None
+
+    def _act(self, kind, x, width=1):
+        if width == 2:
+            return {"tanh": "odil_fast_tanh2({})", "relu": "__builtin_elementwise_max({}, (T2)(0.0f))", "none": "{}"}[kind].format(x)
         return {"tanh": "FN(tanh)({})", "relu": "({0} > (T)0 ? {0} : (T)0)", "none": "{}"}[kind].format(x)
 
     def _emit_mlp(self, n):
+        if n.idx in self.partner and n.idx not in self.pair_first:
+            return  # emitted with its partner
+        group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
+        width = len(group)
+        V = "T2" if width == 2 else "T"
         key, frozen, layers, act = n.attr
         if key not in self.net_slot:
             self.net_slot[key] = len(self.nets)
             self.nets.append((key, layers))
         base = self.net_slot[key]
         nl = len(layers) - 1
-        p = "m{}".format(n.idx)
-        for i, a in enumerate(n.args):
-            self.emit("const T {}_h0_{} = {};".format(p, i, self.r(a)))
+        p = ("mm{}" if width == 2 else "m{}").format(n.idx)
+        for i in range(len(n.args)):
+            vals = [self.r(m.args[i]) for m in group]
+            self.emit("const {} {}_h0_{} = {};".format(V, p, i, vals[0] if width == 1 else "{{{}, {}}}".format(*vals)))
         for l in range(1, nl + 1):
             ni, no = layers[l - 1], layers[l]
             for j in range(no):
                 terms = " + ".join("W({},{},{}) * {}_h{}_{}".format(base, l - 1, j * ni + i, p, l - 1, i) for i in range(ni))
-                self.emit("const T {}_z{}_{} = ({}) + Bv({},{},{});".format(p, l, j, terms, base, l - 1, j))
+                self.emit("const {} {}_z{}_{} = ({}) + Bv({},{},{});".format(V, p, l, j, terms, base, l - 1, j))
                 if l < nl:
-                    self.emit("const T {0}_h{1}_{2} = {3};".format(p, l, j, self._act(act, "{}_z{}_{}".format(p, l, j))))
+                    self.emit("const {0} {1}_h{2}_{3} = {4};".format(V, p, l, j, self._act(act, "{}_z{}_{}".format(p, l, j), width)))
+        if width == 2:  # the outputs under the names the single form gives them (what mlp_out nodes read)
+            for lane, m in zip("xy", group):
+                for j in range(layers[nl]):
+                    self.emit("const T m{}_z{}_{} = {}_z{}_{}.{};".format(m.idx, nl, j, p, nl, j, lane))
 
     def forward(self):
         for n in self.order:
@@ -580,18 +686,26 @@ class _Codegen:
         self.cut_nodes.reverse()
 
     def _reverse_mlp(self, n, defined, acc):
-        if not self.need[n.idx]:
+        if n.idx in self.partner and n.idx not in self.pair_first:
+            return  # handled when the traversal reaches its partner (the earlier node of the pair)
+        group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
+        if not any(self.need[m.idx] for m in group):
             return
+        width = len(group)
+        V = "T2" if width == 2 else "T"
         key, frozen, layers, act = n.attr
-        outs = [m for m in self.order if m.op == "mlp_out" and m.args[0] is n and m.idx in defined]
-        if not outs:
+        outs = [{m.attr: m for m in self.order if m.op == "mlp_out" and m.args[0] is g and m.idx in defined} for g in group]
+        if not any(outs):
             return
         base = self.net_slot[key]
         nl = len(layers) - 1
-        p = "m{}".format(n.idx)
-        by_j = {m.attr: m for m in outs}
+        p = ("mm{}" if width == 2 else "m{}").format(n.idx)
+        sfx = "2" if width == 2 else ""  # packed sums of two evaluations live in their own accumulators
         for j in range(layers[nl]):
-            self.emit("const T {}_d{}_{} = {};".format(p, nl, j, "g{}".format(by_j[j].idx) if j in by_j else "(T)0"))
+            vals = ["g{}".format(o[j].idx) if j in o else "(T)0" for o in outs]
+            self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals[0] if width == 1 else "{{{}, {}}}".format(*vals)))
+        if not frozen and width == 2:
+            self.pg2_used.add(key)
         if not frozen and key not in self.pgrads:
             names = []
             for l in range(nl):
@@ -601,34 +715,38 @@ class _Codegen:
             self.pgrads[key] = names
             self.pg_offset[key] = len(self.pg_decl)
             self.pg_decl.extend(name for group in names for name in group)
-        inputs_need = any(self.need[a.idx] for a in n.args)
+        inputs_need = any(self.need[a.idx] for m in group for a in m.args)
         for l in range(nl, 0, -1):
             ni, no = layers[l - 1], layers[l]
             if not frozen:
                 for j in range(no):
                     for i in range(ni):
-                        self.emit("pw_{0}_{1}_{2} = pw_{0}_{1}_{2} + {3}_d{4}_{5} * {3}_h{6}_{7};".format(
-                            base, l - 1, j * ni + i, p, l, j, l - 1, i))
-                    self.emit("pb_{0}_{1}_{2} = pb_{0}_{1}_{2} + {3}_d{4}_{2};".format(base, l - 1, j, p, l))
+                        self.emit("pw{8}_{0}_{1}_{2} = pw{8}_{0}_{1}_{2} + {3}_d{4}_{5} * {3}_h{6}_{7};".format(
+                            base, l - 1, j * ni + i, p, l, j, l - 1, i, sfx))
+                    self.emit("pb{5}_{0}_{1}_{2} = pb{5}_{0}_{1}_{2} + {3}_d{4}_{2};".format(base, l - 1, j, p, l, sfx))
             if l == 1 and not inputs_need:
                 break
             for i in range(ni):
                 s = " + ".join("W({},{},{}) * {}_d{}_{}".format(base, l - 1, j * ni + i, p, l, j) for j in range(no))
                 if l > 1:
                     h = "{}_h{}_{}".format(p, l - 1, i)
-                    d = {"tanh": "((T)1 - {0} * {0})".format(h), "relu": "({} > (T)0 ? (T)1 : (T)0)".format(h),
-                         "none": "(T)1"}[act]
-                    self.emit("const T {}_d{}_{} = ({}) * {};".format(p, l - 1, i, s, d))
+                    one = "(T)1" if width == 1 else "(T2)(1.0f)"
+                    d = {"tanh": "({1} - {0} * {0})".format(h, one),
+                         "relu": ("({} > (T)0 ? (T)1 : (T)0)" if width == 1 else "odil_step2({})").format(h),
+                         "none": one}[act]
+                    self.emit("const {} {}_d{}_{} = ({}) * {};".format(V, p, l - 1, i, s, d))
                 else:
-                    self.emit("const T {}_d0_{} = {};".format(p, i, s))
+                    self.emit("const {} {}_d0_{} = {};".format(V, p, i, s))
         if inputs_need:
-            for i, a in enumerate(n.args):
-                acc(a, "{}_d0_{}".format(p, i))
+            for lane, m in zip("xy", group):
+                for i, a in enumerate(m.args):
+                    acc(a, "{}_d0_{}{}".format(p, i, "" if width == 1 else "." + lane))
 
     # ---- whole source -----------------------------------------------------------------------
     def source(self):
         tdt = self.tr.torch_dtype
         self.pg_decl, self.pg_offset = [], dict()
+        self.pg2_used = set()
         self.forward()
         fwd, self.lines = self.lines, []
         self.reverse()
@@ -640,6 +758,8 @@ class _Codegen:
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
+        if self.fast:
+            S.append("#define tanhf odil_fast_tanh\n#define expf odil_fast_exp")
         nsrc = max(1, len(self.src_keys))
         slab_members = ""
         if self.slab is not None:
@@ -677,6 +797,9 @@ class _Codegen:
             S.append("  T s_{} = (T)0;".format(k))
         for name in self.pg_decl:
             S.append("  T {} = (T)0;".format(name))
+        pg2 = [name for key in self.pg2_used for group in self.pgrads[key] for name in group]
+        for name in pg2:  # packed partial sums of paired network evaluations
+            S.append("  T2 {}2{} = (T2)(0.0f);".format(name[:2], name[2:]))
         if self.total <= self.max_blocks * 256:  # one grid point per thread
             S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
             S.append("  if (l < {}) {{".format(self.total))
@@ -713,6 +836,8 @@ class _Codegen:
                 term = "(inbox{} ? {} : (T)0)".format(k, term)
             S.append("  s_{0} = s_{0} + {1};".format(k, term))
         S.append("  }")
+        for name in pg2:
+            S.append("  {0} = {0} + ({1}2{2}.x + {1}2{2}.y);".format(name, name[:2], name[2:]))
         for k in range(nout):
             S.append("  {{ const T s = block_sum(s_{0}, sm); if (threadIdx.x == 0) a.part[{0} * a.nblocks + blockIdx.x] = s; }}".format(k))
         for k, name in enumerate(self.pg_decl):
@@ -914,8 +1039,9 @@ def _cache_dirs():
     yield os.path.join(tempfile.gettempdir(), "odil_jit_cache_" + user)
 
 
-def _compile(src):
-    tag = hashlib.sha256((src + " ".join(_HIPCC_FLAGS)).encode()).hexdigest()[:20]
+def _compile(src, flags=None):
+    flags = flags or _HIPCC_FLAGS
+    tag = hashlib.sha256((src + " ".join(flags)).encode()).hexdigest()[:20]
     name = "odil_jit_{}.so".format(tag)
     for d in _cache_dirs():
         if os.path.exists(os.path.join(d, name)):
@@ -933,7 +1059,7 @@ def _compile(src):
             last = e
             continue
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        res = subprocess.run([hipcc] + _HIPCC_FLAGS + ["-o", tmp, hip], capture_output=True, text=True)
+        res = subprocess.run([hipcc] + flags + ["-o", tmp, hip], capture_output=True, text=True)
         if res.returncode != 0:
             os.unlink(tmp)
             raise RuntimeError("hipcc failed for the traced operator ({}):\n{}".format(hip, res.stderr[-4000:]))

@@ -91,7 +91,7 @@ class TracedOperator:
         self.G, self.raw = G, raw
         cg = _Codegen(tr, outs, raw, G, state)
         self.source = cg.source()
-        self.lib, self.lib_path = _compile(self.source)
+        self.lib, self.lib_path = _compile(self.source, cg.flags)
         self.cg, self.tr = cg, tr
         self.tracer_keys = [n.attr for n in tr.nodes if n.op == "tracer"]
         dev, dt = domain.mod.device, tr.torch_dtype
