@@ -218,14 +218,6 @@ int odil_poisson_adjoint_adam_f64(const double* fu, double* gu, double* x, doubl
 int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m, float* v, const int64_t* shape,
                                   int ndim, const float* h2, float scale, float alpha, float one_minus_b1,
                                   float one_minus_b2, float eps, const float* alpha_dev, void* stream);
-/* Fused: gu = (2/size) J^T (J u - rhs) and loss[0] = mean((J u - rhs)^2) in ONE pass over u and
- * rhs; fu is never materialised (3 words per cell instead of 5).  3-D, last extent <= 512,
- * every extent >= 4: `odil_poisson_loss_grad_supported` tells; otherwise use residual + adjoint. */
-int odil_poisson_loss_grad_supported(const int64_t* shape, int ndim);
-int odil_poisson_loss_grad_f64(const double* u, const double* rhs, double* gu, const int64_t* shape, int ndim,
-                               const double* h2, double* partials, double* loss, void* stream);
-int odil_poisson_loss_grad_f32(const float* u, const float* rhs, float* gu, const int64_t* shape, int ndim,
-                               const float* h2, double* partials, float* loss, void* stream);
 /* Per-shift Jacobian coefficient arrays d(sum fu)/d u_shift as
  * `Problem.eval_operator_grad` returns them under `distinct_shift`
  * (core.py:1313-1361): coeffs holds 2*ndim+1 arrays of `shape`, order
@@ -294,6 +286,23 @@ int odil_csr_assemble_f64(const double* coeffs, const int64_t* shifts, int nshif
                           int64_t col_offset, int64_t* indptr, int64_t* indices, double* data, void* stream);
 int odil_csr_assemble_f32(const float* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
                           int64_t col_offset, int64_t* indptr, int64_t* indices, float* data, void* stream);
+
+/* ---- Newton: the dense block of the normal equations on the matrix cores --------------------------------
+ * `Array` / `NeuralNet` unknowns enter `Problem.linearize` as DENSE Jacobian columns (reference core.py:1189-1203);
+ * the normal equations (linsolver.py:17-23) need D^T D, D^T r and, for the Schur complement against the
+ * matrix-free stencil part, (S^T D)^T Z.  out (px x py, row-major) = X^T Y for row-major X (n x px, row stride
+ * ldx) and Y (n x py, row stride ldy), px, py <= 64, by v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 tiles
+ * with a fixed-order two-stage reduction (bit-reproducible).  `workspace`: odil_dense_block_workspace_bytes(). */
+size_t odil_dense_block_workspace_bytes(void);
+int odil_dense_block_xty_f64(const double* x, const double* y, int64_t n, int px, int py, int64_t ldx, int64_t ldy,
+                             double* out, double* workspace, void* stream);
+int odil_dense_block_xty_f32(const float* x, const float* y, int64_t n, int px, int py, int64_t ldx, int64_t ldy,
+                             float* out, float* workspace, void* stream);
+/* The Gram matrix D^T D (p x p) of one block: odil_dense_block_xty with X = Y = D. */
+int odil_dense_block_gram_f64(const double* d, int64_t n, int p, int64_t ld, double* out, double* workspace,
+                              void* stream);
+int odil_dense_block_gram_f32(const float* d, int64_t n, int p, int64_t ld, float* out, float* workspace,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,6 @@ _SIGNATURES = {
     "poisson_residual_restrict": [_P, _P, _P, _I64P, c_int, _P, _R, _P, _P, _P],
     "poisson_residual_synth": [_P, _P, _P, _P, _I64P, _P, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_residual_slab": [_P, _P, _P, _I64P, c_int, _P, c_int64, c_int64, c_double, _P, _P, _P],
-    "poisson_loss_grad": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_adjoint_adam": [_P, _P, _P, _P, _P, _I64P, c_int, _P, _R, _R, _R, _R, _R, _P, _P],
     "poisson_adjoint_transpose_adam": [_P, _P, _P, _I64P, _P, _R, _P, _P, _P, _P, _P, _P, _R, _R, _R, _R, _P, c_int,
@@ -54,11 +53,13 @@ _SIGNATURES = {
     "lincomb": [_P, _R, _P, c_int64, c_int, _P, c_int64, _P],
     "stencil_apply": [_P, _I64P, c_int, _P, _P, _I64P, c_int, c_int, _P],
     "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],
+    "dense_block_xty": [_P, _P, c_int64, c_int, c_int, c_int64, c_int64, _P, _P, _P],
+    "dense_block_gram": [_P, c_int64, c_int, c_int64, _P, _P, _P],
 }
 
 EXPORTED = [
     "odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes", "odil_dots_workspace_bytes",
-    "odil_poisson_loss_grad_supported",
+    "odil_dense_block_workspace_bytes",
 ] + [
     "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
 ]
@@ -88,8 +89,7 @@ def load():
     lib.odil_reduce_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.argtypes = [c_int]
-    lib.odil_poisson_loss_grad_supported.restype = c_int
-    lib.odil_poisson_loss_grad_supported.argtypes = [_I64P, c_int]
+    lib.odil_dense_block_workspace_bytes.restype = c_size_t
     for name, sig in _SIGNATURES.items():
         for suffix, real in (("f64", c_double), ("f32", c_float)):
             fn = getattr(lib, "odil_{}_{}".format(name, suffix))

@@ -49,10 +49,9 @@ class PoissonEvaluator:
         self.scale = self.npdt(2) / self.npdt(self.fu.numel())
         import os
 
-        self.one_pass = ops.poisson_loss_grad_supported(self.cshape) and bool(int(os.environ.get("ODIL_ONE_PASS", 0)))
         # last prolongation fused into the residual (u never stored): 3-D, even extents, >= 2 levels
         self.synth_residual = (
-            self.ndim == 3 and self.nlvl >= 2 and not self.one_pass and all(s % 2 == 0 and s >= 4 for s in self.cshape)
+            self.ndim == 3 and self.nlvl >= 2 and all(s % 2 == 0 and s >= 4 for s in self.cshape)
             and tuple(self.shapes[1]) == tuple(s // 2 for s in self.cshape)
             and bool(int(os.environ.get("ODIL_SYNTH_RESIDUAL", 1))))
         # stencil adjoint, first transposed prolongation and the Adam updates of both levels in one launch
@@ -133,15 +132,6 @@ class PoissonEvaluator:
             toc(b)
         else:
             u = arrays[0]
-        if self.one_pass:
-            b = tic("loss_grad")
-            ops.poisson_loss_grad(u, self.rhs, self.h2, out=self.gw[0], loss=self.loss)
-            toc(b)
-            if self.nlvl > 1:
-                b = tic("mg_synth_adj")
-                ops.mg_synth_adj(self.gw[0], self.shapes, self.loc, grads=self.gw)
-                toc(b)
-            return self.loss, self.gw
         b = tic("residual")
         if self.synth_residual:
             ops.poisson_residual_synth(coarse, arrays[0], self.rhs, self.h2, fu=self.fu, loss=self.loss)
@@ -164,7 +154,7 @@ class PoissonEvaluator:
         gradients.  Returns (..., done=nlvl) or None when this configuration cannot fuse."""
         import os
 
-        if self.nlvl < 2 or self.one_pass or not int(os.environ.get("ODIL_FUSE_ADAM0", 1)):
+        if self.nlvl < 2 or not int(os.environ.get("ODIL_FUSE_ADAM0", 1)):
             return None
         (field,) = state.fields.values()
         arrays = [t.array for t in field.terms]

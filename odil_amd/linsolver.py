@@ -26,15 +26,16 @@ def _dot(a, b):
     return ops.dots(a[None], b)[0]
 
 
-def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=None, x0=None, check_every=25):
-    """Solves (M^T M + damp^2 I + dampdiag^2 diag(M^T M)) x = M^T rhs by Jacobi-preconditioned CG.
+def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=None, x0=None, check_every=25, b=None):
+    """Solves (M^T M + damp^2 I + dampdiag^2 diag(M^T M)) x = M^T rhs (or = b when `b` is given) by
+    Jacobi-preconditioned CG.
 
     The iteration runs without host synchronisation: the scalars <r, z>, <p, A p>, alpha and beta
     stay 0-d device tensors (deterministic odil_dots; updates through odil_lincomb with device
     coefficients) and the residual norm is read back only every `check_every` iterations."""
     n = op.shape[1]
     dtype, device = op.dtype, op.device
-    b = op.rmatvec(rhs)
+    b = op.rmatvec(rhs) if b is None else b
     diag = op.normal_diagonal()
     shift = None
     if damp or dampdiag:
@@ -72,12 +73,12 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
         for _ in range(min(check_every, maxiter - niter)):
             ap = apply_a(p)
             pap = _dot(p, ap)
-            alpha = (rz / pap).reshape(1)
+            alpha = torch.where(pap > 0, rz / pap, torch.zeros_like(rz)).reshape(1)  # converged exactly: stay put
             ops.lincomb(x, 1.0, p[None], alpha)
             ops.lincomb(r, 1.0, ap[None], -alpha)
             ops.addcmul(z, minv, r, accumulate=False)
             rz_new = _dot(r, z)
-            beta = rz_new / rz
+            beta = torch.where(rz > 0, rz_new / rz, torch.zeros_like(rz))
             rz = rz_new
             if not flip:
                 coef[0:1], coef[1:2] = beta, 1.0
@@ -93,6 +94,80 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
         ok = res > tol * max(bnorm, 1e-300) and float(pap) > 0 and res == res
     if status is not None:
         status["residual"] = res
+        status["niter"] = niter
+    if not bool(torch.isfinite(x).all()):
+        raise FloatingPointError("cg_normal: the iterate is not finite (residual {})".format(res))
+    return x
+
+
+def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
+    """`direct` for systems with DENSE columns (`Array` / `NeuralNet` unknowns, reference core.py:1189-1203).
+
+    With M = [S | D] (S: the stencil blocks, matrix-free; D: rows x p dense, p <= 63) the normal equations
+    (reference linsolver.py:17-23) are solved through the Schur complement of the stencil part:
+        G = D^T D,  g = D^T r                      one pass of the MFMA kernel over [D | r]  (ops.dense_xty)
+        C = S^T D,  c = S^T r                      p + 1 transposed stencil applications
+        (S^T S) [Z | z] = [C | c]                  p + 1 matrix-free CG solves (cg_normal on the stencil part)
+        (G - C^T Z) y = g - C^T z                  C^T [Z | z] again on the matrix cores; a p x p solve
+        x = z - Z y
+    Neither M nor S is ever densified.  Returns the full solution vector, or None when the system has no dense
+    columns / too many of them."""
+    dense_keys = []
+    for row0, nrows, kind, key, payload in op.blocks:
+        if kind == "dense" and key not in dense_keys:
+            dense_keys.append(key)
+    dense_keys.sort(key=lambda k: op.key_to_offset[k])
+    p = sum(op.key_to_size[k] for k in dense_keys)
+    if not dense_keys or p > 63:
+        return None
+    dtype, device = op.dtype, op.device
+    col0, pos = dict(), 0
+    for k in dense_keys:
+        col0[k] = pos
+        pos += op.key_to_size[k]
+    # [D | r]: row-major, rows x (p + 1)
+    daug = torch.zeros((op.nrows, p + 1), dtype=dtype, device=device)
+    stencil_blocks = []
+    for blk in op.blocks:
+        row0, nrows, kind, key, payload = blk
+        if kind == "dense":
+            daug[row0:row0 + nrows, col0[key]:col0[key] + payload.shape[1]] += payload
+        else:
+            stencil_blocks.append(blk)
+    daug[:, p] = rhs
+    gg = ops.dense_xty(daug[:, :p], daug)  # p x (p + 1) = [D^T D | D^T r]
+    G, g = gg[:, :p].clone(), gg[:, p].clone()
+    if damp or dampdiag:
+        G.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * G.diagonal().clone())
+    x = torch.zeros(op.ncols, dtype=dtype, device=device)
+    dcols = torch.cat([torch.arange(op.key_to_offset[k], op.key_to_offset[k] + op.key_to_size[k], device=device)
+                       for k in dense_keys])
+    info = dict(method="schur-mfma", dense_columns=p)
+    if not stencil_blocks:
+        y = torch.linalg.solve(G, g)
+        niter = 0
+    else:
+        import copy
+
+        op_s = copy.copy(op)
+        op_s.blocks = stencil_blocks
+        dt = daug.t().contiguous()  # (p + 1) x rows: the columns of [D | r] as contiguous vectors
+        cz = torch.stack([op_s.rmatvec(dt[j]) for j in range(p + 1)])  # rows: C_j = S^T D_j, last: S^T r
+        sub = dict()
+        zs = torch.stack([cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j])
+                          for j in range(p + 1)])
+        niter = sub.get("niter", 0)
+        ct = cz[:p].t().contiguous()  # unknowns x p
+        zt = zs.t().contiguous()      # unknowns x (p + 1)
+        czz = ops.dense_xty(ct, zt)   # C^T [Z | z]
+        y = torch.linalg.solve(G - czz[:, :p], g - czz[:, p])
+        x.copy_(zs[p])
+        ops.lincomb(x, 1.0, zs[:p].contiguous(), (-y).contiguous())
+    x[dcols] = y
+    if status is not None:
+        r = op.rmatvec(op.matvec(x) - rhs)
+        status.update(info)
+        status["residual"] = float(_dot(r, r)) ** 0.5
         status["niter"] = niter
     return x
 
@@ -174,6 +249,10 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
     if linsolver in ("direct", "directsq"):
+        if any(kind == "dense" for _, _, kind, _, _ in matr.blocks):
+            x = schur_normal(matr, rhs, damp, dampdiag, maxiter=maxiter, status=status)
+            if x is not None and bool(torch.isfinite(x).all()):
+                return x
         if _dense_fits(matr):
             x = dense_normal(matr, rhs, damp, dampdiag, status=status)
             if x is not None and bool(torch.isfinite(x).all()):

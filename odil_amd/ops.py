@@ -6,7 +6,7 @@ semantics follow the reference functions cited in include/odil_hip.h.
 """
 
 import math
-from ctypes import c_int, c_int64
+from ctypes import c_int, c_int64, c_void_p
 
 import torch
 
@@ -314,25 +314,6 @@ def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None, zrange=None,
     return fu, loss
 
 
-def poisson_loss_grad_supported(shape):
-    return bool(_lib.load().odil_poisson_loss_grad_supported(i64(shape), c_int(len(shape))))
-
-
-def poisson_loss_grad(u, rhs, h2, out=None, loss=None):
-    """Fused gu = (2/size) J^T (J u - rhs), loss = mean((J u - rhs)^2) without materialising fu."""
-    assert u.shape == rhs.shape and u.dtype == rhs.dtype
-    if out is None:
-        out = torch.empty_like(u)
-    if loss is None:
-        loss = torch.empty((), dtype=u.dtype, device=u.device)
-    h2a, h2p = host_reals(h2, u.dtype)
-    call(
-        "poisson_loss_grad", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p,
-        ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
-    )
-    return out, loss
-
-
 def poisson_adjoint(fu, h2, scale, out=None):
     """gu = J^T (scale * fu)."""
     if out is None:
@@ -387,6 +368,26 @@ def poisson_jac_coeffs(shape, h2, dtype, device):
     out = torch.empty((2 * ndim + 1,) + tuple(shape), dtype=dtype, device=device)
     h2a, h2p = host_reals(h2, dtype)
     call("poisson_jac_coeffs", dtype, ptr(out), i64(shape), c_int(ndim), h2p, stream_ptr())
+    return out
+
+
+_dense_ws = {}
+
+
+def dense_xty(x, y):
+    """X^T Y of two tall, skinny matrices (rows x <= 64 columns each, row-major, any row stride) on the matrix
+    cores: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, deterministic two-stage reduction.  The dense block of
+    the Newton normal equations (reference core.py:1189-1203, linsolver.py:17-23)."""
+    assert x.dim() == 2 and y.dim() == 2 and x.shape[0] == y.shape[0] and x.dtype == y.dtype
+    assert x.stride(1) == 1 and y.stride(1) == 1
+    key = (str(x.device), x.dtype)
+    ws = _dense_ws.get(key)
+    if ws is None:
+        ws = _dense_ws[key] = torch.empty(_lib.load().odil_dense_block_workspace_bytes() // 8, dtype=torch.float64,
+                                          device=x.device).view(x.dtype)
+    out = torch.empty((x.shape[1], y.shape[1]), dtype=x.dtype, device=x.device)
+    call("dense_block_xty", x.dtype, c_void_p(x.data_ptr()), c_void_p(y.data_ptr()), c_int64(x.shape[0]),
+         c_int(x.shape[1]), c_int(y.shape[1]), c_int64(x.stride(0)), c_int64(y.stride(0)), ptr(out), ptr(ws), stream_ptr())
     return out
 
 

@@ -100,7 +100,7 @@ class PoissonMultigridAdam:
         t = self.npdt(self.t)
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)  # optimizer.py:313-315
         omb1, omb2 = 1 - self.b1, 1 - self.b2
-        fuse = self.fuse_adam0 and not self.ev.one_pass and self.nlvl > 1
+        fuse = self.fuse_adam0 and self.nlvl > 1
         if fuse:
             # every level is updated by the lane that forms its gradient (adjoint launch for the
             # finest level, P^T chain for the others): no optimizer launch at all

@@ -152,6 +152,11 @@ def newton_operator(ctx):
     return res
 
 
+def damped_want(g, y):
+    a = g["matrix"].T @ g["matrix"]
+    return np.linalg.solve(a + 0.09 * np.eye(len(a)) + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)
+
+
 def make_newton_problem(mod, g):
     Nx, Ny, Na, Nnet = 3, 2, 5, 5
     domain = odil.Domain(cshape=(Nx, Ny), dimnames=["x", "y"], lower=(0, 0), upper=(Nx, Ny), dtype=np.float64,
@@ -195,6 +200,13 @@ def test_newton_linearize_and_step_vs_golden(mod):
     assert status["niter"] % 7 == 0 and status["niter"] > 0
     want = np.linalg.solve(g["matrix"].T @ g["matrix"], g["matrix"].T @ y)
     assert rel(x_dense, want) < 1e-9 and rel(x_cg, want) < 1e-8
+    # ... and the route `direct` takes for systems with dense columns: D^T D and C^T Z on the matrix cores,
+    # Schur complement against the matrix-free stencil part (no densification of M)
+    status = dict()
+    x_schur = odil.linsolver.schur_normal(op, rhs, status=status)
+    assert status["method"] == "schur-mfma" and status["dense_columns"] == 5 + 25 + 5 and status["residual"] < 1e-9
+    assert rel(x_schur, want) < 1e-9
+    assert rel(odil.linsolver.schur_normal(op, rhs, damp=0.3, dampdiag=0.2), damped_want(g, y)) < 1e-9
     damped = odil.linsolver.dense_normal(op, rhs, damp=0.3, dampdiag=0.2)
     a = g["matrix"].T @ g["matrix"]
     assert rel(damped, np.linalg.solve(a + 0.09 * np.eye(len(a)) + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)) < 1e-9

@@ -387,31 +387,6 @@ def test_large_roundtrip_properties(dev):
     assert abs(a - b) <= 1e-10 * abs(a)
 
 
-@pytest.mark.parametrize("shape", [(4, 4, 4), (5, 7, 9), (16, 16, 16), (6, 9, 512), (12, 5, 130), (70, 6, 33)])
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_poisson_fused_loss_grad_vs_two_kernel_path_and_oracle(dev, shape, dtype):
-    from odil_amd import ops
-
-    assert ops.poisson_loss_grad_supported(shape)
-    assert not ops.poisson_loss_grad_supported((8, 8)) and not ops.poisson_loss_grad_supported((8, 8, 600))
-    rng = np.random.default_rng(17)
-    dw = onp.step(shape, dtype=dtype)
-    h2 = [d**2 for d in dw]
-    u = rng.standard_normal(shape).astype(dtype)
-    rhs = rng.standard_normal(shape).astype(dtype)
-    tu, trhs = to(u, dev), to(rhs, dev)
-    g1, loss1 = ops.poisson_loss_grad(tu, trhs, h2)
-    fu, loss2 = ops.poisson_residual(tu, trhs, h2)
-    g2 = ops.poisson_adjoint(fu, h2, dtype(2) / dtype(fu.numel()))
-    # same operation order as the two-kernel path: identical values
-    assert np.array_equal(g1.cpu().numpy(), g2.cpu().numpy())
-    tol = 1e-14 if dtype == np.float64 else 1e-6
-    assert abs(float(loss1) - float(loss2)) <= tol * abs(float(loss2))
-    fref = onp.poisson_residual(u, rhs, dw)
-    gref = onp.poisson_adjoint(2 * fref / fref.size, dw)
-    assert rel(g1, gref) < (1e-13 if dtype == np.float64 else 1e-5)
-
-
 @pytest.mark.parametrize("fuse", [0, 1])
 def test_device_resident_adam_driver_vs_golden(dev, fuse, monkeypatch):
     """The bench driver (packed state, optional Adam-in-adjoint fusion) follows the reference's
@@ -665,3 +640,28 @@ def test_two_step_transpose_of_space_time_layout(dev, dtype, monkeypatch):
     y = rng.standard_normal((9, 6, 5, 4))
     got = ops.interp_adj(to(y, dev), "n...", (5, 6, 5, 4))
     assert rel(got, onp.interp_to_finer_adj(y, "n...", (5, 6, 5, 4))) < 1e-14
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_block_xty_on_the_matrix_cores(dev, dtype):
+    """odil_dense_block_xty (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 tiles, fixed-order reduction) against
+    NumPy: X^T Y for tall skinny matrices -- the D^T D, D^T r and C^T Z products of the Newton normal equations
+    with dense `Array` / `NeuralNet` columns (reference core.py:1189-1203, linsolver.py:17-23) -- at row counts that
+    are not multiples of anything, every column-tile count, strided (column-sliced) operands; bit-reproducible."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(5)
+    tol = 1e-13 if dtype == np.float64 else 2e-5
+    for n, px, py in [(1, 1, 1), (5, 3, 17), (1000, 16, 16), (4099, 46, 47), (100003, 64, 64), (70001, 33, 1), (257, 64, 5)]:
+        x, y = rng.standard_normal((n, px)).astype(dtype), rng.standard_normal((n, py)).astype(dtype)
+        got = ops.dense_xty(to(x, dev), to(y, dev))
+        want = x.astype(np.float64).T @ y.astype(np.float64)
+        assert got.shape == (px, py)
+        assert np.max(np.abs(got.cpu().numpy() - want)) <= tol * max(1.0, np.max(np.abs(want))) * np.sqrt(n), (n, px, py)
+        assert torch.equal(got, ops.dense_xty(to(x, dev), to(y, dev)))
+    # column slices of one wider matrix (row stride > columns): [D | r] as the solver passes it
+    d = rng.standard_normal((3001, 36)).astype(dtype)
+    td = to(d, dev)
+    got = ops.dense_xty(td[:, :35], td)
+    want = d[:, :35].astype(np.float64).T @ d.astype(np.float64)
+    assert np.max(np.abs(got.cpu().numpy() - want)) <= tol * np.max(np.abs(want)) * 60
