@@ -279,6 +279,15 @@ int odil_stencil_apply_f64(const double* coeffs, const int64_t* shifts, int nshi
                            const int64_t* shape, int ndim, int transpose, void* stream);
 int odil_stencil_apply_f32(const float* coeffs, const int64_t* shifts, int nshift, const float* x, float* y,
                            const int64_t* shape, int ndim, int transpose, void* stream);
+/* x = M^-1 b for such a matrix when it is triangular along `axis` with the coefficient array `diag` (zero shift)
+ * alone on the diagonal block -- the Jacobian of an operator that is explicit in time (wave): every other shift has
+ * a negative (direction > 0, forward substitution) or positive (direction < 0) component along `axis` and no
+ * coefficient that wraps around the ends.  M d = -r then has the solution of the normal equations
+ * M^T M d = -M^T r the reference hands to SuperLU (linsolver.py:17-26).  One launch per level of `axis`. */
+int odil_stencil_march_f64(const double* coeffs, const int64_t* shifts, int nshift, int diag, const double* b, double* x,
+                           const int64_t* shape, int ndim, int axis, int direction, void* stream);
+int odil_stencil_march_f32(const float* coeffs, const int64_t* shifts, int nshift, int diag, const float* b, float* x,
+                           const int64_t* shape, int ndim, int axis, int direction, void* stream);
 /* CSR assembly of the same matrix (core.py:1144-1171, :1214): indptr[n+1], indices,
  * data of nnz = nshift*n entries, columns offset by `col_offset`; rows keep ODIL's
  * order (ascending shift index within a row, not sorted by column). */

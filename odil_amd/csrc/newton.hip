@@ -91,6 +91,38 @@ __global__ __launch_bounds__(kBlock) void k_csr_assemble(const T* __restrict__ c
   }
 }
 
+// One level of a triangular solve along `axis`: for the rows whose `axis` coordinate is `level`,
+//   x[r] = (b[r] - sum_{s != diag} c_s[r] x[r + shift_s]) / c_diag[r],
+// every off-diagonal neighbour lying in a level already solved (the host checks the shifts).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_stencil_march_level(const T* __restrict__ coeffs, const T* __restrict__ b,
+                                                               T* __restrict__ x, ShiftArgs a, int diag, int axis,
+                                                               int64_t level) {
+  int64_t plane = 1;
+  for (int d = 0; d < 4; ++d)
+    if (d != axis) plane *= a.n[d];
+  const int64_t size = a.n[0] * a.n[1] * a.n[2] * a.n[3];
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < plane; p += nthreads) {
+    Coords c;
+    int64_t rem = p, i = 0, stride = 1;
+    for (int d = 3; d >= 0; --d) {
+      if (d == axis) {
+        c.id[d] = level;
+      } else {
+        c.id[d] = rem % a.n[d];
+        rem /= a.n[d];
+      }
+      i += c.id[d] * stride;
+      stride *= a.n[d];
+    }
+    T acc = b[i];
+    for (int s = 0; s < a.nshift; ++s)
+      if (s != diag) acc = acc - coeffs[(int64_t)s * size + i] * x[shifted_index(a, c, s, +1)];
+    x[i] = acc / coeffs[(int64_t)diag * size + i];
+  }
+}
+
 static int fill_shifts(ShiftArgs& a, const int64_t* shifts, int nshift, const int64_t* shape, int ndim) {
   if (ndim < 1 || ndim > ODIL_MAX_NDIM || !shape || !shifts || nshift < 1 || nshift > kMaxShifts) {
     set_error("stencil: invalid ndim=%d or nshift=%d (max %d)", ndim, nshift, kMaxShifts);
@@ -135,6 +167,33 @@ static int csr_assemble(const T* coeffs, const int64_t* shifts, int nshift, cons
   return check_launch("k_csr_assemble");
 }
 
+// M x = b for a stencil matrix that is TRIANGULAR along one axis with a diagonal block on the diagonal (an operator
+// that is explicit in time: every coefficient of the newest time level sits on the unknown itself): forward
+// (direction > 0: all other shifts point to lower levels) or backward substitution, one small launch per level.
+template <typename T>
+static int stencil_march(const T* coeffs, const int64_t* shifts, int nshift, int diag, const T* b, T* x,
+                         const int64_t* shape, int ndim, int axis, int direction, void* stream) {
+  ShiftArgs a;
+  if (int e = fill_shifts(a, shifts, nshift, shape, ndim)) return e;
+  if (!coeffs || !b || !x || diag < 0 || diag >= nshift || axis < 0 || axis >= ndim) {
+    set_error("stencil_march: null pointer, diagonal slot %d or axis %d out of range", diag, axis);
+    return ODIL_E_INVAL;
+  }
+  const int ax = axis + (4 - ndim);
+  for (int d = 0; d < 4; ++d)
+    if (a.shift[diag][d] != 0) {
+      set_error("stencil_march: slot %d is not the diagonal", diag);
+      return ODIL_E_INVAL;
+    }
+  const int64_t levels = a.n[ax], plane = prod4(a.n) / levels;
+  for (int64_t k = 0; k < levels; ++k) {
+    const int64_t level = direction > 0 ? k : levels - 1 - k;
+    hipLaunchKernelGGL(k_stencil_march_level<T>, dim3(grid_for(plane, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       coeffs, b, x, a, diag, ax, level);
+  }
+  return check_launch("k_stencil_march_level");
+}
+
 }  // namespace odil
 
 using namespace odil;
@@ -147,6 +206,14 @@ int odil_stencil_apply_f64(const double* coeffs, const int64_t* shifts, int nshi
 int odil_stencil_apply_f32(const float* coeffs, const int64_t* shifts, int nshift, const float* x, float* y,
                            const int64_t* shape, int ndim, int transpose, void* stream) {
   return stencil_apply<float>(coeffs, shifts, nshift, x, y, shape, ndim, transpose, stream);
+}
+int odil_stencil_march_f64(const double* coeffs, const int64_t* shifts, int nshift, int diag, const double* b, double* x,
+                           const int64_t* shape, int ndim, int axis, int direction, void* stream) {
+  return stencil_march<double>(coeffs, shifts, nshift, diag, b, x, shape, ndim, axis, direction, stream);
+}
+int odil_stencil_march_f32(const float* coeffs, const int64_t* shifts, int nshift, int diag, const float* b, float* x,
+                           const int64_t* shape, int ndim, int axis, int direction, void* stream) {
+  return stencil_march<float>(coeffs, shifts, nshift, diag, b, x, shape, ndim, axis, direction, stream);
 }
 int odil_csr_assemble_f64(const double* coeffs, const int64_t* shifts, int nshift, const int64_t* shape, int ndim,
                           int64_t col_offset, int64_t* indptr, int64_t* indices, double* data, void* stream) {

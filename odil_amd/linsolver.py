@@ -172,6 +172,64 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
     return x
 
 
+def recognise_marching(op):
+    """(coeffs [nshift, size], shifts, diagonal slot, field shape, axis, direction) when M is square, acts on ONE
+    field and is triangular along one axis with only the unknown itself on the diagonal block -- the Jacobian of
+    an operator that is explicit in time (examples/wave: shifts (0, 0), (-1, 0), (-2, 0), (-1, +-1)) -- and no
+    coefficient wraps around the ends of that axis; None otherwise."""
+    from .core import Field
+
+    if len(op.key_to_field) != 1 or op.nrows != op.ncols:
+        return None
+    (key, field), = op.key_to_field.items()
+    if not isinstance(field, Field):
+        return None
+    shape = tuple(field.array.shape)
+    ndim = len(shape)
+    shifts, coeffs = [], []
+    for row0, nrows, kind, k, payload in op.blocks:
+        if kind != "stencil" or row0 != 0 or nrows != op.ncols:
+            return None
+        coeff, shift, loc, vshape = payload
+        if loc != field.loc or tuple(vshape) != shape:
+            return None
+        norm = tuple(((s + n // 2) % n) - n // 2 for s, n in zip(shift, shape))  # periodic roll: |shift| <= n / 2
+        if norm in shifts:
+            coeffs[shifts.index(norm)] = coeffs[shifts.index(norm)] + coeff.reshape(shape)
+        else:
+            shifts.append(norm)
+            coeffs.append(coeff.reshape(shape))
+    zero = (0,) * ndim
+    if zero not in shifts or len(shifts) > 32:
+        return None
+    diag = shifts.index(zero)
+    for axis in range(ndim):
+        for direction in (1, -1):
+            if not all(s == zero or direction * s[axis] < 0 for s in shifts):
+                continue
+            # rows whose neighbour would lie across the end of the axis must not use it
+            ok = float(coeffs[diag].abs().min()) > 0
+            for s, c in zip(shifts, coeffs):
+                k = abs(s[axis])
+                if ok and s != zero:
+                    edge = c.narrow(axis, 0, k) if direction > 0 else c.narrow(axis, shape[axis] - k, k)
+                    ok = float(edge.abs().max()) == 0
+            if ok:
+                return torch.stack(coeffs).contiguous(), shifts, diag, shape, axis, direction
+    return None
+
+
+def march_solve(rec, rhs, status=None):
+    coeffs, shifts, diag, shape, axis, direction = rec
+    x = ops.stencil_march(coeffs, shifts, diag, rhs.reshape(shape).contiguous(), axis, direction)
+    if status is not None:
+        r = ops.stencil_apply(coeffs, shifts, x) - rhs.reshape(shape)
+        status["residual"] = float(_dot(r.reshape(-1), r.reshape(-1))) ** 0.5
+        status["niter"] = 1
+        status["method"] = "substitution along axis {}".format(axis)
+    return x.reshape(-1)
+
+
 DENSE_MAX_UNKNOWNS = 49152  # `direct` factorises the dense normal matrix up to here, memory permitting
 
 
@@ -248,6 +306,12 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             gtol = 1e-12 if linsolver == "direct" else tol
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
+    # Square and triangular along one axis (time-explicit operators): M d = rhs by substitution is exact and has the
+    # solution of the normal equations
+    if not damp and not dampdiag and linsolver in ("direct", "directsq", "multigrid"):
+        rec = recognise_marching(matr)
+        if rec is not None:
+            return march_solve(rec, rhs, status)
     if linsolver in ("direct", "directsq"):
         if any(kind == "dense" for _, _, kind, _, _ in matr.blocks):
             x = schur_normal(matr, rhs, damp, dampdiag, maxiter=maxiter, status=status)

@@ -514,6 +514,18 @@ def stencil_apply(coeffs, shifts, x, transpose=False, out=None):
     return out
 
 
+def stencil_march(coeffs, shifts, diag, b, axis, direction, out=None):
+    """x with M x = b for a stencil matrix triangular along `axis` (see odil_stencil_march in the header)."""
+    if out is None:
+        out = torch.empty_like(b)
+    flat = []
+    for s in shifts:
+        flat += list(s)
+    call("stencil_march", b.dtype, ptr(coeffs), i64(flat), c_int(len(shifts)), c_int(diag), ptr(b), ptr(out),
+         i64(b.shape), c_int(b.dim()), c_int(axis), c_int(direction), stream_ptr())
+    return out
+
+
 def csr_assemble(coeffs, shifts, shape, col_offset=0):
     """(indptr, indices, data) of the stencil matrix (reference core.py:1144-1171)."""
     nshift = len(shifts)
