@@ -25,7 +25,7 @@ from .core import (  # noqa: F401
     restrict_to_coarser,
 )
 from .history import History  # noqa: F401
-from .io import parse_raw_xmf, read_raw, read_raw_with_xmf, write_raw_with_xmf, write_raw_xmf  # noqa: F401
+from .io import parse_raw_xmf, read_raw, read_raw_with_xmf, write_raw_slab, write_raw_with_xmf, write_raw_xmf  # noqa: F401
 from .optimizer import EarlyStopError  # noqa: F401
 from .util import make_callback, optimize, printlog, set_log_file, setup_outdir  # noqa: F401
 

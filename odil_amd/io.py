@@ -78,6 +78,59 @@ def write_raw_with_xmf(u, xmfpath, rawpath=None, spacing=(1, 1, 1), cell=True, n
     return xmfpath
 
 
+def write_raw_slab(u_owned, xmfpath, rank, world, axis=0, rawpath=None, spacing=(1, 1, 1), cell=True, name=None):
+    """Slab-parallel dump: every rank of a slab decomposition (odil_amd/slab.py, slab_traced.py) writes ITS planes
+    of one global field into the one `.raw` file the reference's reader expects (reference src/odil/io.py:145-167
+    writes the whole array from one process), at its own offsets; rank 0 also writes the XDMF 2 description of the
+    GLOBAL array.  `u_owned`: this rank's owned part (device tensor or host array, <= 3-D, the global array cut
+    into `world` equal parts along `axis`).  A device tensor is copied to the host once (its owned planes only,
+    through pinned memory).  No collective is needed: the file is sized by whoever comes first."""
+    import torch
+
+    if hasattr(u_owned, "detach"):
+        t = u_owned.detach()
+        if t.is_cuda:
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            t = host
+        u = t.numpy()
+    else:
+        u = np.asarray(u_owned)
+    if u.dtype not in (np.float32, np.float64):
+        u = u.astype(np.float64)
+    lead = 3 - u.ndim
+    if lead < 0:
+        raise ValueError("Expected at most 3 dimensions, got shape {}".format(u.shape))
+    u = u.reshape((1,) * lead + u.shape)
+    axis3 = axis + lead
+    count = list(u.shape)
+    n = count[axis3]
+    count[axis3] = n * world
+    spacing = list(spacing)
+    while len(spacing) < 3:
+        spacing.append(min(spacing))
+    if rawpath is None:
+        rawpath = os.path.splitext(xmfpath)[0] + ".raw"
+    nbytes = int(np.prod(count)) * u.dtype.itemsize
+    fd = os.open(rawpath, os.O_RDWR | os.O_CREAT, 0o644)
+    try:
+        if os.fstat(fd).st_size != nbytes:
+            os.ftruncate(fd, nbytes)  # same size from every rank: whoever comes first
+    finally:
+        os.close(fd)
+    out = np.memmap(rawpath, dtype=u.dtype, mode="r+", shape=tuple(count))
+    sel = [slice(None)] * 3
+    sel[axis3] = slice(rank * n, (rank + 1) * n)
+    out[tuple(sel)] = u
+    out.flush()
+    del out
+    if rank == 0:
+        rel = os.path.relpath(rawpath, start=os.path.dirname(xmfpath) or ".")
+        write_raw_xmf(xmfpath, rel, count, spacing, name or "data", 4 if u.dtype == np.float32 else 8, cell)
+    return xmfpath
+
+
 def parse_raw_xmf(xmfpath):
     """Metadata of a file written by write_raw_xmf: rawpath, count (Nz, Ny, Nx), spacing (hx, hy, hz),
     name, precision (bytes per value), cell."""
