@@ -132,6 +132,9 @@ class PoissonGMG:
         forms anyway (after its pre-smoothing sweeps, on its way to the coarse grid): the iterate returned
         is that pre-smoothed one, so convergence costs no pass of its own."""
         n = b.numel()
+        # a relative residual below ~50 ulp of the working precision cannot be reached: asking float32 for 1e-12 would
+        # burn every cycle of `maxiter` and report nothing
+        tol = max(tol, 50 * float(torch.finfo(self.dtype).eps))
         x = torch.zeros_like(b) if x0 is None else x0.clone()
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
@@ -142,15 +145,22 @@ class PoissonGMG:
         while self.nlvl > 1:
             x = self.smooth(0, x, b, self.nu1)
             self.coarse_rhs(0, x, b)
-            res = math.sqrt(max(float(self.loss), 0.0) * n)
-            if res <= tol * max(bn, 1e-300) or it >= maxiter:
-                break
+            prev, res = res, math.sqrt(max(float(self.loss), 0.0) * n)
+            if res <= tol * max(bn, 1e-300) or it >= maxiter or (it >= 3 and res >= 0.98 * prev):
+                break  # converged, out of cycles, or stagnating at the rounding floor
             x = self.finish_cycle(0, x, b)
             it += 1
+        converged = res <= tol * max(bn, 1e-300)
+        if not converged:
+            from .util import printlog
+
+            printlog("odil_amd: multigrid stopped at relative residual {:.2e} after {} cycles (tolerance {:.1e})".format(
+                res / max(bn, 1e-300), it, tol))
         if status is not None:
             status["residual"] = res
             status["niter"] = it
             status["method"] = "gmg-vcycle"
+            status["converged"] = converged
         # the iterate may live in one of this object's work buffers: copy=False only for a caller that
         # consumes it before the next solve
         return x.clone() if copy else x

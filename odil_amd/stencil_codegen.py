@@ -1028,15 +1028,22 @@ _Codegen._gather_slab = _gather_slab
 
 
 def _cache_dirs():
-    """In-tree cache first (travels with the checkout); a per-user temp dir if that is read-only."""
-    import getpass
-
+    """In-tree cache first (travels with the checkout); a PRIVATE per-user directory if that is read-only."""
     yield _CACHE_DIR
+    yield os.path.join(os.path.expanduser("~"), ".cache", "odil_amd_jit")
+
+
+def _trusted(d):
+    """A cache directory libraries may be LOADED from: the in-tree one (whoever can write there can rewrite this
+    module as well), or one owned by this user and writable by nobody else (a shared temp directory with a
+    predictable name could be pre-created by another user with a planted library in it)."""
+    if d == _CACHE_DIR:
+        return True
     try:
-        user = getpass.getuser()
-    except Exception:
-        user = str(os.getuid())
-    yield os.path.join(tempfile.gettempdir(), "odil_jit_cache_" + user)
+        st = os.stat(d)
+    except OSError:
+        return False
+    return st.st_uid == os.getuid() and not (st.st_mode & 0o022)
 
 
 def _compile(src, flags=None):
@@ -1044,14 +1051,18 @@ def _compile(src, flags=None):
     tag = hashlib.sha256((src + " ".join(flags)).encode()).hexdigest()[:20]
     name = "odil_jit_{}.so".format(tag)
     for d in _cache_dirs():
-        if os.path.exists(os.path.join(d, name)):
+        if os.path.exists(os.path.join(d, name)) and _trusted(d):
             return ctypes.CDLL(os.path.join(d, name)), os.path.join(d, name)
     last = None
     for d in _cache_dirs():
         try:
-            os.makedirs(d, exist_ok=True)
-            hip = os.path.join(d, "odil_jit_{}.hip".format(tag))
-            with open(hip, "w") as f:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            if not _trusted(d):
+                raise OSError("cache directory {} is not private to this user".format(d))
+            # source and library are written under temporary names and renamed: ranks that compile the same
+            # operator at the same time never read each other's half-written files
+            fd, hip_tmp = tempfile.mkstemp(suffix=".hip", dir=d)
+            with os.fdopen(fd, "w") as f:
                 f.write(src)
             fd, tmp = tempfile.mkstemp(suffix=".so", dir=d)
             os.close(fd)
@@ -1059,11 +1070,13 @@ def _compile(src, flags=None):
             last = e
             continue
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        res = subprocess.run([hipcc] + flags + ["-o", tmp, hip], capture_output=True, text=True)
+        res = subprocess.run([hipcc] + flags + ["-o", tmp, hip_tmp], capture_output=True, text=True)
+        hip = os.path.join(d, "odil_jit_{}.hip".format(tag))
+        os.replace(hip_tmp, hip)  # kept beside the library for inspection
         if res.returncode != 0:
             os.unlink(tmp)
             raise RuntimeError("hipcc failed for the traced operator ({}):\n{}".format(hip, res.stderr[-4000:]))
         path = os.path.join(d, name)
         os.replace(tmp, path)  # atomic: concurrent ranks compiling the same source do not collide
         return ctypes.CDLL(path), path
-    raise FileNotFoundError("no writable cache directory for traced operators: {}".format(last))
+    raise FileNotFoundError("no writable private cache directory for traced operators: {}".format(last))
