@@ -756,6 +756,7 @@ constexpr int kFuC = kTileX + 4;       // packs of two: fine x from 2 jx0 - 4 (p
 constexpr int kFuPacks = kFuR * kFuC;
 constexpr int kFuLoads = (kFuPacks + kBlock - 1) / kBlock;
 constexpr int kGC = kTileC / 2;        // packs per row of the g0 tile
+constexpr int kG0Steps = (kTileR * kFuC + kBlock - 1) / kBlock;  // g0 is formed walking rows of kFuC lanes
 constexpr int kOwnLoads = 2 * kTileY * kTileX / kBlock;  // own packs per thread and plane
 
 template <typename T>
@@ -902,13 +903,19 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
       // slab interfaces (ghost planes beyond them, multi-GPU): the transposed stencil has its interior rows
       // there -- the wall rows of adj_axis sit two planes inside an end that is a wall
       const int zj = z + (c.cut_lo ? 2 : 0), zn = c.fnz + (c.cut_lo ? 2 : 0) + (c.cut_hi ? 2 : 0);
+      // Lanes walk the fu window row by row in ITS row length (kFuC packs, of which the g0 tile takes kGC): the
+      // seven window reads of consecutive lanes are then consecutive packs.  Walking the g0 tile's own rows
+      // (kGC packs) made every wave straddle a row end with a two-pack gap in its window addresses, a two-way
+      // LDS bank conflict in ~4 of 9 lane groups (SQ_LDS_BANK_CONFLICT 7.3e7 of 1.85e8 active cycles,
+      // profiles/r02_v0_poisson_pmc.txt).
 #pragma unroll 1
-      for (int i = 0; i < kTileLoads; ++i) {
-        const int p = threadIdx.x + i * kBlock;
-        if (p < kTilePacks) {
-          const int r = p / kGC, cc = p - r * kGC;
+      for (int i = 0; i < kG0Steps; ++i) {
+        const int w = threadIdx.x + i * kBlock;
+        const int r = w / kFuC, cc = w - r * kFuC;
+        if (r < kTileR && cc < kGC) {
+          const int p = r * kGC + cc;
           const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
-          const int at = (r + 1) * kFuC + cc + 1;  // the same cells in the fu window
+          const int at = w + kFuC + 1;  // = (r + 1) * kFuC + cc + 1: the same cells in the fu window
           P2 g;
           g[0] = T(0), g[1] = T(0);
           if (z >= 0 && z < c.fnz && y >= 0 && y < fny && x >= 0 && x < fnx) {
