@@ -12,7 +12,7 @@ reference solution, discrete rhs, zero initial state; poisson.py:21-24,71-86,264
 
 N > 1: one rank per GPU over RCCL, weak scaling (every rank owns a 512^3 slab of the (N*512, 512, 512) grid;
 config 5: a (128, 32, 256, 256) slab of the tracer workload's (128, N*32, 256, 256) grid -- at N = 8 the
-256^3 x 128t grid BASELINE.json names).  Either the caller starts the ranks (`python -m torch.distributed.run
+256^3 x 128t grid BASELINE.json names, with the domain's own 7 multigrid levels).  Either the caller starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE are then in the environment), or plain
 `python bench.py --gpus N` starts them itself as FRESH child processes before this process has touched the
 GPU, relays rank 0's JSON line and exits with the children's status.
@@ -233,9 +233,9 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
     nt, nx_rank, ny = sc(128), sc(32), sc(256)
     odil.util.set_log_file(open(os.devnull, "w"))
-    nlvl = int(np.log2(nx_rank))  # every level keeps >= 2 cells of x per rank
-    a = veltracer3d.parse_args(["--Nt", str(nt), "--Nx", str(nx_rank * world), "--Ny", str(ny), "--Nz", str(ny),
-                                "--nlvl", str(nlvl)])
+    # the domain's own level count (min over the axes of log2 n, reference core.py:66-73): levels that leave a rank
+    # fewer than 2 cells of x are agglomerated by slab_traced.py
+    a = veltracer3d.parse_args(["--Nt", str(nt), "--Nx", str(nx_rank * world), "--Ny", str(ny), "--Nz", str(ny)])
     dtype = np.float32
     domain = odil.Domain(cshape=(a.Nt, a.Nx, a.Ny, a.Nz), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
                          upper=(1, 1, 1, 1), dtype=dtype, multigrid=a.multigrid, mg_interp=a.mg_interp, mg_nlvl=a.nlvl)
@@ -248,6 +248,7 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     for key in ("u",) + veltracer3d.VEL:
         state.fields[key] = odil.Field(None, loc=veltracer3d.LOC)
     problem = odil.Problem(veltracer3d.operator, domain, extra)
+    nlvl = domain.mg_nlvl
     run = SlabTracedAdam(problem, shape_state(domain, state), rank, world, lr=a.lr, device=dev)
     for _ in range(args.warmup):
         run.epoch(comm)

@@ -28,7 +28,10 @@ Per epoch and rank:
      array P^T kernel: with the outer ghost planes zero, the wall weights of that kernel multiply zeros, and
      its result on the coarse owned planes and inner ghost planes is exactly this rank's share;
   7. ("halo") ONE packed message per neighbour carries the inner ghost planes of the gradients of all
-     levels and fields; the receiver adds them to its owned boundary planes (transpose of step 1);
+     levels and fields; the receiver adds them to its owned boundary planes (transpose of step 1).  Levels too
+     coarse to leave every rank 2 planes are AGGLOMERATED: every rank holds the whole array, prolongates from
+     its window of it, pushes its share of the gradient into a zeroed copy, and one ("sum") all-reduce of
+     those few small arrays replaces their halo-add; all ranks then apply the same update;
   8. ("sum") parameter gradients of networks / Arrays, when there are any; Adam on the packed vector.
 The loss needs one more ("sum") of a few scalars, issued only when a value is read.
 
@@ -54,19 +57,28 @@ G = 2  # ghost planes per interior interface (the generated gathers assume 2)
 class _Level:
     """One level array of one grid field on one rank."""
 
-    def __init__(self, gshape, axis, rank, world):
+    def __init__(self, gshape, axis, rank, world, replicate=False):
         self.gshape, self.axis = tuple(gshape), axis
-        if gshape[axis] % world:
-            raise ValueError("axis {} of a level of shape {} does not divide over {} ranks".format(axis, gshape, world))
-        self.n = gshape[axis] // world
-        if self.n < 2:
-            raise ValueError("a level of shape {} leaves fewer than 2 planes per rank: lower mg_nlvl".format(gshape))
-        self.g_lo = 0 if rank == 0 else G
-        self.g_hi = 0 if rank == world - 1 else G
-        self.off = rank * self.n
+        self.rank, self.world = rank, world
+        # A level with fewer than 2 planes per rank is AGGLOMERATED: every rank keeps the whole (small) array, computes
+        # it redundantly and the ranks' gradient contributions are summed by one all-reduce (SURVEY 8 E (3)).
+        self.replicated = replicate or gshape[axis] % world != 0 or gshape[axis] // world < 2
+        if self.replicated:
+            self.n, self.g_lo, self.g_hi, self.off = gshape[axis], 0, 0, 0
+        else:
+            self.n = gshape[axis] // world
+            self.g_lo = 0 if rank == 0 else G
+            self.g_hi = 0 if rank == world - 1 else G
+            self.off = rank * self.n
         self.shape = tuple(self.g_lo + self.n + self.g_hi if d == axis else s for d, s in enumerate(gshape))
         self.size = math.prod(self.shape)
         self.plane = self.size // self.shape[axis]
+
+    def window_of(self, fine):
+        """(first plane, count) of THIS (replicated, coarse) level that prolongates to the ghost-extended planes
+        of the sharded level `fine` of this rank: half its owned range plus one plane per interior interface."""
+        e_lo, e_hi = (1 if fine.g_lo else 0), (1 if fine.g_hi else 0)
+        return fine.off // 2 - e_lo, fine.n // 2 + e_lo + e_hi
 
     def planes(self, a, first, count=1):
         """`count` planes from owned-relative position `first` along the sharded axis."""
@@ -229,6 +241,11 @@ class SlabTracedAdam:
                 if mgloc[axis] != "c":
                     raise ValueError("field '{}' is not refined / cell-centred on the sharded axis".format(key))
                 levels = [_Level(tuple(t.array.shape), axis, rank, world) for t in f.terms]
+                for l in range(len(levels) - 2, -1, -1):  # a rank's planes must be whole coarse cells at the transition
+                    if levels[l + 1].replicated and not levels[l].replicated and levels[l].n % 2:
+                        levels[l] = _Level(tuple(f.terms[l].array.shape), axis, rank, world, replicate=True)
+                if levels[0].replicated or any(a.replicated and not b.replicated for a, b in zip(levels, levels[1:])):
+                    raise ValueError("field '{}': {} cells on the sharded axis over {} ranks".format(key, N, world))
                 init = [t.array for t in f.terms]
                 self.entries.append(dict(key=key, kind="mg", levels=levels, loc=mgloc, init=init))
                 sizes += [lv.size for lv in levels]
@@ -236,6 +253,8 @@ class SlabTracedAdam:
                 if f.loc[axis] != "c":
                     raise ValueError("field '{}' is not cell-centred on the sharded axis".format(key))
                 levels = [_Level(tuple(f.array.shape), axis, rank, world)]
+                if levels[0].replicated:
+                    raise ValueError("field '{}': {} cells on the sharded axis over {} ranks".format(key, N, world))
                 self.entries.append(dict(key=key, kind="field", levels=levels, loc=f.loc, init=[f.array]))
                 sizes.append(levels[0].size)
             elif isinstance(f, (NeuralNet, Array)):
@@ -248,6 +267,7 @@ class SlabTracedAdam:
         mk = lambda: torch.zeros(total, dtype=dtype, device=self.device)
         self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
         pos = 0
+        self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
         send_own = dict(lo=[], hi=[])
         recv_ghost = dict(lo=[], hi=[])
         for e in self.entries:
@@ -264,7 +284,9 @@ class SlabTracedAdam:
                         lv = e["levels"][k]
                         src = src.narrow(axis, lv.off - lv.g_lo, lv.shape[axis])
                     views["x"][k].copy_(src.to(device=self.device, dtype=dtype))
-                if "levels" in e:
+                if "levels" in e and e["levels"][k].replicated:
+                    self._rep.append((pos, cnt))
+                elif "levels" in e:
                     lv = e["levels"][k]
                     if rank > 0:
                         send_own["lo"].append(lv.plane_index(pos, 0, self.device))
@@ -279,7 +301,8 @@ class SlabTracedAdam:
         self._own = {s: cat(send_own[s]) for s in ("lo", "hi")}
         self._ghost = {s: cat(recv_ghost[s]) for s in ("lo", "hi")}
         self.by_key = {e["key"]: e for e in self.entries}
-        self.n_unknowns_local = sum(lv.n * lv.plane for e in self.entries if "levels" in e for lv in e["levels"]) + sum(
+        self.n_unknowns_local = sum(lv.n * lv.plane for e in self.entries if "levels" in e for lv in e["levels"]
+                                    if not lv.replicated) + sum(
             math.prod(s) for e in self.entries if "shapes" in e for s in e["shapes"])
         self.local_cells = math.prod(domain.cshape) // world
         self.global_cells = math.prod(domain.cshape)
@@ -320,7 +343,12 @@ class SlabTracedAdam:
             coarse = e["x"][L - 1]
             for l in range(L - 2, -1, -1):
                 out = self.u[key] if l == 0 else self.work[key][l]
-                hip_ops.interp_add(e["levels"][l + 1].inner(coarse).contiguous(), e["loc"], add=e["x"][l], out=out)
+                fine, lvc = e["levels"][l], e["levels"][l + 1]
+                if lvc.replicated and not fine.replicated:  # this rank's window of the replicated coarse field
+                    operand = coarse.narrow(self.axis, *lvc.window_of(fine))
+                else:
+                    operand = lvc.inner(coarse)
+                hip_ops.interp_add(operand.contiguous(), e["loc"], add=e["x"][l], out=out)
                 coarse = out
 
     def _end_planes(self, arrays, side):
@@ -345,8 +373,13 @@ class SlabTracedAdam:
         for key in self.kern.gather_keys:
             e = self.by_key[key]
             for l in range(1, len(e["levels"])):
-                lv = e["levels"][l]
-                dst = lv.inner(e["g"][l])
+                lv, fine = e["levels"][l], e["levels"][l - 1]
+                if lv.replicated and not fine.replicated:
+                    # this rank's share of the replicated level: zero but for the window its planes reach
+                    e["g"][l].zero_()
+                    dst = e["g"][l].narrow(self.axis, *lv.window_of(fine))
+                else:
+                    dst = lv.inner(e["g"][l])
                 dst.copy_(hip_ops.interp_adj(e["g"][l - 1], e["loc"], tuple(dst.shape)))
 
     # ---- one epoch -------------------------------------------------------------------------------------
@@ -421,6 +454,12 @@ class SlabTracedAdam:
             self.g.index_add_(0, self._own["lo"], recv_lo)
         if recv_hi is not None:
             self.g.index_add_(0, self._own["hi"], recv_hi)
+        if self._rep and world > 1:  # agglomerated levels: the ranks' shares summed (every rank then updates alike)
+            total = yield ("sum", torch.cat([self.g[a:a + c] for a, c in self._rep]), None)
+            off = 0
+            for a, c in self._rep:
+                self.g[a:a + c].copy_(total[off:off + c])
+                off += c
         toc(b)
         if self.has_params:
             total = yield ("sum", self.kern.pgrad.clone(), None)

@@ -122,7 +122,7 @@ def test_bench_single_gpu_json_contract():
 
 
 # ---- traced operators (odil_amd/slab_traced.py): ranks emulated on one GPU == the undivided HIP path ------------
-def _traced_problem(which, world, dtype_flag):
+def _traced_problem(which, world, dtype_flag, nx_rank=16):
     import os
     import sys
 
@@ -133,7 +133,7 @@ def _traced_problem(which, world, dtype_flag):
         sys.path.insert(0, os.path.join(root, "examples", sub))
     ex = __import__(which)
     odil.util.set_log_file(open(os.devnull, "w"))
-    nx = 16 * world
+    nx = nx_rank * world
     if which == "veltracer":
         argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32"]
     elif which == "veltracer3d":
@@ -149,20 +149,23 @@ def _traced_problem(which, world, dtype_flag):
     return problem, state
 
 
-@pytest.mark.parametrize("which,world,double", [("veltracer", 2, 1), ("veltracer", 3, 1), ("veltracer3d", 2, 1),
-                                                ("heat2d", 2, 1), ("veltracer", 4, 0)])
-def test_slab_traced_emulated_ranks_equal_single_gpu(which, world, double):
+@pytest.mark.parametrize("which,world,double,nx_rank", [("veltracer", 2, 1, 16), ("veltracer", 3, 1, 16),
+                                                        ("veltracer3d", 2, 1, 16), ("heat2d", 2, 1, 16),
+                                                        ("veltracer", 4, 0, 16), ("veltracer", 4, 1, 8),
+                                                        ("veltracer3d", 4, 1, 4)])
+def test_slab_traced_emulated_ranks_equal_single_gpu(which, world, double, nx_rank):
     """The slab-decomposed Adam loop of a traced operator -- generated kernels in slab mode (global indices,
     ghost-extended sources, periodic wrap planes, ghost-writing gathers), exchange-free P^T chain, deferred
     halo-add, summed parameter gradients of the pointwise network -- against the single-GPU traced path of the
-    same problem: loss and every level array after 3 epochs."""
+    same problem: loss and every level array after 3 epochs.  nx_rank = 8, 4: the coarsest of the four / three
+    levels leave a rank 1 (0.5) cells of x and are agglomerated (whole arrays, gradient shares all-reduced)."""
     import argparse
 
     import odil_amd as odil
     from odil_amd.slab import run_lockstep
     from odil_amd.slab_traced import SlabTracedAdam
 
-    problem, state = _traced_problem(which, world, double)
+    problem, state = _traced_problem(which, world, double, nx_rank)
     lr, epochs = 0.01, 3
     # heat2d's fields are cell-centred in t too; x is the axis the workloads shard
     ranks = [SlabTracedAdam(problem, state, r, world, axis=1, lr=lr) for r in range(world)]
