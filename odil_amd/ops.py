@@ -144,6 +144,16 @@ def _two_step_adjoint(gu, shapes, loc, nontrivial):
             and gu.numel() * gu.element_size() >= (64 << 20) and all(s % 2 == 0 for s in gu.shape[1:]))
 
 
+def interp_adj_best(gfine, loc, cshape, out=None):
+    """P^T of ONE level through the fastest route for the layout: large 'nccc' arrays as space part ('.ccc', batched
+    march kernel) then time part ('n...'), as mg_synth_adj does for its first level; interp_adj otherwise."""
+    cshape = tuple(int(s) for s in cshape)
+    if _two_step_adjoint(gfine, [tuple(gfine.shape), cshape], loc, False):
+        space = interp_adj(gfine, "." + loc[1:], (gfine.shape[0],) + cshape[1:])
+        return interp_adj(space, "n...", cshape, out=out)
+    return interp_adj(gfine, loc, cshape, out=out)
+
+
 def mg_synth_adj(gu, shapes, loc, factors=None, grads=None):
     """[f_l (P^T)^l gu]  (cotangent of mg_synth)."""
     nlvl = len(shapes)

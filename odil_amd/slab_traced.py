@@ -380,7 +380,8 @@ class SlabTracedAdam:
                     dst = e["g"][l].narrow(self.axis, *lv.window_of(fine))
                 else:
                     dst = lv.inner(e["g"][l])
-                dst.copy_(hip_ops.interp_adj(e["g"][l - 1], e["loc"], tuple(dst.shape)))
+                best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
+                dst.copy_(best(e["g"][l - 1], e["loc"], tuple(dst.shape)))
 
     # ---- one epoch -------------------------------------------------------------------------------------
     def epoch_gen(self, timers=None):

@@ -969,9 +969,11 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
     slot = self.src_keys.index(key)
     per = [fshape[d] for d in range(self.ndim)]
     S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g) {{'.format(gi))
-    S.append("  const long l = (long)blockIdx.x * NB + threadIdx.x;")
     tot_per = int(np.prod([fshape[d] for d in range(self.ndim) if d != ax]))
-    S.append("  if (l >= (long){} * {}) return;".format(tot_per, nloc + 4))
+    # 32-bit index arithmetic whenever the thread space fits (divisions by constants: a 64-bit one costs ~4x)
+    it = "int" if tot_per * (nloc + 4) < 2**31 - 512 else "long"
+    S.append("  const {0} l = ({0})blockIdx.x * NB + threadIdx.x;".format(it))
+    S.append("  if (l >= ({}){} * {}) return;".format(it, tot_per, nloc + 4))
     rem = "l"
     for d in reversed(range(self.ndim)):
         ext = (nloc + 4) if d == ax else per[d]
@@ -979,10 +981,11 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
             S.append("  const int j0 = (int){};".format(rem))
         else:
             S.append("  const int j{} = (int)({} % {});".format(d, rem, ext))
-            S.append("  const long q{} = {} / {};".format(d, rem, ext))
+            S.append("  const {} q{} = {} / {};".format(it, d, rem, ext))
             rem = "q{}".format(d)
     S.append("  const int jo = j{} - 2;".format(ax))  # owned-relative position on the sharded axis
     S.append("  T acc = (T)0;")
+    loads = []
     for entry, (cslot, attr, coeff) in enumerate(reads):
         _, shift, loc, _ = attr
         idx, valid = [], []
@@ -993,10 +996,12 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
             if s_ > ext // 2:
                 s_ -= ext
             if d == ax:
+                # the load is UNCONDITIONAL on a clamped position and masked afterwards: loads behind per-entry
+                # branches are issued one at a time (each waits for the previous one's branch)
                 name = "c{}".format(entry)
                 S.append("  const int {} = jo - ({});".format(name, s_))
                 valid.append("{0} >= 0 && {0} < {1}".format(name, nloc))
-                idx.append(name)
+                idx.append("min(max({}, 0), {})".format(name, nloc - 1))
                 continue
             pos = "j{}".format(d) if not (floc[d] == "c" and loc[d] == "n") else "(j{} + 1)".format(d)
             e = pos if s_ == 0 else "wrap({} - ({}), {})".format(pos, s_, ext)
@@ -1004,13 +1009,13 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
                 name = "t{}_{}".format(entry, d)
                 S.append("  const int {} = {};".format(name, e))
                 valid.append("{} < {}".format(name, nr))
-                e = name
+                e = "min({}, {})".format(name, nr - 1)  # (the masked load stays inside the array)
             idx.append(e)
-        load = "a.cot[{}][{}]".format(cslot, self._offset(idx, self.GL))
-        if coeff is not None:
-            load = "({}) * {}".format(coeff, load)
-        load = "(({}) ? {} : (T)0)".format(" && ".join(valid), load)
-        S.append("  acc = acc + {};".format(load))
+        S.append("  const T w{} = a.cot[{}][{}];".format(entry, cslot, self._offset(idx, self.GL)))
+        loads.append((entry, coeff, " && ".join(valid)))
+    for entry, coeff, valid in loads:  # every load above is in flight before the first use
+        term = "w{}".format(entry) if coeff is None else "({}) * w{}".format(coeff, entry)
+        S.append("  acc = acc + (({}) ? {} : (T)0);".format(valid, term))
 
     def offset(along, extent):
         full = [along if d == ax else "j{}".format(d) for d in range(self.ndim)]
