@@ -75,7 +75,10 @@ def cpu_baseline(ndim, n_one, n_all, budget_s):
 
     v1, o1 = leg(1, n_one, budget_s)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    vall, oall = leg(cores, n_all, budget_s)  # ~0.3 GB per 128^3 worker
+    # ~0.3 GB per 128^3 worker: at most 64 of them (19 GB) whatever the host offers -- the oracle is memory-bound
+    # NumPy, its aggregate rate is flat well before that (61 M updates/s on 256 cores, 9 x one core)
+    cores = min(cores, 64)
+    vall, oall = leg(cores, n_all, budget_s)
     return {
         "value": v1,
         "unit": "grid-point-updates/s",

@@ -131,10 +131,16 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for sub in ("heat", "velocity_from_tracer"):
         sys.path.insert(0, os.path.join(root, "examples", sub))
+    for sub in ("wave", "infer_constant"):
+        sys.path.insert(0, os.path.join(root, "examples", sub))
     ex = __import__(which)
     odil.util.set_log_file(open(os.devnull, "w"))
     nx = nx_rank * world
-    if which == "veltracer":
+    if which == "wave":  # plain Field unknown (no multigrid decomposition), walls masked on the GLOBAL x index
+        argv = ["--Nt", "16", "--Nx", str(nx), "--multigrid", "0"]
+    elif which == "infer_constant":  # an Array unknown inside the stencil: its gradient is summed over the ranks
+        argv = ["--Nt", "16", "--Nx", str(nx)]
+    elif which == "veltracer":
         argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32"]
     elif which == "veltracer3d":
         argv = ["--Nt", "8", "--Nx", str(nx), "--Ny", "16", "--Nz", "24"]
@@ -152,7 +158,8 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
 @pytest.mark.parametrize("which,world,double,nx_rank", [("veltracer", 2, 1, 16), ("veltracer", 3, 1, 16),
                                                         ("veltracer3d", 2, 1, 16), ("heat2d", 2, 1, 16),
                                                         ("veltracer", 4, 0, 16), ("veltracer", 4, 1, 8),
-                                                        ("veltracer3d", 4, 1, 4)])
+                                                        ("veltracer3d", 4, 1, 4), ("wave", 2, 1, 16),
+                                                        ("infer_constant", 2, 1, 16)])
 def test_slab_traced_emulated_ranks_equal_single_gpu(which, world, double, nx_rank):
     """The slab-decomposed Adam loop of a traced operator -- generated kernels in slab mode (global indices,
     ghost-extended sources, periodic wrap planes, ghost-writing gathers), exchange-free P^T chain, deferred
