@@ -45,6 +45,19 @@ __device__ inline T block_sum(T v, T* sm) {
   return r;
 }
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
+// Adam of the array a gather forms the gradient of, applied by the lane that holds g[l] (reference
+// src/odil/optimizer.py:316-318; x == NULL: gradient only).  alpha_dev != NULL: the step size is read from
+// device memory (epochs replayed as a hipGraph).
+struct AdamP { T* x; T* m; T* v; T alpha, omb1, omb2, eps; const T* alpha_dev; };
+__device__ inline void adam_apply(const AdamP& ad, int l, T g) {
+  if (!ad.x) return;
+  T m = ad.m[l], v = ad.v[l], x = ad.x[l];
+  m = m + (g - m) * ad.omb1;
+  v = v + (g * g - v) * ad.omb2;
+  const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
+  x = x - (m * alpha) / (FN(sqrt)(v) + ad.eps);
+  ad.m[l] = m, ad.v[l] = v, ad.x[l] = x;
+}
 // Float transcendentals of the float kernels.  The library tanhf is ~30 instructions with two divergent branches;
 // a traced operator with a pointwise network evaluates it 40 times per grid point (heat with two space dimensions:
 // 1660 VALU instructions per point, 1200 of them tanh -- profiles/r02_v0_heat2d_pmc.txt).  Here tanh(x) =
@@ -898,7 +911,7 @@ class _Codegen:
                 self._gather_slab(S, gi, key, reads, floc, fshape)
                 continue
             tot = int(np.prod(fshape))
-            S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g) {{'.format(gi))
+            S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
             S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
             S.append("  if (l >= {}) return;".format(tot))
             rem = "l"
@@ -934,6 +947,7 @@ class _Codegen:
                     load = "(({}) ? {} : (T)0)".format(" && ".join(valid), load)
                 S.append("  acc = acc + {};".format(load))
             S.append("  g[l] = acc;")
+            S.append("  adam_apply(ad, l, acc);")
             S.append("}")
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
@@ -942,7 +956,14 @@ class _Codegen:
         S.append("  hipLaunchKernelGGL(k_loss, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
+        S.append('extern "C" int jit_gather_adam(int which, const Args* a, void* g, void* x, void* m, void* v, double alpha,')
+        S.append('                                double omb1, double omb2, double eps, const void* alpha_dev, void* stream);')
         S.append('extern "C" int jit_gather(int which, const Args* a, void* g, void* stream) {')
+        S.append("  return jit_gather_adam(which, a, g, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr, stream);")
+        S.append("}")
+        S.append('extern "C" int jit_gather_adam(int which, const Args* a, void* g, void* x, void* m, void* v, double alpha,')
+        S.append('                                double omb1, double omb2, double eps, const void* alpha_dev, void* stream) {')
+        S.append("  const AdamP ad = {(T*)x, (T*)m, (T*)v, (T)alpha, (T)omb1, (T)omb2, (T)eps, (const T*)alpha_dev};")
         S.append("  switch (which) {")
         for gi, key in enumerate(self.gathers):
             tot = int(np.prod(self._field_shape(key)))
@@ -950,7 +971,7 @@ class _Codegen:
             if self.slab is not None:  # planes -GH .. n + GH of the sharded axis, GH = 2 (slab_traced.G)
                 per = tot // self._field_shape(key)[self.slab[0]]
                 nblk = "(unsigned)(((long){} * ({} + 4) + 255) / 256)".format(per, self.slab[1])
-            S.append("    case {}: hipLaunchKernelGGL(k_gat_{}, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, (T*)g); break;".format(
+            S.append("    case {}: hipLaunchKernelGGL(k_gat_{}, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, (T*)g, ad); break;".format(
                 gi, gi, nblk))
         S.append("    default: return -1;")
         S.append("  }")
@@ -968,7 +989,7 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
     ax, nloc = self.slab
     slot = self.src_keys.index(key)
     per = [fshape[d] for d in range(self.ndim)]
-    S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g) {{'.format(gi))
+    S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP) {{'.format(gi))
     tot_per = int(np.prod([fshape[d] for d in range(self.ndim) if d != ax]))
     # 32-bit index arithmetic whenever the thread space fits (divisions by constants: a 64-bit one costs ~4x)
     it = "int" if tot_per * (nloc + 4) < 2**31 - 512 else "long"

@@ -135,6 +135,8 @@ class TracedOperator:
         self._hs_rows = None  # graph replay: (pinned table, device table, device row, device row index)
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.jit_gather_adam.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 4 + [
+            ctypes.c_void_p, ctypes.c_void_p]
         # structure of the state: which arrays belong to which field
         self.layout = []
         pos = 0
@@ -316,7 +318,34 @@ class TracedOperator:
             raise RuntimeError("traced operator launch failed: hip error {}".format(rc))
         return keep
 
-    def eval_loss_grad(self, state):
+    def eval_loss_grad_adam(self, state, m, v, alpha, omb1, omb2, eps):
+        """eval_loss_grad with the Adam update (reference optimizer.py:316-318) of the leading grid fields applied
+        inside the generated gather for the finest level (the lane that sums g[l] owns x[l], m[l], v[l]: the
+        optimizer's pass over 2^d / (2^d - 1) of the unknowns and its re-read of that gradient disappear); the
+        coarser levels are updated right after their transposes.  m, v: the optimizer's moment arrays in
+        `arrays_from_state` order.  Returns (..., done) with `done` = how many leading arrays were updated (fields
+        that follow a network / Array in the state are left to the optimizer), or None when nothing can fuse."""
+        cg = self.cg
+        done, plan = 0, dict()
+        for key, kind, pos, n in self.layout:
+            fusable = (kind in ("field", "mg") and key in cg.gathers and key not in self.gtmp
+                       and int(os.environ.get("ODIL_FUSE_ADAM0", 1)))
+            if not fusable or pos != done:
+                break
+            plan[key] = (pos, n)
+            done = pos + n
+        if not plan:
+            return None
+        arrays = self.domain.arrays_from_state(state)
+        for key, (pos, n) in plan.items():
+            for k in range(pos, pos + n):
+                for t in (arrays[k], m[k], v[k]):
+                    if not t.is_contiguous() or t.dtype != self.tr.torch_dtype:
+                        return None
+        res = self.eval_loss_grad(state, adam=(plan, arrays, m, v, alpha, omb1, omb2, eps))
+        return res + (done,)
+
+    def eval_loss_grad(self, state, adam=None):
         """loss, grads (views of one packed buffer, overwritten by the next call), terms, names, norms."""
         cg = self.cg
         keep = self._launch(state)
@@ -328,9 +357,18 @@ class TracedOperator:
             if side:
                 s_.wait_stream(cur)
             with torch.cuda.stream(s_):
+                fuse = adam is not None and key in adam[0]
                 if key in cg.gathers:
                     g = self.gtmp.get(key, self.gviews[pos])
-                    rc = self.lib.jit_gather(cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), ops.stream_ptr())
+                    if fuse:
+                        _, arrays, mm, vv, alpha, omb1, omb2, eps = adam
+                        adev = alpha.data_ptr() if isinstance(alpha, torch.Tensor) else None
+                        rc = self.lib.jit_gather_adam(
+                            cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), arrays[pos].data_ptr(),
+                            mm[pos].data_ptr(), vv[pos].data_ptr(), 0.0 if adev else float(alpha), float(omb1), float(omb2),
+                            float(eps), adev, ops.stream_ptr())
+                    else:
+                        rc = self.lib.jit_gather(cg.gathers.index(key), ctypes.byref(self.args), g.data_ptr(), ops.stream_ptr())
                     if rc != 0:
                         raise RuntimeError("traced gather launch failed: hip error {}".format(rc))
                 else:
@@ -338,6 +376,14 @@ class TracedOperator:
                 if kind == "mg":
                     factors, loc, shapes = self.mg_meta[key]
                     ops.mg_synth_adj(g, shapes, loc, factors=factors, grads=self.gviews[pos:pos + n])
+                    if fuse:
+                        # the coarser levels (1 / 2^d of the unknowns and less) keep the fastest transposes (the `*_adam`
+                        # chain has no two-step route for 'nccc': 8.2 instead of 5.2 ms at 32 x 256^3) and get their
+                        # update from the plain kernel, level by level
+                        _, arrays, mm, vv, alpha, omb1, omb2, eps = adam
+                        for k in range(pos + 1, pos + n):
+                            ops.adam_step(arrays[k].view(-1), mm[k].view(-1), vv[k].view(-1), self.gviews[k].view(-1),
+                                          alpha, omb1, omb2, eps)
         for s_ in side:
             cur.wait_stream(s_)
         for key, kind, pos, n in self.layout:

@@ -357,7 +357,7 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
     def fused_adam(arrays, m, v, alpha, omb1, omb2, eps):
         """loss + gradient with the Adam update of the leading array(s) applied inside the fused
         gradient launch; None when the problem has no fused evaluator that can do it."""
-        ev = getattr(problem, "_fused", None)
+        ev = getattr(problem, "_fused", None) or getattr(problem, "_traced", None)
         if ev is None or not hasattr(ev, "eval_loss_grad_adam"):
             return None
         domain.arrays_to_state(arrays, state)
