@@ -20,10 +20,13 @@ extern "C" __global__ __launch_bounds__(256) void k(const Args a) {
 #if @SHIFTS@
       const long offs[8] = {-1, 1, -256, 256, -65536, 65536, -16777216, -16777216 + 1};
 #pragma unroll
-      for (int k = 0; k < @SHIFTS@; ++k) {
+      for (int k = 0; k < @SHIFTS@; ++k) {  // one (unaligned) vector load per shifted read
         long j = l * @VEC@ + offs[k];
-        j = j < 0 ? j + a.n : (j >= a.n ? j - a.n : j);
-        s += a.in[r][j];
+        j = j < 0 ? j + a.n : j;
+        j = j + @VEC@ > a.n ? a.n - @VEC@ : j;  // (stays inside the array)
+        V t;
+        __builtin_memcpy(&t, a.in[r] + j, sizeof(V));
+        s += t;
       }
 #endif
     }
@@ -42,9 +45,9 @@ n = 1 << 28  # 1 GB per array
 NR, NW = 4, 17
 ins = [torch.randn(n, device=dev) for _ in range(NR)]
 outs = [torch.empty(n, device=dev) for _ in range(NW)]
-for vec in (1,):
+for vec in (1, 2, 4):
     for nt in (1,):
-        for chunk, shifts in ((0, 0), (0, 4), (0, 6), (0, 7), (0, 8), (8, 8)):
+        for chunk, shifts in ((0, 0), (0, 8)):
             nblocks = 65536 if chunk == 0 else (n // 256 + chunk - 1) // chunk
             src = SRC.replace("@VEC@", str(vec)).replace("@NR@", str(NR)).replace("@NW@", str(NW)).replace("@NT@", str(nt)).replace("@CHUNK@", str(chunk)).replace("@SHIFTS@", str(shifts))
             lib, _ = _compile(src)
@@ -62,4 +65,4 @@ for vec in (1,):
             for _ in range(3): lib.run(ctypes.byref(a), s)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 3
-            print("chunk %d shifted reads %d per input: %.3f ms  %.2f TB/s (on %d + %d words)" % (chunk, shifts, ms, (NR + NW) * n * 4 / ms / 1e9, NR, NW))
+            print("vec %d, %d shifted reads per input: %.3f ms  %.2f TB/s (on %d + %d words)" % (vec, shifts, ms, (NR + NW) * n * 4 / ms / 1e9, NR, NW))
