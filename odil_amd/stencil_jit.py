@@ -327,9 +327,10 @@ class TracedOperator:
         that follow a network / Array in the state are left to the optimizer), or None when nothing can fuse."""
         cg = self.cg
         done, plan = 0, dict()
-        # launch-bound grids are better off with ONE optimizer launch over the packed vector (heat 256 x 512: 0.19 ms
-        # per epoch against 0.22 fused); the fusion pays where the update is a pass over HBM
-        if self.total < (1 << 22) and not int(os.environ.get("ODIL_FUSE_ADAM_SMALL", 0)):
+        # small and medium grids are better off with ONE optimizer launch over the packed vector (heat 256 x 512: 0.19
+        # ms per epoch against 0.22 fused; tracer 128 x 256^2, three fields on side streams: 0.66 against 0.71); the
+        # fusion pays where the update is a long pass over HBM (heat 256 x 512^2: 3.63 -> 3.52, tracer 32 x 256^3: -12 %)
+        if self.total < (1 << 25) and not int(os.environ.get("ODIL_FUSE_ADAM_SMALL", 0)):
             return None
         for key, kind, pos, n in self.layout:
             fusable = (kind in ("field", "mg") and key in cg.gathers and key not in self.gtmp
