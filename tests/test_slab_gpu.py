@@ -227,3 +227,30 @@ def test_slab_ranks_dump_their_device_fields_into_one_raw_file(tmp_path):
     odil.write_raw_with_xmf(ranks[0].owned_levels()[0], single, spacing=(1.0 / N,) * 3)
     back, _ = odil.read_raw_with_xmf(single)
     assert np.array_equal(back, ranks[0].owned_levels()[0].cpu().numpy())
+
+
+def test_bench_config5_two_ranks_over_torch_distributed(tmp_path):
+    """BASELINE's slab-decomposed tracer workload through `python bench.py --config 5 --gpus 2` (ranks started by
+    bench.py itself, gloo so that both can share this box's one GPU; grids scaled down): the JSON line of the
+    driver's contract, and the loss of the two-rank run equals the one-rank run of the same global problem."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ODIL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--gpus", "2", "--scale", "0.25",
+                          "--steps", "3", "--warmup", "1", "--no_cpu_baseline"], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["decomposition"] == "slab x2" and d["config"]["rccl_ranks"] == 2
+    assert d["dtype"] == "f32" and d["unit"] == "grid-point-updates/s" and d["scaling"] == "weak"
+    assert "velocity_from_tracer" in d["config"]["workload"] and d["config"]["fields"] == 4
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel"].startswith("k_fwd")
+    assert d["value"] > 0 and np.isfinite(d["loss_after"])
+    cells = d["config"]["cells_per_gpu"]
+    assert abs(d["value"] - 2 * cells * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
