@@ -50,18 +50,26 @@ def make_kernels(local_extra):
 
             self.problem, self.axis, self.n = problem, axis, n
             self.geom = og.Geometry.of(problem.domain)
+            from odil_amd.core import Array, NeuralNet
+
             self.locs = {k: f.loc for k, f in state.fields.items() if isinstance(f, (Field, MultigridField))}
             self.src_keys = list(self.locs)
             self.gather_keys = list(self.locs)
-            self.param_groups = dict()
-            self.pgrad = torch.zeros(1, dtype=torch.float64)
+            # replicated unknowns (networks, Arrays): their gradients are partial sums over the rank's cells
+            self.param_fields = {k: f for k, f in state.fields.items() if isinstance(f, (NeuralNet, Array))}
+            self.param_groups, ofs = dict(), 0
+            for k, f in self.param_fields.items():
+                lens = [int(a.numel()) for a in problem.domain.arrays_from_field(f)]
+                self.param_groups[k] = (ofs, lens)
+                ofs += sum(lens)
+            self.pgrad = torch.zeros(max(1, ofs), dtype=torch.float64)
             self.world = problem.domain.cshape[axis] // n
 
         def set_geometry(self, off, lo, ea):
             self.off, self.lo, self.ea = off, lo, ea
 
         def set_params(self, fn):
-            pass
+            self.param_arrays = fn  # key -> this rank's (replicated) parameter arrays
 
         def forward(self, srcs, wlo, whi):
             a, n, lo = self.axis, self.n, self.lo
@@ -71,13 +79,28 @@ def make_kernels(local_extra):
                 left = u.narrow(a, lo - 1, 1) if lo > 0 else wlo[key]
                 right = u.narrow(a, lo + n, 1) if lo + n < u.shape[a] else whi[key]
                 self.leaves[key] = torch.cat([left, u.narrow(a, lo, n), right], dim=a).detach().clone().requires_grad_(True)
+            from odil_amd.core import NeuralNet
+
             extra = local_extra(self.problem.extra, self.off, n)
-            ctx = _SlabContext(self.geom, self.leaves, self.locs, dict(), extra, self.problem.tracers, a, self.off, n)
+            params, pleaves = dict(), []
+            for k, f in self.param_fields.items():
+                arrs = [t.detach().clone().requires_grad_(True) for t in self.param_arrays(k)]
+                pleaves += arrs
+                if isinstance(f, NeuralNet):
+                    nw = len(f.weights)
+                    params[k] = ("net", arrs[:nw], arrs[nw:], f.activation, f.func_in, f.func_out)
+                else:
+                    params[k] = ("array", arrs[0])
+            ctx = _SlabContext(self.geom, self.leaves, self.locs, params, extra, self.problem.tracers, a, self.off, n)
             names, values = og.split_outputs(self.problem.operator(ctx))
             # mean over the GLOBAL output: local sum / (local count * ranks) (windows of these operators are in t)
             self.terms = [(v * v).sum() / (v.numel() * self.world) for v in values]
-            grads = torch.autograd.grad(sum(self.terms), [self.leaves[k] for k in self.src_keys], allow_unused=True)
-            self.grads = {k: (torch.zeros_like(self.leaves[k]) if g is None else g) for k, g in zip(self.src_keys, grads)}
+            leaves = [self.leaves[k] for k in self.src_keys] + pleaves
+            grads = torch.autograd.grad(sum(self.terms), leaves, allow_unused=True)
+            grads = [torch.zeros_like(t) if g is None else g for g, t in zip(grads, leaves)]
+            self.grads = dict(zip(self.src_keys, grads))
+            if pleaves:
+                self.pgrad = torch.cat([g.reshape(-1) for g in grads[len(self.src_keys):]])
 
         def gather(self, key, g, gwlo, gwhi):
             a, n, lo = self.axis, self.n, self.lo

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "examples", "velocity_from_tracer"))
+sys.path.insert(0, os.path.join(ROOT, "examples", "heat"))
 
 
 def make_problem(which, world, nx_rank=8):
@@ -30,6 +31,11 @@ def make_problem(which, world, nx_rank=8):
     ex = __import__(which)
     nx = nx_rank * world
     argv = ["--Nt", "8", "--Nx", str(nx), "--Ny", "8", "--double", "1"] + (["--Nz", "8"] if which == "veltracer3d" else [])
+    if which == "heat2d":
+        # (keep_init 0: with it the operator rolls the constant initial row along x, which the CPU double's per-rank
+        # slices of the constants cannot express -- the generated kernel indexes the GLOBAL constants and is checked
+        # with keep_init 1 by the emulated ranks of tests/test_slab_gpu.py)
+        argv += ["--infer_k", "1", "--imposed", "stripe", "--keep_init", "0"]
     args = ex.parse_args(argv)
     problem, state = ex.make_problem(args)
     rng = np.random.default_rng(7)
@@ -39,7 +45,11 @@ def make_problem(which, world, nx_rank=8):
 
 
 def local_extra(extra, off, n):
-    """u_init / u_final are (x, y[, z]) arrays: the rank's x range."""
+    """The rank's x range of the operator's constant arrays: u_init / u_final are (x, y[, z]) arrays; heat2d's
+    init_u is (x, y), its imposed values and mask (t, x, y) (imp_size, a global count, stays)."""
+    if hasattr(extra, "imp_mask"):
+        return argparse.Namespace(args=extra.args, init_u=extra.init_u[off:off + n], imp_size=extra.imp_size,
+                                  imp_mask=extra.imp_mask[:, off:off + n], imp_u=extra.imp_u[:, off:off + n])
     return argparse.Namespace(args=extra.args, u_init=extra.u_init[off:off + n], u_final=extra.u_final[off:off + n])
 
 
@@ -56,9 +66,8 @@ def worker(rank, world, which, epochs, port, out, nx_rank=8):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         problem, state = make_problem(which, world, nx_rank)
-        run = slab_traced.SlabTracedAdam(problem, state, rank, world, lr=0.01, device=torch.device("cpu"),
+        run = slab_traced.SlabTracedAdam(problem, state, rank, world, axis=1, lr=0.01, device=torch.device("cpu"),
                                          kernels=slab_traced_double.make_kernels(local_extra))
-        assert run.axis == 1
         comm = TorchDistComm(rank, world)
         losses = []
         for _ in range(epochs):
@@ -78,14 +87,32 @@ def undivided(which, world, epochs, nx_rank=8):
     domain = problem.domain
     geom = og.Geometry.of(domain)
     fields = og.fields_of_state(domain, state)
-    keys = list(fields)
-    nlvl = len(fields[keys[0]]["terms"])
-    x0 = [t for k in keys for t in fields[k]["terms"]]
+    def get(fields):  # arrays in `Domain.arrays_from_state` order
+        out = []
+        for f in fields.values():
+            out += list(f["terms"]) if f["kind"] == "mg" else (
+                [f["array"]] if f["kind"] in ("field", "array") else list(f["weights"]) + list(f["biases"]))
+        return out
+
+    def put(fields, x):
+        k = 0
+        for f in fields.values():
+            if f["kind"] == "mg":
+                f["terms"] = x[k:k + len(f["terms"])]
+                k += len(f["terms"])
+            elif f["kind"] in ("field", "array"):
+                f["array"] = x[k]
+                k += 1
+            else:
+                nw, nb = len(f["weights"]), len(f["biases"])
+                f["weights"], f["biases"] = x[k:k + nw], x[k + nw:k + nw + nb]
+                k += nw + nb
+
+    x0 = get(fields)
 
     def loss_grad(x):
-        for i, k in enumerate(keys):
-            fields[k]["terms"] = x[i * nlvl:(i + 1) * nlvl]
-        loss, grads = og.eval_loss_grad(problem.operator, geom, fields, problem.extra)[:2]
+        put(fields, x)
+        loss, grads = og.eval_loss_grad(problem.operator, geom, fields, problem.extra, tracers=problem.tracers)[:2]
         return loss, grads
 
     x, losses = onp.adam_run(x0, loss_grad, epochs, 0.01)
@@ -93,10 +120,11 @@ def undivided(which, world, epochs, nx_rank=8):
 
 
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 8), ("veltracer", 3, 8), ("veltracer3d", 2, 8),
-                                                  ("veltracer", 4, 2), ("veltracer", 2, 4)])
+                                                  ("veltracer", 4, 2), ("veltracer", 2, 4), ("heat2d", 2, 8)])
 def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world, nx_rank):
     """nx_rank = 2, 4: the three multigrid levels (8 cells of t) leave 2, 1, 0.5 / 4, 2, 1 cells of x per rank: the
-    coarsest levels are AGGLOMERATED (whole array on every rank, gradient shares summed by an all-reduce)."""
+    coarsest levels are AGGLOMERATED (whole array on every rank, gradient shares summed by an all-reduce).  heat2d:
+    a pointwise network inside the stencil -- its parameters are replicated, their gradients summed over the ranks."""
     epochs = 3
     port = 29500 + (os.getpid() * 7 + world * 13 + nx_rank + len(which)) % 2000
     mp.spawn(worker, args=(world, which, epochs, port, str(tmp_path), nx_rank), nprocs=world, join=True)
@@ -105,9 +133,12 @@ def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world, nx_ran
     for r in range(world):
         assert np.max(np.abs(np.array(results[r]["losses"]) - np.array(losses_ref)) / np.array(losses_ref)) < 1e-12
     for i, ref in enumerate(x_ref):
-        n = ref.shape[1] // world
         for r in range(world):
             got = results[r]["owned"][i]
-            want = ref if got.shape == ref.shape else ref[:, r * n:(r + 1) * n]  # agglomerated levels are whole
+            if got.shape == ref.shape:  # agglomerated levels and parameter arrays are whole on every rank
+                want = ref
+            else:
+                n = ref.shape[1] // world
+                want = ref[:, r * n:(r + 1) * n]
             assert got.shape == want.shape
             assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.max(np.abs(want))), (i, r)
