@@ -109,13 +109,24 @@ def measured_traffic(kernel, ndim, N, dtype):
     return None, None
 
 
-class Timers:
-    """HIP-event pairs per kernel family, recorded on the stream the kernels run on."""
+class _NoEvent:
+    def record(self):
+        pass
 
-    def __init__(self):
-        self.pairs = {}
+
+class Timers:
+    """HIP-event pairs per kernel family, recorded on the stream the kernels run on.  `only`: the sections that are
+    really timed (the others get no events).  Every recorded event is a barrier packet between two launches: with all
+    sections of the epoch bracketed, the 512^3 epoch measured 3.21 instead of 2.83 ms (tools/host_enqueue.py), so
+    the TIMED region brackets the dominant launch only and the other sections are measured in a few extra epochs
+    after it."""
+
+    def __init__(self, only=None):
+        self.pairs, self.only = {}, only
 
     def section(self, name):
+        if self.only is not None and name not in self.only:
+            return _NoEvent(), _NoEvent()
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         self.pairs.setdefault(name, []).append((a, b))
@@ -183,15 +194,20 @@ def run_poisson(args, rank, world, dev, comm, barrier):
     for _ in range(args.warmup):
         step()
     barrier()
-    timers = Timers()
+    timers = Timers(only=("adjoint_transpose", "adjoint", "adam"))  # the candidates for the dominant launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timers)
     barrier()
     elapsed = time.perf_counter() - t0
     loss = run.last_loss(comm) if world > 1 else run.last_loss()
+    every = Timers()  # the other sections: a few epochs outside the timed region
+    for _ in range(5):
+        step(every)
+    barrier()
     wordsize = 8 if dtype == torch.float64 else 4
-    kt = timers.summary()
+    kt = every.summary()
+    kt.update(timers.summary())
     tname = "double" if wordsize == 8 else "float"
     if "adjoint_transpose" in kt:
         # Dominant kernel: stencil adjoint + first transposed prolongation + the Adam updates of levels 0 and
@@ -256,14 +272,19 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     for _ in range(args.warmup):
         run.epoch(comm)
     barrier()
-    timers = Timers()
+    timers = Timers(only=("forward",))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.epoch(comm, timers)
     barrier()
     elapsed = time.perf_counter() - t0
     loss = run.last_loss(comm)
-    kt = timers.summary()
+    every = Timers()
+    for _ in range(2):
+        run.epoch(comm, every)
+    barrier()
+    kt = every.summary()
+    kt.update(timers.summary())
     nsrc, ncot = len(run.kern.src_keys), len(run.kern.cot)
     moved = float(nsrc + ncot) * run.local_cells * 4  # reads each field once (neighbours are cache hits), writes the cotangents
     return dict(
