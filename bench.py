@@ -168,15 +168,6 @@ def roofline(kernel, model_bytes, moved_bytes, ms, traffic, traffic_source):
     }
 
 
-class LocalComm:
-    """The exchanges of a slab epoch when there is one rank: the periodic closure is the rank itself."""
-
-    def exchange(self, kind, a, b):
-        if kind == "sum":
-            return a
-        return (b, a) if kind == "wrap" else (None, None)
-
-
 def run_poisson(args, rank, world, dev, comm, barrier):
     from odil_amd.poisson_path import PoissonMultigridAdam
     from odil_amd.slab import SlabPoissonAdam
@@ -325,6 +316,8 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # child processes: started before this process initialises the GPU
         cpu = cpu_baseline(args.ndim if args.config == "4a" else 3, args.cpu_N, args.cpu_N_all, args.cpu_budget)
+    from odil_amd.slab import LocalComm
+
     comm = LocalComm()
     dist = None
     if world > 1:

@@ -101,6 +101,7 @@ def parse_args(argv=None):
     parser.add_argument("--kxreg", type=float, default=0.01, help="Laplacian regularization weight")
     parser.add_argument("--ktreg", type=float, default=1, help="Time regularization weight")
     parser.add_argument("--kimp", type=float, default=10, help="Imposed values weight")
+    parser.add_argument("--slab", type=int, default=0, help="Slab decomposition along x over the ranks of torch.distributed")
     odil.util.add_arguments(parser)
     odil.linsolver.add_arguments(parser)
     parser.set_defaults(outdir="out_veltracer3d", frames=5, plot_every=100, report_every=100, history_every=10,
@@ -114,6 +115,27 @@ def parse_args(argv=None):
 
 def main():
     args = parse_args()
+    if args.slab:
+        # one process per GPU (python -m torch.distributed.run --nproc-per-node N veltracer3d.py --slab 1 ...): every
+        # rank builds the global problem, owns a slab of x, logs through rank 0, and all ranks write their part of the
+        # final tracer field into one raw + XDMF2 file
+        from odil_amd.slab import init_distributed
+        from odil_amd.slab_traced import optimize_slab
+
+        rank, world, _ = init_distributed()
+        outdir = os.path.abspath(args.outdir)
+        if rank == 0:
+            odil.setup_outdir(args)
+        else:
+            os.makedirs(outdir, exist_ok=True)
+            odil.util.set_log_file(open(os.devnull, "w"))
+            args.epochs = args.epochs or args.frames * args.plot_every
+        problem, state = make_problem(args)
+        run = optimize_slab(args, problem, state)
+        u_last = run.owned_arrays()[0][-1]  # finest level of u at the final time: this rank's (x, y, z) planes
+        odil.write_raw_slab(u_last, os.path.join(outdir, "u_final.xmf"), rank, world, axis=0,
+                            spacing=[float(h) for h in problem.domain.step()[1:]][::-1], name="u")
+        return run
     odil.setup_outdir(args)
     problem, state = make_problem(args)
     callback = odil.make_callback(problem, args)

@@ -425,6 +425,39 @@ class TorchDistComm:
         return recv_lo, recv_hi
 
 
+class LocalComm:
+    """The exchanges of a slab epoch when there is ONE rank: the periodic closure is the rank itself."""
+
+    def exchange(self, kind, a, b):
+        if kind == "sum":
+            return a
+        return (b, a) if kind == "wrap" else (None, None)
+
+
+def init_distributed():
+    """(rank, world, comm) from the environment a launcher sets (torch.distributed.run: RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR / MASTER_PORT): one process per GPU, backend nccl (= RCCL on ROCm) unless
+    ODIL_DIST_BACKEND says otherwise; a single process gets the local closure.  A rank that cannot initialise its
+    backend raises (no silent fallback)."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    if world == 1:
+        return 0, 1, LocalComm()
+    import torch.distributed as dist
+
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        backend = os.environ.get("ODIL_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, TorchDistComm(rank, world)
+
+
 def run_lockstep(ranks, nepochs=1, timers=None):
     """Several ranks emulated in ONE process (one GPU): advances every rank's epoch generator to
     its next exchange, moves the planes by device copies, continues."""

@@ -505,6 +505,35 @@ class SlabTracedAdam:
         return res
 
 
+def optimize_slab(args, problem, state, callback=None, axis=None):
+    """`odil.util.optimize(args, "adam", ...)` for a run started with one process per GPU (e.g. `python -m
+    torch.distributed.run --nproc-per-node 8 examples/velocity_from_tracer/veltracer3d.py --slab 1`): every rank
+    builds the same GLOBAL problem, owns a slab of it (this module) and runs `args.epochs` Adam epochs; the loss
+    terms are all-reduced and logged by rank 0 every `args.report_every` epochs (the quantity the reference's
+    callback reports, src/odil/util.py:337-467).  `callback(run, epoch, terms)` is called on every rank at those
+    epochs.  Returns the rank's SlabTracedAdam (its `owned_arrays()` are the rank's part of the solution; dump
+    them with `odil.write_raw_slab`)."""
+    from .slab import init_distributed
+    from .util import printlog
+
+    rank, world, comm = init_distributed()
+    kw = {name: getattr(args, "adam_" + name) for name in ("beta_1", "beta_2", "epsilon")
+          if getattr(args, "adam_" + name, None) is not None}
+    run = SlabTracedAdam(problem, state, rank, world, axis=axis, lr=args.lr, **kw)
+    every = getattr(args, "report_every", 0) or 0
+    start = getattr(args, "epoch_start", 0)
+    for epoch in range(start + 1, args.epochs + 1):
+        run.epoch(comm)
+        if every and (epoch % every == 0 or epoch == args.epochs):
+            terms = run.last_terms(comm)  # of the evaluation at the start of this epoch
+            if rank == 0:
+                printlog("epoch={:05d} ranks={} loss={:.8g} terms={}".format(
+                    epoch, world, sum(terms), " ".join("{:.6g}".format(t) for t in terms)))
+            if callback is not None:
+                callback(run, epoch, terms)
+    return run
+
+
 def shape_state(domain, state):
     """The structure `Domain.init_state` would give for `state`, with arrays on the 'meta' device (shapes only):
     what a rank needs of the GLOBAL state when the global arrays would not fit, or need not exist."""
