@@ -268,6 +268,26 @@ def eval_neural_net(net, inputs, mod, frozen=False):
 # ======================================================================================
 # Domain (reference core.py:11-504)
 # ======================================================================================
+def _grid_or_array_field(fields, key, what):
+    """state.fields[key] if it can be read through `field()`; the reference's TypeError otherwise."""
+    found = fields[key]
+    if isinstance(found, (Field, MultigridField, Array)):
+        return found
+    raise TypeError("Expected Field or MultigridField, got type {} for {}'{}'".format(type(found).__name__, what, key))
+
+
+def _net_field(fields, key):
+    found = fields[key]
+    if isinstance(found, NeuralNet):
+        return found
+    raise TypeError("Expected NeuralNet, got type {} for key='{}'".format(type(found).__name__, key))
+
+
+def _no_shift_for_arrays(shift):
+    if len(shift):
+        raise RuntimeError("Array requires an empty shift")
+
+
 class Domain:
     def __init__(self, cshape, dimnames=None, lower=0.0, upper=1.0, dtype=None, multigrid=False,
                  mg_convert_all=True, mg_nlvl=None, mg_factors=None, mg_axes=None, mg_interp=None, mod=None):
@@ -555,34 +575,29 @@ class Domain:
 
     # ---- post-processing accessors (reference core.py:474-499) ---------------------------
     def field(self, state, key, *shift):
-        field = state.fields[key]
-        if not isinstance(field, (Field, MultigridField, Array)):
-            raise TypeError(
-                "Expected Field or MultigridField, got type {} for field '{}'".format(type(field).__name__, key)
-            )
-        if isinstance(field, Array):
-            if len(shift):
-                raise RuntimeError("Array requires an empty shift")
-            return field.array
-        shift = shift or (0,) * self.ndim
-        if len(shift) != self.ndim:
+        """The (synthesised, optionally rolled) array of a field outside any differentiation: what callbacks plot."""
+        found = _grid_or_array_field(state.fields, key, "field ")
+        if isinstance(found, Array):
+            _no_shift_for_arrays(shift)
+            return found.array
+        offsets = tuple(int(s) for s in shift) if shift else (0,) * self.ndim
+        if len(offsets) != self.ndim:
             raise RuntimeError("Expected {} shift components, got shift={}".format(self.ndim, shift))
         with torch.no_grad():
-            array = self.get_regular_array(field)
-            if any(shift):
-                array = ops.field_gather(array.contiguous(), field.loc, tuple(int(s) for s in shift), field.loc)
-        return array
+            values = self.get_regular_array(found)
+            if any(offsets):
+                values = ops.field_gather(values.contiguous(), found.loc, offsets, found.loc)
+        return values
 
     def neural_net(self, state, key):
-        net = state.fields[key]
-        if not isinstance(net, NeuralNet):
-            raise TypeError("Expected NeuralNet, got type {} for key='{}'".format(type(net).__name__, key))
+        """Callable evaluating the network `key` of the state without recording gradients."""
+        net = _net_field(state.fields, key)
 
-        def res(*inputs):
+        def evaluate(*inputs):
             with torch.no_grad():
                 return eval_neural_net(net, inputs, self.mod)
 
-        return res
+        return evaluate
 
     def get_context(self, state, extra=None, tracers=None):
         return Context(self, state, extra=extra, tracers=tracers)
@@ -624,14 +639,9 @@ class Context:
     def field(self, key, *shift, loc=None, frozen=False):
         domain = self.domain
         mod = domain.mod
-        field = self.state.fields[key]
-        if not isinstance(field, (Field, MultigridField, Array)):
-            raise TypeError(
-                "Expected Field or MultigridField, got type {} for key='{}'".format(type(field).__name__, key)
-            )
-        if isinstance(field, Array):
-            if len(shift):
-                raise RuntimeError("Array requires an empty shift")
+        field = _grid_or_array_field(self.state.fields, key, "key=")
+        if isinstance(field, Array):  # a few scalars: no stencil access, dense Jacobian columns (core.py:919-926)
+            _no_shift_for_arrays(shift)
             self.watch_func(field.array)
             self.key_to_array_jac[(key, None, None)] = field.array
             return mod.stop_gradient(field.array) if frozen else field.array
@@ -672,19 +682,14 @@ class Context:
         return array.detach().clone().requires_grad_(True)
 
     def neural_net(self, key, frozen=False):
-        domain = self.domain
-        net = self.state.fields[key]
-        if not isinstance(net, NeuralNet):
-            raise TypeError("Expected NeuralNet, got type {} for key='{}'".format(type(net).__name__, key))
-        arrays = domain.arrays_from_field(net)
-        self.watch_func(arrays)
+        """Callable applying the network `key` pointwise; its weights and biases are watched for the gradient
+        and, when the Jacobian is assembled, registered as dense columns."""
+        net = _net_field(self.state.fields, key)
+        parameters = self.domain.arrays_from_field(net)
+        self.watch_func(parameters)
         if self.distinct_shift:
-            self.key_to_array_jac[(key, None, None)] = arrays
-
-        def res(*inputs):
-            return eval_neural_net(net, inputs, self.mod, frozen=frozen)
-
-        return res
+            self.key_to_array_jac[(key, None, None)] = parameters
+        return lambda *inputs: eval_neural_net(net, inputs, self.mod, frozen=frozen)
 
 
 # ======================================================================================

@@ -22,30 +22,35 @@ import torch
 from .history import History
 from .optimizer import EarlyStopError, Optimizer, make_optimizer  # noqa: F401
 
+# Log sink of `printlog` (the reference's module-level names: examples and tests assign them, reference util.py:13-36)
 g_log_file = sys.stderr
 g_log_echo = False
 
 
 def assert_equal(first, second, msg=""):
-    if not (first == second):
-        raise ValueError("Expected equal '{:}' and '{:}'{}".format(first, second, msg))
+    """ValueError with the reference's wording when the two values differ (reference util.py:15-17)."""
+    if first == second:
+        return
+    raise ValueError("Expected equal '{:}' and '{:}'{}".format(first, second, msg))
 
 
 def set_log_file(f=None, echo=None):
+    """Redirects `printlog` to the open file `f`; `echo` also copies every line to stderr."""
     global g_log_file, g_log_echo
-    if f is not None:
-        g_log_file = f
-    if echo is not None:
-        g_log_echo = echo
+    g_log_file = g_log_file if f is None else f
+    g_log_echo = g_log_echo if echo is None else echo
 
 
 def printlog(*msg):
-    m = " ".join(map(str, msg)) + "\n"
-    if g_log_echo and g_log_file != sys.stderr:
-        sys.stderr.write(m)
-        sys.stderr.flush()
-    g_log_file.write(m)
-    g_log_file.flush()
+    """One line, space-separated like print(), to the log file (and to stderr when echoing), flushed at once so
+    that `tail -f train.log` follows a run."""
+    line = " ".join(str(part) for part in msg) + "\n"
+    sinks = [g_log_file]
+    if g_log_echo and g_log_file is not sys.stderr:
+        sinks.insert(0, sys.stderr)
+    for sink in sinks:
+        sink.write(line)
+        sink.flush()
 
 
 class LazyPinfo(dict):
@@ -333,15 +338,11 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         else:
             packed = domain.pack_state(state)
             domain.unpack_state(packed + delta, state)
-        if callback:
-            pinfo = eval_pinfo(state)
-            pinfo["linsolver"] = linstatus
-            callback(state, epoch + 1, pinfo)
-    arrays = domain.arrays_from_state(state)
-    optinfo = argparse.Namespace()
-    optinfo.epochs = args.epochs
-    optinfo.evals = args.epochs
-    return arrays, optinfo
+        if callback:  # one extra evaluation per step, for the report only (reference util.py:180)
+            report = eval_pinfo(state)
+            report["linsolver"] = linstatus
+            callback(state, epoch + 1, report)
+    return domain.arrays_from_state(state), argparse.Namespace(epochs=args.epochs, evals=args.epochs)
 
 
 def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
