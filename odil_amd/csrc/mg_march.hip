@@ -490,8 +490,11 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march(const T* __restrict
 #define ODIL_ADJ_UNITS_SMALL (kGridCap / 4)  // levels of <= 4 M coarse points: chain 0.690 -> 0.675 ms
 #endif
 #ifndef ODIL_TILE_Y
-#define ODIL_TILE_Y 16  // 16 x 16 coarse columns per workgroup: 512^3 epoch 2.74 ms, 8 x 32: 2.77
-#define ODIL_TILE_X 16
+// 8 x 32 coarse columns per workgroup (rows of 64 fine cells = 512 B per array and plane): the fused adjoint
+// kernel 1.83 -> 1.74 ms at 512^3 against 16 x 16 (tools/mb_tile_traffic.hip: the bare access pattern of the
+// 16 x 16 tile is 5 % slower too); 4 x 64 needs 86 KB of LDS, one workgroup per CU: 3.4 ms
+#define ODIL_TILE_Y 8
+#define ODIL_TILE_X 32
 #endif
 #ifndef ODIL_TILE_UNITS
 #define ODIL_TILE_UNITS (kGridCap / 2)  // 512^3 -> 256^3: 465 / 450 / 455 us for 2048 / 1024 / 512 units
@@ -577,7 +580,8 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
                                                  const typename TileVec<T, CX>::type* __restrict__ tile0,
                                                  const typename TileVec<T, CX>::type* __restrict__ tile1, int k,
                                                  bool live, T (&wc)[CX][6], T (&wr)[CX][6], const AdamArgs<T>& ad,
-                                                 const float* __restrict__ wt = nullptr) {
+                                                 const float* __restrict__ wt = nullptr,
+                                                 const T* __restrict__ cpre = nullptr) {
   typedef typename TileVec<T, CX>::type P2;
   constexpr int NV = 2 * CX;
   const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
@@ -650,7 +654,16 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
 #pragma unroll
     for (int cc = 0; cc < CX; ++cc) {
       const T v = combine_z<T>(wc[cc], wr[cc], jz, c.cnz, c.fnz, xy_special, c.cut_lo, c.cut_hi);
-      emit_coarse<T>(c.gcoarse, c.gscaled, ci + cc, v, c.scale, ad);
+      if (cpre && ad.x) {
+        // this level's x, m, v of the entry were read at the start of the step (the caller's registers): the
+        // update does not wait for a memory round trip at the end of every step
+        c.gcoarse[ci + cc] = v;
+        T xe = cpre[3 * cc], me = cpre[3 * cc + 1], ve = cpre[3 * cc + 2];
+        adam_update<T>(xe, me, ve, v, ad);
+        ad.x[ci + cc] = xe, ad.m[ci + cc] = me, ad.v[ci + cc] = ve;
+      } else {
+        emit_coarse<T>(c.gcoarse, c.gscaled, ci + cc, v, c.scale, ad);
+      }
     }
   }
   slide<T, CX>(wc, wr);
@@ -772,30 +785,46 @@ __device__ __forceinline__ void fu_fetch(const T* __restrict__ fu, int fz0, int 
   }
 }
 
+// The ring holds scale * fu: every cell of g0 reads seven staged values, and the product formed once per staged
+// value is the product k_poisson_adjoint forms at each use (same operands, same rounding).
 template <typename T>
 __device__ __forceinline__ void fu_publish(typename TileVec<T>::type* __restrict__ ring, int fz0,
-                                           const typename TileVec<T>::type (&pre)[2][kFuLoads]) {
+                                           const typename TileVec<T>::type (&pre)[2][kFuLoads], T scale) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     typename TileVec<T>::type* slot = ring + ((fz0 + q + 8) & 3) * kFuPacks;
 #pragma unroll
     for (int i = 0; i < kFuLoads; ++i) {
       const int p = threadIdx.x + i * kBlock;
-      if (p < kFuPacks) slot[p] = pre[q][i];
+      if (p < kFuPacks) slot[p] = scale * pre[q][i];
     }
   }
 }
 
-template <typename T>
+// (s / h2) of one axis away from every wall: the interior row of adj_axis without its index tests.
+template <typename T, bool MUL>
+__device__ __forceinline__ T lap_inner(T fb, T fm, T fp, const H2<T>& h, int ax) {
+  const T s = (fp + fm) + T(-2) * fb;
+  if constexpr (MUL) return s * h.inv[ax];
+  return div_h2<T>(s, h, ax);
+}
+
+// MUL: the three 1 / h^2 are exact (powers of two) and the division is a product -- known at launch, so the
+// instantiation that runs carries no divide.
+template <typename T, bool MUL>
 __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __restrict__ fu, T* __restrict__ g0out,
                                                                  T* __restrict__ gcoarse, MarchArgs a, H2<T> h,
                                                                  T scale, AdamArgs<T> ad0, AdamArgs<T> ad1) {
   typedef typename TileVec<T>::type P2;
-  __shared__ P2 ring[4 * kFuPacks];      // fu planes z & 3
+  __shared__ P2 ring[4 * kFuPacks];      // scale * fu, planes z & 3
   __shared__ P2 gt[2][kTileR * kGC];     // g0 of the current pair of planes
   const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
   int zc, yt, xt;
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
+  if constexpr (MUL) h.mul_ok[0] = h.mul_ok[1] = h.mul_ok[2] = 1;  // (the wall rows lose their divide as well)
+  // the step size of a replayed epoch lives in device memory: one read per workgroup, not one per cell
+  if (ad0.alpha_dev) ad0.alpha = ad1.alpha = *ad0.alpha_dev;
+  ad0.alpha_dev = ad1.alpha_dev = nullptr;
   TileCtx<T> c;
   c.gfine = nullptr, c.gcoarse = gcoarse, c.gscaled = nullptr;
   c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
@@ -811,6 +840,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   c.sx = c.owner && (c.jx < 2 || c.jx >= c.cnx - 2);
   c.sy = c.owner && (c.jy < 2 || c.jy >= cny - 2);
   const int fy0 = 2 * yt * kTileY, fx0 = 2 * xt * kTileX;  // first own fine row / column of the tile
+  // every g0 cell of the tile (own cells and the halo ring) has interior rows of the stencil on y and x
+  const bool tile_inner = fy0 >= 4 && fy0 + 2 * kTileY + 4 <= fny && fx0 >= 4 && fx0 + 2 * kTileX + 4 <= fnx;
   // this thread's packs of a staged fu plane (row-major over the (kFuR, kFuC) window, clamped into the array)
   int64_t src[kFuLoads];
 #pragma unroll
@@ -831,29 +862,45 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   const int npairs = z1 - c.z0 + 2;
   P2 pre[2][kFuLoads];
   fu_fetch<T>(fu, 2 * (c.z0 - 1) - 1, c.fnz, c.fplane, src, pre);
-  fu_publish<T>(ring, 2 * (c.z0 - 1) - 1, pre);
+  fu_publish<T>(ring, 2 * (c.z0 - 1) - 1, pre, scale);
   fu_fetch<T>(fu, 2 * (c.z0 - 1) + 1, c.fnz, c.fplane, src, pre);
-  // own cells of the tile (the finest level's arrays): packs o = threadIdx.x + i kBlock, row-major
+  // own cells of the tile (the finest level's arrays): packs o = threadIdx.x + i kBlock, row-major; offset -1
+  // marks a pack beyond the array (a per-lane flag array would cost scalar registers: the kernel spills them)
   int64_t own_off[kOwnLoads];
-  bool own_ok[kOwnLoads];
 #pragma unroll
   for (int i = 0; i < kOwnLoads; ++i) {
     const int o = threadIdx.x + i * kBlock;
     const int row = o / kTileX, cc = o - row * kTileX;
     const int y = fy0 + row, x = fx0 + 2 * cc;
-    own_ok[i] = y < fny && x < fnx;
-    own_off[i] = (int64_t)(own_ok[i] ? y : 0) * fnx + (own_ok[i] ? x : 0);
+    own_off[i] = y < fny && x < fnx ? (int64_t)y * fnx + x : -1;
   }
   P2 xv[kOwnLoads], mv[kOwnLoads], vv[kOwnLoads];
 #pragma unroll
   for (int i = 0; i < kOwnLoads; ++i) xv[i] = mv[i] = vv[i] = P2{T(0), T(0)};
   bool pending = false;  // the previous plane's update is outstanding
+#ifdef ODIL_X_PHASES
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tp = __builtin_readcyclecounter();
+#define PH(i) { const long long tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
+#else
+#define PH(i)
+#endif
   for (int k = 0; k < npairs; ++k) {
     const int m = c.z0 - 1 + k, zA = 2 * m;
-    __syncthreads();  // readers of the ring slots and of gt that are rewritten below are done
-    fu_publish<T>(ring, zA + 1, pre);
+    // (no barrier here: the ring slots written now were last read by g0 of the previous step's planes, before
+    // that step's last barrier; the transpose that ended the previous step reads gt only, and the next writer of
+    // gt comes after the barrier below)
+    fu_publish<T>(ring, zA + 1, pre, scale);
+    PH(1)
     __syncthreads();
+    PH(2)
     fu_fetch<T>(fu, zA + 3, c.fnz, c.fplane, src, pre);  // next pair of fu planes in flight
+    // the coarse entry this step emits: its x, m, v travel while the step's planes are formed
+    T cpre[3] = {T(0), T(0), T(0)};
+    if (k >= 2 && c.owner && ad1.x) {
+      const int64_t ci = (int64_t)(c.z0 + k - 2) * c.cplane + (int64_t)c.jy * c.cnx + c.jx;
+      cpre[0] = ad1.x[ci], cpre[1] = ad1.m[ci], cpre[2] = ad1.v[ci];
+    }
     // One plane at a time.  The update of the finest level runs one plane behind the plane whose g0 is
     // being formed: its loads (x, m, v of the own cells) are issued before g0 of its plane is formed and
     // consumed at the start of the next step, so they have a whole step to arrive (gt keeps two planes).
@@ -864,20 +911,25 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
       // the next writer of that half by this step's barrier)
       if (pending) {  // plane z - 1: its g0 is in the other half of gt
         const P2* gprev = gt[q ^ 1];
+        const int64_t zoff = (int64_t)(z - 1) * c.fplane;
 #pragma unroll
         for (int i = 0; i < kOwnLoads; ++i) {
           const int o = threadIdx.x + i * kBlock;
           const int row = o / kTileX, cc = o - row * kTileX;
-          if (!own_ok[i]) continue;
+          if (own_off[i] < 0) continue;
           const P2 g = gprev[(row + 2) * kGC + cc + 1];
-          const int64_t off = (int64_t)(z - 1) * c.fplane + own_off[i];
+          const int64_t off = zoff + own_off[i];
           if (g0out) __builtin_nontemporal_store(g, reinterpret_cast<P2*>(g0out + off));
           if (ad0.x) {
             P2 xn = xv[i], mn = mv[i], vn = vv[i];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               T xe = xn[e], me = mn[e], ve = vn[e];
+#ifdef ODIL_X_CHEAP_ADAM
+              me = me + (g[e] - me) * ad0.omb1, ve = ve + (g[e] * g[e] - ve) * ad0.omb2, xe = xe - me * ad0.alpha;
+#else
               adam_update<T>(xe, me, ve, g[e], ad0);
+#endif
               xn[e] = xe, mn[e] = me, vn[e] = ve;
             }
             __builtin_nontemporal_store(xn, reinterpret_cast<P2*>(ad0.x + off));
@@ -886,11 +938,13 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           }
         }
       }
+      PH(3)
       pending = z >= 2 * c.z0 && z < 2 * z1;  // planes of this chunk (the others belong to its neighbours)
       if (pending && ad0.x) {
+        const int64_t zoff = (int64_t)z * c.fplane;
 #pragma unroll
         for (int i = 0; i < kOwnLoads; ++i) {
-          const int64_t off = (int64_t)z * c.fplane + own_off[i];
+          const int64_t off = zoff + (own_off[i] < 0 ? 0 : own_off[i]);
           xv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.x + off));
           mv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.m + off));
           vv[i] = __builtin_nontemporal_load(reinterpret_cast<const P2*>(ad0.v + off));
@@ -903,44 +957,83 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
       // slab interfaces (ghost planes beyond them, multi-GPU): the transposed stencil has its interior rows
       // there -- the wall rows of adj_axis sit two planes inside an end that is a wall
       const int zj = z + (c.cut_lo ? 2 : 0), zn = c.fnz + (c.cut_lo ? 2 : 0) + (c.cut_hi ? 2 : 0);
+      const bool z_in = z >= 0 && z < c.fnz;
       // Lanes walk the fu window row by row in ITS row length (kFuC packs, of which the g0 tile takes kGC): the
       // seven window reads of consecutive lanes are then consecutive packs.  Walking the g0 tile's own rows
       // (kGC packs) made every wave straddle a row end with a two-pack gap in its window addresses, a two-way
       // LDS bank conflict in ~4 of 9 lane groups (SQ_LDS_BANK_CONFLICT 7.3e7 of 1.85e8 active cycles,
       // profiles/r02_v0_poisson_pmc.txt).
+      if (tile_inner && z_in && zj >= 2 && zj < zn - 2) {
+        // No wall within reach of any cell of this plane of the tile (a workgroup-uniform test: 3 of 4 tiles at
+        // 512^3): the interior row of adj_axis on every axis, no index tests -- the same expression, term by
+        // term.  The general form below costs ~3x the instructions (profiles/r02_v3_poisson_pmc.txt).
 #pragma unroll 1
-      for (int i = 0; i < kG0Steps; ++i) {
-        const int w = threadIdx.x + i * kBlock;
-        const int r = w / kFuC, cc = w - r * kFuC;
-        if (r < kTileR && cc < kGC) {
-          const int p = r * kGC + cc;
-          const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
-          const int at = w + kFuC + 1;  // = (r + 1) * kFuC + cc + 1: the same cells in the fu window
-          P2 g;
-          g[0] = T(0), g[1] = T(0);
-          if (z >= 0 && z < c.fnz && y >= 0 && y < fny && x >= 0 && x < fnx) {
+        for (int i = 0; i < kG0Steps; ++i) {
+          const int w = threadIdx.x + i * kBlock;
+          const int r = w / kFuC, cc = w - r * kFuC;
+          if (r < kTileR && cc < kGC) {
+            const int at = w + kFuC + 1;
+#ifdef ODIL_X_NO_G0
+            gq[r * kGC + cc] = pc[at];
+            continue;
+#endif
             const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
             const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
+            P2 g;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              // the expression of k_poisson_adjoint, term by term
-              const T fb = scale * fc[e];
+              const T fb = fc[e];
               T acc = T(0);
-              acc = acc + adj_axis<T>(fb, scale * fzm[e], scale * fzp[e], zj, zn, h, 0);
-              acc = acc + adj_axis<T>(fb, scale * fym[e], scale * fyp[e], y, fny, h, 1);
-              const T xm = scale * (e == 0 ? fl[1] : fc[0]);
-              const T xp = scale * (e == 0 ? fc[1] : fr[0]);
-              acc = acc + adj_axis<T>(fb, xm, xp, x + e, fnx, h, 2);
+              acc = acc + lap_inner<T, MUL>(fb, fzm[e], fzp[e], h, 0);
+              acc = acc + lap_inner<T, MUL>(fb, fym[e], fyp[e], h, 1);
+              acc = acc + lap_inner<T, MUL>(fb, e == 0 ? fl[1] : fc[0], e == 0 ? fc[1] : fr[0], h, 2);
               g[e] = acc;
             }
+            gq[r * kGC + cc] = g;
           }
-          gq[p] = g;
+        }
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < kG0Steps; ++i) {
+          const int w = threadIdx.x + i * kBlock;
+          const int r = w / kFuC, cc = w - r * kFuC;
+          if (r < kTileR && cc < kGC) {
+            const int y = fy0 - 2 + r, x = fx0 - 2 + 2 * cc;
+            const int at = w + kFuC + 1;  // = (r + 1) * kFuC + cc + 1: the same cells in the fu window
+            P2 g;
+            g[0] = T(0), g[1] = T(0);
+            if (z_in && y >= 0 && y < fny && x >= 0 && x < fnx) {
+              const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
+              const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                // the expression of k_poisson_adjoint, term by term
+                const T fb = fc[e];
+                T acc = T(0);
+                acc = acc + adj_axis<T>(fb, fzm[e], fzp[e], zj, zn, h, 0);
+                acc = acc + adj_axis<T>(fb, fym[e], fyp[e], y, fny, h, 1);
+                acc = acc + adj_axis<T>(fb, e == 0 ? fl[1] : fc[0], e == 0 ? fc[1] : fr[0], x + e, fnx, h, 2);
+                g[e] = acc;
+              }
+            }
+            gq[r * kGC + cc] = g;
+          }
         }
       }
+      PH(4)
       __syncthreads();
+      PH(5)
     }
-    tile_reduce_emit<T>(c, gt[0], gt[1], k, true, wc, wr, ad1);
+#ifndef ODIL_X_NO_REDUCE
+    tile_reduce_emit<T>(c, gt[0], gt[1], k, true, wc, wr, ad1, nullptr, cpre);
+#endif
+    PH(6)
   }
+#ifdef ODIL_X_PHASES
+  if ((blockIdx.x == 1001 || blockIdx.x == 2002) && (threadIdx.x & 63) == 0)
+    printf("wg %d wave %d steps %d cycles: top-barrier %lld publish %lld barrier %lld adam %lld loads+g0 %lld barrier %lld reduce %lld\n",
+           (int)blockIdx.x, (int)(threadIdx.x >> 6), npairs, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+#endif
 }
 
 // P^T with a node-centred marching axis: coarse plane J collects fine plane 2J and half of the
@@ -1229,8 +1322,13 @@ int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, 
   }();
   m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, fused_units);
   T h[3] = {h2[0], h2[1], h2[2]};
-  hipLaunchKernelGGL((k_poisson_adjoint_tile<T>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0, g1, m,
-                     make_h2<T>(h), scale, ad0, ad1);
+  const H2<T> hh = make_h2<T>(h);
+  if (hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2])
+    hipLaunchKernelGGL((k_poisson_adjoint_tile<T, true>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0,
+                       g1, m, hh, scale, ad0, ad1);
+  else
+    hipLaunchKernelGGL((k_poisson_adjoint_tile<T, false>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0,
+                       g1, m, hh, scale, ad0, ad1);
   return check_launch("k_poisson_adjoint_tile");
 }
 
