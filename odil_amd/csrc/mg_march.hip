@@ -878,22 +878,13 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
 #pragma unroll
   for (int i = 0; i < kOwnLoads; ++i) xv[i] = mv[i] = vv[i] = P2{T(0), T(0)};
   bool pending = false;  // the previous plane's update is outstanding
-#ifdef ODIL_X_PHASES
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tp = __builtin_readcyclecounter();
-#define PH(i) { const long long tn = __builtin_readcyclecounter(); ph[i] += tn - tp; tp = tn; }
-#else
-#define PH(i)
-#endif
   for (int k = 0; k < npairs; ++k) {
     const int m = c.z0 - 1 + k, zA = 2 * m;
     // (no barrier here: the ring slots written now were last read by g0 of the previous step's planes, before
     // that step's last barrier; the transpose that ended the previous step reads gt only, and the next writer of
     // gt comes after the barrier below)
     fu_publish<T>(ring, zA + 1, pre, scale);
-    PH(1)
     __syncthreads();
-    PH(2)
     fu_fetch<T>(fu, zA + 3, c.fnz, c.fplane, src, pre);  // next pair of fu planes in flight
     // the coarse entry this step emits: its x, m, v travel while the step's planes are formed
     T cpre[3] = {T(0), T(0), T(0)};
@@ -925,11 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               T xe = xn[e], me = mn[e], ve = vn[e];
-#ifdef ODIL_X_CHEAP_ADAM
-              me = me + (g[e] - me) * ad0.omb1, ve = ve + (g[e] * g[e] - ve) * ad0.omb2, xe = xe - me * ad0.alpha;
-#else
               adam_update<T>(xe, me, ve, g[e], ad0);
-#endif
               xn[e] = xe, mn[e] = me, vn[e] = ve;
             }
             __builtin_nontemporal_store(xn, reinterpret_cast<P2*>(ad0.x + off));
@@ -938,7 +925,6 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           }
         }
       }
-      PH(3)
       pending = z >= 2 * c.z0 && z < 2 * z1;  // planes of this chunk (the others belong to its neighbours)
       if (pending && ad0.x) {
         const int64_t zoff = (int64_t)z * c.fplane;
@@ -973,10 +959,6 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           const int r = w / kFuC, cc = w - r * kFuC;
           if (r < kTileR && cc < kGC) {
             const int at = w + kFuC + 1;
-#ifdef ODIL_X_NO_G0
-            gq[r * kGC + cc] = pc[at];
-            continue;
-#endif
             const P2 fc = pc[at], fl = pc[at - 1], fr = pc[at + 1];
             const P2 fym = pc[at - kFuC], fyp = pc[at + kFuC], fzm = pm[at], fzp = pp[at];
             P2 g;
@@ -1020,20 +1002,10 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           }
         }
       }
-      PH(4)
       __syncthreads();
-      PH(5)
     }
-#ifndef ODIL_X_NO_REDUCE
     tile_reduce_emit<T>(c, gt[0], gt[1], k, true, wc, wr, ad1, nullptr, cpre);
-#endif
-    PH(6)
   }
-#ifdef ODIL_X_PHASES
-  if ((blockIdx.x == 1001 || blockIdx.x == 2002) && (threadIdx.x & 63) == 0)
-    printf("wg %d wave %d steps %d cycles: top-barrier %lld publish %lld barrier %lld adam %lld loads+g0 %lld barrier %lld reduce %lld\n",
-           (int)blockIdx.x, (int)(threadIdx.x >> 6), npairs, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
-#endif
 }
 
 // P^T with a node-centred marching axis: coarse plane J collects fine plane 2J and half of the
