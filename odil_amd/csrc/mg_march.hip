@@ -811,10 +811,16 @@ __device__ __forceinline__ T lap_inner(T fb, T fm, T fp, const H2<T>& h, int ax)
 
 // MUL: the three 1 / h^2 are exact (powers of two) and the division is a product -- known at launch, so the
 // instantiation that runs carries no divide.
-template <typename T, bool MUL>
-__global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __restrict__ fu, T* __restrict__ g0out,
+// G0: g0 is also written out (the callers that want the finest gradient itself); both levels share the Adam
+// hyper-parameters (one set in scalar registers: the kernel spills them).
+template <typename T, bool MUL, bool G0>
+__global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __restrict__ fu, T* __restrict__ g0out_,
                                                                  T* __restrict__ gcoarse, MarchArgs a, H2<T> h,
-                                                                 T scale, AdamArgs<T> ad0, AdamArgs<T> ad1) {
+                                                                 T scale, AdamArgs<T> ad0, T* __restrict__ x1,
+                                                                 T* __restrict__ m1, T* __restrict__ v1) {
+  T* const g0out = G0 ? g0out_ : nullptr;
+  AdamArgs<T> ad1 = ad0;
+  ad1.x = x1, ad1.m = m1, ad1.v = v1;
   typedef typename TileVec<T>::type P2;
   __shared__ P2 ring[4 * kFuPacks];      // scale * fu, planes z & 3
   __shared__ P2 gt[2][kTileR * kGC];     // g0 of the current pair of planes
@@ -823,8 +829,9 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
   if constexpr (MUL) h.mul_ok[0] = h.mul_ok[1] = h.mul_ok[2] = 1;  // (the wall rows lose their divide as well)
   // the step size of a replayed epoch lives in device memory: one read per workgroup, not one per cell
-  if (ad0.alpha_dev) ad0.alpha = ad1.alpha = *ad0.alpha_dev;
-  ad0.alpha_dev = ad1.alpha_dev = nullptr;
+  if (ad0.alpha_dev) ad0.alpha = *ad0.alpha_dev;
+  ad0.alpha_dev = nullptr;
+  ad1.alpha = ad0.alpha, ad1.alpha_dev = nullptr;
   TileCtx<T> c;
   c.gfine = nullptr, c.gcoarse = gcoarse, c.gscaled = nullptr;
   c.cnz = a.cn[0], c.cnx = a.cn[2], c.fnz = a.fn[0];
@@ -1295,12 +1302,17 @@ int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, 
   m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, fused_units);
   T h[3] = {h2[0], h2[1], h2[2]};
   const H2<T> hh = make_h2<T>(h);
-  if (hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2])
-    hipLaunchKernelGGL((k_poisson_adjoint_tile<T, true>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0,
-                       g1, m, hh, scale, ad0, ad1);
-  else
-    hipLaunchKernelGGL((k_poisson_adjoint_tile<T, false>), dim3(unit_grid(m.usched)), dim3(kBlock), 0, stream, fu, g0,
-                       g1, m, hh, scale, ad0, ad1);
+  // (the C ABI passes one set of hyper-parameters for both levels)
+  const bool mul = hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2];
+  const dim3 grid(unit_grid(m.usched));
+#define ODIL_LAUNCH_ADJ_TILE(MUL, G0)                                                                             \
+  hipLaunchKernelGGL((k_poisson_adjoint_tile<T, MUL, G0>), grid, dim3(kBlock), 0, stream, fu, g0, g1, m, hh, scale, \
+                     ad0, ad1.x, ad1.m, ad1.v)
+  if (mul && !g0) ODIL_LAUNCH_ADJ_TILE(true, false);
+  else if (mul) ODIL_LAUNCH_ADJ_TILE(true, true);
+  else if (!g0) ODIL_LAUNCH_ADJ_TILE(false, false);
+  else ODIL_LAUNCH_ADJ_TILE(false, true);
+#undef ODIL_LAUNCH_ADJ_TILE
   return check_launch("k_poisson_adjoint_tile");
 }
 
