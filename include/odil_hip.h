@@ -203,6 +203,15 @@ int odil_poisson_residual_synth_f32(const float* coarse, const float* w0, const 
                                     const int64_t* cshape, const float* h2, int64_t z0, int64_t z1, double denom,
                                     double* partials, float* loss, void* stream);
 
+/* One damped-Jacobi sweep (odil_poisson_jacobi) of u = x + P coarse with the prolongation formed in registers:
+ * the coarse-grid correction of a V-cycle and its first post-smoothing sweep in one pass, xout != x.  Equal, bit for
+ * bit, to odil_interp_add followed by odil_poisson_jacobi.  Shapes as odil_poisson_residual_synth.  (The reference
+ * hands the Newton system to pyamg, linsolver.py:61-72.) */
+int odil_poisson_jacobi_synth_f64(const double* coarse, const double* x, const double* rhs, double* xout,
+                                  const int64_t* cshape, const double* h2, double omega, void* stream);
+int odil_poisson_jacobi_synth_f32(const float* coarse, const float* x, const float* rhs, float* xout,
+                                  const int64_t* cshape, const float* h2, float omega, void* stream);
+
 /* gu = J^T (scale * fu): cotangent of the operator above; scale = 2/size gives
  * d mean(fu^2)/du (core.py:1093-1101). */
 int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "poisson_jacobi": [_P, _P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_residual_restrict": [_P, _P, _P, _I64P, c_int, _P, _R, _P, _P, _P],
     "poisson_residual_synth": [_P, _P, _P, _P, _I64P, _P, c_int64, c_int64, c_double, _P, _P, _P],
+    "poisson_jacobi_synth": [_P, _P, _P, _P, _I64P, _P, _R, _P],
     "poisson_residual_slab": [_P, _P, _P, _I64P, c_int, _P, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_adjoint": [_P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_adjoint_adam": [_P, _P, _P, _P, _P, _I64P, c_int, _P, _R, _R, _R, _R, _R, _P, _P],

@@ -53,11 +53,12 @@ struct SynthArgs {
 // Residual of the four own cells of fine plane fz = 2jz + EZ (EZ in {0, 1}).
 //   uc: own values, ub / ua: own values of the planes below / above,
 //   wy[2]: w0 packs of rows 2jy-1 and 2jy+2, wx[2][2]: w0 at x = 2jx-1 / 2jx+2 of the two own rows.
-template <typename T, int EZ>
+// JAC: f is the damped-Jacobi update q - (A u - rhs) wd instead of the residual, wd[iy][ix] = omega / diag of the plane.
+template <typename T, int EZ, bool JAC = false>
 __device__ inline void residual_plane(const T (&v)[3][3][3], const T (&uc)[2][2], const T (&ub)[2][2],
                                       const T (&ua)[2][2], const PackN<T, 2> (&wy)[2], const T (&wx)[2][2],
                                       const PackN<T, 2> (&r)[2], int fz, int fy0, int fx0, int FZ, int FY, int FX,
-                                      const H2<T>& h, T (&f)[2][2]) {
+                                      const H2<T>& h, T (&f)[2][2], const T (*wd)[2] = nullptr) {
   // edge neighbours: rows 2jy-1 and 2jy+2 at the own x, columns 2jx-1 and 2jx+2 at the own rows
   T ylo[2], yhi[2], xlo[2], xhi[2];
   ylo[0] = T(1) * wy[0].e[0] + synth_val<T, EZ, -1, 0>(v);
@@ -79,16 +80,38 @@ __device__ inline void residual_plane(const T (&v)[3][3][3], const T (&uc)[2][2]
       T acc = axis_term<T>(q, ub[iy][ix], ua[iy][ix], fz == 0, fz == FZ - 1, h, 0);
       acc = acc + axis_term<T>(q, ym, yp, y == 0, y == FY - 1, h, 1);
       acc = acc + axis_term<T>(q, xm, xp, x == 0, x == FX - 1, h, 2);
-      f[iy][ix] = acc - r[iy].e[ix];
+      if constexpr (JAC)
+        f[iy][ix] = q - (acc - r[iy].e[ix]) * wd[iy][ix];  // k_poisson_jacobi's expression
+      else
+        f[iy][ix] = acc - r[iy].e[ix];
     }
 }
 
+// omega / diag for the 2 x 2 own cells of a plane; zmul = 1 away from the z walls, 2 on the first / last plane of the
+// array (k_poisson_jacobi: the diagonal is the sum over the axes of (-2 / h^2) (1 + walls touched)).
 template <typename T>
+__device__ __forceinline__ void jacobi_weights(const H2<T>& h, T omega, T zmul, int fy0, int fx0, int FY, int FX,
+                                               T (&w)[2][2]) {
+  const T dz = div_h2<T>(T(-2), h, 0) * zmul;
+#pragma unroll
+  for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix) {
+      const int y = fy0 + iy, x = fx0 + ix;
+      const T dy = div_h2<T>(T(-2), h, 1) * T(1 + (y == 0) + (y == FY - 1));
+      w[iy][ix] = omega / ((dz + dy) + div_h2<T>(T(-2), h, 2) * T(1 + (x == 0 || x == FX - 1)));
+    }
+}
+
+// JAC: one damped-Jacobi sweep of the same operator on u = w0 + P coarse instead of its residual (the first
+// post-smoothing sweep of a V-cycle with the coarse-grid correction formed in registers: x + P x_c is never
+// stored, 3 1/8 words per cell instead of 5 1/8); fu receives the new iterate, no loss.
+template <typename T, bool JAC = false>
 __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __restrict__ coarse,
                                                                    const T* __restrict__ w0,
                                                                    const T* __restrict__ rhs, T* __restrict__ fu,
                                                                    SynthArgs sa, H2<T> h,
-                                                                   double* __restrict__ partials) {
+                                                                   double* __restrict__ partials, T omega = T(0)) {
   const MarchArgs& a = sa.m;
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int FZ = a.fn[0], FY = a.fn[1], FX = a.fn[2];
@@ -108,6 +131,10 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
     const int64_t rowm = (int64_t)(fy0 == 0 ? 0 : fy0 - 1) * FX + fx0;
     const int64_t rowp = (int64_t)(fy0 + 2 >= FY ? FY - 1 : fy0 + 2) * FX + fx0;
     const int xm = fx0 == 0 ? 0 : -1, xp = fx0 + 2 >= FX ? 1 : 2;
+    // omega / diag of the four own cells on a plane away from the z walls (k_poisson_jacobi: the diagonal is
+    // sum over axes of (-2 / h^2) (1 + walls touched)); the two wall planes of the array form theirs where needed
+    T wd_in[2][2];
+    if constexpr (JAC) jacobi_weights<T>(h, omega, T(1), fy0, fx0, FY, FX, wd_in);
     T v[3][3][3];
     load_plane<T, 1>(coarse, z0 - 1, cnz, cplane, cnx, ty, tx, T(1), v[0]);
     load_plane<T, 1>(coarse, z0, cnz, cplane, cnx, ty, tx, T(1), v[1]);
@@ -159,8 +186,22 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
       synth_own<T, 1>(v, wC, uC);
       synth_own<T, 2>(v, wD, uD);
       T fB[2][2], fC[2][2];
-      residual_plane<T, 0>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB);
-      residual_plane<T, 1>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC);
+      if constexpr (JAC) {
+        if (fzB == 0 || fzC == FZ - 1) {  // (uniform) the first or the last plane of the array
+          T wdw[2][2];
+          jacobi_weights<T>(h, omega, T(2), fy0, fx0, FY, FX, wdw);
+          residual_plane<T, 0, true>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB,
+                                     fzB == 0 ? wdw : wd_in);
+          residual_plane<T, 1, true>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC,
+                                     fzC == FZ - 1 ? wdw : wd_in);
+        } else {
+          residual_plane<T, 0, true>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB, wd_in);
+          residual_plane<T, 1, true>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC, wd_in);
+        }
+      } else {
+        residual_plane<T, 0>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB);
+        residual_plane<T, 1>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC);
+      }
       if (fu) {
 #pragma unroll
         for (int iy = 0; iy < 2; ++iy) {
@@ -195,16 +236,18 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
         }
     }
   }
-  const double total = block_sum(local);
-  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+  if constexpr (!JAC) {
+    const double total = block_sum(local);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+  }
 }
 
 template <typename T>
 static int poisson_residual_synth(const T* coarse, const T* w0, const T* rhs, T* fu, const int64_t* cshape,
                                   const T* h2, int64_t z0, int64_t z1, double denom, double* partials, T* loss,
-                                  void* stream) {
-  if (!coarse || !w0 || !rhs || !partials || !loss) {
-    set_error("poisson_residual_synth: null pointer");
+                                  void* stream, bool jacobi = false, T omega = T(0)) {
+  if (!coarse || !w0 || !rhs || (!jacobi && (!partials || !loss)) || (jacobi && (!fu || fu == w0))) {
+    set_error("poisson_residual_synth: null pointer (or the Jacobi sweep in place)");
     return ODIL_E_INVAL;
   }
   SynthArgs sa;
@@ -245,8 +288,13 @@ static int poisson_residual_synth(const T* coarse, const T* w0, const T* rhs, T*
   sa.loss_z0 = z0;
   sa.loss_z1 = z1 < 0 ? m.fn[0] : z1;
   T hh[3] = {h2[0], h2[1], h2[2]};
-  hipLaunchKernelGGL(k_poisson_residual_synth<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, coarse, w0, rhs, fu,
-                     sa, make_h2<T>(hh), partials);
+  if (jacobi) {
+    hipLaunchKernelGGL((k_poisson_residual_synth<T, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, coarse,
+                       w0, rhs, fu, sa, make_h2<T>(hh), partials, omega);
+    return check_launch("k_poisson_residual_synth<jacobi>");
+  }
+  hipLaunchKernelGGL((k_poisson_residual_synth<T, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, coarse, w0,
+                     rhs, fu, sa, make_h2<T>(hh), partials, T(0));
   if (int e = check_launch("k_poisson_residual_synth")) return e;
   const double size = denom > 0.0 ? denom : (double)m.fn[0] * m.fn[1] * m.fn[2];
   return launch_final_reduce<T>(partials, grid, 0, 1, size, loss, (hipStream_t)stream);
@@ -266,5 +314,15 @@ int odil_poisson_residual_synth_f32(const float* coarse, const float* w0, const 
                                     const int64_t* cshape, const float* h2, int64_t z0, int64_t z1, double denom,
                                     double* partials, float* loss, void* stream) {
   return poisson_residual_synth<float>(coarse, w0, rhs, fu, cshape, h2, z0, z1, denom, partials, loss, stream);
+}
+int odil_poisson_jacobi_synth_f64(const double* coarse, const double* x, const double* rhs, double* xout,
+                                  const int64_t* cshape, const double* h2, double omega, void* stream) {
+  return poisson_residual_synth<double>(coarse, x, rhs, xout, cshape, h2, 0, -1, 0.0, nullptr, nullptr, stream, true,
+                                        omega);
+}
+int odil_poisson_jacobi_synth_f32(const float* coarse, const float* x, const float* rhs, float* xout,
+                                  const int64_t* cshape, const float* h2, float omega, void* stream) {
+  return poisson_residual_synth<float>(coarse, x, rhs, xout, cshape, h2, 0, -1, 0.0, nullptr, nullptr, stream, true,
+                                       omega);
 }
 }  // extern "C"

@@ -77,12 +77,16 @@ class PoissonGMG:
         spectrum of D^-1 A that the coarse grid cannot see (eigenvalues (1/d) sum_i (1 - cos theta_i) with
         some |theta_i| >= pi/2): two sweeps damp it by 0.34 (d = 3) where omega = 6/7 gives 0.51, three by
         0.15 instead of 0.36."""
-        if chebyshev:
-            lo, hi = 1.0 / self.ndim, 2.0
-            mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
-            weights = [1.0 / (mid - half * math.cos(math.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
-        else:
-            weights = [self.omega] * n
+        return self.sweeps(lvl, x, b, self.weights(n, chebyshev))
+
+    def weights(self, n, chebyshev=True):
+        if not chebyshev:
+            return [self.omega] * n
+        lo, hi = 1.0 / self.ndim, 2.0
+        mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+        return [1.0 / (mid - half * math.cos(math.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
+
+    def sweeps(self, lvl, x, b, weights):
         for w in weights:
             y = self.spare[lvl]
             ops.poisson_jacobi(x, b, self.h2s[lvl], w, out=y)
@@ -110,9 +114,15 @@ class PoissonGMG:
         if xc_new is not xc:  # keep the zeroed-per-cycle buffer distinct from the level's spare
             self.x[lvl + 1] = xc_new
         out = self.spare[lvl]
-        ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
+        weights = self.weights(self.nu2)
+        if weights and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
+            # x + P x_c is formed in registers by the first post-smoothing sweep (3 1/8 words per cell instead of 5 1/8)
+            ops.poisson_jacobi_synth(xc_new, x, b, self.h2s[lvl], weights[0], out=out)
+            weights = weights[1:]
+        else:
+            ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
         self.spare[lvl] = x
-        return self.smooth(lvl, out, b, self.nu2)
+        return self.sweeps(lvl, out, b, weights)
 
     def vcycle(self, lvl, x, b):
         """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate."""
@@ -127,7 +137,26 @@ class PoissonGMG:
         self.coarse_rhs(lvl, x, b)
         return self.finish_cycle(lvl, x, b)
 
-    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True):
+    def full_multigrid(self, b):
+        """First iterate by nested iteration: the right-hand side is restricted to every level, the coarsest problem is
+        solved, and each finer level starts one V-cycle from the prolongated solution of the level below.  Costs about
+        one V-cycle of the finest level plus 1/7 and leaves the error near the discretisation level instead of O(1):
+        the cycles that follow only have to cover the remaining distance to the tolerance."""
+        fb = [b]
+        for lvl in range(self.nlvl - 1):
+            fb.append(ops.restrict_to_coarser(fb[-1], self.loc))
+        x = None
+        for lvl in range(self.nlvl - 1, -1, -1):
+            if x is None:
+                start = torch.zeros(self.shapes[lvl], dtype=self.dtype, device=self.device)
+            else:
+                start = ops.interp_add(x, self.loc)  # (a fresh tensor: the cycle's work buffers rotate underneath)
+            # (the tensor returned is never this level's coarse-correction buffer self.x[lvl], which the next finer
+            # cycle zeroes: a cycle rotates its argument with self.spare[lvl] only)
+            x = self.vcycle(lvl, start, fb[lvl])
+        return x
+
+    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True, fmg=True):
         """Solves A x = b to ||A x - b|| <= tol * ||b||.  The residual that is tested is the one every cycle
         forms anyway (after its pre-smoothing sweeps, on its way to the coarse grid): the iterate returned
         is that pre-smoothed one, so convergence costs no pass of its own."""
@@ -135,7 +164,12 @@ class PoissonGMG:
         # a relative residual below ~50 ulp of the working precision cannot be reached: asking float32 for 1e-12 would
         # burn every cycle of `maxiter` and report nothing
         tol = max(tol, 50 * float(torch.finfo(self.dtype).eps))
-        x = torch.zeros_like(b) if x0 is None else x0.clone()
+        if x0 is not None:
+            x = x0.clone()
+        elif fmg and self.nlvl > 2:
+            x = self.full_multigrid(b)
+        else:
+            x = torch.zeros_like(b)
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
         if self.nlvl == 1:

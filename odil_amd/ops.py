@@ -303,6 +303,22 @@ def poisson_jacobi(u, rhs, h2, omega, out):
     return out
 
 
+def jacobi_synth_supported(shape, dtype):
+    """3-D arrays with even extents >= 4 (the coarse array they are prolongated from has extents >= 2)."""
+    return len(shape) == 3 and all(s % 2 == 0 and s >= 4 for s in shape)
+
+
+def poisson_jacobi_synth(coarse, x, rhs, h2, omega, out):
+    """out = u - omega (A u - rhs) / diag(A) with u = x + P coarse formed in registers: the coarse-grid correction of
+    a V-cycle and its first post-smoothing sweep in one pass (out is not x)."""
+    assert coarse.dim() == 3 and tuple(x.shape) == tuple(2 * s for s in coarse.shape) and x.shape == rhs.shape == out.shape
+    assert coarse.is_contiguous() and x.is_contiguous() and rhs.is_contiguous() and out.data_ptr() != x.data_ptr()
+    h2a, h2p = host_reals(h2, x.dtype)
+    call("poisson_jacobi_synth", x.dtype, ptr(coarse), ptr(x), ptr(rhs), ptr(out), i64(coarse.shape), h2p, float(omega),
+         stream_ptr())
+    return out
+
+
 def poisson_residual_synth(coarse, w0, rhs, h2, fu=None, loss=None, zrange=None, denom=None):
     """fu = Lap(w0 + P coarse) - rhs, loss = mean(fu**2): the residual with the last prolongation of
     the multigrid synthesis fused in (u is never stored).  3-D cell-centred arrays, w0.shape == 2 * coarse.shape.

@@ -454,6 +454,27 @@ def test_poisson_residual_with_fused_prolongation_is_bit_identical(dev, dtype, c
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cshape", [(4, 6, 10), (2, 2, 2), (9, 5, 7), (32, 40, 64), (5, 130, 3)])
+def test_jacobi_sweep_with_fused_prolongation_is_bit_identical(dev, dtype, cshape):
+    """odil_poisson_jacobi_synth: the sweep of x + P coarse with the prolongation in registers equals, bit for bit,
+    odil_interp_add followed by odil_poisson_jacobi (walls on every side included: the diagonal changes there)."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(14)
+    fshape = tuple(2 * s for s in cshape)
+    coarse = to(rng.standard_normal(cshape).astype(dtype), dev)
+    x = to(rng.standard_normal(fshape).astype(dtype), dev)
+    b = to(rng.standard_normal(fshape).astype(dtype), dev)
+    assert ops.jacobi_synth_supported(fshape, x.dtype)
+    for h2 in ([0.25**2, 0.125**2, 0.5**2], [0.1**2, 0.3**2, 0.07**2]):
+        h2 = [dtype(v) for v in h2]
+        u = ops.interp_add(coarse, "ccc", add=x)
+        want = ops.poisson_jacobi(u, b, h2, 0.8, torch.empty_like(u))
+        got = ops.poisson_jacobi_synth(coarse, x, b, h2, 0.8, torch.empty_like(x))
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(12,), (6, 10), (8, 6, 10), (5, 7, 9)])
 def test_poisson_jacobi_sweep(dev, dtype, shape):
     """odil_poisson_jacobi == x - omega (A x - b) / diag(A) with A, diag from the residual / Jacobian kernels."""
