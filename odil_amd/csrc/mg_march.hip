@@ -504,6 +504,26 @@ constexpr int kTileR = 2 * kTileY + 4, kTileC = 2 * kTileX + 4;       // fine ro
 constexpr int kTilePacks = kTileR * (kTileC / 2);                       // packs of two values per plane
 constexpr int kTileLoads = (kTilePacks + kBlock - 1) / kBlock;          // per thread and plane
 static_assert(kTileY * kTileX == kBlock, "one thread per coarse column of the tile");
+// Row stride of a staged plane in LDS, in packs: two more than the row holds, so that the two tile rows a group of
+// sixteen lanes reads (eight lanes each, see tile_column) start 128 B apart modulo the 256 B of the banks.
+constexpr int kTileRS = kTileC / 2 + 2;
+constexpr int kTileLds = kTileR * kTileRS + 64;  // + a landing zone for the surplus packs of the last load round
+// Coarse columns of the tile by thread: a WAVE owns a strip of kTileX / 4 columns over all kTileY rows.  The two
+// columns next to a wall need the general 6 x 6 weights (ten times the arithmetic of the interior ones) and drag their
+// whole wave through that path: with rows of the tile per wave every wave of a tile that touches an x wall had such
+// lanes (planes of 256^2: every tile), with strips one wave in four has.
+constexpr bool kTileStrips = (kBlock / 64) * (64 / kTileY) == kTileX;
+__device__ __forceinline__ void tile_column(int& lx, int& ly) {
+  if constexpr (kTileStrips) {
+    constexpr int W = 64 / kTileY;  // columns per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lx = wave * W + lane % W;
+    ly = lane / W;
+  } else {
+    lx = threadIdx.x % kTileX;
+    ly = threadIdx.x / kTileX;
+  }
+}
 
 template <typename T, int CX = 1>
 struct TileVec {
@@ -575,19 +595,68 @@ __device__ __forceinline__ void tile_tables_load(const float* __restrict__ wt, A
 // Away from the walls the weights are the constants (1, 3, 3, 1) / 4 per axis and the C and R sums coincide;
 // the weight tables of the two columns / rows next to a wall are formed where they are needed instead of
 // being carried in registers (24 VGPRs in double).  Zero-weight terms are skipped: the sums keep their bits.
-template <typename T, int CX = 1>
+// RS: row stride of the staged planes in packs; lxl: this thread's pack column in them (c.lx unless the caller stages
+// a narrower window than the tile).
+template <typename T, int CX = 1, int RS = kTileRS>
 __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
                                                  const typename TileVec<T, CX>::type* __restrict__ tile0,
                                                  const typename TileVec<T, CX>::type* __restrict__ tile1, int k,
                                                  bool live, T (&wc)[CX][6], T (&wr)[CX][6], const AdamArgs<T>& ad,
                                                  const float* __restrict__ wt = nullptr,
-                                                 const T* __restrict__ cpre = nullptr) {
+                                                 const T* __restrict__ cpre = nullptr, int lxl = -1) {
   typedef typename TileVec<T, CX>::type P2;
   constexpr int NV = 2 * CX;
+  if (lxl < 0) lxl = c.lx;
   const int f2[2] = {2 * (c.z0 - 1 + k), 2 * (c.z0 - 1 + k) + 1};
   T c2[2][CX], r2[2][CX];
   const bool xy_special = c.sx || c.sy;
-  if (xy_special) {
+  const bool wave_sy = __any(c.sy);  // (wave-uniform) some lane of this wave is next to a y wall
+  if (xy_special && !wave_sy) {
+    // next to an x wall only: the rows keep their constants (1, 3, 3, 1) / 4 and the two outer rows of the 6-row
+    // window their zero weights (skipped: the sums keep their value), the columns take their tables -- a third of
+    // the general path below, which is left to the waves that touch a y wall
+    Adj6 ax[CX];
+    if (wt) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CX; ++cc) {
+          ax[cc].wc[i] = wt[(12 + 12 * cc + i) * kBlock + threadIdx.x];
+          ax[cc].wr[i] = wt[(18 + 12 * cc + i) * kBlock + threadIdx.x];
+        }
+    } else {
+      column_taps<CX>(c.jx, c.cnx, ax);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const P2* tq = q == 0 ? tile0 : tile1;
+      const bool inside = f2[q] >= 0 && f2[q] < c.fnz;
+      T sc[CX], sr[CX];
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) sc[cc] = sr[cc] = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const P2* row = tq + (2 * c.ly + 1 + r) * RS + lxl;
+        const P2 g[3] = {row[0], row[1], row[2]};
+#pragma unroll
+        for (int cc = 0; cc < CX; ++cc) {
+          T xc = T(0), xr = T(0);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int e = NV - 2 + 2 * cc + i;
+            const T val = g[e / NV][e % NV];
+            xc = xc + T(ax[cc].wc[i]) * val;
+            xr = xr + T(ax[cc].wr[i]) * val;
+          }
+          const T wy = T((r == 0 || r == 3) ? 0.25 : 0.75);
+          sc[cc] = sc[cc] + wy * xc;
+          sr[cc] = sr[cc] + wy * xr;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < CX; ++cc) c2[q][cc] = inside ? sc[cc] : T(0), r2[q][cc] = inside ? sr[cc] : T(0);
+    }
+  } else if (xy_special) {
     // weight tables of this thread: from the LDS copy made at kernel start when there is one (tiles with a
     // wall send every wave through this branch, and forming three tables costs more than the reduction)
     Adj6 ax[CX], ay;
@@ -611,7 +680,7 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-          const P2 t = tq[(2 * c.ly + r) * (kTileC / 2) + c.lx + w];
+          const P2 t = tq[(2 * c.ly + r) * RS + lxl + w];
 #pragma unroll
           for (int e = 0; e < NV; ++e) g[0][r][w].e[e] = t[e];
         }
@@ -629,7 +698,7 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
       for (int cc = 0; cc < CX; ++cc) sc[cc] = T(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const P2* row = tq + (2 * c.ly + 1 + r) * (kTileC / 2) + c.lx;
+        const P2* row = tq + (2 * c.ly + 1 + r) * RS + lxl;
         const P2 g[3] = {row[0], row[1], row[2]};
 #pragma unroll
         for (int cc = 0; cc < CX; ++cc) {
@@ -675,14 +744,14 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
 template <typename T, int CX = 1>
 __device__ __forceinline__ void tile_stage(const TileCtx<T>& c, typename TileVec<T, CX>::type* __restrict__ tile0,
                                            typename TileVec<T, CX>::type* __restrict__ tile1, int k, int ahead,
-                                           bool live, const int64_t (&src)[kTileLoads],
+                                           bool live, const int64_t (&src)[kTileLoads], const int (&dst)[kTileLoads],
                                            typename TileVec<T, CX>::type (&pre)[2][kTileLoads], T (&wc)[CX][6],
                                            T (&wr)[CX][6], const AdamArgs<T>& ad, const float* __restrict__ wt) {
   __syncthreads();  // the previous pair has been consumed
 #pragma unroll
   for (int i = 0; i < kTileLoads; ++i) {
-    tile0[threadIdx.x + i * kBlock] = pre[0][i];
-    tile1[threadIdx.x + i * kBlock] = pre[1][i];
+    tile0[dst[i]] = pre[0][i];
+    tile1[dst[i]] = pre[1][i];
   }
   __syncthreads();
   // (unconditional: past the last pair it re-reads clamped planes, which keeps the staging registers out
@@ -699,9 +768,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
                                                             AdamArgs<T> ad) {
   typedef typename TileVec<T, CX>::type P2;  // a native vector type: staged values stay in registers
   constexpr int NV = 2 * CX;
-  // flat, row-major over (row, pack); padded to a whole number of packs per thread so that loads and
-  // LDS writes need no guards (the surplus packs re-read pack 0 and land behind the tile)
-  __shared__ P2 tile[2][kTileLoads * kBlock];
+  // row-major over (row, pack) with rows of kTileRS packs; the loads are padded to a whole number of packs per
+  // thread so that they and the LDS writes need no guards (the surplus packs re-read pack 0 and land behind the tile)
+  __shared__ P2 tile[2][kTileLds];
   __shared__ float wtab[12 * (CX + 1) * kBlock];  // weight tables of the threads next to a wall
   const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
   int zc, yt, xt;
@@ -718,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   c.scale = scale;
   c.z0 = zc * a.usched.ZC;
   const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
-  c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
+  tile_column(c.lx, c.ly);
   c.jy = yt * kTileY + c.ly, c.jx = (xt * kTileX + c.lx) * CX;  // first of this thread's CX columns
   c.owner = c.jy < cny && c.jx < c.cnx;  // (CX = 2 needs an even cnx: both columns exist or neither)
   c.cny = cny;
@@ -732,10 +801,12 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   // this thread's share of a staged plane: packs p = threadIdx.x + k kBlock of the tile, row-major; the window
   // of a row starts 2 CX fine cells left of the tile (pack aligned; 2 are needed)
   int64_t src[kTileLoads];
+  int dst[kTileLoads];
 #pragma unroll
   for (int k = 0; k < kTileLoads; ++k) {
     const int p = threadIdx.x + k * kBlock;
     const int r = p < kTilePacks ? p / (kTileC / 2) : 0, cc = p < kTilePacks ? p - r * (kTileC / 2) : 0;
+    dst[k] = p < kTilePacks ? r * kTileRS + cc : kTileR * kTileRS + (threadIdx.x & 63);
     int fy = 2 * yt * kTileY - 2 + r, fx = NV * (xt * kTileX - 1 + cc);
     fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);
     fx = fx < 0 ? 0 : (fx >= fnx ? fnx - NV : fx);
@@ -752,7 +823,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_tile(const T* __restrict_
   const int npairs = z1 - c.z0 + 2;
   P2 pre[2][kTileLoads];
   tile_fetch<T, CX>(gfine, 2 * (c.z0 - 1), c.fnz, c.fplane, src, pre);
-  for (int k = 0; k < npairs; ++k) tile_stage<T, CX>(c, tile[0], tile[1], k, 1, true, src, pre, wc, wr, ad, wtab);
+  for (int k = 0; k < npairs; ++k) {
+    tile_stage<T, CX>(c, tile[0], tile[1], k, 1, true, src, dst, pre, wc, wr, ad, wtab);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -768,7 +841,7 @@ constexpr int kFuR = 2 * kTileY + 6;   // fine rows from 2 jy0 - 3
 constexpr int kFuC = kTileX + 4;       // packs of two: fine x from 2 jx0 - 4 (pack aligned)
 constexpr int kFuPacks = kFuR * kFuC;
 constexpr int kFuLoads = (kFuPacks + kBlock - 1) / kBlock;
-constexpr int kGC = kTileC / 2;        // packs per row of the g0 tile
+constexpr int kGC = kTileC / 2;        // packs per row of the g0 tile (stored with the row stride kTileRS)
 constexpr int kG0Steps = (kTileR * kFuC + kBlock - 1) / kBlock;  // g0 is formed walking rows of kFuC lanes
 constexpr int kOwnLoads = 2 * kTileY * kTileX / kBlock;  // own packs per thread and plane
 
@@ -823,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   ad1.x = x1, ad1.m = m1, ad1.v = v1;
   typedef typename TileVec<T>::type P2;
   __shared__ P2 ring[4 * kFuPacks];      // scale * fu, planes z & 3
-  __shared__ P2 gt[2][kTileR * kGC];     // g0 of the current pair of planes
+  __shared__ P2 gt[2][kTileR * kTileRS]; // g0 of the current pair of planes
   const int cny = a.cn[1], fny = a.fn[1], fnx = a.fn[2];
   int zc, yt, xt;
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
@@ -840,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
   c.scale = T(1);
   c.z0 = zc * a.usched.ZC;
   const int z1 = c.z0 + a.usched.ZC < c.cnz ? c.z0 + a.usched.ZC : c.cnz;
-  c.lx = threadIdx.x % kTileX, c.ly = threadIdx.x / kTileX;
+  tile_column(c.lx, c.ly);
   c.jy = yt * kTileY + c.ly, c.jx = xt * kTileX + c.lx;
   c.owner = c.jy < cny && c.jx < c.cnx;
   c.cny = cny;
@@ -915,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
           const int o = threadIdx.x + i * kBlock;
           const int row = o / kTileX, cc = o - row * kTileX;
           if (own_off[i] < 0) continue;
-          const P2 g = gprev[(row + 2) * kGC + cc + 1];
+          const P2 g = gprev[(row + 2) * kTileRS + cc + 1];
           const int64_t off = zoff + own_off[i];
           if (g0out) __builtin_nontemporal_store(g, reinterpret_cast<P2*>(g0out + off));
           if (ad0.x) {
@@ -978,7 +1051,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
               acc = acc + lap_inner<T, MUL>(fb, e == 0 ? fl[1] : fc[0], e == 0 ? fc[1] : fr[0], h, 2);
               g[e] = acc;
             }
-            gq[r * kGC + cc] = g;
+            gq[r * kTileRS + cc] = g;
           }
         }
       } else {
@@ -1005,7 +1078,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_adjoint_tile(const T* __rest
                 g[e] = acc;
               }
             }
-            gq[r * kGC + cc] = g;
+            gq[r * kTileRS + cc] = g;
           }
         }
       }
