@@ -564,7 +564,7 @@ static int mg_synth(const T* const* terms, const T* factors, T* const* work, T* 
   if (nlvl == 1) {  // u = f_0 * w_0
     int64_t n0 = 1;
     for (int d = 0; d < ndim; ++d) n0 *= shapes[d];
-    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_for(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, terms[0],
+    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_flat(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, terms[0],
                        u, n0, factors ? factors[0] : T(1));
     return check_launch("k_scale_copy");
   }
@@ -602,7 +602,7 @@ static int mg_synth_adj(const T* gu, T* const* grads, const T* factors, T* const
     const int64_t* s0 = shapes;
     int64_t n0 = 1;
     for (int d = 0; d < ndim; ++d) n0 *= s0[d];
-    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_for(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, gu,
+    hipLaunchKernelGGL(k_scale_copy<T>, dim3(grid_flat(n0, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, gu,
                        grads[0], n0, f0);
     if (int e = check_launch("k_scale_copy")) return e;
   }

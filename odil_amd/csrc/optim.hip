@@ -26,7 +26,9 @@ __device__ inline void adam_one(T& x, T& m, T& v, T g, T alpha, T omb1, T omb2, 
   x = x - (m * alpha) / (sqrt(v) + eps);
 }
 
-template <typename T>
+// NT: the arrays are far larger than the caches (chosen by the launcher): streaming loads and stores, +4-6 % on
+// top of the uncapped grid (6.3 / 6.5 TB/s for f32 / f64 at 1 G / 128 M elements).
+template <typename T, bool NT>
 __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restrict__ m, T* __restrict__ v,
                                                 const T* __restrict__ g, int64_t n, T alpha, T omb1, T omb2, T eps,
                                                 int vec_ok, const T* __restrict__ alpha_dev) {
@@ -38,30 +40,31 @@ __global__ __launch_bounds__(kBlock) void k_adam(T* __restrict__ x, T* __restric
   if (vec_ok) {
     const int64_t nv = n / V;
     for (int64_t i = tid; i < nv; i += nthreads) {
-#ifdef ODIL_NT_LOAD
-      VT xv = __builtin_nontemporal_load(reinterpret_cast<VT*>(x) + i);
-      VT mv = __builtin_nontemporal_load(reinterpret_cast<VT*>(m) + i);
-      VT vv = __builtin_nontemporal_load(reinterpret_cast<VT*>(v) + i);
-      const VT gv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(g) + i);
-#else
-      VT xv = reinterpret_cast<VT*>(x)[i], mv = reinterpret_cast<VT*>(m)[i], vv = reinterpret_cast<VT*>(v)[i];
-      const VT gv = reinterpret_cast<const VT*>(g)[i];
-#endif
+      VT xv, mv, vv, gv;
+      if constexpr (NT) {
+        xv = __builtin_nontemporal_load(reinterpret_cast<VT*>(x) + i);
+        mv = __builtin_nontemporal_load(reinterpret_cast<VT*>(m) + i);
+        vv = __builtin_nontemporal_load(reinterpret_cast<VT*>(v) + i);
+        gv = __builtin_nontemporal_load(reinterpret_cast<const VT*>(g) + i);
+      } else {
+        xv = reinterpret_cast<VT*>(x)[i], mv = reinterpret_cast<VT*>(m)[i], vv = reinterpret_cast<VT*>(v)[i];
+        gv = reinterpret_cast<const VT*>(g)[i];
+      }
       T* xp = reinterpret_cast<T*>(&xv);
       T* mp = reinterpret_cast<T*>(&mv);
       T* vp = reinterpret_cast<T*>(&vv);
       const T* gp = reinterpret_cast<const T*>(&gv);
 #pragma unroll
       for (int k = 0; k < V; ++k) adam_one<T>(xp[k], mp[k], vp[k], gp[k], alpha, omb1, omb2, eps);
-#ifdef ODIL_NT_STORE
-      __builtin_nontemporal_store(xv, reinterpret_cast<VT*>(x) + i);
-      __builtin_nontemporal_store(mv, reinterpret_cast<VT*>(m) + i);
-      __builtin_nontemporal_store(vv, reinterpret_cast<VT*>(v) + i);
-#else
-      reinterpret_cast<VT*>(x)[i] = xv;
-      reinterpret_cast<VT*>(m)[i] = mv;
-      reinterpret_cast<VT*>(v)[i] = vv;
-#endif
+      if constexpr (NT) {
+        __builtin_nontemporal_store(xv, reinterpret_cast<VT*>(x) + i);
+        __builtin_nontemporal_store(mv, reinterpret_cast<VT*>(m) + i);
+        __builtin_nontemporal_store(vv, reinterpret_cast<VT*>(v) + i);
+      } else {
+        reinterpret_cast<VT*>(x)[i] = xv;
+        reinterpret_cast<VT*>(m)[i] = mv;
+        reinterpret_cast<VT*>(v)[i] = vv;
+      }
     }
     for (int64_t i = nv * V + tid; i < n; i += nthreads) adam_one<T>(x[i], m[i], v[i], g[i], alpha, omb1, omb2, eps);
   } else {
@@ -90,8 +93,12 @@ int adam_launch(T* x, T* m, T* v, const T* g, int64_t n, T alpha, T omb1, T omb2
   }
   if (n == 0) return 0;
   const int vec_ok = aligned16(x) && aligned16(m) && aligned16(v) && aligned16(g);
-  hipLaunchKernelGGL(k_adam<T>, dim3(grid_for(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, stream, x, m, v, g, n, alpha,
-                     omb1, omb2, eps, vec_ok, alpha_dev);
+  if (7 * n * (int64_t)sizeof(T) > kStreamBytes)
+    hipLaunchKernelGGL((k_adam<T, true>), dim3(grid_flat(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, stream, x, m, v, g,
+                       n, alpha, omb1, omb2, eps, vec_ok, alpha_dev);
+  else
+    hipLaunchKernelGGL((k_adam<T, false>), dim3(grid_flat(n, kBlock * Vec16<T>::N)), dim3(kBlock), 0, stream, x, m, v, g,
+                       n, alpha, omb1, omb2, eps, vec_ok, alpha_dev);
   return check_launch("k_adam");
 }
 template int adam_launch<double>(double*, double*, double*, const double*, int64_t, double, double, double, double,
@@ -112,7 +119,7 @@ static int axpy(T* y, const T* x, int64_t n, T a, void* stream) {
     return ODIL_E_INVAL;
   }
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_axpy<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, x, n, a);
+  hipLaunchKernelGGL(k_axpy<T>, dim3(grid_flat(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, x, n, a);
   return check_launch("k_axpy");
 }
 
@@ -132,7 +139,7 @@ static int scale(const T* x, T* y, int64_t n, T a, const T* adev, void* stream) 
     return ODIL_E_INVAL;
   }
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_scale<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, y, n, a, adev);
+  hipLaunchKernelGGL(k_scale<T>, dim3(grid_flat(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, y, n, a, adev);
   return check_launch("k_scale");
 }
 
@@ -154,7 +161,7 @@ static int addcmul(T* y, const T* a, const T* b, int64_t n, int accumulate, void
     return ODIL_E_INVAL;
   }
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_addcmul<T>, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, a, b, n,
+  hipLaunchKernelGGL(k_addcmul<T>, dim3(grid_flat(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, a, b, n,
                      accumulate);
   return check_launch("k_addcmul");
 }
