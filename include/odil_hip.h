@@ -244,6 +244,15 @@ int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t
                        double one_minus_b1, double one_minus_b2, double eps, const double* alpha_dev, void* stream);
 int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
                        float one_minus_b2, float eps, const float* alpha_dev, void* stream);
+/* The same update on `npieces` (<= 65535) contiguous pieces of `count` elements, piece o at o * stride + offset: the
+ * planes next to the slab interfaces of a ghost-extended array whose sharded axis is not the leading one (the rest of
+ * such an array is updated by the launch that forms its gradient; these planes wait for the neighbour's share). */
+int odil_adam_step_pieces_f64(double* x, double* m, double* v, const double* g, int64_t npieces, int64_t stride,
+                              int64_t offset, int64_t count, double alpha, double one_minus_b1, double one_minus_b2,
+                              double eps, const double* alpha_dev, void* stream);
+int odil_adam_step_pieces_f32(float* x, float* m, float* v, const float* g, int64_t npieces, int64_t stride,
+                              int64_t offset, int64_t count, float alpha, float one_minus_b1, float one_minus_b2,
+                              float eps, const float* alpha_dev, void* stream);
 /* y += a * x  (GdOptimizer: x -= lr*g, optimizer.py:270; Newton update util.py:177). */
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream);
 int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);

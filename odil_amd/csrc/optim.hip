@@ -106,6 +106,58 @@ template int adam_launch<double>(double*, double*, double*, const double*, int64
 template int adam_launch<float>(float*, float*, float*, const float*, int64_t, float, float, float, float,
                                 hipStream_t, const float*);
 
+// Adam on a strided family of contiguous pieces: elements o * stride + offset + j, o < gridDim.y, j < count (the
+// planes next to the slab interfaces of a ghost-extended array whose sharded axis is not the leading one: the rest
+// of the array was updated by the launch that formed its gradient, these wait for the neighbour's contribution).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_adam_pieces(T* __restrict__ x, T* __restrict__ m, T* __restrict__ v,
+                                                       const T* __restrict__ g, int64_t stride, int64_t offset,
+                                                       int64_t count, T alpha, T omb1, T omb2, T eps, int vec_ok,
+                                                       const T* __restrict__ alpha_dev) {
+  if (alpha_dev) alpha = *alpha_dev;
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type VT;
+  const int64_t base = (int64_t)blockIdx.y * stride + offset;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  if (vec_ok) {
+    for (int64_t i = tid; i < count / V; i += nthreads) {
+      const int64_t at = base + i * V;
+      VT xv = *reinterpret_cast<VT*>(x + at), mv = *reinterpret_cast<VT*>(m + at), vv = *reinterpret_cast<VT*>(v + at);
+      const VT gv = *reinterpret_cast<const VT*>(g + at);
+      T* xp = reinterpret_cast<T*>(&xv);
+      T* mp = reinterpret_cast<T*>(&mv);
+      T* vp = reinterpret_cast<T*>(&vv);
+      const T* gp = reinterpret_cast<const T*>(&gv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) adam_one<T>(xp[k], mp[k], vp[k], gp[k], alpha, omb1, omb2, eps);
+      *reinterpret_cast<VT*>(x + at) = xv;
+      *reinterpret_cast<VT*>(m + at) = mv;
+      *reinterpret_cast<VT*>(v + at) = vv;
+    }
+  } else {
+    for (int64_t i = tid; i < count; i += nthreads)
+      adam_one<T>(x[base + i], m[base + i], v[base + i], g[base + i], alpha, omb1, omb2, eps);
+  }
+}
+
+template <typename T>
+static int adam_pieces(T* x, T* m, T* v, const T* g, int64_t npieces, int64_t stride, int64_t offset, int64_t count,
+                       T alpha, T omb1, T omb2, T eps, const T* alpha_dev, void* stream) {
+  if (!x || !m || !v || !g || npieces < 0 || count < 0 || offset < 0 || npieces > 65535) {
+    set_error("adam_step_pieces: null pointer, negative size or more than 65535 pieces");
+    return ODIL_E_INVAL;
+  }
+  if (npieces == 0 || count == 0) return 0;
+  constexpr int V = Vec16<T>::N;
+  const int vec_ok = aligned16(x) && aligned16(m) && aligned16(v) && aligned16(g) && stride % V == 0 &&
+                     offset % V == 0 && count % V == 0;
+  const dim3 grid(grid_flat(count, kBlock * V), (unsigned)npieces);
+  hipLaunchKernelGGL(k_adam_pieces<T>, grid, dim3(kBlock), 0, (hipStream_t)stream, x, m, v, g, stride, offset, count,
+                     alpha, omb1, omb2, eps, vec_ok, alpha_dev);
+  return check_launch("k_adam_pieces");
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_axpy(T* __restrict__ y, const T* __restrict__ x, int64_t n, T a) {
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
@@ -446,6 +498,18 @@ int odil_adam_step_f64(double* x, double* m, double* v, const double* g, int64_t
 int odil_adam_step_f32(float* x, float* m, float* v, const float* g, int64_t n, float alpha, float one_minus_b1,
                        float one_minus_b2, float eps, const float* alpha_dev, void* stream) {
   return adam_step<float>(x, m, v, g, n, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev, stream);
+}
+int odil_adam_step_pieces_f64(double* x, double* m, double* v, const double* g, int64_t npieces, int64_t stride,
+                              int64_t offset, int64_t count, double alpha, double one_minus_b1, double one_minus_b2,
+                              double eps, const double* alpha_dev, void* stream) {
+  return adam_pieces<double>(x, m, v, g, npieces, stride, offset, count, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev,
+                             stream);
+}
+int odil_adam_step_pieces_f32(float* x, float* m, float* v, const float* g, int64_t npieces, int64_t stride,
+                              int64_t offset, int64_t count, float alpha, float one_minus_b1, float one_minus_b2,
+                              float eps, const float* alpha_dev, void* stream) {
+  return adam_pieces<float>(x, m, v, g, npieces, stride, offset, count, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev,
+                            stream);
 }
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream) {
   return axpy<double>(y, x, n, a, stream);

@@ -427,6 +427,17 @@ def adam_step(x, m, v, g, alpha, one_minus_b1, one_minus_b2, eps):
     )
 
 
+def adam_step_pieces(x, m, v, g, npieces, stride, offset, count, alpha, one_minus_b1, one_minus_b2, eps):
+    """adam_step on the elements o * stride + offset + j (o < npieces, j < count) of four flat vectors."""
+    assert x.numel() == m.numel() == v.numel() == g.numel() and x.is_contiguous()
+    assert npieces == 0 or (npieces - 1) * stride + offset + count <= x.numel()
+    a, adev = _step_size(alpha, x.dtype)
+    call(
+        "adam_step_pieces", x.dtype, ptr(x), ptr(m), ptr(v), ptr(g), c_int64(npieces), c_int64(stride), c_int64(offset),
+        c_int64(count), a, float(one_minus_b1), float(one_minus_b2), float(eps), adev, stream_ptr(),
+    )
+
+
 def axpy(y, x, a):
     """y += a * x in place."""
     assert y.numel() == x.numel() and y.dtype == x.dtype

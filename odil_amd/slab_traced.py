@@ -42,6 +42,7 @@ and with all ranks emulated in one process on one GPU (slab.run_lockstep, tests/
 
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -144,6 +145,7 @@ class HipSlabKernels:
                 ("off", ctypes.c_int), ("lo", ctypes.c_int), ("ea", ctypes.c_int), ("hw", ctypes.c_int),
                 ("wlo", ctypes.c_void_p * nsrc), ("whi", ctypes.c_void_p * nsrc),
                 ("gwlo", ctypes.c_void_p * nsrc), ("gwhi", ctypes.c_void_p * nsrc),
+                ("alo", ctypes.c_int), ("ahi", ctypes.c_int),
             ]
 
         a = self.args = Args()
@@ -155,6 +157,9 @@ class HipSlabKernels:
         a.out, a.pgrad, a.nblocks, a.hs = self.out.data_ptr(), self.pgrad.data_ptr(), self.nblocks, None
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.jit_gather_adam.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 4 + [
+            ctypes.c_void_p, ctypes.c_void_p]
+        a.alo = a.ahi = 0
         self.src_keys, self.gather_keys = list(cg.src_keys), list(cg.gathers)
         self.param_groups = {key: (cg.pg_offset[key], [len(g) for g in groups]) for key, groups in cg.pgrads.items()}
 
@@ -189,11 +194,26 @@ class HipSlabKernels:
         if rc != 0:
             raise RuntimeError("traced slab kernel launch failed: hip error {}".format(rc))
 
-    def gather(self, key, g, gwlo, gwhi):
-        """Ghost-extended gradient of field `key` (level 0) into g, wrap contributions into gwlo / gwhi."""
+    fused_adam = True  # gather() can apply the optimizer's update to the planes whose gradient it completes
+
+    def gather(self, key, g, gwlo, gwhi, adam=None):
+        """Ghost-extended gradient of field `key` (level 0) into g, wrap contributions into gwlo / gwhi.
+        adam = (x, m, v, alpha, one_minus_b1, one_minus_b2, eps, lo, hi): Adam (reference optimizer.py:316-318) of the
+        array's entries on the owned planes lo <= plane < hi of the sharded axis, by the lane that forms their gradient
+        (x, m, v laid out as g)."""
         i = self.src_keys.index(key)
         self.args.gwlo[i], self.args.gwhi[i] = gwlo.data_ptr(), gwhi.data_ptr()
-        rc = self.lib.jit_gather(self.gather_keys.index(key), ctypes.byref(self.args), g.data_ptr(), hip_ops.stream_ptr())
+        which = self.gather_keys.index(key)
+        if adam is None:
+            self.args.alo = self.args.ahi = 0
+            rc = self.lib.jit_gather(which, ctypes.byref(self.args), g.data_ptr(), hip_ops.stream_ptr())
+        else:
+            x, m, v, alpha, omb1, omb2, eps, lo, hi = adam
+            assert x.shape == g.shape and x.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+            self.args.alo, self.args.ahi = int(lo), int(hi)
+            rc = self.lib.jit_gather_adam(which, ctypes.byref(self.args), g.data_ptr(), x.data_ptr(), m.data_ptr(),
+                                          v.data_ptr(), float(alpha), float(omb1), float(omb2), float(eps), None,
+                                          hip_ops.stream_ptr())
         if rc != 0:
             raise RuntimeError("traced slab gather launch failed: hip error {}".format(rc))
 
@@ -332,6 +352,35 @@ class SlabTracedAdam:
         self.lr, self.b1, self.b2, self.eps = self.npdt(lr), self.npdt(beta_1), self.npdt(beta_2), epsilon
         self.t = 0
         self.has_params = any(e["kind"] == "par" for e in self.entries) and bool(self.kern.param_groups)
+        # ---- the optimizer's update inside the gathers ------------------------------------------------
+        # A gather completes the gradient of the owned planes 1 .. n - 2 of its array (plane 0 / n - 1 wait for the
+        # neighbour's share or the periodic closure): the kernels that can, update those entries where they form the
+        # gradient, and the launches at the end of the epoch cover the rest of the packed vector -- the two end pieces of
+        # every such array (strided when the sharded axis is not the leading one) and the ranges between the arrays
+        # (coarser levels, fields without a gather, parameters).  ODIL_SLAB_FUSE_ADAM=0: one launch over everything.
+        self._fused, self._post_flat, self._post_pieces = dict(), [], []
+        if getattr(self.kern, "fused_adam", False) and os.environ.get("ODIL_SLAB_FUSE_ADAM", "1") != "0":
+            spans = []
+            for key in self.kern.gather_keys:
+                e = self.by_key[key]
+                lv = e["levels"][0]
+                if lv.n < 4:
+                    continue
+                self._fused[key] = (1, lv.n - 1)
+                spans.append((e["start"], lv.size))
+                outer = math.prod(lv.shape[:axis])
+                inner = lv.plane // outer
+                stride = lv.shape[axis] * inner
+                first, last = lv.g_lo + 1, lv.g_lo + lv.n - 1  # planes [0, first) and [last, extent) of the array
+                self._post_pieces.append((e["start"], lv.size, outer, stride, 0, first * inner))
+                self._post_pieces.append((e["start"], lv.size, outer, stride, last * inner, (lv.shape[axis] - last) * inner))
+            at = 0
+            for start, size in sorted(spans):
+                if start > at:
+                    self._post_flat.append((at, start))
+                at = start + size
+            if at < total:
+                self._post_flat.append((at, total))
 
     # ---- pieces of the epoch -------------------------------------------------------------------------
     def _synthesise(self):
@@ -426,10 +475,17 @@ class SlabTracedAdam:
         b = tic("forward")
         self.kern.forward(self.u, {k: w["lo"] for k, w in self.wrap.items()}, {k: w["hi"] for k, w in self.wrap.items()})
         toc(b)
+        t = self.npdt(self.t + 1)
+        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
+        hyper = (alpha, 1 - self.b1, 1 - self.b2, self.eps)
         b = tic("gather")
         for key in self.kern.gather_keys:
-            w = self.wrap[key]
-            self.kern.gather(key, self.by_key[key]["g"][0], w["glo"], w["ghi"])
+            w, e = self.wrap[key], self.by_key[key]
+            if key in self._fused:
+                self.kern.gather(key, e["g"][0], w["glo"], w["ghi"],
+                                 adam=(e["x"][0], e["m"][0], e["v"][0]) + hyper + self._fused[key])
+            else:
+                self.kern.gather(key, e["g"][0], w["glo"], w["ghi"])
         toc(b)
         if h and self.kern.gather_keys:
             b = tic("halo")
@@ -469,10 +525,16 @@ class SlabTracedAdam:
                     view.copy_(total[ofs:ofs + cnt].view(view.shape))
                     ofs += cnt
         self.t += 1
-        t = self.npdt(self.t)
-        alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
         b = tic("adam")
-        hip_ops.adam_step(self.x, self.m, self.v, self.g, alpha, 1 - self.b1, 1 - self.b2, self.eps)
+        if not self._fused:
+            hip_ops.adam_step(self.x, self.m, self.v, self.g, *hyper)
+        else:
+            for lo, hi in self._post_flat:
+                hip_ops.adam_step(self.x[lo:hi], self.m[lo:hi], self.v[lo:hi], self.g[lo:hi], *hyper)
+            for start, size, pieces, stride, offset, count in self._post_pieces:
+                span = slice(start, start + size)
+                hip_ops.adam_step_pieces(self.x[span], self.m[span], self.v[span], self.g[span], pieces, stride, offset,
+                                         count, *hyper)
         toc(b)
 
     def epoch(self, comm, timers=None):

@@ -779,7 +779,7 @@ class _Codegen:
             # off: global index of the first owned cell; lo / ea: ghost cells below the owned ones / extent of the
             # local arrays along the sharded axis; hw: cells in a wrap plane buffer; wlo / whi: wrap planes of the
             # sources (read), gwlo / gwhi: of the gradients (written by the gathers where the array has no ghosts)
-            slab_members = " int off, lo, ea, hw; const T* wlo[{0}]; const T* whi[{0}]; T* gwlo[{0}]; T* gwhi[{0}];".format(nsrc)
+            slab_members = " int off, lo, ea, hw; const T* wlo[{0}]; const T* whi[{0}]; T* gwlo[{0}]; T* gwhi[{0}]; int alo, ahi;".format(nsrc)
         # host scalars (functions of `tracers`): BY VALUE in the argument struct (hsv) -- an eager launch owns its
         # copy, nothing the host rewrites later is read by a queued kernel; a launch captured into a hipGraph
         # reads them from device memory instead (hs != NULL: the row of the epoch being replayed)
@@ -989,7 +989,7 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
     ax, nloc = self.slab
     slot = self.src_keys.index(key)
     per = [fshape[d] for d in range(self.ndim)]
-    S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP) {{'.format(gi))
+    S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
     tot_per = int(np.prod([fshape[d] for d in range(self.ndim) if d != ax]))
     # 32-bit index arithmetic whenever the thread space fits (divisions by constants: a 64-bit one costs ~4x)
     it = "int" if tot_per * (nloc + 4) < 2**31 - 512 else "long"
@@ -1044,7 +1044,13 @@ def _gather_slab(self, S, gi, key, reads, floc, fshape):
         return self._offset(full, shape)
 
     S.append("  const int jl = jo + a.lo;")
-    S.append("  if (jl >= 0 && jl < a.ea) g[{}] = acc;".format(offset("jl", "a.ea")))
+    # owned planes a.alo <= jo < a.ahi have their whole gradient here (no neighbour's cell reads them): the optimizer's
+    # update is applied on the spot; the planes next to an interface wait for the halo sum (slab_traced.py)
+    S.append("  if (jl >= 0 && jl < a.ea) {")
+    S.append("    const int o = {};".format(offset("jl", "a.ea")))
+    S.append("    g[o] = acc;")
+    S.append("    if (jo >= a.alo && jo < a.ahi) adam_apply(ad, o, acc);")
+    S.append("  }")
     S.append("  else if (jo < 0 && jo >= -a.hw) a.gwlo[{}][{}] = acc;".format(slot, offset("(jo + a.hw)", "a.hw")))
     S.append("  else if (jo >= {0} && jo < {0} + a.hw) a.gwhi[{1}][{2}] = acc;".format(nloc, slot, offset("(jo - {})".format(nloc), "a.hw")))
     S.append("}")
