@@ -247,6 +247,32 @@ def test_adam_step_vs_oracle(dev, dtype):
     ops.adam_step(tx[1:], tm[1:], tv[1:], tg[1:], alpha, 1 - b1, 1 - b2, eps)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("geom", [(5, 3 * 64, 0, 64), (5, 3 * 64, 2 * 64, 64), (7, 100, 3, 41), (1, 4096, 1024, 2048)])
+def test_adam_step_pieces_equals_the_update_of_the_slices(dev, dtype, geom):
+    """odil_adam_step_pieces (planes next to a slab interface of an array whose sharded axis is not the leading one):
+    the listed pieces get exactly odil_adam_step's update, everything else is untouched."""
+    from odil_amd import ops
+
+    pieces, stride, offset, count = geom
+    n = pieces * stride + 17
+    rng = np.random.default_rng(5)
+    mk = lambda scale=1.0: to((rng.standard_normal(n) * scale).astype(dtype), dev)
+    x, m, g = mk(), mk(0.1), mk()
+    v = to((rng.random(n) * 0.1).astype(dtype), dev)
+    want = [t.clone() for t in (x, m, v)]
+    hyper = (1e-3, 0.1, 0.001, 1e-7)
+    for o in range(pieces):
+        sl = slice(o * stride + offset, o * stride + offset + count)
+        xs, ms, vs = (t[sl].clone() for t in want)
+        ops.adam_step(xs, ms, vs, g[sl].clone(), *hyper)
+        for t, u in zip(want, (xs, ms, vs)):
+            t[sl] = u
+    ops.adam_step_pieces(x, m, v, g, pieces, stride, offset, count, *hyper)
+    for got, ref in zip((x, m, v), want):
+        assert torch.equal(got, ref)
+
+
 def test_vector_ops(dev):
     from odil_amd import ops
 
