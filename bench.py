@@ -207,7 +207,8 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         # of levels 0 and 1 (7 + 7/8) = 11 words per fine cell.  The launch itself moves less -- g never reaches
         # memory: read fu; read + write x, m, v of level 0; write g1 and read + write x, m, v of level 1 =
         # 7 + 7/8 words.
-        kernel = "k_poisson_adjoint_tile<{}> (adjoint + first P^T + Adam of levels 0 and 1)".format(tname)
+        # (rocprofv3 lists it with its template arguments: <T, 1/h^2 as a product, g0 not stored>)
+        kernel = "k_poisson_adjoint_tile<{}, true, false> (adjoint + first P^T + Adam of levels 0 and 1)".format(tname)
         model = 11.0 * run.local_cells * wordsize
         moved = (7.0 + 7.0 / 8.0) * run.local_cells * wordsize
         ms = kt["adjoint_transpose"]
