@@ -382,6 +382,19 @@ __device__ inline T combine_z(const T (&wc)[6], const T (&wr)[6], int jz, int cn
                               int cut_lo, int cut_hi) {
   const bool z_special = ((jz == 0 || jz == 1) && !cut_lo) || ((jz == cnz - 2 || jz == cnz - 1) && !cut_hi);
   if (!z_special && !xy_special) return (T(0.25) * wc[1] + T(0.75) * wc[2]) + (T(0.75) * wc[3] + T(0.25) * wc[4]);
+  if (!z_special) {
+    // a column next to an x / y wall on a plane away from the z walls: the z weights are the constants
+    // (0, 1, 3, 3, 1, 0) / 4 for both sums -- the general loop below with its weights known (same terms, same order);
+    // forming them from the indices cost the waves that hold such columns more than the rest of their step
+    T sc = T(0), sr = T(0);
+    const T zw[6] = {T(0), T(0.25), T(0.75), T(0.75), T(0.25), T(0)};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      sc = sc + zw[i] * wc[i];
+      sr = sr + zw[i] * wr[i];
+    }
+    return T(2) * sc - sr;
+  }
   T sc = T(0), sr = T(0);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -698,17 +711,24 @@ __device__ __forceinline__ void tile_reduce_emit(const TileCtx<T>& c,
       for (int cc = 0; cc < CX; ++cc) sc[cc] = T(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const P2* row = tq + (2 * c.ly + 1 + r) * RS + lxl;
-        const P2 g[3] = {row[0], row[1], row[2]};
+        // the window of the CX columns: the last value of the pack on the left, the own pack, the first value of the
+        // pack on the right -- read as exactly that (one value, one pack, one value: 2/3 of the LDS bytes of three
+        // packs in double, half in float; the reduction's time is its LDS reads, not its arithmetic)
+        const T* rowv = reinterpret_cast<const T*>(tq + (2 * c.ly + 1 + r) * RS + lxl);
+        const P2 own = *reinterpret_cast<const P2*>(rowv + NV);
+        T val[NV + 2];
+        val[0] = rowv[NV - 1];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) val[1 + e] = own[e];
+        val[NV + 1] = rowv[2 * NV];
 #pragma unroll
         for (int cc = 0; cc < CX; ++cc) {
-          // window entries 2 CX - 2 + 2 cc + (1 .. 4) of the three packs, weights (1, 3, 3, 1) / 4
-          const int e0 = NV - 2 + 2 * cc + 1;
+          // window entries 2 cc + (0 .. 3), weights (1, 3, 3, 1) / 4
           T xc = T(0);
-          xc = xc + T(0.25) * g[e0 / NV][e0 % NV];
-          xc = xc + T(0.75) * g[(e0 + 1) / NV][(e0 + 1) % NV];
-          xc = xc + T(0.75) * g[(e0 + 2) / NV][(e0 + 2) % NV];
-          xc = xc + T(0.25) * g[(e0 + 3) / NV][(e0 + 3) % NV];
+          xc = xc + T(0.25) * val[2 * cc];
+          xc = xc + T(0.75) * val[2 * cc + 1];
+          xc = xc + T(0.75) * val[2 * cc + 2];
+          xc = xc + T(0.25) * val[2 * cc + 3];
           sc[cc] = sc[cc] + T((r == 0 || r == 3) ? 0.25 : 0.75) * xc;
         }
       }

@@ -87,6 +87,13 @@ __device__ inline float w_cell(int64_t j, int64_t k, int64_t F) {
   int64_t d = k - 2 * j;
   return (d == 0 || d == 1) ? 0.75f : ((d == -1 || d == 2) ? 0.25f : 0.f);
 }
+// (the march / tile kernels index with int: a 64-bit compare is several instructions, and the wall paths evaluate
+// dozens of these per step)
+__device__ inline float w_cell(int j, int k, int F) {
+  if (k < 0 || k >= F) return 0.f;
+  const int d = k - 2 * j;
+  return (d == 0 || d == 1) ? 0.75f : ((d == -1 || d == 2) ? 0.25f : 0.f);
+}
 
 __device__ inline AdjTaps make_adj_taps(int loc, int64_t J, int64_t n, int64_t F, bool cut_lo = false,
                                        bool cut_hi = false) {
@@ -106,7 +113,7 @@ __device__ inline AdjTaps make_adj_taps(int loc, int64_t J, int64_t n, int64_t F
     for (int i = 0; i < 6; ++i) {
       int64_t k = t.k0 + i;
       float w = i < t.cnt ? w_cell(J, k, F) : 0.f;
-      float lo = w_cell(-1, k, F), hi = w_cell(n, k, F);
+      float lo = w_cell((int64_t)-1, k, F), hi = w_cell(n, k, F);
       t.wc[i] = i < t.cnt ? w + (c_lo ? lo : 0.f) + (c_hi ? hi : 0.f) : 0.f;
       t.wr[i] = i < t.cnt ? w + (r_lo ? lo : 0.f) + (r_hi ? hi : 0.f) : 0.f;
     }
