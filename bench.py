@@ -121,14 +121,27 @@ class Timers:
     the TIMED region brackets the dominant launch only and the other sections are measured in a few extra epochs
     after it."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, prealloc=0):
+        """prealloc: event pairs created AND recorded once before they are needed.  The runtime grows its pool of
+        timing events in chunks; the allocation of the second chunk stalled the queue for 33 ms in the middle of
+        whichever launch the ~32nd event of the process bracketed (ODIL_BENCH_DEBUG=1 prints the launch epoch by
+        epoch) -- with `--warmup 5 --steps 20` that is a timed epoch, +1.6 ms on the mean of 20."""
         self.pairs, self.only = {}, only
+        self.spare = []
+        for _ in range(2 * prealloc):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.spare.append(e)
+        if prealloc:
+            torch.cuda.synchronize()
+
+    def _event(self):
+        return self.spare.pop() if self.spare else torch.cuda.Event(enable_timing=True)
 
     def section(self, name):
         if self.only is not None and name not in self.only:
             return _NoEvent(), _NoEvent()
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
+        a, b = self._event(), self._event()
         self.pairs.setdefault(name, []).append((a, b))
         return a, b
 
@@ -182,10 +195,11 @@ def run_poisson(args, rank, world, dev, comm, barrier):
     else:
         run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev)
         step = lambda timers=None: run.epoch(timers)
+    # (created and primed before the warm-up: growing the runtime's event pool stalls the queue, see Timers)
+    timers = Timers(only=("adjoint_transpose", "adjoint", "adam"), prealloc=2 * args.steps + 8)
     for _ in range(args.warmup):
         step()
     barrier()
-    timers = Timers(only=("adjoint_transpose", "adjoint", "adam"))  # the candidates for the dominant launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timers)
@@ -199,6 +213,9 @@ def run_poisson(args, rank, world, dev, comm, barrier):
     wordsize = 8 if dtype == torch.float64 else 4
     kt = every.summary()
     kt.update(timers.summary())
+    if os.environ.get("ODIL_BENCH_DEBUG") and rank == 0:  # the dominant launch epoch by epoch (clock ramp, outliers)
+        for name, pairs in timers.pairs.items():
+            print(name, " ".join("%.2f" % a.elapsed_time(b) for a, b in pairs), file=sys.stderr)
     tname = "double" if wordsize == 8 else "float"
     if "adjoint_transpose" in kt:
         # Dominant kernel: stencil adjoint + first transposed prolongation + the Adam updates of levels 0 and
@@ -261,10 +278,10 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     problem = odil.Problem(veltracer3d.operator, domain, extra)
     nlvl = domain.mg_nlvl
     run = SlabTracedAdam(problem, shape_state(domain, state), rank, world, lr=a.lr, device=dev)
+    timers = Timers(only=("forward",), prealloc=args.steps + 4)
     for _ in range(args.warmup):
         run.epoch(comm)
     barrier()
-    timers = Timers(only=("forward",))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.epoch(comm, timers)
