@@ -114,7 +114,7 @@ static int field_gather(const T* src, T* out, const int64_t* sshape, int ndim, c
     set_error("field_gather: null pointer");
     return ODIL_E_INVAL;
   }
-  hipLaunchKernelGGL(k_field_gather<T>, dim3(grid_for(prod4(a.on), kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_field_gather<T>, dim3(grid_flat(prod4(a.on), kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream,
                      src, out, a);
   return check_launch("k_field_gather");
 }

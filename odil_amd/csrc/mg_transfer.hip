@@ -439,7 +439,7 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
   }
   if (a.loc[0] == kNode && a.loc[1] == kNone && a.loc[2] == kNone && a.loc[3] == kNone && a.cut_axis < 0) {
     const int64_t vol = a.cn[1] * a.cn[2] * a.cn[3];
-    hipLaunchKernelGGL(k_interp_adj_lead_node<T>, dim3(grid_for(a.cn[0] * vol, kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(k_interp_adj_lead_node<T>, dim3(grid_flat(a.cn[0] * vol, kBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, gfine, gcoarse, gscaled, a.cn[0], a.fn[0], vol, scale);
     if (int e = check_launch("k_interp_adj_lead_node")) return e;
     if (ad.x)
@@ -523,7 +523,7 @@ static int restrict_adj(const T* gcoarse, T* gfine, const int64_t* fshape, int n
     hipLaunchKernelGGL(k_restrict_adj_cells<T>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, gcoarse, gfine, a);
     return check_launch("k_restrict_adj_cells");
   }
-  hipLaunchKernelGGL(k_restrict_adj<T>, dim3(grid_for(prod4(a.fn), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_restrict_adj<T>, dim3(grid_flat(prod4(a.fn), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                      gcoarse, gfine, a);
   return check_launch("k_restrict_adj");
 }

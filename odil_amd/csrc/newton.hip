@@ -148,7 +148,7 @@ static int stencil_apply(const T* coeffs, const int64_t* shifts, int nshift, con
     set_error("stencil_apply: null pointer");
     return ODIL_E_INVAL;
   }
-  hipLaunchKernelGGL(k_stencil_apply<T>, dim3(grid_for(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_stencil_apply<T>, dim3(grid_flat(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                      coeffs, x, y, a, transpose);
   return check_launch("k_stencil_apply");
 }
@@ -162,7 +162,7 @@ static int csr_assemble(const T* coeffs, const int64_t* shifts, int nshift, cons
     set_error("csr_assemble: null pointer");
     return ODIL_E_INVAL;
   }
-  hipLaunchKernelGGL(k_csr_assemble<T>, dim3(grid_for(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_csr_assemble<T>, dim3(grid_flat(prod4(a.n), kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                      coeffs, a, col_offset, indptr, indices, data);
   return check_launch("k_csr_assemble");
 }

@@ -533,7 +533,7 @@ static int poisson_jac(T* coeffs, const int64_t* shape, int ndim, const T* h2, v
     return ODIL_E_INVAL;
   }
   const int64_t size = a.n[0] * a.n[1] * a.n[2];
-  hipLaunchKernelGGL(k_poisson_jac<T>, dim3(grid_for(size, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coeffs, a,
+  hipLaunchKernelGGL(k_poisson_jac<T>, dim3(grid_flat(size, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coeffs, a,
                      ndim, h[0], h[1], h[2]);
   return check_launch("k_poisson_jac");
 }
