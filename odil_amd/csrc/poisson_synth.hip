@@ -58,7 +58,7 @@ template <typename T, int EZ, bool JAC = false>
 __device__ inline void residual_plane(const T (&v)[3][3][3], const T (&uc)[2][2], const T (&ub)[2][2],
                                       const T (&ua)[2][2], const PackN<T, 2> (&wy)[2], const T (&wx)[2][2],
                                       const PackN<T, 2> (&r)[2], int fz, int fy0, int fx0, int FZ, int FY, int FX,
-                                      const H2<T>& h, T (&f)[2][2], const T (*wd)[2] = nullptr) {
+                                      const H2<T>& h, T (&f)[2][2], const T (*wd)[2][2] = nullptr) {
   // edge neighbours: rows 2jy-1 and 2jy+2 at the own x, columns 2jx-1 and 2jx+2 at the own rows
   T ylo[2], yhi[2], xlo[2], xhi[2];
   ylo[0] = T(1) * wy[0].e[0] + synth_val<T, EZ, -1, 0>(v);
@@ -80,27 +80,40 @@ __device__ inline void residual_plane(const T (&v)[3][3][3], const T (&uc)[2][2]
       T acc = axis_term<T>(q, ub[iy][ix], ua[iy][ix], fz == 0, fz == FZ - 1, h, 0);
       acc = acc + axis_term<T>(q, ym, yp, y == 0, y == FY - 1, h, 1);
       acc = acc + axis_term<T>(q, xm, xp, x == 0, x == FX - 1, h, 2);
-      if constexpr (JAC)
-        f[iy][ix] = q - (acc - r[iy].e[ix]) * wd[iy][ix];  // k_poisson_jacobi's expression
+      if constexpr (JAC) {  // k_poisson_jacobi's expression
+        const bool zw = fz == 0 || fz == FZ - 1, yw = y == 0 || y == FY - 1, xw = x == 0 || x == FX - 1;
+        const T w = zw ? (yw ? (xw ? wd[1][1][1] : wd[1][1][0]) : (xw ? wd[1][0][1] : wd[1][0][0]))
+                       : (yw ? (xw ? wd[0][1][1] : wd[0][1][0]) : (xw ? wd[0][0][1] : wd[0][0][0]));
+        f[iy][ix] = q - (acc - r[iy].e[ix]) * w;
+      }
       else
         f[iy][ix] = acc - r[iy].e[ix];
     }
 }
 
-// omega / diag for the 2 x 2 own cells of a plane; zmul = 1 away from the z walls, 2 on the first / last plane of the
-// array (k_poisson_jacobi: the diagonal is the sum over the axes of (-2 / h^2) (1 + walls touched)).
+// The same value in every lane, kept in scalar registers.
+__device__ __forceinline__ double uniform_value(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float uniform_value(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+
+// omega / diag by walls touched, w[z wall][y wall][x wall] (k_poisson_jacobi: the diagonal is the sum over the axes of
+// (-2 / h^2) (1 + walls touched)): eight values that are the same in every lane -- scalar registers; one set per own
+// cell in vector registers pushed this kernel over its register budget (255 + 20 spilled).
 template <typename T>
-__device__ __forceinline__ void jacobi_weights(const H2<T>& h, T omega, T zmul, int fy0, int fx0, int FY, int FX,
-                                               T (&w)[2][2]) {
-  const T dz = div_h2<T>(T(-2), h, 0) * zmul;
+__device__ __forceinline__ void jacobi_weight_table(const H2<T>& h, T omega, T (&w)[2][2][2]) {
 #pragma unroll
-  for (int iy = 0; iy < 2; ++iy)
+  for (int zw = 0; zw < 2; ++zw)
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix) {
-      const int y = fy0 + iy, x = fx0 + ix;
-      const T dy = div_h2<T>(T(-2), h, 1) * T(1 + (y == 0) + (y == FY - 1));
-      w[iy][ix] = omega / ((dz + dy) + div_h2<T>(T(-2), h, 2) * T(1 + (x == 0 || x == FX - 1)));
-    }
+    for (int yw = 0; yw < 2; ++yw)
+#pragma unroll
+      for (int xw = 0; xw < 2; ++xw) {
+        const T dz = div_h2<T>(T(-2), h, 0) * T(1 + zw), dy = div_h2<T>(T(-2), h, 1) * T(1 + yw);
+        w[zw][yw][xw] = uniform_value(omega / ((dz + dy) + div_h2<T>(T(-2), h, 2) * T(1 + xw)));
+      }
 }
 
 // JAC: one damped-Jacobi sweep of the same operator on u = w0 + P coarse instead of its residual (the first
@@ -133,8 +146,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
     const int xm = fx0 == 0 ? 0 : -1, xp = fx0 + 2 >= FX ? 1 : 2;
     // omega / diag of the four own cells on a plane away from the z walls (k_poisson_jacobi: the diagonal is
     // sum over axes of (-2 / h^2) (1 + walls touched)); the two wall planes of the array form theirs where needed
-    T wd_in[2][2];
-    if constexpr (JAC) jacobi_weights<T>(h, omega, T(1), fy0, fx0, FY, FX, wd_in);
+    T wdt[2][2][2];
+    if constexpr (JAC) jacobi_weight_table<T>(h, omega, wdt);
     T v[3][3][3];
     load_plane<T, 1>(coarse, z0 - 1, cnz, cplane, cnx, ty, tx, T(1), v[0]);
     load_plane<T, 1>(coarse, z0, cnz, cplane, cnx, ty, tx, T(1), v[1]);
@@ -187,17 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_synth(const T* __re
       synth_own<T, 2>(v, wD, uD);
       T fB[2][2], fC[2][2];
       if constexpr (JAC) {
-        if (fzB == 0 || fzC == FZ - 1) {  // (uniform) the first or the last plane of the array
-          T wdw[2][2];
-          jacobi_weights<T>(h, omega, T(2), fy0, fx0, FY, FX, wdw);
-          residual_plane<T, 0, true>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB,
-                                     fzB == 0 ? wdw : wd_in);
-          residual_plane<T, 1, true>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC,
-                                     fzC == FZ - 1 ? wdw : wd_in);
-        } else {
-          residual_plane<T, 0, true>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB, wd_in);
-          residual_plane<T, 1, true>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC, wd_in);
-        }
+        residual_plane<T, 0, true>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB, wdt);
+        residual_plane<T, 1, true>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC, wdt);
       } else {
         residual_plane<T, 0>(v, uB, uA, uC, wyB, wxB, rB, fzB, fy0, fx0, FZ, FY, FX, h, fB);
         residual_plane<T, 1>(v, uC, uB, uD, wyC, wxC, rC, fzC, fy0, fx0, FZ, FY, FX, h, fC);
