@@ -63,7 +63,7 @@ def worker(rank, world, N, epochs, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_two_ranks_equals_global_oracle(tmp_path, world):
     N, epochs = 8, 3
     port = 29500 + (os.getpid() + world) % 2000

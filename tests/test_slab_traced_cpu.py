@@ -120,7 +120,8 @@ def undivided(which, world, epochs, nx_rank=8):
 
 
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 8), ("veltracer", 3, 8), ("veltracer3d", 2, 8),
-                                                  ("veltracer", 4, 2), ("veltracer", 2, 4), ("heat2d", 2, 8)])
+                                                  ("veltracer", 4, 2), ("veltracer", 2, 4), ("heat2d", 2, 8),
+                                                  ("veltracer3d", 8, 4)])
 def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world, nx_rank):
     """nx_rank = 2, 4: the three multigrid levels (8 cells of t) leave 2, 1, 0.5 / 4, 2, 1 cells of x per rank: the
     coarsest levels are AGGLOMERATED (whole array on every rank, gradient shares summed by an all-reduce).  heat2d:
