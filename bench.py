@@ -197,6 +197,10 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         step = lambda timers=None: run.epoch(timers)
     # (created and primed before the warm-up: growing the runtime's event pool stalls the queue, see Timers)
     timers = Timers(only=("adjoint_transpose", "adjoint", "adam"), prealloc=2 * args.steps + 8)
+    import gc
+
+    gc.collect()
+    gc.disable()  # (a collection of the interpreter in the middle of the loop starves the queue: see DESIGN section 5)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -205,8 +209,9 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         step(timers)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     loss = run.last_loss(comm) if world > 1 else run.last_loss()
-    every = Timers()  # the other sections: a few epochs outside the timed region
+    every = Timers(prealloc=8 * 5)  # the other sections: a few epochs outside the timed region (events primed: see Timers)
     for _ in range(5):
         step(every)
     barrier()
@@ -279,6 +284,10 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     nlvl = domain.mg_nlvl
     run = SlabTracedAdam(problem, shape_state(domain, state), rank, world, lr=a.lr, device=dev)
     timers = Timers(only=("forward",), prealloc=args.steps + 4)
+    import gc
+
+    gc.collect()
+    gc.disable()  # (as in run_poisson)
     for _ in range(args.warmup):
         run.epoch(comm)
     barrier()
@@ -287,8 +296,9 @@ def run_tracer(args, rank, world, dev, comm, barrier):
         run.epoch(comm, timers)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     loss = run.last_loss(comm)
-    every = Timers()
+    every = Timers(prealloc=8 * 2)
     for _ in range(2):
         run.epoch(comm, every)
     barrier()
