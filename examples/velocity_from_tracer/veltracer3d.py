@@ -122,11 +122,15 @@ def main():
         from odil_amd.slab import init_distributed
         from odil_amd.slab_traced import optimize_slab
 
+        import torch.distributed as dist
+
         rank, world, _ = init_distributed()
         outdir = os.path.abspath(args.outdir)
         if rank == 0:
-            odil.setup_outdir(args)
-        else:
+            odil.setup_outdir(args)  # (may clear the directory: the other ranks touch it only after the barrier)
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
             os.makedirs(outdir, exist_ok=True)
             odil.util.set_log_file(open(os.devnull, "w"))
             args.epochs = args.epochs or args.frames * args.plot_every
@@ -134,7 +138,8 @@ def main():
         run = optimize_slab(args, problem, state)
         u_last = run.owned_arrays()[0][-1]  # finest level of u at the final time: this rank's (x, y, z) planes
         odil.write_raw_slab(u_last, os.path.join(outdir, "u_final.xmf"), rank, world, axis=0,
-                            spacing=[float(h) for h in problem.domain.step()[1:]][::-1], name="u")
+                            spacing=[float(h) for h in problem.domain.step()[1:]][::-1], name="u",
+                            barrier=dist.barrier if world > 1 else None)
         return run
     odil.setup_outdir(args)
     problem, state = make_problem(args)

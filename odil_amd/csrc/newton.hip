@@ -117,8 +117,14 @@ __global__ __launch_bounds__(kBlock) void k_stencil_march_level(const T* __restr
       stride *= a.n[d];
     }
     T acc = b[i];
-    for (int s = 0; s < a.nshift; ++s)
-      if (s != diag) acc = acc - coeffs[(int64_t)s * size + i] * x[shifted_index(a, c, s, +1)];
+    // a zero coefficient contributes nothing WHATEVER its neighbour holds: the rows at the ends of `axis` have
+    // neighbours that wrap periodically into levels not solved yet (recognise_marching only proves their
+    // coefficients zero), i.e. memory this solve has not written -- 0 * NaN must not enter the substitution
+    for (int s = 0; s < a.nshift; ++s) {
+      if (s == diag) continue;
+      const T cs = coeffs[(int64_t)s * size + i];
+      if (cs != T(0)) acc = acc - cs * x[shifted_index(a, c, s, +1)];
+    }
     x[i] = acc / coeffs[(int64_t)diag * size + i];
   }
 }

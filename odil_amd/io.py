@@ -78,13 +78,18 @@ def write_raw_with_xmf(u, xmfpath, rawpath=None, spacing=(1, 1, 1), cell=True, n
     return xmfpath
 
 
-def write_raw_slab(u_owned, xmfpath, rank, world, axis=0, rawpath=None, spacing=(1, 1, 1), cell=True, name=None):
+def write_raw_slab(u_owned, xmfpath, rank, world, axis=0, rawpath=None, spacing=(1, 1, 1), cell=True, name=None,
+                   barrier=None):
     """Slab-parallel dump: every rank of a slab decomposition (odil_amd/slab.py, slab_traced.py) writes ITS planes
     of one global field into the one `.raw` file the reference's reader expects (reference src/odil/io.py:145-167
     writes the whole array from one process), at its own offsets; rank 0 also writes the XDMF 2 description of the
     GLOBAL array.  `u_owned`: this rank's owned part (device tensor or host array, <= 3-D, the global array cut
     into `world` equal parts along `axis`).  A device tensor is copied to the host once (its owned planes only,
-    through pinned memory).  No collective is needed: the file is sized by whoever comes first."""
+    through pinned memory).  `barrier`: a callable that synchronises the ranks (`torch.distributed.barrier`).  With
+    it rank 0 creates / TRUNCATES the file first (planes of an older run of the same size cannot survive a rank that
+    fails or is late), everybody writes after a barrier, and the description appears only after a second barrier
+    -- a reader that sees the `.xmf` sees a complete `.raw`.  Without it (ranks emulated one after the other in one
+    process) the file is sized by whoever comes first and never truncated."""
     import torch
 
     if hasattr(u_owned, "detach"):
@@ -113,18 +118,31 @@ def write_raw_slab(u_owned, xmfpath, rank, world, axis=0, rawpath=None, spacing=
     if rawpath is None:
         rawpath = os.path.splitext(xmfpath)[0] + ".raw"
     nbytes = int(np.prod(count)) * u.dtype.itemsize
-    fd = os.open(rawpath, os.O_RDWR | os.O_CREAT, 0o644)
-    try:
-        if os.fstat(fd).st_size != nbytes:
-            os.ftruncate(fd, nbytes)  # same size from every rank: whoever comes first
-    finally:
-        os.close(fd)
+    if barrier is not None:
+        if rank == 0:
+            fd = os.open(rawpath, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                os.ftruncate(fd, nbytes)
+            finally:
+                os.close(fd)
+            if os.path.exists(xmfpath):
+                os.unlink(xmfpath)  # (the description of the previous dump goes before its data does)
+        barrier()
+    else:
+        fd = os.open(rawpath, os.O_RDWR | os.O_CREAT, 0o644)
+        try:
+            if os.fstat(fd).st_size != nbytes:
+                os.ftruncate(fd, nbytes)  # same size from every rank: whoever comes first
+        finally:
+            os.close(fd)
     out = np.memmap(rawpath, dtype=u.dtype, mode="r+", shape=tuple(count))
     sel = [slice(None)] * 3
     sel[axis3] = slice(rank * n, (rank + 1) * n)
     out[tuple(sel)] = u
     out.flush()
     del out
+    if barrier is not None:
+        barrier()
     if rank == 0:
         rel = os.path.relpath(rawpath, start=os.path.dirname(xmfpath) or ".")
         write_raw_xmf(xmfpath, rel, count, spacing, name or "data", 4 if u.dtype == np.float32 else 8, cell)

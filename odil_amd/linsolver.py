@@ -153,10 +153,14 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
         op_s.blocks = stencil_blocks
         dt = daug.t().contiguous()  # (p + 1) x rows: the columns of [D | r] as contiguous vectors
         cz = torch.stack([op_s.rmatvec(dt[j]) for j in range(p + 1)])  # rows: C_j = S^T D_j, last: S^T r
-        sub = dict()
-        zs = torch.stack([cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j])
-                          for j in range(p + 1)])
-        niter = sub.get("niter", 0)
+        zs, niter, worst = [], 0, 0.0
+        for j in range(p + 1):
+            sub = dict()
+            zs.append(cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j]))
+            niter = max(niter, sub.get("niter", 0))
+            worst = max(worst, sub.get("residual", 0.0))
+        zs = torch.stack(zs)
+        info.update(inner_solves=p + 1, inner_residual_max=worst)  # (an inner solve cut short by maxiter shows here)
         ct = cz[:p].t().contiguous()  # unknowns x p
         zt = zs.t().contiguous()      # unknowns x (p + 1)
         czz = ops.dense_xty(ct, zt)   # C^T [Z | z]
@@ -230,6 +234,7 @@ def march_solve(rec, rhs, status=None):
     return x.reshape(-1)
 
 
+SCHUR_MIN_UNKNOWNS = 16384  # systems with dense columns: Schur complement above this size, dense Cholesky below
 DENSE_MAX_UNKNOWNS = 49152  # `direct` factorises the dense normal matrix up to here, memory permitting
 
 
@@ -311,10 +316,19 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
     if not damp and not dampdiag and linsolver in ("direct", "directsq", "multigrid"):
         rec = recognise_marching(matr)
         if rec is not None:
-            return march_solve(rec, rhs, status)
+            x = march_solve(rec, rhs, status)
+            if bool(torch.isfinite(x).all()):
+                return x
+            # (a singular diagonal block met on the way: the general solvers below regularise or report it)
     if linsolver in ("direct", "directsq"):
-        if any(kind == "dense" for _, _, kind, _, _ in matr.blocks):
-            x = schur_normal(matr, rhs, damp, dampdiag, maxiter=maxiter, status=status)
+        has_dense = any(kind == "dense" for _, _, kind, _, _ in matr.blocks)
+        # small systems: ONE dense Cholesky of the normal matrix beats the p + 1 inner CG solves of the Schur route
+        small = _dense_fits(matr) and matr.ncols <= SCHUR_MIN_UNKNOWNS
+        if has_dense and not small:
+            try:
+                x = schur_normal(matr, rhs, damp, dampdiag, maxiter=maxiter, status=status)
+            except FloatingPointError:  # an inner CG solve broke down: the dense / CG routes below still apply
+                x = None
             if x is not None and bool(torch.isfinite(x).all()):
                 return x
         if _dense_fits(matr):

@@ -79,6 +79,17 @@ __device__ inline T2 odil_fast_tanh2(T2 x) {  // two lanes: the arithmetic packs
   const T2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
   return 1.0f - 2.0f * r;
 }
+// tanh of USER expressions in float kernels: the same exp2 / rcp form away from zero, the odd series below |x| = 0.1
+// (1 - 2 / (e^2x + 1) cancels there: absolute error 1e-7 is a relative error of 1e-3 at |x| = 1e-4; the series'
+// next term, 17 x^6 / 315, is 5e-8 relative at 0.1).  The hidden-layer activations of pointwise networks keep the
+// bare form above: their arguments are O(1) sums and their values enter O(1) sums.
+__device__ inline float odil_tanh_f32(float x) {
+  const float ax = __builtin_fabsf(x), x2 = x * x;
+  const float e = __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f);
+  const float far = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float near = ax * (1.0f + x2 * (-0.33333333333333333f + x2 * 0.13333333333333333f));
+  return __builtin_copysignf(ax < 0.1f ? near : far, x);
+}
 __device__ inline T2 odil_step2(T2 h) { T2 r = {h.x > 0.0f ? 1.0f : 0.0f, h.y > 0.0f ? 1.0f : 0.0f}; return r; }
 """
 
@@ -492,7 +503,8 @@ class _Codegen:
     def _act(self, kind, x, width=1):
         if width == 2:
             return {"tanh": "odil_fast_tanh2({})", "relu": "__builtin_elementwise_max({}, (T2)(0.0f))", "none": "{}"}[kind].format(x)
-        return {"tanh": "FN(tanh)({})", "relu": "({0} > (T)0 ? {0} : (T)0)", "none": "{}"}[kind].format(x)
+        tanh = "odil_fast_tanh({})" if self.fast else "FN(tanh)({})"  # (network activations: see the prelude)
+        return {"tanh": tanh, "relu": "({0} > (T)0 ? {0} : (T)0)", "none": "{}"}[kind].format(x)
 
     def _emit_mlp(self, n):
         if n.idx in self.partner and n.idx not in self.pair_first:
@@ -772,7 +784,7 @@ class _Codegen:
         fn = "name" if T == "double" else "name##f"
         S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
-            S.append("#define tanhf odil_fast_tanh\n#define expf odil_fast_exp")
+            S.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
         nsrc = max(1, len(self.src_keys))
         slab_members = ""
         if self.slab is not None:

@@ -125,3 +125,39 @@ def test_slab_parallel_dump_equals_whole_array_dump(tmp_path, axis, world):
     assert open(tmp_path / "whole.xmf").read().replace("whole.raw", "slab.raw") == open(tmp_path / "slab.xmf").read()
     got, meta = io.read_raw_with_xmf(str(tmp_path / "slab.xmf"))
     assert np.array_equal(got, u) and meta["name"] == "u"
+
+
+def test_slab_parallel_dump_with_a_barrier_replaces_a_stale_file(tmp_path):
+    """With `barrier` rank 0 truncates the shared file before anybody writes and the description appears after
+    everybody has: a stale dump of the same size cannot leak planes, whatever order the ranks arrive in."""
+    import threading
+
+    from odil_amd import io
+
+    world, axis = 3, 1
+    rng = np.random.default_rng(4)
+    stale = rng.standard_normal((4, 6, 8)).astype(np.float32)
+    u = rng.standard_normal((4, 6, 8)).astype(np.float32)
+    path = str(tmp_path / "slab.xmf")
+    io.write_raw_with_xmf(stale, path, spacing=(0.1, 0.2, 0.3), name="u")
+    n = u.shape[axis] // world
+    bar = threading.Barrier(world)
+    seen = []
+
+    def rank_main(rank):
+        part = np.take(u, np.arange(rank * n, (rank + 1) * n), axis=axis)
+        if rank == 0:  # (the truncating rank arrives last)
+            import time
+
+            time.sleep(0.2)
+        io.write_raw_slab(part, path, rank, world, axis=axis, spacing=(0.1, 0.2, 0.3), name="u", barrier=bar.wait)
+        seen.append(rank)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(seen) == list(range(world))
+    got, _ = io.read_raw_with_xmf(path)
+    assert np.array_equal(got, u)
