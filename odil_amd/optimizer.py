@@ -164,8 +164,12 @@ class AdamNativeOptimizer(Optimizer):
         self.mod = mod
 
     def run(self, x0, loss_grad, epochs=None, callback=None, lr=1e-3, epoch_start=0, beta_1=0.9, beta_2=0.999,
-            epsilon=1e-7, jit=True, **kwargs):
-        """Keras-convention Adam (epsilon outside the sqrt), reference optimizer.py:286-341."""
+            epsilon=1e-7, jit=True, moments=None, steps_done=0, **kwargs):
+        """Keras-convention Adam (epsilon outside the sqrt), reference optimizer.py:286-341.
+
+        Beyond the reference: `moments=(m, v)` (lists shaped like x0) and `steps_done` resume a run where another
+        left it -- the reference restarts m = v = 0 and the bias correction with every call (optimizer.py:327-334),
+        which is what the defaults do.  The final moments are returned in `optinfo.m / optinfo.v`."""
         tdtype = x0[0].dtype
         npdt = np.float64 if tdtype == torch.float64 else np.float32
         lr, beta_1, beta_2 = npdt(lr), npdt(beta_1), npdt(beta_2)
@@ -175,6 +179,9 @@ class AdamNativeOptimizer(Optimizer):
         vf = torch.zeros_like(xf)
         mviews = [t.view(a.shape) for t, a in zip(mf.split([a.numel() for a in x]), x)]
         vviews = [t.view(a.shape) for t, a in zip(vf.split([a.numel() for a in x]), x)]
+        if moments is not None:
+            copy_into(mf, mviews, moments[0])
+            copy_into(vf, vviews, moments[1])
         scratch = dict(gf=None, gviews=None)
 
         def step(alpha):
@@ -201,7 +208,7 @@ class AdamNativeOptimizer(Optimizer):
             return pinfo
 
         def step_size(epoch):
-            t = npdt(epoch - epoch_start)
+            t = npdt(epoch - epoch_start + steps_done)
             return lr * np.sqrt(1 - beta_2**t) / (1 - beta_1**t)  # optimizer.py:313-315
 
         first, last = epoch_start + 1, epoch_start + epochs
@@ -236,6 +243,7 @@ class AdamNativeOptimizer(Optimizer):
         optinfo = Namespace()
         optinfo.epochs = epochs
         optinfo.evals = self.evals
+        optinfo.m, optinfo.v = mviews, vviews
         return x, optinfo
 
 
@@ -503,6 +511,10 @@ class LbfgsVectors:
         out = ops.dots3(self.w[: 2 * nphys], bs).cpu().numpy()[: len(bs)]
         return out[:, 0::2], out[:, 1::2]
 
+    def dot(self, a, b):
+        """<a, b> on the host (warm start of the memory only: not on the per-iteration path)."""
+        return float(ops.dots3(a[None], [b]).cpu().numpy()[0, 0])
+
     def history_lincomb(self, y, nphys, cs, cy):
         """y += sum_k cs[k] s_k + cy[k] y_k in one pass over the history."""
         if nphys == 0:
@@ -515,7 +527,8 @@ class LbfgsVectors:
         ops.lincomb(y, 1.0, self.w[: 2 * nphys], self.coef[: 2 * nphys])
 
 
-def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, maxfun=math.inf, callback=None):
+def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, maxfun=math.inf, callback=None,
+                    history=None):
     """L-BFGS-B 3.0 without bounds.  `x`: flat vector (updated in place); `fg(x) -> (f, g)`
     with g written/returned as a flat vector (f may stay on the device: it reaches the host through
     `vec.read_probes`); `vec`: vector backend.  Returns dict(task, warnflag, nit, funcalls, f).
@@ -524,7 +537,12 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
     max |g| together with the <d, d> and <g_old, d> of the direction), once after the pass over the
     history that forms the new rows of S^T Y, S^T S, Y^T Y.  From the second iteration on the first
     trial step is 1, so the first evaluation of a line search is launched before <g_old, d> is
-    known; a non-descent direction (never seen with a positive-definite memory) discards it."""
+    known; a non-descent direction (never seen with a positive-definite memory) discards it.
+
+    `history`: warm start -- [(s_i, y_i, <g_i, s_i>)] oldest first, the correction pairs of earlier iterations
+    (s_i = x_{i+1} - x_i, y_i = g_{i+1} - g_i): they pass through the same acceptance test and matrix update as
+    pairs formed here, and the first line search starts from step 1 as every iteration but the very first does.
+    (Resuming a run; the teacher-forced parity test hands over the reference's own iterates this way.)"""
     from scipy.linalg import solve_triangular
 
     epsmch = np.finfo(np.float64).eps
@@ -551,6 +569,38 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
         vec.probe_eval(fobj, g, d)
 
     pending = None  # (Y^T g, S^T g) for the next direction, when already known
+
+    def push_pair(s, y, dr, ss_new):
+        """matupd: the accepted pair (s, y), dr = <s, y>, enters the memory; one pass over the history gives the new
+        rows of S^T Y, S^T S, Y^T Y and, for the next direction, S^T g and Y^T g (the history is the dominant
+        traffic of an iteration)."""
+        nonlocal col, theta, pending
+        if col < m:
+            slot = col
+            slots.append(slot)
+            col += 1
+        else:
+            slot = slots.pop(0)
+            slots.append(slot)
+            sy[:-1, :-1] = sy[1:, 1:]
+            ss[:-1, :-1] = ss[1:, 1:]
+            yy[:-1, :-1] = yy[1:, 1:]
+        vec.store_pair(slot, s, y)
+        (s_y, s_s, s_g), (y_y, y_s, y_g) = vec.history_products(len(slots), [y, s, g])
+        pending = (y_g, s_g)
+        rr = float(y_y[slot])  # y_new . y_new is one of the products of that pass: no separate reduction
+        theta = rr / dr
+        c = col - 1
+        order = np.asarray(slots)
+        idx = np.arange(col)
+        sy[idx, c] = s_y[order]
+        sy[c, idx] = y_s[order]
+        ss[idx, c] = ss[c, idx] = s_s[order]
+        yy[idx, c] = yy[c, idx] = y_y[order]
+        sy[c, c] = dr
+        ss[c, c] = float(s_s[slot]) if ss_new is None else ss_new
+        yy[c, c] = rr
+
     fobj, gnew = fg(x)
     vec.copy(g, gnew)
     nfev += 1
@@ -558,6 +608,14 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
     _, _, _, sbgnrm, f = vec.read_probes()
     if sbgnrm <= pgtol:
         return dict(task="CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL", warnflag=0, nit=0, funcalls=nfev, f=f)
+    first = True  # the very first line search of a cold start scales its trial step by 1 / |d|
+    for s_old, y_old, gs_old in history or []:
+        first = False
+        s_y = vec.dot(s_old, y_old)
+        if s_y <= epsmch * (-float(gs_old)):
+            nskip += 1
+            continue
+        push_pair(s_old, y_old, s_y, None)
 
     while True:
         # ---- search direction d = -B^{-1} g (compact representation) --------------------
@@ -592,7 +650,8 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
         fold = f
         stpmx = big
         launched = False
-        if nit == 0:
+        if first:
+            first = False
             dtd, gd = vec.read_probes()[:2]
             stp = min(1.0 / math.sqrt(dtd), stpmx)
         else:
@@ -664,33 +723,7 @@ def lbfgsb_minimize(x, fg, vec, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0,
             nskip += 1
             pending = None
             continue
-        if col < m:
-            slot = col
-            slots.append(slot)
-            col += 1
-        else:
-            slot = slots.pop(0)
-            slots.append(slot)
-            sy[:-1, :-1] = sy[1:, 1:]
-            ss[:-1, :-1] = ss[1:, 1:]
-            yy[:-1, :-1] = yy[1:, 1:]
-        vec.store_pair(slot, d, r)
-        # one pass over the history gives the new rows of S^T Y, S^T S, Y^T Y and, for the next direction,
-        # S^T g and Y^T g (the history is the dominant traffic of an iteration)
-        (s_y, s_s, s_g), (y_y, y_s, y_g) = vec.history_products(len(slots), [r, d, g])
-        pending = (y_g, s_g)
-        rr = float(y_y[slot])  # y_new . y_new is one of the products of that pass: no separate reduction
-        theta = rr / dr
-        c = col - 1
-        order = np.asarray(slots)
-        idx = np.arange(col)
-        sy[idx, c] = s_y[order]
-        sy[c, idx] = y_s[order]
-        ss[idx, c] = ss[c, idx] = s_s[order]
-        yy[idx, c] = yy[c, idx] = y_y[order]
-        sy[c, c] = dr
-        ss[c, c] = stp * stp * dtd if stp != 1.0 else dtd
-        yy[c, c] = rr
+        push_pair(d, r, dr, stp * stp * dtd if stp != 1.0 else dtd)
 
 
 class LbfgsbOptimizer(Optimizer):

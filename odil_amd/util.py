@@ -345,10 +345,11 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
     return domain.arrays_from_state(state), argparse.Namespace(epochs=args.epochs, evals=args.epochs)
 
 
-def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
-    """Gradient-based optimisation (reference util.py:190-240)."""
+def make_loss_grad(problem, state):
+    """The `loss_grad(arrays) -> (loss, grads, pinfo)` callable the optimizers drive (reference util.py:197-206),
+    with this package's hooks attached: `fused_adam` (update inside the gradient launches), `graph_safe` /
+    `graph_begin` / `refresh` / `graph_end` (epochs replayed as a hipGraph)."""
     domain = problem.domain
-    mod = domain.mod
 
     def loss_grad(arrays):
         domain.arrays_to_state(arrays, state)
@@ -384,6 +385,14 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
     # replayed epochs: host scalars of a traced operator travel as rows of a device table (stencil_jit.py)
     loss_grad.graph_begin, loss_grad.refresh, loss_grad.graph_end = (
         graph_hook("graph_begin"), graph_hook("graph_upload"), graph_hook("graph_end"))
+    return loss_grad
+
+
+def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
+    """Gradient-based optimisation (reference util.py:190-240)."""
+    domain = problem.domain
+    mod = domain.mod
+    loss_grad = make_loss_grad(problem, state)
 
     def callback_wrap(arrays, epoch, pinfo):
         domain.arrays_to_state(arrays, state)

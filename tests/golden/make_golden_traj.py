@@ -104,9 +104,88 @@ def lbfgsb_pair():
     save("traj_lbfgsb_2d_N32_pair", **data)
 
 
+def adam_states(ndim, N, epochs, sample):
+    """Teacher-forcing fixture: the reference optimizer's OWN state (x, m, v) at the start of the sampled epochs k
+    and k + 1 and the loss of every epoch, so that ONE epoch of an implementation started from the reference's
+    state at k can be compared with the reference's state at k + 1 -- every sampled epoch is pinned at round-off
+    level, with no amplification along the trajectory.  m and v are locals of the reference's `run`
+    (optimizer.py:327-335); they are read from its frame when it calls `loss_grad`, the reference code itself is
+    not touched."""
+    import sys
+
+    domain, state, extra = make_poisson(ndim, N)
+    want = sorted(set(sample) | {k + 1 for k in sample})
+    data = dict(ndim=np.array(ndim), N=np.array(N), lr=np.array(0.005), epochs=np.array(epochs),
+                rhs=npy(extra.rhs), sample=np.array(sorted(sample)))
+    losses = []
+
+    def loss_grad(arrays):
+        frame = sys._getframe(1)
+        assert frame.f_code.co_name == "run" and "m" in frame.f_locals and "v" in frame.f_locals
+        k = len(losses) + 1  # the epoch about to be evaluated (1-based, = the reference's local_epoch)
+        if k in want:
+            for name in ("x", "m", "v"):
+                for i, a in enumerate(frame.f_locals[name]):
+                    data[f"{name}{i}_e{k}"] = npy(a).copy()
+        loss, grads, terms, _ = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+        losses.append(float(loss))
+        return loss, grads, None
+
+    opt = odil.optimizer.AdamNativeOptimizer(dtype=np.float64, mod=mod)
+    opt.run(domain.arrays_from_state(state), loss_grad, epochs=epochs, lr=0.005, jit=False)
+    data["losses"] = np.array(losses)
+    ref = load_losses(f"traj_adam_{ndim}d_N{N}")
+    assert np.array_equal(ref[: len(losses)], data["losses"]), "not the run the trajectory fixture holds"
+    save(f"traj_adam_states_{ndim}d_N{N}", **data)
+
+
+def lbfgsb_iterates():
+    """Teacher-forcing fixture for L-BFGS-B: EVERY iterate x_k of the reference run `a` of lbfgsb_pair() (the
+    arrays the reference's callback receives, optimizer.py:84-88).  The limited-memory pairs of iteration k are
+    s_i = x_{i+1} - x_i, y_i = g(x_{i+1}) - g(x_i), i < k: an implementation handed that history and x_k must
+    produce the reference's x_{k+1} -- one iteration at a time, far beyond the 18 iterations over which two
+    reference runs agree with each other."""
+    import os
+
+    pair = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traj_lbfgsb_2d_N32_pair.npz"))
+    domain, state, extra = make_poisson(2, 32)
+    nlvl = len(domain.arrays_from_state(state))
+    start = [pair[f"start{i}"] for i in range(nlvl)]
+    epochs = int(pair["epochs"])
+    evals, iters, xs = [], [], [np.concatenate([a.ravel() for a in start])]
+
+    def loss_grad(arrays):
+        loss, grads, terms, _ = ref_loss_grad(domain, state, extra, poisson.operator, arrays)
+        evals.append(float(loss))
+        return loss, grads, None
+
+    def callback(arrays, epoch, pinfo):
+        iters.append(evals[-1])
+        xs.append(np.concatenate([npy(a).ravel() for a in arrays]))
+
+    opt = odil.optimizer.LbfgsbOptimizer(dtype=np.float64, mod=mod, m=50, maxls=50)
+    try:
+        opt.run([T(a) for a in start], loss_grad, epochs=epochs, callback=callback)
+    except odil.EarlyStopError as e:
+        print("early stop", e)
+    assert np.array_equal(np.array(iters), pair["iter_losses_a"]), "not the run the pair fixture holds"
+    save("traj_lbfgsb_2d_N32_iterates", x=np.array(xs), iter_losses=np.array(iters), evals_per_iter=np.array(len(evals)),
+         rhs=npy(extra.rhs), m=np.array(50), maxls=np.array(50), shapes=np.array([a.shape for a in start]))
+
+
+def load_losses(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"))["losses"]
+
+
 if __name__ == "__main__":
     adam_traj(1, 256, 400)
     adam_traj(2, 32, 300)
     adam_traj(3, 16, 100)
     gd_traj()
     lbfgsb_pair()
+    adam_states(1, 256, 400, [1, 2, 3, 5, 8, 12, 16, 20, 24, 25, 26, 30] + list(range(40, 400, 13)))
+    adam_states(2, 32, 300, [1, 2, 3, 10, 50, 100, 124, 125, 126, 150, 200, 250, 299])
+    adam_states(3, 16, 100, [1, 2, 50, 99])
+    lbfgsb_iterates()

@@ -53,6 +53,9 @@ class NumpyVectors:
         out = np.array([self.w[: 2 * nphys] @ b for b in bs]).reshape(len(bs), 2 * nphys)
         return out[:, 0::2], out[:, 1::2]
 
+    def dot(self, a, b):
+        return float(a @ b)
+
     def history_lincomb(self, y, nphys, cs, cy):
         if nphys:
             c = np.zeros(2 * nphys)
@@ -119,3 +122,65 @@ def test_poisson_multigrid_iterates_match_scipy_and_golden():
     # iteration 3, 1e-10 at 12): the first 12 iterations are compared at the 1e-6 tolerance
     assert rel[:12].max() < 1e-6, rel
     assert res["nit"] == int(g["epochs"]) and res["warnflag"] == 1
+
+
+def teacher_forced_lbfgsb(fun, xs, vec_factory, ks, m=50):
+    """One iteration of `lbfgsb_minimize` from the reference's iterate x_k with the memory built from the
+    reference's own earlier iterates (s_i = x_{i+1} - x_i, y_i = g(x_{i+1}) - g(x_i), i < k; at most the last m):
+    -> [(k, max |x_{k+1} - x_ref_{k+1}| / max |x_ref_{k+1} - x_ref_k|)] -- the error of the STEP, so that a wrong
+    direction or step length cannot hide behind the size of x."""
+    grads = dict()
+
+    def grad(i):
+        if i not in grads:
+            grads[i] = np.array(fun(xs[i].copy())[1], dtype=np.float64)
+        return grads[i]
+
+    out = []
+    for k in ks:
+        lo = max(0, k - m)
+        history = []
+        for i in range(lo, k):
+            s_i = xs[i + 1] - xs[i]
+            history.append((s_i, grad(i + 1) - grad(i), float(grad(i) @ s_i)))
+        vec, to, back = vec_factory()
+        x = to(xs[k].copy())
+        lbfgsb_minimize(x, lambda v: fun_on(fun, v, to, back), vec, maxiter=1, m=m, maxls=50, pgtol=1e-16, factr=0.0,
+                        history=[(to(a), to(b), c) for a, b, c in history])
+        step = np.max(np.abs(xs[k + 1] - xs[k]))
+        out.append((k, float(np.max(np.abs(back(x) - xs[k + 1])) / step)))
+    return out
+
+
+def fun_on(fun, v, to, back):
+    f, g = fun(back(v))
+    return f, to(np.asarray(g, dtype=np.float64))
+
+
+def poisson_fun(rhs):
+    cshape = rhs.shape
+    dw = onp.step(cshape)
+    shapes = onp.mg_cshapes(cshape)
+    sizes = [int(np.prod(s)) for s in shapes]
+
+    def fun(x):
+        terms = [a.reshape(s) for a, s in zip(np.split(np.asarray(x), np.cumsum(sizes)[:-1]), shapes)]
+        loss, grads, _ = onp.poisson_loss_grad(terms, rhs, dw)
+        return float(loss), np.concatenate([a.ravel() for a in grads])
+
+    return fun
+
+
+def test_every_lbfgsb_iteration_of_the_reference_teacher_forced():
+    """Beyond the 18 iterations over which two reference runs agree with each other (test_trajectories.py): each of
+    the reference's 60 iterations reproduced ONE AT A TIME from the reference's own iterates.  The step
+    x_{k+1} - x_k is reproduced to 1e-10 of its size at every k (measured: 6e-14) (compact-representation direction, More'-Thuente
+    step length, acceptance of pairs) -- there is no trajectory along which a rounding difference could grow."""
+    g = load_golden("traj_lbfgsb_2d_N32_iterates")
+    xs = g["x"]
+    fun = poisson_fun(g["rhs"])
+    n = xs.shape[1]
+    res = teacher_forced_lbfgsb(fun, xs, lambda: (NumpyVectors(n, 50), (lambda a: a), (lambda a: a)),
+                                range(0, len(xs) - 1))
+    worst = max(e for _, e in res)
+    assert len(res) == 60 and worst < 1e-10, sorted(res, key=lambda r: -r[1])[:5]
