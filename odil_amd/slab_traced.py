@@ -122,7 +122,7 @@ class HipSlabKernels:
         self.dtype = dt
         self.total = cg.total
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
-        self.nblocks = min((self.total + 255) // 256, cap)
+        self.nblocks = min((self.total // cg.vw + 255) // 256, cap)
         nout = len(outs)
         self.nout = nout
         self.cot = [torch.empty(cg.GL, dtype=dt, device=device) for _ in range(cg.ncot)]

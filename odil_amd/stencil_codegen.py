@@ -14,6 +14,7 @@ import tempfile
 import numpy as np
 import torch
 
+from . import stencil_grad
 from .stencil_trace import _B, _CMP, _I, _R, TraceUnsupported, _promote
 
 _CACHE_DIR = os.environ.get("ODIL_JIT_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_jit_cache"))
@@ -57,6 +58,23 @@ __device__ inline void adam_apply(const AdamP& ad, int l, T g) {
   const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
   x = x - (m * alpha) / (FN(sqrt)(v) + ad.eps);
   ad.m[l] = m, ad.v[l] = v, ad.x[l] = x;
+}
+// Four consecutive points of the last axis per thread (VW == 4): 16-byte accesses (two for doubles).  The type is
+// aligned like its element: rows and arrays packed back to back in one buffer need not start on 16 bytes, and
+// gfx950 takes unaligned dwordx4 accesses.
+typedef T T4a __attribute__((ext_vector_type(4)));
+typedef T4a T4 __attribute__((aligned(sizeof(T))));
+__device__ inline void adam_apply4(const AdamP& ad, int l, const T* g) {
+  if (!ad.x) return;
+  T4 m = *(const T4*)(ad.m + l), v = *(const T4*)(ad.v + l), x = *(const T4*)(ad.x + l);
+  const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    m[p] = m[p] + (g[p] - m[p]) * ad.omb1;
+    v[p] = v[p] + (g[p] * g[p] - v[p]) * ad.omb2;
+    x[p] = x[p] - (m[p] * alpha) / (FN(sqrt)(v[p]) + ad.eps);
+  }
+  *(T4*)(ad.m + l) = m, *(T4*)(ad.v + l) = v, *(T4*)(ad.x + l) = x;
 }
 // Float transcendentals of the float kernels.  The library tanhf is ~30 instructions with two divergent branches;
 // a traced operator with a pointwise network evaluates it 40 times per grid point (heat with two space dimensions:
@@ -174,9 +192,16 @@ class _Codegen:
         if self.fast and int(os.environ.get("ODIL_TRACE_PAIR_MLP", 1)):
             self._pair_mlps()
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
-        self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
         self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
         self.out_count = [int(np.prod(l)) if l is not None else int(np.prod(self.G)) for l in self.out_lens]  # GLOBAL counts
+        # four points of the last axis per thread, 16-byte accesses (ODIL_TRACE_VEC=0: one point per thread)
+        last = self.ndim - 1
+        self.vw = 4 if (int(os.environ.get("ODIL_TRACE_VEC", 1)) and self.GL[last] % 4 == 0 and self.GL[last] >= 8
+                        and slab is None) else 1
+        self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
+        self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
+        self.out_mode = self._choose_output_cuts()
+        self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
 
     def _needs_grad(self):
         need = dict()
@@ -239,10 +264,17 @@ class _Codegen:
             for a in n.args:
                 consumers.setdefault(a.idx, []).append(n)
         outputs = {o.idx for o in self.outputs}
+        # nodes only the recomputed outputs reach are never visited by k_fwd's reverse pass
+        legacy_live, stack = set(), [o for k, o in enumerate(self.outputs) if self.out_mode[k] == "legacy"]
+        while stack:
+            n = stack.pop()
+            if n.idx not in legacy_live:
+                legacy_live.add(n.idx)
+                stack.extend(n.args)
         cuts = dict()
         for n in self.order:
             form = self._affine(n, memo)
-            if n.op == "read" or not form or len(form) < 2 or n.kind != _R:
+            if n.op == "read" or not form or len(form) < 2 or n.kind != _R or n.idx not in legacy_live:
                 continue
             outside = n.idx in outputs or any(self._affine(c, memo) is None for c in consumers.get(n.idx, []))
             if outside:
@@ -261,9 +293,78 @@ class _Codegen:
                     break
         return cuts
 
+    # ---- cotangents cut at the OUTPUTS, local Jacobians re-evaluated by the gathers (stencil_grad.py) ---------
+    def _regular(self, n):
+        """A read the symbolic gathers can shift: same location and shape as its field, on the grid itself."""
+        key, _, loc, _ = n.attr
+        return loc == self.state.fields[key].loc and tuple(self._field_shape(key)) == self.G
+
+    def _choose_output_cuts(self):
+        """Per output: 'legacy' (k_fwd differentiates it down to its reads / affine cuts and stores those cotangents),
+        'jac' (its adjoint -- the seed 2 f / n -- is stored ONCE; every gather re-evaluates d f / d read at the
+        neighbouring points from the source fields) or 'virt' (nothing stored: the gathers re-evaluate the output
+        itself too; for outputs that read a few values -- imposed values, a time difference)."""
+        nout = len(self.outputs)
+        mode = ["legacy"] * nout
+        self.seed_key = [None] * nout
+        self.out_adj = [None] * nout  # jac / virt: {read idx: adjoint expression at the point of evaluation}
+        # pad / trim reads ('c' fields read at 'n' and back) keep the legacy gathers: one such read anywhere and
+        # the whole operator stays with them
+        self.all_regular = all(self._regular(n) for n in self.order if n.op == "read")
+        if not int(os.environ.get("ODIL_TRACE_RECOMPUTE", 1)) or self.slab is not None or not self.all_regular:
+            return mode
+        virt_max = int(os.environ.get("ODIL_TRACE_VIRT_MAX", 12))
+        used = {a.idx for n in self.order for a in n.args}
+        self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
+        out_ids = [o.idx for o in self.outputs]
+        for k, o in enumerate(self.outputs):
+            if not self.need.get(o.idx, False) or o.idx in used or out_ids.count(o.idx) != 1:
+                continue
+            nodes = stencil_grad.subdag(o)
+            live = [n for n in nodes if n.op == "read" and self.need.get(n.idx, False)]
+            if not live or not stencil_grad.differentiable(nodes, self.need) or not all(self._regular(n) for n in live):
+                continue
+            gb = stencil_grad.GradBuilder(self.tr, self.G, self.need, stop=())
+            loads, heavy = stencil_grad.cost([n for n in nodes if not n.host])
+            shifts = {(n.attr[0], n.attr[1]) for n in live}
+            virt = heavy == 0 and loads * len(shifts) <= virt_max
+            scale = (1.0 if self.raw[k] else 2.0) / self.out_count[k]
+            try:
+                if virt:
+                    seed = gb.const(scale) if self.raw[k] else gb.mul(gb.real(o), gb.const(scale))
+                else:
+                    key = "@o{}".format(k)
+                    self.tr.state_locs[key] = self.gloc
+                    seed = self.tr.node("read", attr=(key, (0,) * self.ndim, self.gloc, True), shape=self.G, kind=_R)
+                if virt and self.out_lens[k] is not None:
+                    inbox = None
+                    for d in range(self.ndim):
+                        if self.out_lens[k][d] < self.G[d]:
+                            idx = self.tr.node("index", attr=(d, self.gloc), shape=self.G, kind=_I)
+                            c = gb.cmp("lt", idx, self.tr.const(int(self.out_lens[k][d])))
+                            inbox = c if inbox is None else gb._node("and", (inbox, c), kind=_B)
+                    if inbox is not None:
+                        seed = gb.where(inbox, seed, None)
+                adj = gb.adjoints(o, seed, nodes)
+            except TraceUnsupported:
+                continue
+            if not virt:
+                # a Jacobian that needs transcendentals at every neighbour costs more than the arrays it saves
+                extra = set()
+                for e in adj.values():
+                    extra.update(n.idx for n in stencil_grad.subdag(e) if not n.host)
+                jheavy = stencil_grad.cost([self.tr.nodes[i] for i in extra])[1]
+                if jheavy > int(os.environ.get("ODIL_TRACE_JAC_HEAVY_MAX", 0)):
+                    continue
+            mode[k] = "virt" if virt else "jac"
+            self.seed_key[k] = None if virt else key
+            self.out_adj[k] = adj
+        return mode
+
     def _stored_arrays(self, cuts):
         """How many cotangent arrays the reverse pass stores for a given set of cut nodes."""
-        reached = {o.idx for o in self.outputs if self.need.get(o.idx, False)}
+        reached = {o.idx for k, o in enumerate(self.outputs)
+                   if self.need.get(o.idx, False) and self.out_mode[k] == "legacy"}
         stored = 0
         for n in reversed(self.order):
             if n.idx not in reached:
@@ -283,6 +384,9 @@ class _Codegen:
         if n.op == "const":
             return _lit(n.attr, n.kind)
         if n.host:
+            if n.idx not in self.hs_slot:  # (host scalars of the gradient expressions: met after the forward pass)
+                self.hs_slot[n.idx] = len(self.hs)
+                self.hs.append(n)
             e = "HS({})".format(self.hs_slot[n.idx])
             return {"r": "((T){})", "i": "((long){})", "b": "({} != 0.0)"}[n.kind].format(e)
         return "v{}".format(n.idx)
@@ -333,38 +437,118 @@ class _Codegen:
         return e
 
     # ---- forward ----------------------------------------------------------------------------
+    def _source_of(self, key):
+        """(pointer expression, array shape, location) of a field's regular array, or of a stored adjoint array
+        ('@...' pseudo-fields of the gradient expressions: on the grid itself)."""
+        if key.startswith("@"):
+            return "a.cot[{}]".format(self.pseudo_slot[key]), self.GL, self.gloc
+        return "a.src[{}]".format(self._src_slot(key)), self._field_shape(key), self.state.fields[key].loc
+
+    def _begin(self):
+        """Fresh emission state of one kernel body."""
+        self.lines, self.pre, self.loads, self.groups = [], [], dict(), dict()
+
     def _emit_read(self, n):
         key, shift, loc, _ = n.attr
         desc = (key, shift, loc)
         if desc in self.loads:
             self.emit("const T v{} = {};".format(n.idx, self.loads[desc]))
             return
-        floc = self.state.fields[key].loc
-        fshape = self._field_shape(key)
-        slot = self._src_slot(key)
         if self.slab is not None:
-            self._emit_read_slab(n, slot, fshape, floc)
+            self._emit_read_slab(n, self._src_slot(key), self._field_shape(key), self.state.fields[key].loc)
             return
-        idx, zero = [], []
+        ptr, fshape, floc = self._source_of(key)
+        last = self.ndim - 1
+        idx, zero, pre_lines = [], [], []
+        fast = self.vw == 4 and floc[last] == loc[last] and fshape[last] == self.G[last]
+        s_last = 0
         for d in range(self.ndim):
             ns = fshape[d]
             ext = max(ns, self.G[d])  # extent of the padded / untrimmed array the roll acts on
             s = shift[d] % ext
             if s > ext // 2:
                 s -= ext
+            if d == last and fast:
+                if abs(s) > 1:
+                    fast = False
+                else:
+                    s_last = s
+                    idx.append("0")
+                    continue
             j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
             if floc[d] == "c" and loc[d] == "n":  # zero padded at the low end
+                name = "p{}_{}".format(n.idx, d)
+                pre_lines.append("const int {} = {};".format(name, j))
+                zero.append("{} == 0".format(name))
+                j = "({} == 0 ? 0 : {} - 1)".format(name, name)
+            idx.append(j)
+        if not fast:
+            if self.vw == 4 and idx[last] == "0":  # (left over from an aborted fast path: recompute this axis)
+                return self._emit_read_scalar(n, ptr, fshape, floc)
+            for line in pre_lines:
+                self.emit(line)
+            e = "{}[{}]".format(ptr, self._offset(idx, fshape))
+            if zero:
+                e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
+            self.emit("const T v{} = {};".format(n.idx, e))
+            self.loads[desc] = "v{}".format(n.idx)
+            return
+        # four points per thread: the row of this (field, shift on the other axes) is loaded once as a 16-byte pack
+        # plus the element left / right of it where a read of the row is shifted along the last axis
+        gkey = (key, tuple(shift[:last]), loc)
+        grp = self.groups.get(gkey)
+        if grp is None:
+            gid = len(self.groups)
+            grp = self.groups[gkey] = dict(id=gid, left=False, right=False, zero=" || ".join(zero))
+            for line in pre_lines:
+                self.pre.append("  " + line.replace("p{}_".format(n.idx), "pg{}_".format(gid)))
+            row = self._offset(idx, fshape).replace("p{}_".format(n.idx), "pg{}_".format(gid))
+            grp["zero"] = grp["zero"].replace("p{}_".format(n.idx), "pg{}_".format(gid))
+            self.pre.append("  const T* const R{} = {} + {};".format(gid, ptr, row))
+            self.pre.append("  const T4 R{0}v = *(const T4*)(R{0} + ib);".format(gid))
+        gid, nl = grp["id"], self.G[last]
+        if s_last < 0 and not grp["left"]:
+            grp["left"] = True
+            self.pre.append("  const T R{0}l = R{0}[ib == 0 ? {1} : ib - 1];".format(gid, nl - 1))
+        if s_last > 0 and not grp["right"]:
+            grp["right"] = True
+            self.pre.append("  const T R{0}r = R{0}[ib + 4 == {1} ? 0 : ib + 4];".format(gid, nl))
+        e = "R{}a[p + {}]".format(gid, 1 + s_last)
+        if grp["zero"]:
+            e = "(({}) ? (T)0 : {})".format(grp["zero"], e)
+        self.emit("const T v{} = {};".format(n.idx, e))
+        self.loads[desc] = "v{}".format(n.idx)
+
+    def _emit_read_scalar(self, n, ptr, fshape, floc):
+        """One load per point (reads shifted by more than one cell along the last axis in a four-point kernel)."""
+        key, shift, loc, _ = n.attr
+        idx, zero = [], []
+        for d in range(self.ndim):
+            ext = max(fshape[d], self.G[d])
+            s = shift[d] % ext
+            if s > ext // 2:
+                s -= ext
+            j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
+            if floc[d] == "c" and loc[d] == "n":
                 name = "p{}_{}".format(n.idx, d)
                 self.emit("const int {} = {};".format(name, j))
                 zero.append("{} == 0".format(name))
                 j = "({} == 0 ? 0 : {} - 1)".format(name, name)
             idx.append(j)
-        off = self._offset(idx, fshape)
-        e = "a.src[{}][{}]".format(slot, off)
+        e = "{}[{}]".format(ptr, self._offset(idx, fshape))
         if zero:
             e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
         self.emit("const T v{} = {};".format(n.idx, e))
-        self.loads[desc] = "v{}".format(n.idx)
+        self.loads[(key, shift, loc)] = "v{}".format(n.idx)
+
+    def _group_arrays(self):
+        """Declarations of the per-row register windows [left, 4 values, right] the fast reads index."""
+        out = []
+        for grp in self.groups.values():
+            g = grp["id"]
+            out.append("  const T R{0}a[6] = {{{1}, R{0}v.x, R{0}v.y, R{0}v.z, R{0}v.w, {2}}};".format(
+                g, "R{}l".format(g) if grp["left"] else "(T)0", "R{}r".format(g) if grp["right"] else "(T)0"))
+        return out
 
     def _emit_read_slab(self, n, slot, fshape, floc):
         """A read on one rank's slab: as above on the other axes; along the sharded axis no wrap inside the
@@ -423,23 +607,39 @@ class _Codegen:
         return "i{}g".format(d) if self.slab is not None and d == self.slab[0] else "i{}".format(d)
 
     def _emit_tensor(self, n):
-        t = self.tr.tensors[n.attr]
+        slot, roll = (n.attr, None) if n.op == "tensor" else n.attr
+        t = self.tr.tensors[slot]
         shape = (1,) * (self.ndim - t.dim()) + tuple(t.shape)
         if len(shape) != self.ndim or any(s > g for s, g in zip(shape, self.G)):
             raise TraceUnsupported("tensor of shape {} on grid {}".format(tuple(t.shape), self.G))
+        last = self.ndim - 1
         terms, stride = [], 1
         for d in reversed(range(self.ndim)):
             if shape[d] != 1:
                 # shorter than the grid: an operand of a windowed value; clamped outside its window
                 i = self.gi(d) if shape[d] == self.G[d] else "min({}, {})".format(self.gi(d), shape[d] - 1)
+                if roll is not None and roll[d]:  # numpy.roll by roll[d]: the value at i comes from i - roll[d]
+                    i = "({0} >= {1} ? {0} - {1} : {0} + {2})".format(self.gi(d), roll[d], self.G[d] - roll[d])
                 terms.append("{} * {}".format(i, stride) if stride != 1 else i)
                 stride *= shape[d]
         ctype = {torch.float32: "float", torch.float64: "double", torch.int32: "int", torch.int64: "long",
                  torch.bool: "unsigned char"}[t.dtype]
         cast = {"r": "(T)", "i": "(long)", "b": "0 != "}[n.kind]
         ktype = {"r": "T", "i": "long", "b": "bool"}[n.kind]
-        self.emit("const {} v{} = {}((const {}*)a.ten[{}])[{}];".format(
-            ktype, n.idx, cast, ctype, n.attr, " + ".join(terms) or "0"))
+        line = "const {} v{} = {}((const {}*)a.ten[{}])[{}];".format(
+            ktype, n.idx, cast, ctype, slot, " + ".join(terms) or "0")
+        tdt = "float" if self.tr.torch_dtype == torch.float32 else "double"
+        if self.vw == 4 and shape[last] == 1:
+            self.pre.append("  " + line)  # the same value for the thread's four points: loaded once
+        elif (self.vw == 4 and shape[last] == self.G[last] and ctype == tdt and (roll is None or not roll[last])
+              and n.kind == _R):
+            # a full row of a constant array of the kernel's own type: one 16-byte pack for the four points
+            # (terms[0] is the last axis' own index)
+            self.pre.append("  const T4 v{}q = *(const T4*)((const T*)a.ten[{}] + {} + ib);".format(
+                n.idx, slot, " + ".join(terms[1:]) or "0"))
+            self.emit("const T v{0} = v{0}q[p];".format(n.idx))
+        else:
+            self.emit(line)
 
     # ---- pointwise networks: two evaluations of the same network per pair of float lanes ---------------------
     def _pair_mlps(self):
@@ -543,7 +743,7 @@ class _Codegen:
             v = "const {} v{} = ".format(kt, n.idx)
             if op == "read":
                 self._emit_read(n)
-            elif op == "tensor":
+            elif op in ("tensor", "rtensor"):
                 self._emit_tensor(n)
             elif op == "index":
                 self.emit(v + "(long){};".format(self.gi(n.attr[0])))
@@ -620,6 +820,14 @@ class _Codegen:
                 self.r(o), 2.0 / self.out_count[k])
             if self.out_lens[k] is not None:
                 seed = "(inbox{} ? {} : (T)0)".format(k, seed)
+            if self.out_mode[k] == "virt":
+                continue  # the gathers re-evaluate the output
+            if self.out_mode[k] == "jac":
+                # the seed IS the adjoint of this output (nothing else consumes it): stored once, expanded onto the
+                # reads by the gathers with the local derivatives re-evaluated there
+                self.emit("const T gs{} = {};".format(k, seed))
+                self.jac_store.append((k, "gs{}".format(k)))
+                continue
             acc(o, seed)
         self.pgrads = dict()  # net key -> list of per-array lists of accumulator names
         for n in reversed(self.order):
@@ -768,38 +976,94 @@ class _Codegen:
                     acc(a, "{}_d0_{}{}".format(p, i, "" if width == 1 else "." + lane))
 
     # ---- whole source -----------------------------------------------------------------------
+    def _index_prologue(self, S, shape, names, vw, flat="l"):
+        """Decomposition of the flat thread index into grid indices names[d]; with vw == 4 the thread owns four
+        consecutive points of the last axis starting at `ib` (the loop over p defines names[last] = ib + p)."""
+        rem = flat
+        last = len(shape) - 1
+        for d in reversed(range(len(shape))):
+            ext = shape[d] // vw if d == last else shape[d]
+            var = "ib" if (vw == 4 and d == last) else names[d]
+            mul = " * 4" if (vw == 4 and d == last) else ""
+            if d == 0:
+                S.append("  const int {} = ({}){};".format(var, rem, mul))
+            else:
+                S.append("  const int {} = ({} % {}){};".format(var, rem, ext, mul))
+                S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
+                rem = "r{}_".format(d)
+
+    def _loop_open(self, S, vw):
+        last = self.ndim - 1
+        if vw == 4:
+            S.append("#pragma unroll")
+            S.append("  for (int p = 0; p < 4; ++p) {")
+            S.append("  const int i{} = ib + p;".format(last))
+            S.append("  const int l = l4 * 4 + p;")
+
+    def _gradient_terms(self):
+        """Per regular field: the gradient expression G_F(j) = sum of [A_c * dc/dr](j - shift_r) over every stored
+        or re-evaluated cut c and live read r of the field (module docstring of stencil_grad.py).  Fields with pad /
+        trim reads keep the legacy gather (their reads are never below an output cut)."""
+        tr = self.tr
+        stop = set(self.cut_set) | {n.idx for n in self.cots}
+        terms = dict()  # key -> [expression at the point of evaluation, read attr]
+        gb = stencil_grad.GradBuilder(tr, self.G, self.need, stop)
+
+        def pseudo(tag, slot):
+            key = "@{}{}".format(tag, slot)
+            tr.state_locs[key] = self.gloc
+            self.pseudo_slot[key] = slot
+            return tr.node("read", attr=(key, (0,) * self.ndim, self.gloc, True), shape=self.G, kind=_R)
+
+        for slot, n in enumerate(self.cots):
+            if self._regular(n):
+                terms.setdefault(n.attr[0], []).append((pseudo("r", slot), n.attr))
+        for k, n in enumerate(self.cut_nodes):
+            slot = len(self.cots) + k
+            reads = [tr.nodes[i] for i in self.cut_set[n.idx]]
+            if not all(self._regular(r) for r in reads):
+                continue
+            adj = gb.adjoints(n, pseudo("c", slot), stencil_grad.subdag(n, stop))
+            for ridx, expr in adj.items():
+                terms.setdefault(tr.nodes[ridx].attr[0], []).append((expr, tr.nodes[ridx].attr))
+        for k, adj in enumerate(self.out_adj):
+            if adj is None:
+                continue
+            for ridx, expr in adj.items():
+                terms.setdefault(tr.nodes[ridx].attr[0], []).append((expr, tr.nodes[ridx].attr))
+        exprs = dict()
+        for key, lst in terms.items():
+            total = None
+            for expr, attr in lst:
+                shifted = tr.roll(expr, tuple(attr[1]), virtual=True)
+                total = gb.add(total, shifted)
+            exprs[key] = total
+        return exprs
+
     def source(self):
         tdt = self.tr.torch_dtype
         self.pg_decl, self.pg_offset = [], dict()
         self.pg2_used = set()
+        self.jac_store = []
+        vw, last = self.vw, self.ndim - 1
+        self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
+        self._begin()
         self.forward()
-        fwd, self.lines = self.lines, []
+        fwd = self.lines
+        self.lines = []
         self.reverse()
-        rev, self.lines = self.lines, []
+        rev = self.lines
+        fwd_pre = self.pre + self._group_arrays()
         nout = len(self.outputs)
         self.npar = sum(len(g) for names in self.pgrads.values() for g in names)
         par_arrays = sum(2 * (len(layers) - 1) for _, layers in self.nets) + len(self.arrays)
         self.par_arrays = par_arrays
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
-        S = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
+        HEAD = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
-            S.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
-        nsrc = max(1, len(self.src_keys))
-        slab_members = ""
-        if self.slab is not None:
-            # off: global index of the first owned cell; lo / ea: ghost cells below the owned ones / extent of the
-            # local arrays along the sharded axis; hw: cells in a wrap plane buffer; wlo / whi: wrap planes of the
-            # sources (read), gwlo / gwhi: of the gradients (written by the gathers where the array has no ghosts)
-            slab_members = " int off, lo, ea, hw; const T* wlo[{0}]; const T* whi[{0}]; T* gwlo[{0}]; T* gwhi[{0}]; int alo, ahi;".format(nsrc)
-        # host scalars (functions of `tracers`): BY VALUE in the argument struct (hsv) -- an eager launch owns its
-        # copy, nothing the host rewrites later is read by a queued kernel; a launch captured into a hipGraph
-        # reads them from device memory instead (hs != NULL: the row of the epoch being replayed)
-        S.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
-                 "double hsv[{}]; T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks;{} }};".format(
-                     nsrc, max(1, len(self.tr.tensors)), max(1, len(self.cots) + len(self.cut_nodes)),
-                     max(1, par_arrays), max(1, len(self.hs)), slab_members))
-        S.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
+            HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
+        S = []
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
         wofs, bofs, o = dict(), dict(), 0
         for s, (key, layers) in enumerate(self.nets):
@@ -816,6 +1080,7 @@ class _Codegen:
             S.append("#define WOFS_{}_{} {}".format(s, l, v))
         for (s, l), v in bofs.items():
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
+        # ---- k_fwd ---------------------------------------------------------------------------------------------
         S.append('extern "C" __global__ __launch_bounds__(NB) void k_fwd(const Args a) {')
         S.append("  __shared__ T sm[NB / 64];")
         for k in range(nout):
@@ -825,41 +1090,54 @@ class _Codegen:
         pg2 = [name for key in self.pg2_used for group in self.pgrads[key] for name in group]
         for name in pg2:  # packed partial sums of paired network evaluations
             S.append("  T2 {}2{} = (T2)(0.0f);".format(name[:2], name[2:]))
-        if self.total <= self.max_blocks * 256:  # one grid point per thread
-            S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
-            S.append("  if (l < {}) {{".format(self.total))
+        threads = self.total // vw
+        flat = "l4" if vw == 4 else "l"
+        if threads <= self.max_blocks * 256:  # one thread per point (or four points)
+            S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
+            S.append("  if ({} < {}) {{".format(flat, threads))
         else:
-            S.append("  for (int l = blockIdx.x * NB + threadIdx.x; l < {}; l += a.nblocks * NB) {{".format(self.total))
-        rem = "l"
-        for d in reversed(range(self.ndim)):
-            if d == 0:
-                S.append("  const int i0 = {};".format(rem))
-            else:
-                S.append("  const int i{} = {} % {};".format(d, rem, self.GL[d]))
-                S.append("  const int r{} = {} / {};".format(d, rem, self.GL[d]))
-                rem = "r{}".format(d)
+            S.append("  for (int {0} = blockIdx.x * NB + threadIdx.x; {0} < {1}; {0} += a.nblocks * NB) {{".format(flat, threads))
+        self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
         if self.slab is not None:
             S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
+        esize = 8 if tdt == torch.float64 else 4
+        stored = ([(n, "g{}".format(n.idx)) for n in self.cots] + [(n, "g{}".format(n.idx)) for n in self.cut_nodes]
+                  + [(self.outputs[k], name) for k, name in self.jac_store])  # cut arrays follow the read cotangents
+        self.ncot = len(stored)
+        for slot_k, (k, _) in enumerate(self.jac_store):
+            self.pseudo_slot[self.seed_key[k]] = len(self.cots) + len(self.cut_nodes) + slot_k
+        stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
+        S.extend(fwd_pre)
+        if vw == 4:
+            for slot in range(len(stored)):
+                S.append("  T O{}[4];".format(slot))
+        self._loop_open(S, vw)
         for k, lens in enumerate(self.out_lens):
             if lens is not None:
                 conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
                 S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
         S.extend(fwd)
         S.extend(rev)
-        esize = 8 if tdt == torch.float64 else 4
-        stored = list(self.cots) + list(self.cut_nodes)  # cut arrays follow the read cotangents
-        self.ncot = len(stored)
-        stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
-        for slot, n in enumerate(stored):
-            if stream:
-                S.append("  __builtin_nontemporal_store(g{}, &a.cot[{}][l]);".format(n.idx, slot))
+        for slot, (n, name) in enumerate(stored):
+            if vw == 4:
+                S.append("  O{}[p] = {};".format(slot, name))
+            elif stream:
+                S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
             else:
-                S.append("  a.cot[{}][l] = g{};".format(slot, n.idx))
+                S.append("  a.cot[{}][l] = {};".format(slot, name))
         for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
             term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
             if self.out_lens[k] is not None:
                 term = "(inbox{} ? {} : (T)0)".format(k, term)
             S.append("  s_{0} = s_{0} + {1};".format(k, term))
+        if vw == 4:
+            S.append("  }")  # p
+            for slot in range(len(stored)):
+                vec = "(T4){{O{0}[0], O{0}[1], O{0}[2], O{0}[3]}}".format(slot)
+                if stream:
+                    S.append("  __builtin_nontemporal_store({}, (T4*)(a.cot[{}] + l4 * 4));".format(vec, slot))
+                else:
+                    S.append("  *(T4*)(a.cot[{}] + l4 * 4) = {};".format(slot, vec))
         S.append("  }")
         for name in pg2:
             S.append("  {0} = {0} + ({1}2{2}.x + {1}2{2}.y);".format(name, name[:2], name[2:]))
@@ -900,8 +1178,9 @@ class _Codegen:
         S.append("  for (int k = 0; k < {}; ++k) loss = loss + a.out[1 + k];".format(nout))
         S.append("  a.out[0] = loss;")
         S.append("}")
-        # gathers
-        self.gathers = []  # (key, [cot slots]) for fields that need a gather launch
+        # ---- gathers -------------------------------------------------------------------------------------------
+        self.gathers = []  # keys of the fields that need a gather launch
+        self.gather_reads_sources = dict()  # key -> the gather reads the fields' own arrays (not only stored adjoints)
         self.direct = dict()  # key -> cot slot that already IS the gradient
         by_key = dict()  # key -> [(slot, read attr, coefficient expression or None)]
         for slot, n in enumerate(self.cots):
@@ -910,10 +1189,17 @@ class _Codegen:
             for ridx, coeff in self.cut_set[n.idx].items():
                 attr = self.tr.nodes[ridx].attr
                 by_key.setdefault(attr[0], []).append((len(self.cots) + k, attr, coeff))
-        for key, reads in by_key.items():
+        symbolic = dict()
+        if self.slab is None and self.all_regular and int(os.environ.get("ODIL_TRACE_NEWGATHER", 1)):
+            symbolic = self._gradient_terms()
+        self.gather_blocks = dict()
+        keys = list(by_key) + [k for k in symbolic if k not in by_key]
+        for key in keys:
+            reads = by_key.get(key, [])
             floc = self.state.fields[key].loc
             fshape = self._field_shape(key)
-            if (self.slab is None and len(reads) == 1 and reads[0][2] is None and not any(reads[0][1][1])
+            only_legacy = all(adj is None or not any(self.tr.nodes[r].attr[0] == key for r in adj) for adj in self.out_adj)
+            if (self.slab is None and only_legacy and len(reads) == 1 and reads[0][2] is None and not any(reads[0][1][1])
                     and reads[0][1][2] == floc):
                 self.direct[key] = reads[0][0]
                 continue
@@ -922,7 +1208,12 @@ class _Codegen:
             if self.slab is not None:
                 self._gather_slab(S, gi, key, reads, floc, fshape)
                 continue
+            regular = tuple(fshape) == self.G and all(attr[2] == floc for _, attr, _ in reads)
+            if key in symbolic and regular and symbolic[key] is not None:
+                self._gather_symbolic(S, gi, key, symbolic[key])
+                continue
             tot = int(np.prod(fshape))
+            self.gather_blocks[gi] = (tot + 255) // 256
             S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
             S.append("  const int l = blockIdx.x * NB + threadIdx.x;")
             S.append("  if (l >= {}) return;".format(tot))
@@ -979,7 +1270,7 @@ class _Codegen:
         S.append("  switch (which) {")
         for gi, key in enumerate(self.gathers):
             tot = int(np.prod(self._field_shape(key)))
-            nblk = str((tot + 255) // 256)
+            nblk = str(self.gather_blocks.get(gi, (tot + 255) // 256))
             if self.slab is not None:  # planes -GH .. n + GH of the sharded axis, GH = 2 (slab_traced.G)
                 per = tot // self._field_shape(key)[self.slab[0]]
                 nblk = "(unsigned)(((long){} * ({} + 4) + 255) / 256)".format(per, self.slab[1])
@@ -989,7 +1280,60 @@ class _Codegen:
         S.append("  }")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
-        return "\n".join(S) + "\n"
+        # the argument block: sized last (the gradient expressions add host scalars of their own)
+        nsrc = max(1, len(self.src_keys))
+        slab_members = ""
+        if self.slab is not None:
+            # off: global index of the first owned cell; lo / ea: ghost cells below the owned ones / extent of the
+            # local arrays along the sharded axis; hw: cells in a wrap plane buffer; wlo / whi: wrap planes of the
+            # sources (read), gwlo / gwhi: of the gradients (written by the gathers where the array has no ghosts)
+            slab_members = " int off, lo, ea, hw; const T* wlo[{0}]; const T* whi[{0}]; T* gwlo[{0}]; T* gwhi[{0}]; int alo, ahi;".format(nsrc)
+        # host scalars (functions of `tracers`): BY VALUE in the argument struct (hsv) -- an eager launch owns its
+        # copy, nothing the host rewrites later is read by a queued kernel; a launch captured into a hipGraph
+        # reads them from device memory instead (hs != NULL: the row of the epoch being replayed)
+        HEAD.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
+                    "double hsv[{}]; T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks;{} }};".format(
+                        nsrc, max(1, len(self.tr.tensors)), max(1, self.ncot),
+                        max(1, par_arrays), max(1, len(self.hs)), slab_members))
+        HEAD.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
+        return "\n".join(HEAD + S) + "\n"
+
+    def _gather_symbolic(self, S, gi, key, root):
+        """The gather of a regular field as a pointwise kernel over its gradient expression (one thread per point,
+        or per four points of the last axis), the optimizer's update applied by the lane that holds g."""
+        vw, last = self.vw, self.ndim - 1
+        saved = (self.order, self.lines, self.pre, self.loads, self.groups)
+        nodes = stencil_grad.subdag(root)
+        self.order = nodes
+        self._begin()
+        self.forward()
+        body, pre = self.lines, self.pre + self._group_arrays()
+        value = self.r(root)
+        self.gather_reads_sources[key] = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})
+        self.order, self.lines, self.pre, self.loads, self.groups = saved
+        tot = self.total
+        threads = tot // vw
+        self.gather_blocks[gi] = (threads + 255) // 256
+        flat = "l4" if vw == 4 else "l"
+        S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
+        S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
+        S.append("  if ({} >= {}) return;".format(flat, threads))
+        self._index_prologue(S, self.G, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
+        S.extend(pre)
+        if vw == 4:
+            S.append("  T acc[4];")
+        self._loop_open(S, vw)
+        S.extend(body)
+        if vw == 4:
+            S.append("  acc[p] = {};".format(value))
+            S.append("  }")
+            S.append("  *(T4*)(g + l4 * 4) = (T4){acc[0], acc[1], acc[2], acc[3]};")
+            S.append("  adam_apply4(ad, l4 * 4, acc);")
+        else:
+            S.append("  const T acc = {};".format(value))
+            S.append("  g[l] = acc;")
+            S.append("  adam_apply(ad, l, acc);")
+        S.append("}")
 
 
 def _gather_slab(self, S, gi, key, reads, floc, fshape):

@@ -101,7 +101,7 @@ class TracedOperator:
         # space dimensions (46 parameters, 67 M points): 6.6 ms / epoch at 65536 blocks, 5.2 at 4096; plain
         # stencils prefer many (tracer 4-D: 62.0 ms at 65536, 64.5 at 4096).
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
-        self.nblocks = min((self.total + 255) // 256, cap)
+        self.nblocks = min((self.total // cg.vw + 255) // 256, cap)
         nout = len(outs)
         self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in range(cg.ncot)]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)
@@ -332,8 +332,12 @@ class TracedOperator:
         # fusion pays where the update is a long pass over HBM (heat 256 x 512^2: 3.63 -> 3.52, tracer 32 x 256^3: -12 %)
         if self.total < (1 << 25) and not int(os.environ.get("ODIL_FUSE_ADAM_SMALL", 0)):
             return None
+        # gathers that re-evaluate local derivatives read the fields' own regular arrays: for a plain `Field` that array
+        # IS the unknown, which no launch may update while another gather of this epoch still reads it
+        reread = {k for keys in cg.gather_reads_sources.values() for k in keys}
         for key, kind, pos, n in self.layout:
             fusable = (kind in ("field", "mg") and key in cg.gathers and key not in self.gtmp
+                       and not (kind == "field" and key in reread)
                        and int(os.environ.get("ODIL_FUSE_ADAM0", 1)))
             if not fusable or pos != done:
                 break

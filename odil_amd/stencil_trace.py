@@ -315,14 +315,16 @@ class Tracer:
         shape = tuple(l for l, q in zip(lens, sq) if not q)
         return self.node("win", (x,), shape=shape, kind=x.kind, win=win)
 
-    def roll(self, n, shifts):
+    def roll(self, n, shifts, virtual=False):
         """The grid function i -> n(i - shifts) (periodic, numpy.roll convention), built by pushing
         the shift into the leaves: reads change their stencil offset, index leaves wrap, tensors are
-        rolled once on the device; everything else is pointwise."""
+        rolled once on the device (virtual: indexed with an offset instead -- the gradient expressions of
+        stencil_grad.py shift whole sub-expressions to every stencil neighbour, and a rolled copy of a constant
+        field per neighbour would cost its size each); everything else is pointwise."""
         if not any(shifts) or n.host:
             return n
         memo = self.__dict__.setdefault("_roll_memo", dict())
-        key = (n.idx, shifts)
+        key = (n.idx, shifts, virtual)
         if key in memo:
             return memo[key]
         G = self.grid_shape()
@@ -339,19 +341,33 @@ class Tracer:
             else:  # (i - r) mod size
                 moved = self.binary("sub", n, r)
                 res = self.where(self.binary("lt", moved, 0), self.binary("add", moved, size), moved)
-        elif n.op == "tensor":
-            t = self.tensors[n.attr]
-            dims, amounts = [], []
+        elif n.op in ("tensor", "rtensor"):
+            slot, before = (n.attr, (0,) * len(G)) if n.op == "tensor" else n.attr
+            t = self.tensors[slot]
+            dims, amounts, full = [], [], True
             for d, r in enumerate(shifts):
                 td = d - (len(G) - t.dim())
                 if r and td >= 0 and t.shape[td] > 1:
                     dims.append(td)
                     amounts.append(int(r))
-            res = self.tensor(torch.roll(t, amounts, dims)) if dims else n
+                    full = full and t.shape[td] == G[d]
+            if not dims:
+                res = n
+            elif (virtual and full) or n.op == "rtensor":
+                if not full:
+                    raise TraceUnsupported("roll of a constant array shorter than the grid")
+                total = [0] * len(G)
+                for td, r in zip(dims, amounts):
+                    total[td + len(G) - t.dim()] = r
+                total = tuple((a + b) % G[d] for d, (a, b) in enumerate(zip(before, total)))
+                res = self.node("rtensor", attr=(slot, total), shape=n.shape, kind=n.kind) if any(total) else self.node(
+                    "tensor", attr=slot, shape=n.shape, kind=n.kind)
+            else:
+                res = self.tensor(torch.roll(t, amounts, dims))
         elif n.op == "aparam":
             res = n
         else:
-            args = tuple(self.roll(a, shifts) for a in n.args)
+            args = tuple(self.roll(a, shifts, virtual) for a in n.args)
             res = self.node(n.op, args, attr=n.attr, shape=n.shape, kind=n.kind, host=n.host, win=n.win)
         memo[key] = res
         return res

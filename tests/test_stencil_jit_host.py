@@ -31,11 +31,20 @@ def test_examples_trace_and_compile(cpu_mod):
     problem, state = veltracer.make_problem(veltracer.parse_args(["--Nx", "16", "--Nt", "8"]))
     tro = stencil_jit.TracedOperator(problem, state)
     assert sorted(tro.cg.gathers) == ["u", "vx", "vy"]
-    # 18 live reads; the Laplacian regularisers of vx and vy are cut: one stored adjoint each instead of
-    # one cotangent array per stencil point
-    assert len(tro.cg.cut_nodes) == 2 and tro.cg.ncot == 12
+    # 18 live reads.  Cotangents are cut at the OUTPUTS: the transport residual and the two Laplacian regularisers
+    # store their adjoint once (3 arrays), the imposed-values term and the time differences are re-evaluated by the
+    # gathers (nothing stored) -- instead of one cotangent array per stencil point
+    assert tro.cg.out_mode == ["jac", "virt", "jac", "jac", "virt", "virt"] and tro.cg.ncot == 3
+    assert not tro.cg.cots and tro.cg.vw == 4
     assert hasattr(tro.lib, "jit_fwd") and hasattr(tro.lib, "jit_gather")
     assert "k_gat_2" in tro.source and "k_final" in tro.source
+    # the legacy form (one cotangent per live read, affine sub-expressions cut): ODIL_TRACE_RECOMPUTE=0
+    os.environ["ODIL_TRACE_RECOMPUTE"] = "0"
+    try:
+        old = stencil_jit.TracedOperator(problem, state)
+    finally:
+        del os.environ["ODIL_TRACE_RECOMPUTE"]
+    assert len(old.cg.cut_nodes) == 2 and old.cg.ncot == 12
 
     args = heat.parse_args(["--Nx", "16", "--Nt", "8", "--infer_k", "1", "--imposed", "stripe", "--kxreg", "0.1",
                             "--kxregdecay", "100"])
