@@ -50,6 +50,9 @@ def parse_args():
     p.add_argument("--cpu_N_all", type=int, default=128, help="grid size per core of the all-cores CPU-baseline leg")
     p.add_argument("--cpu_budget", type=float, default=10.0, help="seconds of timed CPU work per leg")
     p.add_argument("--scale", type=float, default=1.0, help="shrinks the grids of the non-default configs (smoke runs)")
+    p.add_argument("--spinup_ms", type=float, default=80.0, help="untimed read-modify-write spin-up before the warm-up steps")
+    p.add_argument("--no_other_configs", action="store_true",
+                   help="skip the short runs of configs 3b, 5 (one rank) and 4b after the timed region")
     return p.parse_args()
 
 
@@ -74,10 +77,17 @@ def cpu_baseline(ndim, n_one, n_all, budget_s):
         return sum(o["cells"] * o["epochs"] / o["seconds"] for o in outs), outs
 
     v1, o1 = leg(1, n_one, budget_s)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # ~0.3 GB per 128^3 worker: at most 64 of them (19 GB) whatever the host offers -- the oracle is memory-bound
-    # NumPy, its aggregate rate is flat well before that (61 M updates/s on 256 cores, 9 x one core)
-    cores = min(cores, 64)
+    present = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # one worker per host core, as many as memory allows: ~0.35 GB per 128^3 worker (f64 multigrid state, moments,
+    # gradients, NumPy temporaries), half of what is available at most
+    try:
+        import psutil
+
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 32 << 30
+    per_worker = 0.35e9 * (n_all / 128.0) ** ndim
+    cores = max(1, min(present, int(0.5 * avail / per_worker)))
     vall, oall = leg(cores, n_all, budget_s)
     return {
         "value": v1,
@@ -89,8 +99,9 @@ def cpu_baseline(ndim, n_one, n_all, budget_s):
         "all_cores": {
             "value": vall,
             "cores": cores,
-            "sample": "{} concurrent single-thread workers, each Poisson {}-D {}^{} f64 multigrid Adam, {:.1f} s".format(
-                cores, ndim, n_all, ndim, max(o["seconds"] for o in oall)),
+            "cores_present": present,
+            "sample": "{} concurrent single-thread workers (of {} cores present), each Poisson {}-D {}^{} f64 multigrid Adam, {:.1f} s".format(
+                cores, present, ndim, n_all, ndim, max(o["seconds"] for o in oall)),
         },
     }
 
@@ -181,6 +192,22 @@ def roofline(kernel, model_bytes, moved_bytes, ms, traffic, traffic_source):
     }
 
 
+def spin_up(dev, ms):
+    """UNTIMED, before the warm-up steps: read-modify-write passes over a 1 GB buffer for `ms` milliseconds.  After
+    start-up or ~20 ms of idle the part runs its first epochs 5-15 % slow (2.9, 2.7, 2.6 ... ms for the 512^3 epoch)
+    until the memory side has been busy in both directions for a while; fills alone do not end that, read-modify-write
+    passes do (tools/idle_ramp2.py).  Not part of any timed region."""
+    if ms <= 0:
+        return
+    buf = torch.zeros(256 << 20, dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            buf.add_(1.0)
+        torch.cuda.synchronize()
+    del buf
+
+
 def run_poisson(args, rank, world, dev, comm, barrier):
     from odil_amd.poisson_path import PoissonMultigridAdam
     from odil_amd.slab import SlabPoissonAdam
@@ -201,6 +228,7 @@ def run_poisson(args, rank, world, dev, comm, barrier):
 
     gc.collect()
     gc.disable()  # (a collection of the interpreter in the middle of the loop starves the queue: see DESIGN section 5)
+    spin_up(dev, args.spinup_ms)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -288,6 +316,7 @@ def run_tracer(args, rank, world, dev, comm, barrier):
 
     gc.collect()
     gc.disable()  # (as in run_poisson)
+    spin_up(dev, args.spinup_ms)
     for _ in range(args.warmup):
         run.epoch(comm)
     barrier()
@@ -315,6 +344,111 @@ def run_tracer(args, rank, world, dev, comm, barrier):
         roofline=roofline("k_fwd (generated: residuals + reverse pass, {} fields in, {} cotangent arrays out)".format(nsrc, ncot),
                           moved, moved, kt["forward"], None, None),
         abytes=None, dtype="f32", exchanges_per_epoch=4 if world > 1 else 0)
+
+
+def other_configs(args, dev):
+    """After the timed region of the default run (N = 1 only, outside every timed window): a few epochs each of the
+    other single-GPU BASELINE workloads, so that the driver's record carries them -- 3b heat inverse 256 x 512^2
+    (traced operator, Adam), 5 the tracer workload's per-rank slab (128, 32, 256, 256) as one rank, 4b one Newton step
+    of Poisson 512^3 with the geometric-multigrid solve.  ms_per_step by HIP events around the steps after a warm-up
+    step; frac_model prices the SURVEY 8(d) minimum-traffic model of an Adam epoch against 8 TB/s."""
+    import copy
+    import gc
+
+    out = dict()
+
+    def timed(step, nwarm, nsteps):
+        for _ in range(nwarm):
+            step()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(nsteps):
+            step()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / nsteps
+
+    def attempt(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:  # the headline line must not depend on these
+            out[name] = {"error": "{}: {}".format(type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+        out[name]["wall_s"] = time.perf_counter() - t0
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def heat():
+        import bench_configs
+        import odil_amd as odil
+
+        modname, argv, optname, _, _, name = bench_configs.CONFIGS["3b"]
+        sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
+        import importlib
+
+        ex = importlib.import_module(modname)
+        a = ex.parse_args(argv(sc))
+        odil.util.set_log_file(open(os.devnull, "w"))
+        problem, state = ex.make_problem(a)
+        loss_grad = odil.util.make_loss_grad(problem, state)
+        opt = odil.optimizer.AdamNativeOptimizer(dtype=problem.domain.dtype, mod=problem.domain.mod)
+        arrays = problem.domain.arrays_from_state(state)
+        carry = dict(x=arrays, m=None, done=0)
+
+        def step():
+            x, info = opt.run(carry["x"], loss_grad, epochs=1, lr=a.lr, moments=carry["m"], steps_done=carry["done"])
+            carry.update(x=x, m=(info.m, info.v), done=carry["done"] + 1)
+
+        ms = timed(step, 2, 5)
+        cells = int(np.prod(problem.domain.cshape))
+        nout = len(problem.eval_loss_grad(state)[2])
+        model = bench_configs.model_bytes_per_update(problem, state, "adam", nout)
+        return {"workload": name.format(problem.domain.cshape[0], problem.domain.cshape[-1]), "ms_per_step": ms,
+                "value": cells / (ms * 1e-3), "frac_model": cells * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traced": problem._traced is not None}
+
+    def tracer():
+        from odil_amd.slab import LocalComm
+
+        sub = copy.copy(args)
+        sub.steps, sub.warmup, sub.spinup_ms = 5, 2, 0.0
+        res = run_tracer(sub, 0, 1, dev, LocalComm(), torch.cuda.synchronize)
+        ms = 1e3 * res["elapsed"] / sub.steps
+        # SURVEY 8(d) model of an Adam epoch with k = 4 multigrid fields and 8 outputs, S = 16 / 15
+        S = sum(2.0 ** (-4 * l) for l in range(res["config"]["levels"]))
+        model = (4 * (10 * S + 2) + 2 * 8 + 1) * 4
+        return {"workload": res["workload"], "ms_per_step": ms, "value": res["cells"] / (ms * 1e-3),
+                "frac_model": res["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": res["kernel_ms"]}
+
+    def newton():
+        import bench_configs
+        import importlib
+
+        import odil_amd as odil
+
+        modname, argv, _, _, _, name = bench_configs.CONFIGS["4b"]
+        sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
+        ex = importlib.import_module(modname)
+        a = ex.parse_args(argv(sc))
+        odil.util.set_log_file(open(os.devnull, "w"))
+        problem, state = ex.make_problem(a)
+        a.epoch_start, a.epochs = 0, 1
+
+        def step():
+            odil.util.optimize(a, "newton", problem, state, None)
+
+        ms = timed(step, 1, 1)
+        cells = int(np.prod(problem.domain.cshape))
+        return {"workload": name.format(problem.domain.cshape[0], problem.domain.cshape[-1]), "ms_per_step": ms,
+                "value": cells / (ms * 1e-3), "frac_model": None, "loss_after": float(problem.eval_loss_grad(state)[0])}
+
+    for sub in ("poisson", "heat", "velocity_from_tracer"):
+        sys.path.insert(0, os.path.join(ROOT, "examples", sub))
+    attempt("3b", heat)
+    attempt("5_one_rank", tracer)
+    attempt("4b", newton)
+    return out
 
 
 def run_api(args, dev):
@@ -376,8 +510,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    others = None
     if args.config == "4a":
         res = run_poisson(args, rank, world, dev, comm, barrier)
+        if world == 1 and not args.no_other_configs and (args.ndim, args.N) == (3, 512):
+            res_run = res.pop("run", None)
+            del res_run
+            torch.cuda.empty_cache()
+            others = other_configs(args, dev)
     elif args.config == "5":
         res = run_tracer(args, rank, world, dev, comm, barrier)
     else:
@@ -413,6 +553,9 @@ def main():
         out["loss_after"] = res["loss"]
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if others is not None:
+            out["other_configs"] = others
+        out["spinup_ms"] = args.spinup_ms
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

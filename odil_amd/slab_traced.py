@@ -161,6 +161,8 @@ class HipSlabKernels:
             ctypes.c_void_p, ctypes.c_void_p]
         a.alo = a.ahi = 0
         self.src_keys, self.gather_keys = list(cg.src_keys), list(cg.gathers)
+        # fields whose own arrays the gathers read again (local derivatives re-evaluated there, stencil_grad.py)
+        self.reread = {k for keys in cg.gather_reads_sources.values() for k in keys}
         self.param_groups = {key: (cg.pg_offset[key], [len(g) for g in groups]) for key, groups in cg.pgrads.items()}
 
     _host_value = TracedOperator._host_value  # host scalars (functions of problem.tracers): the single-GPU evaluator
@@ -366,6 +368,8 @@ class SlabTracedAdam:
                 lv = e["levels"][0]
                 if lv.n < 4:
                     continue
+                if self.u[key] is e["x"][0] and key in getattr(self.kern, "reread", ()):
+                    continue  # the array a gather reads IS the unknown: no launch of this epoch may update it
                 self._fused[key] = (1, lv.n - 1)
                 spans.append((e["start"], lv.size))
                 outer = math.prod(lv.shape[:axis])

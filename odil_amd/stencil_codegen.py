@@ -197,8 +197,9 @@ class _Codegen:
         # four points of the last axis per thread, 16-byte accesses (ODIL_TRACE_VEC=0: one point per thread)
         last = self.ndim - 1
         self.vw = 4 if (int(os.environ.get("ODIL_TRACE_VEC", 1)) and self.GL[last] % 4 == 0 and self.GL[last] >= 8
-                        and slab is None) else 1
+                        and (slab is None or slab[0] != last)) else 1
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
+        self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
         self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
@@ -311,7 +312,7 @@ class _Codegen:
         # pad / trim reads ('c' fields read at 'n' and back) keep the legacy gathers: one such read anywhere and
         # the whole operator stays with them
         self.all_regular = all(self._regular(n) for n in self.order if n.op == "read")
-        if not int(os.environ.get("ODIL_TRACE_RECOMPUTE", 1)) or self.slab is not None or not self.all_regular:
+        if not int(os.environ.get("ODIL_TRACE_RECOMPUTE", 1)) or not self.all_regular:
             return mode
         virt_max = int(os.environ.get("ODIL_TRACE_VIRT_MAX", 12))
         used = {a.idx for n in self.order for a in n.args}
@@ -454,27 +455,34 @@ class _Codegen:
         if desc in self.loads:
             self.emit("const T v{} = {};".format(n.idx, self.loads[desc]))
             return
-        if self.slab is not None:
-            self._emit_read_slab(n, self._src_slot(key), self._field_shape(key), self.state.fields[key].loc)
-            return
         ptr, fshape, floc = self._source_of(key)
         last = self.ndim - 1
+        ax = self.slab[0] if self.slab is not None else None
         idx, zero, pre_lines = [], [], []
         fast = self.vw == 4 and floc[last] == loc[last] and fshape[last] == self.G[last]
-        s_last = 0
+        s_last, sa = 0, 0
         for d in range(self.ndim):
             ns = fshape[d]
             ext = max(ns, self.G[d])  # extent of the padded / untrimmed array the roll acts on
             s = shift[d] % ext
             if s > ext // 2:
                 s -= ext
-            if d == last and fast:
-                if abs(s) > 1:
-                    fast = False
-                else:
-                    s_last = s
-                    idx.append("0")
-                    continue
+            if d == ax:
+                # the sharded axis of a slab rank: no wrap inside the rank -- cell i reads cell i + s of the
+                # ghost-extended array, or a wrap plane where i + s falls off the GLOBAL grid (_address)
+                if floc[d] != "c" or loc[d] != "c":
+                    raise TraceUnsupported("slab axis {} must be cell-centred for field '{}'".format(ax, key))
+                sa = s
+                if not self.in_gather:
+                    self.halo = max(self.halo, abs(s))
+                idx.append(None)
+                continue
+            if d == last and fast and abs(s) <= 1:
+                s_last = s
+                idx.append("0")
+                continue
+            if d == last:
+                fast = False
             j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
             if floc[d] == "c" and loc[d] == "n":  # zero padded at the low end
                 name = "p{}_{}".format(n.idx, d)
@@ -483,11 +491,9 @@ class _Codegen:
                 j = "({} == 0 ? 0 : {} - 1)".format(name, name)
             idx.append(j)
         if not fast:
-            if self.vw == 4 and idx[last] == "0":  # (left over from an aborted fast path: recompute this axis)
-                return self._emit_read_scalar(n, ptr, fshape, floc)
             for line in pre_lines:
                 self.emit(line)
-            e = "{}[{}]".format(ptr, self._offset(idx, fshape))
+            e = "*({})".format(self._address(key, ptr, fshape, idx, sa))
             if zero:
                 e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
             self.emit("const T v{} = {};".format(n.idx, e))
@@ -499,12 +505,11 @@ class _Codegen:
         grp = self.groups.get(gkey)
         if grp is None:
             gid = len(self.groups)
-            grp = self.groups[gkey] = dict(id=gid, left=False, right=False, zero=" || ".join(zero))
+            rename = lambda text: text.replace("p{}_".format(n.idx), "pg{}_".format(gid))
+            grp = self.groups[gkey] = dict(id=gid, left=False, right=False, zero=rename(" || ".join(zero)))
             for line in pre_lines:
-                self.pre.append("  " + line.replace("p{}_".format(n.idx), "pg{}_".format(gid)))
-            row = self._offset(idx, fshape).replace("p{}_".format(n.idx), "pg{}_".format(gid))
-            grp["zero"] = grp["zero"].replace("p{}_".format(n.idx), "pg{}_".format(gid))
-            self.pre.append("  const T* const R{} = {} + {};".format(gid, ptr, row))
+                self.pre.append("  " + rename(line))
+            self.pre.append("  const T* const R{} = {};".format(gid, rename(self._address(key, ptr, fshape, idx, sa))))
             self.pre.append("  const T4 R{0}v = *(const T4*)(R{0} + ib);".format(gid))
         gid, nl = grp["id"], self.G[last]
         if s_last < 0 and not grp["left"]:
@@ -519,27 +524,43 @@ class _Codegen:
         self.emit("const T v{} = {};".format(n.idx, e))
         self.loads[desc] = "v{}".format(n.idx)
 
-    def _emit_read_scalar(self, n, ptr, fshape, floc):
-        """One load per point (reads shifted by more than one cell along the last axis in a four-point kernel)."""
-        key, shift, loc, _ = n.attr
-        idx, zero = [], []
-        for d in range(self.ndim):
-            ext = max(fshape[d], self.G[d])
-            s = shift[d] % ext
-            if s > ext // 2:
-                s -= ext
-            j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
-            if floc[d] == "c" and loc[d] == "n":
-                name = "p{}_{}".format(n.idx, d)
-                self.emit("const int {} = {};".format(name, j))
-                zero.append("{} == 0".format(name))
-                j = "({} == 0 ? 0 : {} - 1)".format(name, name)
-            idx.append(j)
-        e = "{}[{}]".format(ptr, self._offset(idx, fshape))
-        if zero:
-            e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
-        self.emit("const T v{} = {};".format(n.idx, e))
-        self.loads[(key, shift, loc)] = "v{}".format(n.idx)
+    def _address(self, key, ptr, fshape, idx, sa):
+        """Pointer expression of the element at `idx` (None on the sharded axis of a slab rank, where the position is
+        the thread's cell + sa)."""
+        if self.slab is None:
+            return "{} + {}".format(ptr, self._offset(idx, fshape))
+        ax, nloc = self.slab
+
+        def at(base, along, extent):
+            full = [along if d == ax else idx[d] for d in range(self.ndim)]
+            shape = [extent if d == ax else fshape[d] for d in range(self.ndim)]
+            return "{} + {}".format(base, self._offset(full, shape))
+
+        if key.startswith("@"):  # a stored adjoint array: owned cells only, no ghosts
+            if not self.in_gather:
+                raise TraceUnsupported("stored adjoint read by the forward kernel")
+            return at(ptr, "min(max(jo + ({}), 0), {})".format(sa, nloc - 1), nloc)
+        slot = self._src_slot(key)
+        if not self.in_gather:
+            # owned cell i (0 <= i < n): position i + lo + sa of the ghost-extended array is always there (|sa| <= the
+            # ghost depth at interfaces); off the GLOBAL grid -- first / last rank only -- a wrap plane
+            main = at(ptr, "(i{} + a.lo + ({}))".format(ax, sa), "a.ea")
+            if sa == 0:
+                return main
+            if sa < 0:
+                cond = "i{}g + ({}) < 0".format(ax, sa)
+                alt = at("a.wlo[{}]".format(slot), "(i{} + ({}) + a.hw)".format(ax, sa), "a.hw")
+            else:
+                cond = "i{}g + ({}) >= {}".format(ax, sa, self.G[ax])
+                alt = at("a.whi[{}]".format(slot), "(i{} + ({}) - {})".format(ax, sa, nloc), "a.hw")
+            return "(({}) ? ({}) : ({}))".format(cond, alt, main)
+        # gather thread at owned-relative plane jo (-2 <= jo < n + 2): a term is kept only where the cell it belongs to
+        # is owned, and then the position is in reach as above; everything else is masked AFTER the (clamped) load
+        gpos = "(jo + a.off + ({}))".format(sa)
+        main = at(ptr, "min(max(jo + a.lo + ({}), 0), a.ea - 1)".format(sa), "a.ea")
+        lo = at("a.wlo[{}]".format(slot), "min(max({} + a.hw, 0), max(a.hw - 1, 0))".format(gpos), "a.hw")
+        hi = at("a.whi[{}]".format(slot), "min(max({} - {}, 0), max(a.hw - 1, 0))".format(gpos, self.G[ax]), "a.hw")
+        return "({0} < 0 ? ({1}) : ({0} >= {2} ? ({3}) : ({4})))".format(gpos, lo, self.G[ax], hi, main)
 
     def _group_arrays(self):
         """Declarations of the per-row register windows [left, 4 values, right] the fast reads index."""
@@ -549,58 +570,6 @@ class _Codegen:
             out.append("  const T R{0}a[6] = {{{1}, R{0}v.x, R{0}v.y, R{0}v.z, R{0}v.w, {2}}};".format(
                 g, "R{}l".format(g) if grp["left"] else "(T)0", "R{}r".format(g) if grp["right"] else "(T)0"))
         return out
-
-    def _emit_read_slab(self, n, slot, fshape, floc):
-        """A read on one rank's slab: as above on the other axes; along the sharded axis no wrap inside the
-        rank -- owned cell i reads cell i + s of the ghost-extended array, or a wrap plane when i + s falls off
-        the GLOBAL grid (only the first / last rank of the decomposition ever does)."""
-        key, shift, loc, _ = n.attr
-        ax, nloc = self.slab
-        if floc[ax] != "c" or loc[ax] != "c":
-            raise TraceUnsupported("slab axis {} must be cell-centred for field '{}'".format(ax, key))
-        sa = shift[ax] % self.G[ax]
-        if sa > self.G[ax] // 2:
-            sa -= self.G[ax]
-        self.halo = max(self.halo, abs(sa))
-        idx, zero = [], []
-        for d in range(self.ndim):
-            if d == ax:
-                idx.append(None)
-                continue
-            ns = fshape[d]
-            ext = max(ns, self.G[d])
-            s = shift[d] % ext
-            if s > ext // 2:
-                s -= ext
-            j = "i{}".format(d) if s == 0 else "wrap(i{} + ({}), {})".format(d, s, ext)
-            if floc[d] == "c" and loc[d] == "n":
-                name = "p{}_{}".format(n.idx, d)
-                self.emit("const int {} = {};".format(name, j))
-                zero.append("{} == 0".format(name))
-                j = "({} == 0 ? 0 : {} - 1)".format(name, name)
-            idx.append(j)
-
-        def offset(along, extent):
-            full = [along if d == ax else idx[d] for d in range(self.ndim)]
-            shape = [extent if d == ax else fshape[d] for d in range(self.ndim)]
-            return self._offset(full, shape)
-
-        main = "a.src[{}] + {}".format(slot, offset("(i{} + a.lo + ({}))".format(ax, sa), "a.ea"))
-        if sa == 0:
-            e = "*({})".format(main)
-        else:
-            # the wrap planes hold `halo` cells; their extent is not known before every read was seen: a.hw
-            if sa < 0:
-                cond = "i{}g + ({}) < 0".format(ax, sa)
-                alt = "a.wlo[{}] + {}".format(slot, offset("(i{} + ({}) + a.hw)".format(ax, sa), "a.hw"))
-            else:
-                cond = "i{}g + ({}) >= {}".format(ax, sa, self.G[ax])
-                alt = "a.whi[{}] + {}".format(slot, offset("(i{} + ({}) - {})".format(ax, sa, nloc), "a.hw"))
-            e = "*(({}) ? ({}) : ({}))".format(cond, alt, main)
-        if zero:
-            e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
-        self.emit("const T v{} = {};".format(n.idx, e))
-        self.loads[(key, shift, loc)] = "v{}".format(n.idx)
 
     def gi(self, d):
         """Index expression of grid axis d as user code sees it (global on the sharded axis)."""
@@ -747,6 +716,8 @@ class _Codegen:
                 self._emit_tensor(n)
             elif op == "index":
                 self.emit(v + "(long){};".format(self.gi(n.attr[0])))
+            elif op == "lindex":
+                self.emit(v + "(long){};".format("jo" if self.in_gather else "i{}".format(n.attr[0])))
             elif op == "win":
                 self.emit(v + "{};".format(self.typed(A[0], n.kind)))
             elif op == "aparam":
@@ -1032,9 +1003,18 @@ class _Codegen:
             for ridx, expr in adj.items():
                 terms.setdefault(tr.nodes[ridx].attr[0], []).append((expr, tr.nodes[ridx].attr))
         exprs = dict()
+        owned = None
+        if self.slab is not None:
+            # one rank of a slab decomposition: a term belongs to this rank where the cell it is evaluated at is OWNED
+            # (the neighbour forms the others and the halo-add of slab_traced.py joins them)
+            ax, nloc = self.slab
+            li = tr.node("lindex", attr=(ax,), shape=self.G, kind=_I)
+            owned = gb._node("and", (gb.cmp("ge", li, tr.const(0)), gb.cmp("lt", li, tr.const(int(nloc)))), kind=_B)
         for key, lst in terms.items():
             total = None
             for expr, attr in lst:
+                if owned is not None:
+                    expr = gb.where(owned, expr, None)
                 shifted = tr.roll(expr, tuple(attr[1]), virtual=True)
                 total = gb.add(total, shifted)
             exprs[key] = total
@@ -1190,7 +1170,7 @@ class _Codegen:
                 attr = self.tr.nodes[ridx].attr
                 by_key.setdefault(attr[0], []).append((len(self.cots) + k, attr, coeff))
         symbolic = dict()
-        if self.slab is None and self.all_regular and int(os.environ.get("ODIL_TRACE_NEWGATHER", 1)):
+        if self.all_regular and int(os.environ.get("ODIL_TRACE_NEWGATHER", 1)):
             symbolic = self._gradient_terms()
         self.gather_blocks = dict()
         keys = list(by_key) + [k for k in symbolic if k not in by_key]
@@ -1205,12 +1185,12 @@ class _Codegen:
                 continue
             gi = len(self.gathers)
             self.gathers.append(key)
-            if self.slab is not None:
-                self._gather_slab(S, gi, key, reads, floc, fshape)
-                continue
             regular = tuple(fshape) == self.G and all(attr[2] == floc for _, attr, _ in reads)
             if key in symbolic and regular and symbolic[key] is not None:
                 self._gather_symbolic(S, gi, key, symbolic[key])
+                continue
+            if self.slab is not None:
+                self._gather_slab(S, gi, key, reads, floc, fshape)
                 continue
             tot = int(np.prod(fshape))
             self.gather_blocks[gi] = (tot + 255) // 256
@@ -1271,7 +1251,7 @@ class _Codegen:
         for gi, key in enumerate(self.gathers):
             tot = int(np.prod(self._field_shape(key)))
             nblk = str(self.gather_blocks.get(gi, (tot + 255) // 256))
-            if self.slab is not None:  # planes -GH .. n + GH of the sharded axis, GH = 2 (slab_traced.G)
+            if self.slab is not None and gi not in self.gather_blocks:  # planes -GH .. n + GH of the sharded axis, GH = 2 (slab_traced.G)
                 per = tot // self._field_shape(key)[self.slab[0]]
                 nblk = "(unsigned)(((long){} * ({} + 4) + 255) / 256)".format(per, self.slab[1])
             S.append("    case {}: hipLaunchKernelGGL(k_gat_{}, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, (T*)g, ad); break;".format(
@@ -1300,25 +1280,40 @@ class _Codegen:
 
     def _gather_symbolic(self, S, gi, key, root):
         """The gather of a regular field as a pointwise kernel over its gradient expression (one thread per point,
-        or per four points of the last axis), the optimizer's update applied by the lane that holds g."""
+        or per four points of the last axis), the optimizer's update applied by the lane that holds g.  Slab mode:
+        threads cover planes -2 .. n + 2 of the sharded axis; planes that exist in the rank's ghost-extended gradient
+        array are stored there (ghost planes: what this rank's cells contribute to the neighbour's), planes beyond an
+        end of the decomposition that a periodic read reached go to the wrap buffers (as the legacy slab gather)."""
         vw, last = self.vw, self.ndim - 1
         saved = (self.order, self.lines, self.pre, self.loads, self.groups)
         nodes = stencil_grad.subdag(root)
         self.order = nodes
         self._begin()
+        self.in_gather = True
         self.forward()
+        self.in_gather = False
         body, pre = self.lines, self.pre + self._group_arrays()
         value = self.r(root)
         self.gather_reads_sources[key] = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})
         self.order, self.lines, self.pre, self.loads, self.groups = saved
-        tot = self.total
-        threads = tot // vw
+        shape = list(self.G)
+        names = ["i{}".format(d) for d in range(self.ndim)]
+        if self.slab is not None:
+            ax, nloc = self.slab
+            shape[ax] = nloc + 4
+            names[ax] = "jx"
+        threads = int(np.prod(shape)) // vw
+        if threads >= 2**31 - 1024:
+            raise TraceUnsupported("grid too large for 32-bit indexing")
         self.gather_blocks[gi] = (threads + 255) // 256
         flat = "l4" if vw == 4 else "l"
         S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
         S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
         S.append("  if ({} >= {}) return;".format(flat, threads))
-        self._index_prologue(S, self.G, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
+        self._index_prologue(S, shape, names, vw, flat)
+        if self.slab is not None:
+            S.append("  const int jo = jx - 2;")  # owned-relative position on the sharded axis
+            S.append("  const int i{}g = wrap(jo + a.off, {});".format(ax, self.G[ax]))
         S.extend(pre)
         if vw == 4:
             S.append("  T acc[4];")
@@ -1327,12 +1322,37 @@ class _Codegen:
         if vw == 4:
             S.append("  acc[p] = {};".format(value))
             S.append("  }")
-            S.append("  *(T4*)(g + l4 * 4) = (T4){acc[0], acc[1], acc[2], acc[3]};")
-            S.append("  adam_apply4(ad, l4 * 4, acc);")
         else:
             S.append("  const T acc = {};".format(value))
-            S.append("  g[l] = acc;")
-            S.append("  adam_apply(ad, l, acc);")
+        if self.slab is None:
+            if vw == 4:
+                S.append("  *(T4*)(g + l4 * 4) = (T4){acc[0], acc[1], acc[2], acc[3]};")
+                S.append("  adam_apply4(ad, l4 * 4, acc);")
+            else:
+                S.append("  g[l] = acc;")
+                S.append("  adam_apply(ad, l, acc);")
+            S.append("}")
+            return
+        slot = self.src_keys.index(key)
+
+        def offset(along, extent):
+            full = [along if d == ax else ("ib" if (vw == 4 and d == last) else "i{}".format(d)) for d in range(self.ndim)]
+            ext = [extent if d == ax else self.G[d] for d in range(self.ndim)]
+            return self._offset(full, ext)
+
+        put = (lambda dst, o: "*(T4*)({} + {}) = (T4){{acc[0], acc[1], acc[2], acc[3]}};".format(dst, o)) if vw == 4 else (
+            lambda dst, o: "{}[{}] = acc;".format(dst, o))
+        S.append("  const int jl = jo + a.lo;")
+        # owned planes a.alo <= jo < a.ahi have their whole gradient here (no neighbour's cell reads them): the optimizer's
+        # update is applied on the spot; the planes next to an interface wait for the halo sum (slab_traced.py)
+        S.append("  if (jl >= 0 && jl < a.ea) {")
+        S.append("    const int o = {};".format(offset("jl", "a.ea")))
+        S.append("    " + put("g", "o"))
+        S.append("    if (jo >= a.alo && jo < a.ahi) {}(ad, o, acc);".format("adam_apply4" if vw == 4 else "adam_apply"))
+        S.append("  }")
+        S.append("  else if (jo < 0 && jo >= -a.hw) {}".format(put("a.gwlo[{}]".format(slot), offset("(jo + a.hw)", "a.hw"))))
+        S.append("  else if (jo >= {0} && jo < {0} + a.hw) {1}".format(
+            nloc, put("a.gwhi[{}]".format(slot), offset("(jo - {})".format(nloc), "a.hw"))))
         S.append("}")
 
 

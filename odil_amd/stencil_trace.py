@@ -341,6 +341,8 @@ class Tracer:
             else:  # (i - r) mod size
                 moved = self.binary("sub", n, r)
                 res = self.where(self.binary("lt", moved, 0), self.binary("add", moved, size), moved)
+        elif n.op == "lindex":  # rank-local cell index of a slab decomposition: shifts, never wraps
+            res = self.binary("sub", n, shifts[n.attr[0]]) if shifts[n.attr[0]] else n
         elif n.op in ("tensor", "rtensor"):
             slot, before = (n.attr, (0,) * len(G)) if n.op == "tensor" else n.attr
             t = self.tensors[slot]
