@@ -253,6 +253,16 @@ int odil_adam_step_pieces_f64(double* x, double* m, double* v, const double* g, 
 int odil_adam_step_pieces_f32(float* x, float* m, float* v, const float* g, int64_t npieces, int64_t stride,
                               int64_t offset, int64_t count, float alpha, float one_minus_b1, float one_minus_b2,
                               float eps, const float* alpha_dev, void* stream);
+/* Planes of ghost-extended arrays <-> contiguous message buffers of the slab exchanges (odil_amd/slab.py,
+ * slab_traced.py; no reference counterpart).  `descs`: DEVICE array of ndesc (<= 65535) records
+ * of five int64 {base, outer, ostride, inner, boff}: plane k of the message is `outer` runs of `inner` contiguous
+ * elements of `arr`, run o at base + o * ostride, and the contiguous range [boff, boff + outer * inner) of `buf`.
+ * mode 0: buf <- arr (pack); 1: arr <- buf (unpack); 2: arr += buf (halo-add: the transpose of the pack).
+ * max_count: the largest outer * inner; vec_ok != 0: every inner is a multiple of 4 (16-byte packs).  One launch. */
+int odil_planes_copy_f64(double* arr, double* buf, const int64_t* descs, int ndesc, int64_t max_count, int vec_ok,
+                         int mode, void* stream);
+int odil_planes_copy_f32(float* arr, float* buf, const int64_t* descs, int ndesc, int64_t max_count, int vec_ok,
+                         int mode, void* stream);
 /* y += a * x  (GdOptimizer: x -= lr*g, optimizer.py:270; Newton update util.py:177). */
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream);
 int odil_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
     "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P, _P],
     "adam_step_pieces": [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _R, _R, _R, _R, _P, _P],
+    "planes_copy": [_P, _P, _P, c_int, c_int64, c_int, c_int, _P],
     "axpy": [_P, _P, c_int64, _R, _P],
     "scale": [_P, _P, c_int64, _R, _P, _P],
     "addcmul": [_P, _P, _P, c_int64, c_int, _P],

@@ -563,6 +563,42 @@ def stencil_march(coeffs, shifts, diag, b, axis, direction, out=None):
     return out
 
 
+class PlaneList:
+    """Planes of arrays inside one packed vector and their places in a contiguous message buffer (see
+    odil_planes_copy in the header).  planes: [(base, outer, ostride, inner)] in message order; start: where the first
+    plane begins in the message (lists over different arrays can share one message); `count`: the message length
+    up to the end of this list's planes."""
+
+    def __init__(self, planes, device, start=0):
+        rows, off, self.max_count = [], int(start), 1
+        for base, outer, ostride, inner in planes:
+            rows.append((int(base), int(outer), int(ostride), int(inner), off))
+            off += int(outer) * int(inner)
+            self.max_count = max(self.max_count, int(outer) * int(inner))
+        self.count, self.n = off, len(rows)
+        self.vec_ok = int(all(r[3] % 4 == 0 for r in rows))
+        self.descs = torch.tensor(rows or [[0] * 5], dtype=torch.int64, device=device).contiguous()
+
+    def _run(self, arr, buf, mode):
+        assert buf.numel() >= self.count and buf.dtype == arr.dtype and arr.dim() == 1
+        if self.n:
+            call("planes_copy", arr.dtype, ptr(arr), ptr(buf), ptr(self.descs), c_int(self.n), c_int64(self.max_count),
+                 c_int(self.vec_ok), c_int(mode), stream_ptr())
+        return buf
+
+    def pack(self, arr, out=None):
+        """The planes of `arr` (flat packed vector) as one contiguous message."""
+        if out is None:
+            out = torch.empty(self.count, dtype=arr.dtype, device=arr.device)
+        return self._run(arr, out, 0)
+
+    def unpack(self, arr, buf):
+        self._run(arr, buf, 1)
+
+    def unpack_add(self, arr, buf):
+        self._run(arr, buf, 2)
+
+
 def csr_assemble(coeffs, shifts, shape, col_offset=0):
     """(indptr, indices, data) of the stencil matrix (reference core.py:1144-1171)."""
     nshift = len(shifts)

@@ -94,17 +94,12 @@ class _Level:
         hi = a.shape[self.axis] - (self.g_hi - 1 if self.g_hi else 0)
         return a.narrow(self.axis, lo, hi - lo)
 
-    def plane_index(self, start, pos, device):
-        """Flat positions, in the packed vector, of the plane at owned-relative position `pos`."""
-        strides = np.cumprod((1,) + self.shape[::-1])[::-1][1:]
-        idx = torch.full((1,) * len(self.shape), int(start + (self.g_lo + pos) * strides[self.axis]), dtype=torch.int64, device=device)
-        for d, s in enumerate(self.shape):
-            if d == self.axis:
-                continue
-            shape = [1] * len(self.shape)
-            shape[d] = s
-            idx = idx + (torch.arange(s, dtype=torch.int64, device=device) * int(strides[d])).view(shape)
-        return idx.reshape(-1)
+    def plane_desc(self, start, pos):
+        """(base, outer, ostride, inner) of the plane at owned-relative position `pos` inside the packed vector whose
+        entry `start` is this array's first element: `outer` runs of `inner` contiguous elements (ops.PlaneList)."""
+        outer = math.prod(self.shape[:self.axis])
+        inner = self.plane // outer
+        return (start + (self.g_lo + pos) * inner, outer, self.shape[self.axis] * inner, inner)
 
 
 class HipSlabKernels:
@@ -122,7 +117,7 @@ class HipSlabKernels:
         self.dtype = dt
         self.total = cg.total
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
-        self.nblocks = min((self.total // cg.vw + 255) // 256, cap)
+        self.nblocks = min((self.total // cg.vw_fwd + 255) // 256, cap)
         nout = len(outs)
         self.nout = nout
         self.cot = [torch.empty(cg.GL, dtype=dt, device=device) for _ in range(cg.ncot)]
@@ -290,7 +285,7 @@ class SlabTracedAdam:
         self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
         pos = 0
         self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
-        send_own = dict(lo=[], hi=[])
+        send_own = dict(lo=[], hi=[])  # plane descriptors (ops.PlaneList): owned boundary planes / inner ghost planes
         recv_ghost = dict(lo=[], hi=[])
         for e in self.entries:
             shapes = [lv.shape for lv in e["levels"]] if "levels" in e else e["shapes"]
@@ -311,17 +306,22 @@ class SlabTracedAdam:
                 elif "levels" in e:
                     lv = e["levels"][k]
                     if rank > 0:
-                        send_own["lo"].append(lv.plane_index(pos, 0, self.device))
-                        recv_ghost["lo"].append(lv.plane_index(pos, -1, self.device))
+                        send_own["lo"].append(lv.plane_desc(pos, 0))
+                        recv_ghost["lo"].append(lv.plane_desc(pos, -1))
                     if rank < world - 1:
-                        send_own["hi"].append(lv.plane_index(pos, lv.n - 1, self.device))
-                        recv_ghost["hi"].append(lv.plane_index(pos, lv.n, self.device))
+                        send_own["hi"].append(lv.plane_desc(pos, lv.n - 1))
+                        recv_ghost["hi"].append(lv.plane_desc(pos, lv.n))
                 pos += cnt
             e.update(views)
             del e["init"]
-        cat = lambda parts: torch.cat(parts) if parts else None
-        self._own = {s: cat(send_own[s]) for s in ("lo", "hi")}
-        self._ghost = {s: cat(recv_ghost[s]) for s in ("lo", "hi")}
+        # one launch packs / unpacks / adds every plane of every level and field of an exchange (odil_planes_copy); the
+        # send buffers of the two exchange points are allocated once
+        mk_list = lambda planes: hip_ops.PlaneList(planes, self.device) if planes else None
+        self._own = {s: mk_list(send_own[s]) for s in ("lo", "hi")}
+        self._ghost = {s: mk_list(recv_ghost[s]) for s in ("lo", "hi")}
+        mk_buf = lambda pl: None if pl is None else torch.empty(pl.count, dtype=dtype, device=self.device)
+        self._send_x = {s: mk_buf(self._own[s]) for s in ("lo", "hi")}
+        self._send_g = {s: mk_buf(self._ghost[s]) for s in ("lo", "hi")}
         self.by_key = {e["key"]: e for e in self.entries}
         self.n_unknowns_local = sum(lv.n * lv.plane for e in self.entries if "levels" in e for lv in e["levels"]
                                     if not lv.replicated) + sum(
@@ -336,18 +336,45 @@ class SlabTracedAdam:
             raise TraceUnsupported("reads {} cells away along the sharded axis (the exchange keeps 1 plane)".format(h))
         self.h = h
         self.u, self.work, self.wrap = dict(), dict(), dict()
+        # the periodic closure's planes (`h` planes per field at each end): the four sets -- u received from across
+        # the low / high end, gradient contributions the gathers write for across them -- are each ONE buffer with
+        # a view per field, so a set travels as one message without a pack (or is filled by one copy)
+        hw = max(h, 1)
+        wsizes = {key: math.prod(hw if d == axis else s_ for d, s_ in enumerate(self.by_key[key]["levels"][0].shape))
+                  for key in self.kern.src_keys}
+        self._wrapbuf = {name: torch.zeros(sum(wsizes.values()), dtype=dtype, device=self.device)
+                         for name in ("lo", "hi", "glo", "ghi")}
+        woff = 0
         for key in self.kern.src_keys:
             e = self.by_key[key]
             lv0 = e["levels"][0]
-            wshape = tuple(max(h, 1) if d == axis else s for d, s in enumerate(lv0.shape))
-            z = lambda shape=wshape: torch.zeros(shape, dtype=dtype, device=self.device)
-            self.wrap[key] = dict(lo=z(), hi=z(), glo=z(), ghi=z())
+            wshape = tuple(hw if d == axis else s_ for d, s_ in enumerate(lv0.shape))
+            self.wrap[key] = {name: buf[woff:woff + wsizes[key]].view(wshape) for name, buf in self._wrapbuf.items()}
+            woff += wsizes[key]
             if e["kind"] == "mg" and len(e["levels"]) > 1:
                 self.u[key] = torch.zeros(lv0.shape, dtype=dtype, device=self.device)
                 self.work[key] = [None] + [torch.zeros(lv.shape, dtype=dtype, device=self.device)
                                            for lv in e["levels"][1:-1]] + [None]
             else:
                 self.u[key] = e["x"][0]
+        # where the wrap contributions of the gradients land: the first / last `h` owned planes of every gathered
+        # field's finest level, in message order (odil_planes_copy, mode add)
+        self._wrap_add = dict()
+        if h:
+            for side, pos in (("lo", 0), ("hi", None)):
+                off, lists = 0, []
+                for key in self.kern.src_keys:
+                    e = self.by_key[key]
+                    lv = e["levels"][0]
+                    if key in self.kern.gather_keys:
+                        first_plane = 0 if pos == 0 else lv.n - h
+                        if hasattr(hip_ops.PlaneList, "_run"):
+                            base, outer, ostride, inner = lv.plane_desc(e["start"], first_plane)
+                            lists.append(hip_ops.PlaneList([(base, outer, ostride, inner * h)], self.device, start=off))
+                        else:  # (CPU double of the plane kernels: tests over gloo)
+                            lists.append((key, lv, first_plane))
+                    off += wsizes[key]
+                self._wrap_add[side] = lists
         lv0 = self.by_key[self.kern.src_keys[0]]["levels"][0]
         self.kern.set_geometry(lv0.off, lv0.g_lo, lv0.shape[axis])
         self.kern.set_params(lambda key: self.by_key[key]["x"])
@@ -454,12 +481,12 @@ class SlabTracedAdam:
 
         b = tic("halo")
         lo, hi = self._own["lo"], self._own["hi"]
-        recv_lo, recv_hi = yield ("halo", None if lo is None else self.x.index_select(0, lo),
-                                  None if hi is None else self.x.index_select(0, hi))
+        recv_lo, recv_hi = yield ("halo", None if lo is None else lo.pack(self.x, self._send_x["lo"]),
+                                  None if hi is None else hi.pack(self.x, self._send_x["hi"]))
         if recv_lo is not None:
-            self.x.index_copy_(0, self._ghost["lo"], recv_lo)
+            self._ghost["lo"].unpack(self.x, recv_lo)
         if recv_hi is not None:
-            self.x.index_copy_(0, self._ghost["hi"], recv_hi)
+            self._ghost["hi"].unpack(self.x, recv_hi)
         toc(b)
         b = tic("mg_synth")
         self._synthesise()
@@ -470,11 +497,9 @@ class SlabTracedAdam:
             recv_lo, recv_hi = yield ("wrap", self._end_planes(ufield, "lo") if first else None,
                                       self._end_planes(ufield, "hi") if last else None)
             if recv_lo is not None:
-                for key, t in self._split_planes(recv_lo).items():
-                    self.wrap[key]["lo"].copy_(t)
+                self._wrapbuf["lo"].copy_(recv_lo.reshape(-1))
             if recv_hi is not None:
-                for key, t in self._split_planes(recv_hi).items():
-                    self.wrap[key]["hi"].copy_(t)
+                self._wrapbuf["hi"].copy_(recv_hi.reshape(-1))
             toc(b)
         b = tic("forward")
         self.kern.forward(self.u, {k: w["lo"] for k, w in self.wrap.items()}, {k: w["hi"] for k, w in self.wrap.items()})
@@ -493,28 +518,31 @@ class SlabTracedAdam:
         toc(b)
         if h and self.kern.gather_keys:
             b = tic("halo")
-            pack = lambda side: torch.cat([self.wrap[key][side].reshape(-1) for key in self.kern.src_keys])
-            recv_lo, recv_hi = yield ("wrap", pack("glo") if first else None, pack("ghi") if last else None)
+            recv_lo, recv_hi = yield ("wrap", self._wrapbuf["glo"] if first else None, self._wrapbuf["ghi"] if last else None)
             # what arrives from across the low end belongs to this rank's FIRST owned planes, and vice versa
-            for recv, pos in ((recv_lo, 0), (recv_hi, None)):
+            for recv, side in ((recv_lo, "lo"), (recv_hi, "hi")):
                 if recv is None:
                     continue
-                for key, t in self._split_planes(recv).items():
-                    if key in self.kern.gather_keys:
-                        lv = self.by_key[key]["levels"][0]
-                        lv.planes(self.by_key[key]["g"][0], 0 if pos == 0 else lv.n - h, h).add_(t)
+                parts = None
+                for item in self._wrap_add[side]:
+                    if isinstance(item, tuple):
+                        parts = parts or self._split_planes(recv)
+                        key, lv, first_plane = item
+                        lv.planes(self.by_key[key]["g"][0], first_plane, h).add_(parts[key])
+                    else:
+                        item.unpack_add(self.g, recv.reshape(-1))
             toc(b)
         b = tic("mg_synth_adj")
         self._transpose_chain()
         toc(b)
         b = tic("halo")
         glo, ghi = self._ghost["lo"], self._ghost["hi"]
-        recv_lo, recv_hi = yield ("halo", None if glo is None else self.g.index_select(0, glo),
-                                  None if ghi is None else self.g.index_select(0, ghi))
+        recv_lo, recv_hi = yield ("halo", None if glo is None else glo.pack(self.g, self._send_g["lo"]),
+                                  None if ghi is None else ghi.pack(self.g, self._send_g["hi"]))
         if recv_lo is not None:
-            self.g.index_add_(0, self._own["lo"], recv_lo)
+            self._own["lo"].unpack_add(self.g, recv_lo)
         if recv_hi is not None:
-            self.g.index_add_(0, self._own["hi"], recv_hi)
+            self._own["hi"].unpack_add(self.g, recv_hi)
         if self._rep and world > 1:  # agglomerated levels: the ranks' shares summed (every rank then updates alike)
             total = yield ("sum", torch.cat([self.g[a:a + c] for a, c in self._rep]), None)
             off = 0

@@ -196,8 +196,15 @@ class _Codegen:
         self.out_count = [int(np.prod(l)) if l is not None else int(np.prod(self.G)) for l in self.out_lens]  # GLOBAL counts
         # four points of the last axis per thread, 16-byte accesses (ODIL_TRACE_VEC=0: one point per thread)
         last = self.ndim - 1
-        self.vw = 4 if (int(os.environ.get("ODIL_TRACE_VEC", 1)) and self.GL[last] % 4 == 0 and self.GL[last] >= 8
-                        and (slab is None or slab[0] != last)) else 1
+        can_vec = self.GL[last] % 4 == 0 and self.GL[last] >= 8 and (slab is None or slab[0] != last)
+        vec = os.environ.get("ODIL_TRACE_VEC", "auto")  # 0 / 1 / auto; ODIL_TRACE_VEC_FWD overrides for k_fwd
+        # a forward kernel with a pointwise network is bound by its arithmetic, not by its loads: four points per thread
+        # only cost it registers (heat with two space dimensions: 2.0 -> 2.5 ms)
+        has_net = any(n.op == "mlp" for n in self.order)
+        vec_fwd = os.environ.get("ODIL_TRACE_VEC_FWD", vec)
+        self.vw_gat = 4 if can_vec and vec != "0" else 1
+        self.vw_fwd = 4 if can_vec and (vec_fwd == "1" or (vec_fwd == "auto" and not has_net)) else 1
+        self.vw = self.vw_fwd
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
@@ -256,17 +263,21 @@ class _Codegen:
         memo[n.idx] = res
         return res
 
-    def _choose_cuts(self):
+    def _choose_cuts(self, modes=None):
         """Nodes whose adjoint is stored as ONE array for all the reads below them: a regulariser
         `lap = (q+ - 2 q + q-) / h^2 + ...` needs one array, not one per stencil point.  A node is cut when
         it is linear in at least two live reads and somebody non-linear (or the loss) consumes it."""
-        memo, consumers = dict(), dict()
-        for n in self.order:
-            for a in n.args:
-                consumers.setdefault(a.idx, []).append(n)
+        modes = self.out_mode if modes is None else modes
+        memo = self.__dict__.setdefault("_affine_memo", dict())
+        consumers = self.__dict__.get("_consumers")
+        if consumers is None:
+            consumers = self._consumers = dict()
+            for n in self.order:
+                for a in n.args:
+                    consumers.setdefault(a.idx, []).append(n)
         outputs = {o.idx for o in self.outputs}
         # nodes only the recomputed outputs reach are never visited by k_fwd's reverse pass
-        legacy_live, stack = set(), [o for k, o in enumerate(self.outputs) if self.out_mode[k] == "legacy"]
+        legacy_live, stack = set(), [o for k, o in enumerate(self.outputs) if modes[k] == "legacy"]
         while stack:
             n = stack.pop()
             if n.idx not in legacy_live:
@@ -282,13 +293,13 @@ class _Codegen:
                 cuts[n.idx] = form
         # a cut only pays when it makes read cotangents disappear: drop cuts greedily while that lowers
         # the number of stored arrays (ties: fewer cuts)
-        best = self._stored_arrays(cuts)
+        best = len(self._stored_nodes(cuts, modes))
         improved = True
         while cuts and improved:
             improved = False
             for idx in list(cuts):
                 trial = {k: v for k, v in cuts.items() if k != idx}
-                count = self._stored_arrays(trial)
+                count = len(self._stored_nodes(trial, modes))
                 if count <= best:
                     cuts, best, improved = trial, count, True
                     break
@@ -360,18 +371,73 @@ class _Codegen:
             mode[k] = "virt" if virt else "jac"
             self.seed_key[k] = None if virt else key
             self.out_adj[k] = adj
+        # ---- which of the candidates pay: words per grid point written by k_fwd and read by the gathers ---------
+        cand = [k for k in range(nout) if mode[k] != "legacy"]
+        if not cand:
+            return mode
+        total = float(np.prod(self.G))
+
+        def arrays_of(expr):
+            res = dict()
+            for n in stencil_grad.subdag(expr):
+                if n.op == "read":
+                    res[("arr", n.attr[0])] = 1.0
+                elif n.op in ("tensor", "rtensor"):
+                    slot = n.attr if n.op == "tensor" else n.attr[0]
+                    res[("ten", slot)] = self.tr.tensors[slot].numel() / total
+            return res
+
+        per_out = dict()  # candidate -> {field: {array: words}}
+        for k in cand:
+            per_out[k] = dict()
+            for ridx, expr in self.out_adj[k].items():
+                per_out[k].setdefault(self.tr.nodes[ridx].attr[0], dict()).update(arrays_of(expr))
+
+        def traffic(on):
+            modes = [mode[k] if k in on else "legacy" for k in range(nout)]
+            cuts = self._choose_cuts(modes) if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
+            stored = self._stored_nodes(cuts, modes)
+            words = len(stored) + sum(1 for k in on if mode[k] == "jac")  # written once by k_fwd
+            reads = dict()
+            for n in stored:
+                keys = {n.attr[0]} if n.op == "read" else {self.tr.nodes[r].attr[0] for r in cuts[n.idx]}
+                for key in keys:
+                    reads.setdefault(key, dict())[("arr", "@{}".format(n.idx))] = 1.0
+            for k in on:
+                for key, arrs in per_out[k].items():
+                    reads.setdefault(key, dict()).update(arrs)
+            return words + sum(sum(arrs.values()) for arrs in reads.values())
+
+        def descend(on):
+            best = traffic(on)
+            while True:
+                trials = [(traffic(on ^ {k}), k) for k in cand]
+                cost, k = min(trials)
+                if cost >= best - 1e-9:
+                    return best, on
+                best, on = cost, on ^ {k}
+
+        if int(os.environ.get("ODIL_TRACE_RECOMPUTE_ALL", 0)):
+            chosen = set(cand)
+        else:
+            (c0, on0), (c1, on1) = descend(frozenset()), descend(frozenset(cand))
+            chosen = on1 if c1 < c0 - 1e-9 else on0
+        self.traffic_words = dict(legacy=traffic(frozenset()), chosen=traffic(frozenset(chosen)))
+        for k in cand:
+            if k not in chosen:
+                mode[k], self.seed_key[k], self.out_adj[k] = "legacy", None, None
         return mode
 
-    def _stored_arrays(self, cuts):
-        """How many cotangent arrays the reverse pass stores for a given set of cut nodes."""
-        reached = {o.idx for k, o in enumerate(self.outputs)
-                   if self.need.get(o.idx, False) and self.out_mode[k] == "legacy"}
-        stored = 0
+    def _stored_nodes(self, cuts, modes=None):
+        """The nodes (live reads, cut nodes) whose adjoint k_fwd's reverse pass stores for a given set of cut nodes."""
+        modes = self.out_mode if modes is None else modes
+        reached = {o.idx for k, o in enumerate(self.outputs) if self.need.get(o.idx, False) and modes[k] == "legacy"}
+        stored = []
         for n in reversed(self.order):
             if n.idx not in reached:
                 continue
             if n.idx in cuts or n.op == "read":
-                stored += 1
+                stored.append(n)
                 continue
             if n.op in ("stopgrad", "floor", "tensor", "index", "aparam"):
                 continue
@@ -1025,6 +1091,7 @@ class _Codegen:
         self.pg_decl, self.pg_offset = [], dict()
         self.pg2_used = set()
         self.jac_store = []
+        self.vw = self.vw_fwd
         vw, last = self.vw, self.ndim - 1
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         self._begin()
@@ -1284,6 +1351,7 @@ class _Codegen:
         threads cover planes -2 .. n + 2 of the sharded axis; planes that exist in the rank's ghost-extended gradient
         array are stored there (ghost planes: what this rank's cells contribute to the neighbour's), planes beyond an
         end of the decomposition that a periodic read reached go to the wrap buffers (as the legacy slab gather)."""
+        self.vw = self.vw_gat
         vw, last = self.vw, self.ndim - 1
         saved = (self.order, self.lines, self.pre, self.loads, self.groups)
         nodes = stencil_grad.subdag(root)
@@ -1292,6 +1360,7 @@ class _Codegen:
         self.in_gather = True
         self.forward()
         self.in_gather = False
+        self.vw = self.vw_fwd
         body, pre = self.lines, self.pre + self._group_arrays()
         value = self.r(root)
         self.gather_reads_sources[key] = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})

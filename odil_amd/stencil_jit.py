@@ -101,7 +101,7 @@ class TracedOperator:
         # space dimensions (46 parameters, 67 M points): 6.6 ms / epoch at 65536 blocks, 5.2 at 4096; plain
         # stencils prefer many (tracer 4-D: 62.0 ms at 65536, 64.5 at 4096).
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
-        self.nblocks = min((self.total // cg.vw + 255) // 256, cap)
+        self.nblocks = min((self.total // cg.vw_fwd + 255) // 256, cap)
         nout = len(outs)
         self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in range(cg.ncot)]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)

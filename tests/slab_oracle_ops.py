@@ -63,3 +63,29 @@ def adam_step(x, m, v, g, alpha, one_minus_b1, one_minus_b2, eps):
     mn += (gn - mn) * one_minus_b1
     vn += (np.square(gn) - vn) * one_minus_b2
     xn -= (mn * alpha) / (np.sqrt(vn) + eps)
+
+
+class PlaneList:
+    """CPU double of odil_amd.ops.PlaneList (odil_planes_copy): same descriptors, index arithmetic in torch."""
+
+    def __init__(self, planes, device, start=0):
+        assert start == 0, "the CPU double packs one array per message"
+        idx, self.count = [], 0
+        for base, outer, ostride, inner in planes:
+            o = torch.arange(outer, dtype=torch.int64).view(-1, 1) * ostride
+            idx.append((base + o + torch.arange(inner, dtype=torch.int64).view(1, -1)).reshape(-1))
+            self.count += outer * inner
+        self.index = torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64)
+
+    def pack(self, arr, out=None):
+        res = arr.index_select(0, self.index)
+        if out is not None:
+            out[: self.count].copy_(res)
+            return out
+        return res
+
+    def unpack(self, arr, buf):
+        arr.index_copy_(0, self.index, buf[: self.count])
+
+    def unpack_add(self, arr, buf):
+        arr.index_add_(0, self.index, buf[: self.count])

@@ -712,3 +712,36 @@ def test_dense_block_xty_on_the_matrix_cores(dev, dtype):
     got = ops.dense_xty(td[:, :35], td)
     want = d[:, :35].astype(np.float64).T @ d.astype(np.float64)
     assert np.max(np.abs(got.cpu().numpy() - want)) <= tol * np.max(np.abs(want)) * 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_planes_copy_vs_index_arithmetic(dtype):
+    """odil_planes_copy (pack / unpack / unpack-add of the slab exchanges' planes, one launch) against the index
+    arithmetic it replaces (tests/slab_oracle_ops.PlaneList): planes of arrays cut along an inner and along the
+    leading axis, runs that are / are not multiples of four elements, a single-element plane; bit-exact."""
+    from slab_oracle_ops import PlaneList as RefList
+
+    from odil_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    for planes in (
+        [(5, 7, 6 * 24, 24), (7 * 6 * 24 + 3 * 24 + 5, 7, 6 * 24, 24), (3000, 1, 40, 40)],   # inner-axis cuts, runs of 24 / 40
+        [(2, 3, 50, 10), (400, 9, 11, 1), (600, 1, 1, 1)],                                      # runs of 10, 1: scalar path
+    ):
+        n = 4000
+        arr = torch.randn(n, generator=gen, dtype=dtype)
+        ref, got = RefList(planes, "cpu"), ops.PlaneList(planes, dev)
+        assert got.count == ref.count
+        d_arr = arr.to(dev)
+        msg = got.pack(d_arr)
+        assert torch.equal(msg.cpu(), ref.pack(arr))
+        buf = torch.randn(ref.count, generator=gen, dtype=dtype)
+        a1, a2 = arr.clone(), arr.clone()
+        ref.unpack(a1, buf)
+        ref.unpack_add(a2, buf)
+        d1, d2 = arr.to(dev), arr.to(dev)
+        got.unpack(d1, buf.to(dev))
+        got.unpack_add(d2, buf.to(dev))
+        assert torch.equal(d1.cpu(), a1) and torch.equal(d2.cpu(), a2)

@@ -54,7 +54,15 @@ def symbolic_gradients(problem, state, arrays_np):
                     box = box & (idx < n)
                 seed = np.where(box, seed, 0.0)
             ev.arrays[cg.seed_key[k]] = seed
-    assert not cg.cots and not cg.cut_nodes, "legacy cotangents need k_fwd's reverse pass: not interpreted here"
+    assert not cg.cots, "legacy read cotangents need k_fwd's reverse pass: not interpreted here"
+    for k, n in enumerate(cg.cut_nodes):  # affine cuts directly below an output: their adjoint is that output's seed
+        (kout,) = [j for j, o in enumerate(outs) if o.idx == n.idx or (o.op in ("mul", "win") and any(a.idx == n.idx for a in o.args))]
+        f = np.asarray(ev(outs[kout]), dtype=np.float64) * np.ones(G)
+        seed = 2.0 * f / cg.out_count[kout]
+        if outs[kout].idx != n.idx:  # output = cut * constant
+            other = [a for a in outs[kout].args if a.idx != n.idx][0]
+            seed = seed * float(ev(other))
+        ev.arrays["@c{}".format(len(cg.cots) + k)] = seed
     return {key: np.asarray(ev(e), dtype=np.float64) * np.ones(G) for key, e in exprs.items()}, cg
 
 

@@ -34,8 +34,10 @@ def test_examples_trace_and_compile(cpu_mod):
     # 18 live reads.  Cotangents are cut at the OUTPUTS: the transport residual and the two Laplacian regularisers
     # store their adjoint once (3 arrays), the imposed-values term and the time differences are re-evaluated by the
     # gathers (nothing stored) -- instead of one cotangent array per stencil point
-    assert tro.cg.out_mode == ["jac", "virt", "jac", "jac", "virt", "virt"] and tro.cg.ncot == 3
-    assert not tro.cg.cots and tro.cg.vw == 4
+    assert tro.cg.out_mode == ["jac", "virt", "legacy", "legacy", "virt", "virt"] and tro.cg.ncot == 3
+    assert not tro.cg.cots and len(tro.cg.cut_nodes) == 2 and tro.cg.vw_fwd == 4 and tro.cg.vw_gat == 4
+    # (the regularisers are linear: as affine cuts of the in-register reverse pass they cost the same one array each)
+    assert tro.cg.traffic_words["chosen"] < 0.7 * tro.cg.traffic_words["legacy"]
     assert hasattr(tro.lib, "jit_fwd") and hasattr(tro.lib, "jit_gather")
     assert "k_gat_2" in tro.source and "k_final" in tro.source
     # the legacy form (one cotangent per live read, affine sub-expressions cut): ODIL_TRACE_RECOMPUTE=0
