@@ -1042,7 +1042,7 @@ class _Codegen:
         or re-evaluated cut c and live read r of the field (module docstring of stencil_grad.py).  Fields with pad /
         trim reads keep the legacy gather (their reads are never below an output cut)."""
         tr = self.tr
-        stop = set(self.cut_set) | {n.idx for n in self.cots}
+        stop = set(self.cut_set)  # (reads are terminal anyway; a read below a cut ALSO collects through that cut)
         terms = dict()  # key -> [expression at the point of evaluation, read attr]
         gb = stencil_grad.GradBuilder(tr, self.G, self.need, stop)
 

@@ -102,9 +102,10 @@ class GradBuilder:
         return self._node("cast", (n,))
 
     # ---- reverse accumulation --------------------------------------------------------------------------------
-    def adjoints(self, root, seed, order):
+    def adjoints(self, root, seed, order, record_stops=False):
         """{read idx: adjoint expression} of the live reads below `root` given the adjoint `seed` of root.
-        `order`: topologically sorted nodes (ascending) that contain the sub-DAG."""
+        `order`: topologically sorted nodes (ascending) that contain the sub-DAG.  record_stops: the adjoints that
+        arrive at the `stop` nodes are returned as well (what k_fwd's reverse pass stores for them)."""
         adj = {root.idx: seed}
         out = dict()
         for n in reversed(order):
@@ -112,6 +113,8 @@ class GradBuilder:
             if a is None:
                 continue
             if n.idx != root.idx and n.idx in self.stop:
+                if record_stops:
+                    out[n.idx] = self.add(out.get(n.idx), a)
                 continue
             if n.op == "read":
                 out[n.idx] = self.add(out.get(n.idx), a)
@@ -177,8 +180,8 @@ class GradBuilder:
             return [(A[0], self.mul(g, self._node("sub", (self.const(1.0), self.mul(n, n)))))]
         if op == "sqrt":
             return [(A[0], self.div(g, self.mul(self.const(2.0), n)))]
-        if op in ("floor", "stopgrad", "tensor", "rtensor", "index", "const", "tracer"):
-            return []
+        if op in ("floor", "stopgrad", "tensor", "rtensor", "index", "lindex", "const", "tracer", "aparam"):
+            return []  # (parameters: their gradients are reduced by k_fwd; here they are coefficients)
         raise TraceUnsupported("symbolic derivative of " + op)
 
 

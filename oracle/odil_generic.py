@@ -94,7 +94,7 @@ class Mod:
         return isinstance(x, torch.Tensor)
 
 
-for _name in ("exp", "log", "sin", "cos", "tanh", "sqrt", "abs", "floor"):
+for _name in ("exp", "log", "sin", "cos", "tanh", "sqrt", "abs", "floor", "relu"):
     setattr(Mod, _name, staticmethod(getattr(torch, _name)))
 
 

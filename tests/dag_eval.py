@@ -36,6 +36,8 @@ class DagEval:
             return n.attr
         if op == "tracer":
             return float(self.tracers[n.attr])
+        if op == "aparam":  # Array unknown a[k]: arrays[key] holds the parameter vector
+            return float(np.asarray(self.arrays[n.attr[0]]).reshape(-1)[n.attr[1]])
         if op == "read":
             key, shift, loc, _ = n.attr
             return np.roll(self.arrays[key], [-s for s in shift], axis=tuple(range(nd)))  # value at i: u[i + shift]

@@ -35,34 +35,50 @@ def cpu_mod():
 
 def symbolic_gradients(problem, state, arrays_np):
     """Gradient of the loss with respect to every regular field array, evaluated from the expressions the gathers
-    are generated from: stored adjoints (read cotangents, affine cuts, output seeds) are produced by evaluating the
-    forward DAG, then every field's expression G_F."""
+    are generated from.  The stored adjoint arrays k_fwd would write are produced by the interpreter too: output
+    seeds 2 f / n ('jac' outputs), and -- for the outputs k_fwd differentiates in registers -- the adjoints that
+    arrive at the stored reads / affine cuts, built with the same symbolic reverse accumulation."""
+    from odil_amd import stencil_grad
+    from odil_amd.stencil_trace import _B, _I, _R
+
     tr, outs, raw, names, G = stencil_jit.trace_outputs(problem, state)
     cg = _Codegen(tr, outs, raw, G, state)
-    cg.source()  # decides cuts / slots and builds nothing we do not also rebuild below
+    cg.source()  # decides cuts and slots
     exprs = cg._gradient_terms()
     ev = DagEval(tr, G, dict(arrays_np), problem.tracers)
-    # the stored adjoint arrays k_fwd would write
+
+    def seed_array(k):
+        f = np.asarray(ev(outs[k]), dtype=np.float64) * np.ones(G)
+        seed = (1.0 if raw[k] else 2.0 * f) / cg.out_count[k] * np.ones(G)
+        if cg.out_lens[k] is not None:
+            box = np.ones(G, dtype=bool)
+            for d, n in enumerate(cg.out_lens[k]):
+                idx = np.arange(G[d]).reshape([-1 if e == d else 1 for e in range(len(G))])
+                box = box & (idx < n)
+            seed = np.where(box, seed, 0.0)
+        return seed
+
+    stored = list(cg.cots) + list(cg.cut_nodes)
+    stop = {n.idx for n in cg.cut_nodes}
+    acc = {n.idx: np.zeros(G) for n in stored}
     for k, mode in enumerate(cg.out_mode):
         if mode == "jac":
-            f = np.asarray(ev(outs[k]), dtype=np.float64) * np.ones(G)
-            seed = (1.0 if raw[k] else 2.0 * f) / cg.out_count[k] * np.ones(G)
-            if cg.out_lens[k] is not None:
-                box = np.ones(G, dtype=bool)
-                for d, n in enumerate(cg.out_lens[k]):
-                    idx = np.arange(G[d]).reshape([-1 if e == d else 1 for e in range(len(G))])
-                    box = box & (idx < n)
-                seed = np.where(box, seed, 0.0)
-            ev.arrays[cg.seed_key[k]] = seed
-    assert not cg.cots, "legacy read cotangents need k_fwd's reverse pass: not interpreted here"
-    for k, n in enumerate(cg.cut_nodes):  # affine cuts directly below an output: their adjoint is that output's seed
-        (kout,) = [j for j, o in enumerate(outs) if o.idx == n.idx or (o.op in ("mul", "win") and any(a.idx == n.idx for a in o.args))]
-        f = np.asarray(ev(outs[kout]), dtype=np.float64) * np.ones(G)
-        seed = 2.0 * f / cg.out_count[kout]
-        if outs[kout].idx != n.idx:  # output = cut * constant
-            other = [a for a in outs[kout].args if a.idx != n.idx][0]
-            seed = seed * float(ev(other))
-        ev.arrays["@c{}".format(len(cg.cots) + k)] = seed
+            ev.arrays[cg.seed_key[k]] = seed_array(k)
+        elif mode == "legacy" and cg.need.get(outs[k].idx, False):
+            key = "@seed{}".format(k)
+            ev.arrays[key] = seed_array(k)
+            tr.state_locs[key] = cg.gloc
+            seed = tr.node("read", attr=(key, (0,) * len(G), cg.gloc, True), shape=G, kind=_R)
+            gb = stencil_grad.GradBuilder(tr, G, cg.need, stop)
+            if outs[k].idx in stop:
+                acc[outs[k].idx] = acc[outs[k].idx] + ev.arrays[key]
+                continue
+            adj = gb.adjoints(outs[k], seed, stencil_grad.subdag(outs[k], stop), record_stops=True)  # reads + cuts
+            for idx, e in adj.items():
+                if idx in acc:
+                    acc[idx] = acc[idx] + np.asarray(ev(e), dtype=np.float64) * np.ones(G)
+    for slot, n in enumerate(stored):
+        ev.arrays["@{}{}".format("r" if slot < len(cg.cots) else "c", slot)] = acc[n.idx]
     return {key: np.asarray(ev(e), dtype=np.float64) * np.ones(G) for key, e in exprs.items()}, cg
 
 
@@ -91,3 +107,35 @@ def test_symbolic_gradient_of_tracer_operators_equals_autograd(cpu_mod, which):
     for key, want in zip(keys, grads):
         err = np.max(np.abs(got[key] - want)) / max(np.max(np.abs(want)), 1e-300)
         assert err < 1e-12, (key, err)
+
+
+@pytest.mark.parametrize("mode", ["chosen", "all_legacy", "all_recomputed"])
+@pytest.mark.parametrize("seed", range(32))
+def test_symbolic_gradient_of_random_operators_equals_autograd(cpu_mod, seed, mode, monkeypatch):
+    """The random operators of the GPU parity test (tests/random_ops.py: shifted reads of two fields, masks, rolls,
+    rows imposed by concatenation, `Array` parameters, windows): whatever mix of stored cotangents, affine cuts, stored
+    output seeds and re-evaluated outputs the generator chooses, the gathers' expressions give autograd's gradient."""
+    from random_ops import random_operator
+
+    if mode == "all_legacy":  # every output differentiated in registers: stored read cotangents and affine cuts only
+        monkeypatch.setenv("ODIL_TRACE_RECOMPUTE", "0")
+    elif mode == "all_recomputed":  # every output that can be is cut, whatever the traffic model says
+        monkeypatch.setenv("ODIL_TRACE_RECOMPUTE_ALL", "1")
+    domain = odil.Domain(cshape=(8, 8), dimnames=("t", "x"), dtype=np.float64, multigrid=False)
+    state = odil.State(fields={"a": odil.Field(None, loc="cc"), "b": odil.Field(None, loc="cc"),
+                               "coeff": odil.Array([0.7, -0.4, 1.3])})
+    state = domain.init_state(state)
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    rows = torch.randn((8,), generator=gen, dtype=torch.float64)
+    arrays = [torch.randn(tuple(a.shape), generator=gen, dtype=torch.float64) for a in domain.arrays_from_state(state)]
+    domain.arrays_to_state(arrays, state)
+    operator = random_operator(seed)
+    problem = odil.Problem(operator, domain, extra=rows)
+    loss, grads, terms, names, values = og.eval_loss_grad(operator, og.Geometry.of(domain), og.fields_of_state(domain, state), rows)
+    got, cg = symbolic_gradients(problem, state, {"a": arrays[0].numpy(), "b": arrays[1].numpy(), "coeff": arrays[2].numpy()})
+    scale = max(np.max(np.abs(g)) for g in grads[:2])
+    for key, want in zip(("a", "b"), grads[:2]):
+        if key in got:
+            assert np.max(np.abs(got[key] - want)) <= 1e-11 * scale, (key, cg.out_mode)
+        else:
+            assert np.max(np.abs(want)) == 0
