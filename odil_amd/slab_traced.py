@@ -158,6 +158,10 @@ class HipSlabKernels:
         self.src_keys, self.gather_keys = list(cg.src_keys), list(cg.gathers)
         # fields whose own arrays the gathers read again (local derivatives re-evaluated there, stencil_grad.py)
         self.reread = {k for keys in cg.gather_reads_sources.values() for k in keys}
+        self.merged = list(cg.merged) if int(os.environ.get("ODIL_TRACE_MERGE", 1)) else []
+        if self.merged:
+            self.lib.jit_gather_all.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [
+                ctypes.c_double] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
         self.param_groups = {key: (cg.pg_offset[key], [len(g) for g in groups]) for key, groups in cg.pgrads.items()}
 
     _host_value = TracedOperator._host_value  # host scalars (functions of problem.tracers): the single-GPU evaluator
@@ -211,6 +215,29 @@ class HipSlabKernels:
             rc = self.lib.jit_gather_adam(which, ctypes.byref(self.args), g.data_ptr(), x.data_ptr(), m.data_ptr(),
                                           v.data_ptr(), float(alpha), float(omb1), float(omb2), float(eps), None,
                                           hip_ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("traced slab gather launch failed: hip error {}".format(rc))
+
+    def gather_all(self, items, hyper=None, planes=(0, 0)):
+        """Every merged field's ghost-extended gradient in ONE launch (see `gather`): items = [(key, g, gwlo, gwhi,
+        (x, m, v) or None)] for exactly the keys of `self.merged`; hyper = (alpha, one_minus_b1, one_minus_b2, eps)."""
+        nk = len(self.merged)
+        arr = lambda: (ctypes.c_void_p * nk)()
+        gp, xp, mp, vp = arr(), arr(), arr(), arr()
+        by_key = {it[0]: it for it in items}
+        for k, key in enumerate(self.merged):
+            _, g, gwlo, gwhi, xmv = by_key[key]
+            i = self.src_keys.index(key)
+            self.args.gwlo[i], self.args.gwhi[i] = gwlo.data_ptr(), gwhi.data_ptr()
+            gp[k] = g.data_ptr()
+            if xmv is not None:
+                x, m, v = xmv
+                assert x.shape == g.shape and x.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+                xp[k], mp[k], vp[k] = x.data_ptr(), m.data_ptr(), v.data_ptr()
+        self.args.alo, self.args.ahi = int(planes[0]), int(planes[1])
+        alpha, omb1, omb2, eps = hyper if hyper is not None else (0.0, 0.0, 0.0, 0.0)
+        rc = self.lib.jit_gather_all(ctypes.byref(self.args), gp, xp, mp, vp, float(alpha), float(omb1), float(omb2),
+                                     float(eps), None, hip_ops.stream_ptr())
         if rc != 0:
             raise RuntimeError("traced slab gather launch failed: hip error {}".format(rc))
 
@@ -508,7 +535,20 @@ class SlabTracedAdam:
         alpha = self.lr * np.sqrt(1 - self.b2**t) / (1 - self.b1**t)
         hyper = (alpha, 1 - self.b1, 1 - self.b2, self.eps)
         b = tic("gather")
+        merged = list(getattr(self.kern, "merged", []))
+        spans = {self._fused[key] for key in merged if key in self._fused}
+        if merged and len(spans) <= 1:  # one launch for all of them (the fused planes are the same for every field)
+            items = []
+            for key in merged:
+                w, e = self.wrap[key], self.by_key[key]
+                items.append((key, e["g"][0], w["glo"], w["ghi"],
+                              (e["x"][0], e["m"][0], e["v"][0]) if key in self._fused else None))
+            self.kern.gather_all(items, hyper, spans.pop() if spans else (0, 0))
+        else:
+            merged = []
         for key in self.kern.gather_keys:
+            if key in merged:
+                continue
             w, e = self.wrap[key], self.by_key[key]
             if key in self._fused:
                 self.kern.gather(key, e["g"][0], w["glo"], w["ghi"],

@@ -46,6 +46,13 @@ __device__ inline T block_sum(T v, T* sm) {
   return r;
 }
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
+// (float kernels with ODIL_TRACE_FAST_F32: the quotient of the update through v_rcp_f32, ~1 ulp, as every other
+// division of those kernels; an IEEE float division is ~10 instructions, sixteen of them per thread in a merged gather)
+#ifdef ODIL_FAST_F32
+#define ADAM_QUOT(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#else
+#define ADAM_QUOT(a, b) ((a) / (b))
+#endif
 // Adam of the array a gather forms the gradient of, applied by the lane that holds g[l] (reference
 // src/odil/optimizer.py:316-318; x == NULL: gradient only).  alpha_dev != NULL: the step size is read from
 // device memory (epochs replayed as a hipGraph).
@@ -56,7 +63,7 @@ __device__ inline void adam_apply(const AdamP& ad, int l, T g) {
   m = m + (g - m) * ad.omb1;
   v = v + (g * g - v) * ad.omb2;
   const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
-  x = x - (m * alpha) / (FN(sqrt)(v) + ad.eps);
+  x = x - ADAM_QUOT(m * alpha, FN(sqrt)(v) + ad.eps);
   ad.m[l] = m, ad.v[l] = v, ad.x[l] = x;
 }
 // Four consecutive points of the last axis per thread (VW == 4): 16-byte accesses (two for doubles).  The type is
@@ -72,7 +79,7 @@ __device__ inline void adam_apply4(const AdamP& ad, int l, const T* g) {
   for (int p = 0; p < 4; ++p) {
     m[p] = m[p] + (g[p] - m[p]) * ad.omb1;
     v[p] = v[p] + (g[p] * g[p] - v[p]) * ad.omb2;
-    x[p] = x[p] - (m[p] * alpha) / (FN(sqrt)(v[p]) + ad.eps);
+    x[p] = x[p] - ADAM_QUOT(m[p] * alpha, FN(sqrt)(v[p]) + ad.eps);
   }
   *(T4*)(ad.m + l) = m, *(T4*)(ad.v + l) = v, *(T4*)(ad.x + l) = x;
 }
@@ -1107,7 +1114,7 @@ class _Codegen:
         self.par_arrays = par_arrays
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
-        HEAD = [_PRELUDE.replace("@T@", T).replace("@FN@", fn)]
+        HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
             HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
         S = []
@@ -1128,7 +1135,9 @@ class _Codegen:
         for (s, l), v in bofs.items():
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
         # ---- k_fwd ---------------------------------------------------------------------------------------------
-        S.append('extern "C" __global__ __launch_bounds__(NB) void k_fwd(const Args a) {')
+        occ = int(os.environ.get("ODIL_TRACE_WAVES_FWD", 0))  # register budget of k_fwd as waves per SIMD (0: the compiler's)
+        S.append('extern "C" __global__ __launch_bounds__(NB) {}void k_fwd(const Args a) {{'.format(
+            "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else ""))
         S.append("  __shared__ T sm[NB / 64];")
         for k in range(nout):
             S.append("  T s_{} = (T)0;".format(k))
@@ -1299,6 +1308,28 @@ class _Codegen:
             S.append("  g[l] = acc;")
             S.append("  adam_apply(ad, l, acc);")
             S.append("}")
+        # every symbolic gather in ONE launch: the fields' expressions share most of what they read (stored seeds, each
+        # other's arrays), a merged pass reads it once (tracer with three space dimensions: 52 -> 36 words per point)
+        self.merged = []
+        sym_keys = [key for key in self.gathers if key in symbolic and symbolic[key] is not None
+                    and tuple(self._field_shape(key)) == self.G
+                    and all(attr[2] == self.state.fields[key].loc for _, attr, _ in by_key.get(key, []))]
+        if len(sym_keys) >= 2 and int(os.environ.get("ODIL_TRACE_MERGE", 1)):
+            self.merged = sym_keys
+            nk = len(sym_keys)
+            S.append("struct GatAll {{ T* g[{0}]; AdamP ad[{0}]; }};".format(nk))
+            threads = self._gather_kernel(S, "k_gat_all", [(key, symbolic[key]) for key in sym_keys], "const GatAll ga",
+                                          lambda k: "ga.g[{}]".format(k), lambda k: "ga.ad[{}]".format(k))
+            S.append('extern "C" int jit_gather_all(const Args* a, void* const* g, void* const* x, void* const* m, void* const* v,')
+            S.append('                               double alpha, double omb1, double omb2, double eps, const void* alpha_dev, void* stream) {')
+            S.append("  GatAll ga;")
+            S.append("  for (int k = 0; k < {}; ++k) {{".format(nk))
+            S.append("    ga.g[k] = (T*)g[k];")
+            S.append("    ga.ad[k] = AdamP{(T*)x[k], (T*)m[k], (T*)v[k], (T)alpha, (T)omb1, (T)omb2, (T)eps, (const T*)alpha_dev};")
+            S.append("  }")
+            S.append("  hipLaunchKernelGGL(k_gat_all, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, ga);".format((threads + 255) // 256))
+            S.append("  return (int)hipGetLastError();")
+            S.append("}")
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
         S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3(NB), 0, (hipStream_t)stream, *a);")
@@ -1346,15 +1377,27 @@ class _Codegen:
         return "\n".join(HEAD + S) + "\n"
 
     def _gather_symbolic(self, S, gi, key, root):
-        """The gather of a regular field as a pointwise kernel over its gradient expression (one thread per point,
-        or per four points of the last axis), the optimizer's update applied by the lane that holds g.  Slab mode:
-        threads cover planes -2 .. n + 2 of the sharded axis; planes that exist in the rank's ghost-extended gradient
-        array are stored there (ghost planes: what this rank's cells contribute to the neighbour's), planes beyond an
-        end of the decomposition that a periodic read reached go to the wrap buffers (as the legacy slab gather)."""
+        """The gather of ONE regular field as a pointwise kernel over its gradient expression."""
+        threads = self._gather_kernel(S, "k_gat_{}".format(gi), [(key, root)], "T* __restrict__ g, const AdamP ad",
+                                      lambda k: "g", lambda k: "ad")
+        self.gather_blocks[gi] = (threads + 255) // 256
+
+    def _gather_kernel(self, S, name, items, params, G_, AD_):
+        """A pointwise kernel over the gradient expressions of `items` = [(field key, expression)] (one thread per
+        point, or per four points of the last axis): common sub-expressions and loads of the fields' expressions are
+        shared, every field's gradient is stored, and the optimizer's update applied, by the lane that holds it.
+        Slab mode: threads cover planes -2 .. n + 2 of the sharded axis; planes that exist in the rank's ghost-extended
+        gradient array are stored there (ghost planes: what this rank's cells contribute to the neighbour's), planes
+        beyond an end of the decomposition that a periodic read reached go to the wrap buffers (as the legacy slab
+        gather).  Returns the number of threads."""
         self.vw = self.vw_gat
         vw, last = self.vw, self.ndim - 1
         saved = (self.order, self.lines, self.pre, self.loads, self.groups)
-        nodes = stencil_grad.subdag(root)
+        seen = dict()
+        for _, root in items:
+            for n in stencil_grad.subdag(root):
+                seen[n.idx] = n
+        nodes = [seen[i] for i in sorted(seen)]
         self.order = nodes
         self._begin()
         self.in_gather = True
@@ -1362,8 +1405,10 @@ class _Codegen:
         self.in_gather = False
         self.vw = self.vw_fwd
         body, pre = self.lines, self.pre + self._group_arrays()
-        value = self.r(root)
-        self.gather_reads_sources[key] = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})
+        values = [self.r(root) for _, root in items]
+        sources = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})
+        for key, _ in items:
+            self.gather_reads_sources[key] = sorted(set(self.gather_reads_sources.get(key, [])) | set(sources))
         self.order, self.lines, self.pre, self.loads, self.groups = saved
         shape = list(self.G)
         names = ["i{}".format(d) for d in range(self.ndim)]
@@ -1374,9 +1419,10 @@ class _Codegen:
         threads = int(np.prod(shape)) // vw
         if threads >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
-        self.gather_blocks[gi] = (threads + 255) // 256
         flat = "l4" if vw == 4 else "l"
-        S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
+        occ = int(os.environ.get("ODIL_TRACE_WAVES_GAT", 0))
+        S.append('extern "C" __global__ __launch_bounds__(NB) {}void {}(const Args a, {}) {{'.format(
+            "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else "", name, params))
         S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
         S.append("  if ({} >= {}) return;".format(flat, threads))
         self._index_prologue(S, shape, names, vw, flat)
@@ -1384,45 +1430,50 @@ class _Codegen:
             S.append("  const int jo = jx - 2;")  # owned-relative position on the sharded axis
             S.append("  const int i{}g = wrap(jo + a.off, {});".format(ax, self.G[ax]))
         S.extend(pre)
-        if vw == 4:
-            S.append("  T acc[4];")
+        for k in range(len(items)):
+            S.append("  T acc{}[{}];".format(k, vw))
         self._loop_open(S, vw)
         S.extend(body)
+        for k, value in enumerate(values):
+            S.append("  acc{}[{}] = {};".format(k, "p" if vw == 4 else "0", value))
         if vw == 4:
-            S.append("  acc[p] = {};".format(value))
             S.append("  }")
-        else:
-            S.append("  const T acc = {};".format(value))
+        adam = "adam_apply4({ad}, {o}, acc{k});" if vw == 4 else "adam_apply({ad}, {o}, acc{k}[0]);"
+        put = "*(T4*)({dst} + {o}) = (T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}};" if vw == 4 else "{dst}[{o}] = acc{k}[0];"
         if self.slab is None:
-            if vw == 4:
-                S.append("  *(T4*)(g + l4 * 4) = (T4){acc[0], acc[1], acc[2], acc[3]};")
-                S.append("  adam_apply4(ad, l4 * 4, acc);")
-            else:
-                S.append("  g[l] = acc;")
-                S.append("  adam_apply(ad, l, acc);")
+            o = "l4 * 4" if vw == 4 else "l"
+            for k in range(len(items)):
+                S.append("  " + put.format(dst=G_(k), o=o, k=k))
+                S.append("  " + adam.format(ad=AD_(k), o=o, k=k))
             S.append("}")
-            return
-        slot = self.src_keys.index(key)
+            return threads
 
         def offset(along, extent):
             full = [along if d == ax else ("ib" if (vw == 4 and d == last) else "i{}".format(d)) for d in range(self.ndim)]
             ext = [extent if d == ax else self.G[d] for d in range(self.ndim)]
             return self._offset(full, ext)
 
-        put = (lambda dst, o: "*(T4*)({} + {}) = (T4){{acc[0], acc[1], acc[2], acc[3]}};".format(dst, o)) if vw == 4 else (
-            lambda dst, o: "{}[{}] = acc;".format(dst, o))
         S.append("  const int jl = jo + a.lo;")
         # owned planes a.alo <= jo < a.ahi have their whole gradient here (no neighbour's cell reads them): the optimizer's
         # update is applied on the spot; the planes next to an interface wait for the halo sum (slab_traced.py)
         S.append("  if (jl >= 0 && jl < a.ea) {")
         S.append("    const int o = {};".format(offset("jl", "a.ea")))
-        S.append("    " + put("g", "o"))
-        S.append("    if (jo >= a.alo && jo < a.ahi) {}(ad, o, acc);".format("adam_apply4" if vw == 4 else "adam_apply"))
+        for k in range(len(items)):
+            S.append("    " + put.format(dst=G_(k), o="o", k=k))
+            S.append("    if (jo >= a.alo && jo < a.ahi) " + adam.format(ad=AD_(k), o="o", k=k))
         S.append("  }")
-        S.append("  else if (jo < 0 && jo >= -a.hw) {}".format(put("a.gwlo[{}]".format(slot), offset("(jo + a.hw)", "a.hw"))))
-        S.append("  else if (jo >= {0} && jo < {0} + a.hw) {1}".format(
-            nloc, put("a.gwhi[{}]".format(slot), offset("(jo - {})".format(nloc), "a.hw"))))
+        S.append("  else if (jo < 0 && jo >= -a.hw) {")
+        S.append("    const int o = {};".format(offset("(jo + a.hw)", "a.hw")))
+        for k, (key, _) in enumerate(items):
+            S.append("    " + put.format(dst="a.gwlo[{}]".format(self.src_keys.index(key)), o="o", k=k))
+        S.append("  }")
+        S.append("  else if (jo >= {0} && jo < {0} + a.hw) {{".format(nloc))
+        S.append("    const int o = {};".format(offset("(jo - {})".format(nloc), "a.hw")))
+        for k, (key, _) in enumerate(items):
+            S.append("    " + put.format(dst="a.gwhi[{}]".format(self.src_keys.index(key)), o="o", k=k))
+        S.append("  }")
         S.append("}")
+        return threads
 
 
 def _gather_slab(self, S, gi, key, reads, floc, fshape):

@@ -137,6 +137,9 @@ class TracedOperator:
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather_adam.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 4 + [
             ctypes.c_void_p, ctypes.c_void_p]
+        if cg.merged:
+            self.lib.jit_gather_all.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [
+                ctypes.c_double] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
         # structure of the state: which arrays belong to which field
         self.layout = []
         pos = 0
@@ -360,6 +363,27 @@ class TracedOperator:
         keep = self._launch(state)
         cur = torch.cuda.current_stream()
         chains = [item for item in self.layout if item[1] in ("field", "mg") and (item[0] in cg.gathers or item[0] in cg.direct)]
+        merged = set()
+        if cg.merged and int(os.environ.get("ODIL_TRACE_MERGE", 1)):
+            # the gradients of all these fields in ONE launch (what their expressions read is read once)
+            by_key = {key: (pos, n) for key, kind, pos, n in self.layout}
+            nk = len(cg.merged)
+            arr = lambda: (ctypes.c_void_p * nk)()
+            gp, xp, mp, vp = arr(), arr(), arr(), arr()
+            alpha, omb1, omb2, eps, adev = 0.0, 0.0, 0.0, 0.0, None
+            for k, key in enumerate(cg.merged):
+                pos = by_key[key][0]
+                gp[k] = self.gtmp.get(key, self.gviews[pos]).data_ptr()
+                if adam is not None and key in adam[0]:
+                    _, arrays, mm, vv, alpha, omb1, omb2, eps = adam
+                    xp[k], mp[k], vp[k] = arrays[pos].data_ptr(), mm[pos].data_ptr(), vv[pos].data_ptr()
+            if isinstance(alpha, torch.Tensor):
+                adev, alpha = alpha.data_ptr(), 0.0
+            rc = self.lib.jit_gather_all(ctypes.byref(self.args), gp, xp, mp, vp, float(alpha), float(omb1), float(omb2),
+                                         float(eps), adev, ops.stream_ptr())
+            if rc != 0:
+                raise RuntimeError("traced gather launch failed: hip error {}".format(rc))
+            merged = set(cg.merged)
         side = self._side_streams(len(chains))
         for i, (key, kind, pos, n) in enumerate(chains):
             s_ = side[i % len(side)] if side else cur
@@ -367,7 +391,9 @@ class TracedOperator:
                 s_.wait_stream(cur)
             with torch.cuda.stream(s_):
                 fuse = adam is not None and key in adam[0]
-                if key in cg.gathers:
+                if key in merged:
+                    g = self.gtmp.get(key, self.gviews[pos])
+                elif key in cg.gathers:
                     g = self.gtmp.get(key, self.gviews[pos])
                     if fuse:
                         _, arrays, mm, vv, alpha, omb1, omb2, eps = adam

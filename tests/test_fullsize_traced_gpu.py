@@ -1,0 +1,207 @@
+"""The traced-operator path at the sizes BASELINE.json names for its workloads, where neither the oracle nor the
+reference fixtures can follow: heat inverse with two space dimensions (t, x, y) = 256 x 512^2 float32 (config 3) and
+the flow-reconstruction workload's per-rank slab (t, x, y, z) = (128, 32, 256, 256) float32 (config 5).  What changes
+with size in the generated kernels -- flat indices of 67 M / 270 M points, grid caps, the streaming-store switch, four
+points per thread -- is covered by properties that do not need a second implementation at that size:
+
+* a WINDOW of the full-size gradient against autograd: the operators are local (reach <= 2 cells) and depend on the
+  position only through the time index and the walls, so a small problem that spans all of t and a window of the
+  space axes away from the walls, fed the full problem's values on that window, has -- in the window's interior --
+  the full problem's gradient up to the ratio of the point counts (every term is a mean over the whole grid).  The
+  small problem runs through the GENERIC autograd path (torch autograd over the user's operator);
+* run-to-run bit reproducibility (deterministic reductions, no atomics);
+* the gradient is the derivative of the loss: central difference of the loss along a random direction in float64
+  at full size against <g, d>;
+* config 5: two emulated ranks of the full per-rank shape against the undivided traced path.
+"""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+for sub in ("heat", "velocity_from_tracer"):
+    sys.path.insert(0, os.path.join(ROOT, "examples", sub))
+
+
+def _quiet():
+    import odil_amd as odil
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    return odil
+
+
+def _randomise(problem, state, seed, scale=0.1):
+    """Random values in every unknown array (device generator: no host staging of GB-sized arrays)."""
+    domain = problem.domain
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    new = [torch.randn(tuple(a.shape), generator=gen, dtype=a.dtype, device=a.device) * scale
+           for a in domain.arrays_from_state(state)]
+    domain.arrays_to_state(new, state)
+    return new
+
+
+def test_heat2d_full_size_window_vs_autograd_and_reproducible():
+    """Config 3's shape, 256 x 512^2 float32, 46 network parameters inside the stencil."""
+    import heat2d as ex
+
+    odil = _quiet()
+    full_argv = ["--Nt", "256", "--Nx", "512", "--Ny", "512", "--infer_k", "1", "--imposed", "stripe", "--multigrid", "0"]
+    problem, state = ex.make_problem(ex.parse_args(full_argv))
+    domain = problem.domain
+    mod = domain.mod
+    _randomise(problem, state, 1, scale=0.3)
+    loss, grads = problem.eval_loss_grad(state)[:2]
+    assert problem._traced is not None, "operator was not traced"
+    loss = float(loss)
+    g_full = [g.clone() for g in grads]
+    loss2, grads2 = problem.eval_loss_grad(state)[:2]
+    assert float(loss2) == loss and all(torch.equal(a, b) for a, b in zip(g_full, grads2))  # bit-reproducible
+    assert np.isfinite(loss) and all(bool(torch.isfinite(g).all()) for g in g_full)
+    # ---- the window: all of t, 24 x 24 cells of (x, y) away from the walls --------------------------------------
+    nt, nx = domain.cshape[0], 24
+    lo = (200, 311)
+    small_args = ex.parse_args(["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(nx), "--infer_k", "1", "--imposed", "stripe",
+                                "--multigrid", "0"])
+    sdom = odil.Domain(cshape=(nt, nx, nx), dimnames=("t", "x", "y"), multigrid=False, dtype=domain.dtype,
+                       lower=(0, 0, 0), upper=(1, nx / 512.0, nx / 512.0))
+    sel = (slice(None), slice(lo[0], lo[0] + nx), slice(lo[1], lo[1] + nx))
+    extra = argparse.Namespace(**vars(problem.extra))
+    extra.args = small_args
+    for name, value in vars(problem.extra).items():
+        if torch.is_tensor(value) and value.dim() == 3 and tuple(value.shape) == tuple(domain.cshape):
+            setattr(extra, name, value[sel].contiguous())
+        elif torch.is_tensor(value) and value.dim() == 2 and tuple(value.shape) == tuple(domain.cshape[1:]):
+            setattr(extra, name, value[sel[1:]].contiguous())
+    # the imposed-points weight is kimp * sqrt(points / imposed points) of the WHOLE grid: keep that ratio
+    n_full, n_small = float(np.prod(domain.cshape)), float(nt * nx * nx)
+    extra.imp_size = problem.extra.imp_size * n_small / n_full
+    sstate = odil.State(fields={k: (odil.Field(f.array[sel].contiguous(), loc=f.loc) if isinstance(f, odil.Field) else f)
+                                for k, f in state.fields.items()})
+    sstate = sdom.init_state(sstate)
+    odil.runtime.enable_trace = False
+    try:
+        small = odil.Problem(ex.operator, sdom, extra, tracers=dict(problem.tracers))
+        sloss, sgrads = small.eval_loss_grad(sstate)[:2]
+        assert small._traced is None
+    finally:
+        odil.runtime.enable_trace = True
+    keys = list(state.fields)
+    iu = keys.index("u")
+    inner = (slice(None), slice(2, nx - 2), slice(2, nx - 2))
+    want = sgrads[iu][inner] * (n_small / n_full)
+    got = g_full[iu][sel][inner]
+    scale = float(want.abs().max())
+    assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale, float((got - want).abs().max()) / scale
+
+
+def _tracer_problem(nt, nx, ny, double, multigrid):
+    import veltracer3d as ex
+
+    argv = ["--Nt", str(nt), "--Nx", str(nx), "--Ny", str(ny), "--Nz", str(ny), "--multigrid", str(multigrid)]
+    if double:
+        argv += ["--double", "1"]
+    return ex, ex.make_problem(ex.parse_args(argv))
+
+
+def test_tracer_slab_shape_window_vs_autograd_and_reproducible():
+    """Config 5's per-rank shape (128, 32, 256, 256) float32 as one undivided problem: 270 M points, 4 fields."""
+    odil = _quiet()
+    ex, (problem, state) = _tracer_problem(128, 32, 256, 0, 0)
+    domain = problem.domain
+    _randomise(problem, state, 2, scale=0.3)
+    loss, grads = problem.eval_loss_grad(state)[:2]
+    assert problem._traced is not None
+    cg = problem._traced.cg
+    assert cg.vw_fwd == 4 and cg.ncot <= 5  # output seeds instead of one cotangent array per stencil read
+    loss = float(loss)
+    g_full = [g.clone() for g in grads]
+    loss2, grads2 = problem.eval_loss_grad(state)[:2]
+    assert float(loss2) == loss and all(torch.equal(a, b) for a, b in zip(g_full, grads2))
+    # ---- window: all of t, 12^3 cells of (x, y, z); the operator is periodic in space, so any window will do ------
+    nt, nb = domain.cshape[0], 12
+    lo = (17, 100, 201)
+    sel = (slice(None),) + tuple(slice(l, l + nb) for l in lo)
+    sdom = odil.Domain(cshape=(nt, nb, nb, nb), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
+                       upper=(1, nb / 32.0, nb / 256.0, nb / 256.0), dtype=domain.dtype, multigrid=False)
+    extra = argparse.Namespace(args=problem.extra.args, u_init=problem.extra.u_init[sel[1:]].contiguous(),
+                               u_final=problem.extra.u_final[sel[1:]].contiguous())
+    sstate = odil.State(fields={k: odil.Field(f.array[sel].contiguous(), loc=f.loc) for k, f in state.fields.items()})
+    sstate = sdom.init_state(sstate)
+    odil.runtime.enable_trace = False
+    try:
+        small = odil.Problem(ex.operator, sdom, extra)
+        sgrads = small.eval_loss_grad(sstate)[1]
+        assert small._traced is None
+    finally:
+        odil.runtime.enable_trace = True
+    ratio = float(np.prod(sdom.cshape)) / float(np.prod(domain.cshape))
+    inner = (slice(None),) + (slice(2, nb - 2),) * 3
+    for i, key in enumerate(state.fields):
+        want = sgrads[i][inner] * ratio
+        got = g_full[i][sel][inner]
+        scale = float(want.abs().max())
+        assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale, (key, float((got - want).abs().max()) / scale)
+
+
+def test_tracer_full_size_gradient_is_the_derivative_of_the_loss():
+    """float64 at (64, 32, 256, 256) (134 M points; the float kernels are the same generated source with another
+    scalar type): (L(x + e d) - L(x - e d)) / 2e against <g, d> for a random direction d."""
+    odil = _quiet()
+    ex, (problem, state) = _tracer_problem(64, 32, 256, 1, 0)
+    domain = problem.domain
+    x0 = _randomise(problem, state, 3, scale=0.3)
+    loss, grads = problem.eval_loss_grad(state)[:2]
+    assert problem._traced is not None
+    g = [t.clone() for t in grads]
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    d = [torch.randn(tuple(a.shape), generator=gen, dtype=a.dtype, device=a.device) for a in x0]
+    slope = sum(float((a * b).sum()) for a, b in zip(g, d))
+    eps = 1e-5
+    vals = []
+    for sign in (1.0, -1.0):
+        domain.arrays_to_state([a + sign * eps * b for a, b in zip(x0, d)], state)
+        vals.append(float(problem.eval_loss_grad(state)[0]))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - slope) <= 1e-6 * max(abs(slope), 1e-30), (fd, slope)
+
+
+def test_two_emulated_ranks_at_the_full_per_rank_shape_equal_the_undivided_path():
+    """Config 5 with two ranks of (128, 32, 256, 256) float32 each (global (128, 64, 256, 256), the domain's own
+    multigrid levels): loss after 2 epochs and the finest-level arrays against the single-GPU traced path."""
+    odil = _quiet()
+    from odil_amd.slab import run_lockstep
+    from odil_amd.slab_traced import SlabTracedAdam
+
+    world, epochs, lr = 2, 2, 0.01
+    ex, (problem, state) = _tracer_problem(128, 64, 256, 0, 1)
+    _randomise(problem, state, 5, scale=0.1)
+    ranks = [SlabTracedAdam(problem, state, r, world, axis=1, lr=lr) for r in range(world)]
+    run_lockstep(ranks, epochs)
+    run_lockstep(ranks, 1)  # evaluates the loss at the state after `epochs` updates
+    got_loss = sum(r.last_loss() for r in ranks)
+    a = argparse.Namespace(epoch_start=0, epochs=epochs, lr=lr, bfgs_m=None, bfgs_pgtol=None, bfgs_maxls=None,
+                           adam_epsilon=None, adam_beta_1=None, adam_beta_2=None, callback_update_state=0)
+    start = [t.clone() for t in problem.domain.arrays_from_state(state)]
+    odil.util.optimize_grad(a, "adam", problem, state, None)
+    assert problem._traced is not None
+    want_loss = float(problem.eval_loss_grad(state)[0])
+    assert abs(got_loss - want_loss) <= 2e-4 * abs(want_loss), (got_loss, want_loss)
+    # the ranks have made epochs + 1 updates: the undivided problem again from the start
+    problem.domain.arrays_to_state(start, state)
+    a.epochs = epochs + 1
+    odil.util.optimize_grad(a, "adam", problem, state, None)
+    want = problem.domain.arrays_from_state(state)
+    for r, run in enumerate(ranks):
+        for i, (got, ref) in enumerate(zip(run.owned_arrays(), want)):
+            if got.shape != ref.shape:
+                n = ref.shape[1] // world
+                ref = ref[:, r * n:(r + 1) * n]
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= 1e-4 * scale, (r, i)
