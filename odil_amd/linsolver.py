@@ -100,7 +100,7 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     return x
 
 
-def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
+def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inner=None):
     """`direct` for systems with DENSE columns (`Array` / `NeuralNet` unknowns, reference core.py:1189-1203).
 
     With M = [S | D] (S: the stencil blocks, matrix-free; D: rows x p dense, p <= 63) the normal equations
@@ -111,7 +111,8 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
         (G - C^T Z) y = g - C^T z                  C^T [Z | z] again on the matrix cores; a p x p solve
         x = z - Z y
     Neither M nor S is ever densified.  Returns the full solution vector, or None when the system has no dense
-    columns / too many of them."""
+    columns / too many of them.  inner: callable [k, n_s] -> [k, n_s] that applies (S^T S + damping)^{-1} to all
+    right-hand sides at once (the block-tridiagonal direct solver, blocktri.py) instead of the CG solves."""
     dense_keys = []
     for row0, nrows, kind, key, payload in op.blocks:
         if kind == "dense" and key not in dense_keys:
@@ -154,12 +155,20 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
         dt = daug.t().contiguous()  # (p + 1) x rows: the columns of [D | r] as contiguous vectors
         cz = torch.stack([op_s.rmatvec(dt[j]) for j in range(p + 1)])  # rows: C_j = S^T D_j, last: S^T r
         zs, niter, worst = [], 0, 0.0
-        for j in range(p + 1):
-            sub = dict()
-            zs.append(cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j]))
-            niter = max(niter, sub.get("niter", 0))
-            worst = max(worst, sub.get("residual", 0.0))
-        zs = torch.stack(zs)
+        if inner is not None:
+            # the stencil unknowns may be a sub-range of the vector: the inner solver sees its own field only
+            zs = torch.zeros_like(cz)
+            off, size = inner.offset, inner.size
+            zs[:, off:off + size] = inner.solve(cz[:, off:off + size].contiguous())
+            niter = 1
+            info["method"] = "schur-mfma + block-tridiagonal direct"
+        else:
+            for j in range(p + 1):
+                sub = dict()
+                zs.append(cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j]))
+                niter = max(niter, sub.get("niter", 0))
+                worst = max(worst, sub.get("residual", 0.0))
+            zs = torch.stack(zs)
         info.update(inner_solves=p + 1, inner_residual_max=worst)  # (an inner solve cut short by maxiter shows here)
         ct = cz[:p].t().contiguous()  # unknowns x p
         zt = zs.t().contiguous()      # unknowns x (p + 1)
@@ -173,6 +182,45 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None):
         status.update(info)
         status["residual"] = float(_dot(r, r)) ** 0.5
         status["niter"] = niter
+    return x
+
+
+def blocktri_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
+    """`direct` for operators whose stencil part acts on ONE field and couples neighbouring levels of one axis only
+    (implicit time stepping: reference examples/heat/heat.py:36-137): the normal equations (reference
+    linsolver.py:17-26) by block cyclic reduction (blocktri.py), dense `NeuralNet` / `Array` columns through the
+    Schur complement.  None when the structure is not there (the caller goes on to the general routes)."""
+    from . import blocktri
+    from .core import Field
+
+    keys = {key for _, _, kind, key, _ in op.blocks if kind == "stencil"}
+    if len(keys) != 1:
+        return None
+    (key,) = keys
+    if not isinstance(op.key_to_field[key], Field):
+        return None
+    dense_keys = {k for _, _, kind, k, _ in op.blocks if kind == "dense"}
+    if set(op.key_to_field) - {key} - dense_keys and any(op.key_to_size[k] for k in set(op.key_to_field) - {key} - dense_keys):
+        return None  # unknowns no block refers to: the general routes regularise or report them
+    if key in dense_keys:
+        return None
+    inner = blocktri.BlockTridiagonalNormal(op, key, damp, dampdiag)
+    if not inner.ok:
+        return None
+    inner.offset, inner.size = op.key_to_offset[key], op.key_to_size[key]
+    if dense_keys:
+        if sum(op.key_to_size[k] for k in dense_keys) > 63:
+            return None
+        return schur_normal(op, rhs, damp, dampdiag, status=status, inner=inner)
+    b = op.rmatvec(rhs)
+    x = torch.zeros(op.ncols, dtype=op.dtype, device=op.device)
+    x[inner.offset:inner.offset + inner.size] = inner.solve(b[inner.offset:inner.offset + inner.size][None].contiguous())[0]
+    if status is not None:
+        r = op.rmatvec(op.matvec(x) - rhs)
+        status["residual"] = float(_dot(r, r)) ** 0.5
+        status["niter"] = 1
+        status["method"] = "block-tridiagonal direct (axis {}, {} levels of {} points)".format(
+            inner.axis, inner.shape[inner.axis], inner.size // inner.shape[inner.axis])
     return x
 
 
@@ -321,6 +369,9 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                 return x
             # (a singular diagonal block met on the way: the general solvers below regularise or report it)
     if linsolver in ("direct", "directsq"):
+        x = blocktri_normal(matr, rhs, damp, dampdiag, status)
+        if x is not None and bool(torch.isfinite(x).all()):
+            return x
         has_dense = any(kind == "dense" for _, _, kind, _, _ in matr.blocks)
         # small systems: ONE dense Cholesky of the normal matrix beats the p + 1 inner CG solves of the Schur route
         small = _dense_fits(matr) and matr.ncols <= SCHUR_MIN_UNKNOWNS

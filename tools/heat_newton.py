@@ -11,6 +11,10 @@ for nt, nx in ((32, 64), (64, 128), (128, 256), (256, 512)):
     problem, state = heat.make_problem(args)
     odil.util.set_log_file(open(os.devnull, "w"))
     args.epoch_start, args.epochs = 0, 1
+    try:
+        odil.util.optimize_newton(args, problem, state)  # first step: allocations, library start-up
+    except Exception as e:
+        pass
     torch.cuda.synchronize(); t0 = time.perf_counter()
     try:
         odil.util.optimize_newton(args, problem, state)
