@@ -7,7 +7,7 @@ With S the stencil part of M acting on one field, A = S^T S is again a stencil o
 sums of products of S's coefficient arrays (formed on the device, a few elementwise passes over the grid).  When the
 shifts of A along one axis stay within -1 .. +1 and nothing wraps around the ends of that axis, A is BLOCK
 TRIDIAGONAL along it: n levels, blocks of nb = (points of one level) squared.  Block cyclic reduction solves such a
-system in log2(n) rounds of batched dense LU factorisations and GEMMs (rocSOLVER / rocBLAS through torch: the f64
+system in log2(n) rounds of batched dense Cholesky factorisations and GEMMs (rocSOLVER / rocBLAS through torch: the f64
 matrix cores), every round halving the number of levels -- no sequential sweep over the levels, no iteration, the
 answer to round-off.  256 x 512 (heat): ~4e11 flop, tens of milliseconds; the Jacobi-preconditioned CG on the same
 normal equations it replaces took 0.7 - 2.3 s.  Dense columns (`NeuralNet` / `Array` unknowns) are eliminated by the
@@ -101,16 +101,30 @@ def dense_blocks(normal, shape, axis):
     return tuple(t.view(n, nb, nb) for t in out)
 
 
+class NotPositiveDefinite(ArithmeticError):
+    pass
+
+
+def _cholesky(A):
+    c, info = torch.linalg.cholesky_ex(A)
+    if bool(info.any()):
+        raise NotPositiveDefinite("a diagonal block of the normal equations is not positive definite")
+    return c
+
+
 def solve_block_tridiagonal(L, D, U, B):
-    """X with L[i] X[i-1] + D[i] X[i] + U[i] X[i+1] = B[i] (L[0], U[n-1] ignored) by block cyclic reduction.
-    L, D, U: [n, nb, nb]; B: [n, nb, k].  Every round eliminates the odd levels with ONE batched LU."""
+    """X with L[i] X[i-1] + D[i] X[i] + U[i] X[i+1] = B[i] (L[0], U[n-1] ignored) by block cyclic reduction, for a
+    symmetric positive definite system.  L, D, U: [n, nb, nb]; B: [n, nb, k].  Every round eliminates the odd levels
+    with ONE batched Cholesky factorisation.  Raises NotPositiveDefinite for a singular / indefinite system."""
     n = D.shape[0]
     if n == 1:
-        return torch.linalg.solve(D, B)
+        return torch.cholesky_solve(B, _cholesky(D))
     nb, k = D.shape[1], B.shape[2]
     ne, m = (n + 1) // 2, n // 2  # even / odd levels
-    lu, piv = torch.linalg.lu_factor(D[1::2])
-    sol = torch.linalg.lu_solve(lu, piv, torch.cat([L[1::2], U[1::2], B[1::2]], dim=2))
+    # the diagonal blocks of an SPD block-tridiagonal matrix and of its Schur complements are SPD: batched Cholesky
+    # (128 x 512 x 512 with 1025 right-hand sides: 8 ms; the batched LU route of this stack takes 250 ms at that size
+    # when its triangular solves do not fail outright -- tools/probe_batched_solve.py)
+    sol = torch.cholesky_solve(torch.cat([L[1::2], U[1::2], B[1::2]], dim=2), _cholesky(D[1::2]))
     iL, iU, iB = sol[:, :, :nb], sol[:, :, nb:2 * nb], sol[:, :, 2 * nb:]
     Le, De, Ue, Be = L[0::2], D[0::2].clone(), U[0::2], B[0::2].clone()
     Ln, Un = torch.zeros_like(De), torch.zeros_like(De)

@@ -208,13 +208,16 @@ def blocktri_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
     if not inner.ok:
         return None
     inner.offset, inner.size = op.key_to_offset[key], op.key_to_size[key]
-    if dense_keys:
-        if sum(op.key_to_size[k] for k in dense_keys) > 63:
-            return None
-        return schur_normal(op, rhs, damp, dampdiag, status=status, inner=inner)
-    b = op.rmatvec(rhs)
-    x = torch.zeros(op.ncols, dtype=op.dtype, device=op.device)
-    x[inner.offset:inner.offset + inner.size] = inner.solve(b[inner.offset:inner.offset + inner.size][None].contiguous())[0]
+    try:
+        if dense_keys:
+            if sum(op.key_to_size[k] for k in dense_keys) > 63:
+                return None
+            return schur_normal(op, rhs, damp, dampdiag, status=status, inner=inner)
+        b = op.rmatvec(rhs)
+        x = torch.zeros(op.ncols, dtype=op.dtype, device=op.device)
+        x[inner.offset:inner.offset + inner.size] = inner.solve(b[inner.offset:inner.offset + inner.size][None].contiguous())[0]
+    except blocktri.NotPositiveDefinite:
+        return None  # a singular normal matrix: the general routes (damping, CG) deal with it
     if status is not None:
         r = op.rmatvec(op.matvec(x) - rhs)
         status["residual"] = float(_dot(r, r)) ** 0.5
