@@ -212,4 +212,6 @@ def test_two_emulated_ranks_at_the_full_per_rank_shape_equal_the_undivided_path(
                 n = ref.shape[1] // world
                 ref = ref[:, r * n:(r + 1) * n]
             scale = max(1.0, float(ref.abs().max()))
-            assert float((got - ref).abs().max()) <= 1e-4 * scale, (r, i)
+            # (float32, three Adam updates of size lr = 0.01 each: an entry whose gradient is at round-off level moves by
+            # a rounding-dependent fraction of a step)
+            assert float((got - ref).abs().max()) <= 1e-3 * scale, (r, i)
