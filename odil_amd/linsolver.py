@@ -64,7 +64,9 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     p.copy_(z)
     rz = _dot(r, z)
     bnorm = float(_dot(b, b)) ** 0.5
-    maxiter = maxiter or 20 * n
+    # (no --linsolver_maxiter: 20 n as SciPy's CG would, but bounded -- a singular system never reaches the tolerance,
+    # and 20 n iterations at a few hundred thousand unknowns are hours)
+    maxiter = maxiter or min(20 * n, 50000)
     niter = 0
     res = float(_dot(r, r)) ** 0.5
     coef = torch.ones(3, dtype=dtype, device=device)  # (beta, 1) on rows 0:2, or (1, beta) on rows 1:3
@@ -97,6 +99,22 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
         status["niter"] = niter
     if not bool(torch.isfinite(x).all()):
         raise FloatingPointError("cg_normal: the iterate is not finite (residual {})".format(res))
+    return x
+
+
+def _solve_small_spd(a, b, info=None):
+    """x with a x = b for the p x p (p <= 63) Schur complement of the dense columns.  Network weights often leave it
+    SINGULAR (redundant directions: the reference's SuperLU then returns some member of the solution set): when the
+    plain solve is not finite or misses the equations, the minimum-norm solution through the eigen-decomposition."""
+    try:
+        x = torch.linalg.solve(a, b)
+        ok = bool(torch.isfinite(x).all()) and float((a @ x - b).norm()) <= 1e-8 * max(float(b.norm()), 1e-300)
+    except RuntimeError:
+        x, ok = None, False
+    if not ok:
+        x = torch.linalg.pinv(a, hermitian=True) @ b
+        if info is not None:
+            info["schur_complement"] = "singular: minimum-norm solution"
     return x
 
 
@@ -145,7 +163,7 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
                        for k in dense_keys])
     info = dict(method="schur-mfma", dense_columns=p)
     if not stencil_blocks:
-        y = torch.linalg.solve(G, g)
+        y = _solve_small_spd(G, g, info)
         niter = 0
     else:
         import copy
@@ -173,7 +191,7 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
         ct = cz[:p].t().contiguous()  # unknowns x p
         zt = zs.t().contiguous()      # unknowns x (p + 1)
         czz = ops.dense_xty(ct, zt)   # C^T [Z | z]
-        y = torch.linalg.solve(G - czz[:, :p], g - czz[:, p])
+        y = _solve_small_spd(G - czz[:, :p], g - czz[:, p], info)
         x.copy_(zs[p])
         ops.lincomb(x, 1.0, zs[:p].contiguous(), (-y).contiguous())
     x[dcols] = y

@@ -279,8 +279,7 @@ class SlabTracedAdam:
         sizes = []
         for key, f in state.fields.items():
             if isinstance(f, MultigridField):
-                if not all(float(x) == 1.0 for x in (f.factors or domain.mg_factors or [1])):
-                    raise NotImplementedError("slab decomposition with multigrid factors")
+                factors = [float(x) for x in (f.factors or domain.mg_factors or [1] * len(f.terms))]
                 mgloc = domain._mg_loc(f)
                 if mgloc[axis] != "c":
                     raise ValueError("field '{}' is not refined / cell-centred on the sharded axis".format(key))
@@ -291,7 +290,11 @@ class SlabTracedAdam:
                 if levels[0].replicated or any(a.replicated and not b.replicated for a, b in zip(levels, levels[1:])):
                     raise ValueError("field '{}': {} cells on the sharded axis over {} ranks".format(key, N, world))
                 init = [t.array for t in f.terms]
-                self.entries.append(dict(key=key, kind="mg", levels=levels, loc=mgloc, init=init))
+                # u = f_0 w_0 + P(f_1 w_1 + P(...)) (reference core.py:245-263); None: every factor is 1
+                if len(levels) == 1 and factors[0] != 1.0:
+                    raise NotImplementedError("slab decomposition of a one-level multigrid field with a factor")
+                self.entries.append(dict(key=key, kind="mg", levels=levels, loc=mgloc, init=init,
+                                         factors=None if all(x == 1.0 for x in factors) else factors))
                 sizes += [lv.size for lv in levels]
             elif isinstance(f, Field):
                 if f.loc[axis] != "c":
@@ -310,18 +313,24 @@ class SlabTracedAdam:
         total = sum(sizes)
         mk = lambda: torch.zeros(total, dtype=dtype, device=self.device)
         self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
+        # fields with multigrid factors: the UNSCALED cotangents h_l = (P^T)^l g_u travel down the levels, the gradient
+        # of level l is g_l = f_l h_l -- a second packed vector with the layout of g
+        scaled = any(e.get("factors") for e in self.entries)
+        self.hvec = mk() if scaled else None
         pos = 0
         self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
         send_own = dict(lo=[], hi=[])  # plane descriptors (ops.PlaneList): owned boundary planes / inner ghost planes
         recv_ghost = dict(lo=[], hi=[])
         for e in self.entries:
             shapes = [lv.shape for lv in e["levels"]] if "levels" in e else e["shapes"]
-            views = dict(x=[], m=[], v=[], g=[])
+            views = dict(x=[], m=[], v=[], g=[], h=[])
             e["start"] = pos
             for k, shape in enumerate(shapes):
                 cnt = math.prod(shape)
                 for name, buf in (("x", self.x), ("m", self.m), ("v", self.v), ("g", self.g)):
                     views[name].append(buf[pos:pos + cnt].view(shape))
+                # where the gathers / transposes write: g itself, or the unscaled twin when the field has factors
+                views["h"].append((self.hvec if e.get("factors") else self.g)[pos:pos + cnt].view(shape))
                 src = e["init"][k]
                 if src is not None and src.device.type != "meta":
                     if "levels" in e:
@@ -397,9 +406,11 @@ class SlabTracedAdam:
                         first_plane = 0 if pos == 0 else lv.n - h
                         if hasattr(hip_ops.PlaneList, "_run"):
                             base, outer, ostride, inner = lv.plane_desc(e["start"], first_plane)
-                            lists.append(hip_ops.PlaneList([(base, outer, ostride, inner * h)], self.device, start=off))
+                            lists.append((hip_ops.PlaneList([(base, outer, ostride, inner * h)], self.device, start=off),
+                                          bool(e.get("factors"))))
                         else:  # (CPU double of the plane kernels: tests over gloo)
                             lists.append((key, lv, first_plane))
+                            assert len(lists[-1]) == 3
                     off += wsizes[key]
                 self._wrap_add[side] = lists
         lv0 = self.by_key[self.kern.src_keys[0]]["levels"][0]
@@ -424,6 +435,8 @@ class SlabTracedAdam:
                     continue
                 if self.u[key] is e["x"][0] and key in getattr(self.kern, "reread", ()):
                     continue  # the array a gather reads IS the unknown: no launch of this epoch may update it
+                if e.get("factors"):
+                    continue  # the gather forms h_0, the gradient is f_0 h_0
                 self._fused[key] = (1, lv.n - 1)
                 spans.append((e["start"], lv.size))
                 outer = math.prod(lv.shape[:axis])
@@ -448,6 +461,8 @@ class SlabTracedAdam:
             if e["kind"] != "mg" or L == 1:
                 continue
             coarse = e["x"][L - 1]
+            fac = e.get("factors") or [1.0] * L
+            cscale = fac[L - 1]
             for l in range(L - 2, -1, -1):
                 out = self.u[key] if l == 0 else self.work[key][l]
                 fine, lvc = e["levels"][l], e["levels"][l + 1]
@@ -455,8 +470,9 @@ class SlabTracedAdam:
                     operand = coarse.narrow(self.axis, *lvc.window_of(fine))
                 else:
                     operand = lvc.inner(coarse)
-                hip_ops.interp_add(operand.contiguous(), e["loc"], add=e["x"][l], out=out)
-                coarse = out
+                hip_ops.interp_add(operand.contiguous(), e["loc"], add=e["x"][l], coarse_scale=cscale, add_scale=fac[l],
+                                   out=out)
+                coarse, cscale = out, 1.0
 
     def _end_planes(self, arrays, side):
         """The h owned planes at the low ('lo') / high end of each source field's array, packed."""
@@ -479,16 +495,24 @@ class SlabTracedAdam:
     def _transpose_chain(self):
         for key in self.kern.gather_keys:
             e = self.by_key[key]
+            fac = e.get("factors")
+            if fac:  # g_0 = f_0 h_0 (ghost planes included: they are this rank's share of the neighbour's gradient)
+                torch.mul(e["h"][0], fac[0], out=e["g"][0])
             for l in range(1, len(e["levels"])):
                 lv, fine = e["levels"][l], e["levels"][l - 1]
                 if lv.replicated and not fine.replicated:
                     # this rank's share of the replicated level: zero but for the window its planes reach
-                    e["g"][l].zero_()
-                    dst = e["g"][l].narrow(self.axis, *lv.window_of(fine))
+                    e["h"][l].zero_()
+                    if fac:
+                        e["g"][l].zero_()
+                    view = lambda a: a.narrow(self.axis, *lv.window_of(fine))
                 else:
-                    dst = lv.inner(e["g"][l])
+                    view = lv.inner
+                dst = view(e["h"][l])
                 best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
-                dst.copy_(best(e["g"][l - 1], e["loc"], tuple(dst.shape)))
+                dst.copy_(best(e["h"][l - 1], e["loc"], tuple(dst.shape)))
+                if fac:
+                    torch.mul(dst, fac[l], out=view(e["g"][l]))
 
     # ---- one epoch -------------------------------------------------------------------------------------
     def epoch_gen(self, timers=None):
@@ -541,7 +565,7 @@ class SlabTracedAdam:
             items = []
             for key in merged:
                 w, e = self.wrap[key], self.by_key[key]
-                items.append((key, e["g"][0], w["glo"], w["ghi"],
+                items.append((key, e["h"][0], w["glo"], w["ghi"],
                               (e["x"][0], e["m"][0], e["v"][0]) if key in self._fused else None))
             self.kern.gather_all(items, hyper, spans.pop() if spans else (0, 0))
         else:
@@ -551,10 +575,10 @@ class SlabTracedAdam:
                 continue
             w, e = self.wrap[key], self.by_key[key]
             if key in self._fused:
-                self.kern.gather(key, e["g"][0], w["glo"], w["ghi"],
+                self.kern.gather(key, e["h"][0], w["glo"], w["ghi"],
                                  adam=(e["x"][0], e["m"][0], e["v"][0]) + hyper + self._fused[key])
             else:
-                self.kern.gather(key, e["g"][0], w["glo"], w["ghi"])
+                self.kern.gather(key, e["h"][0], w["glo"], w["ghi"])
         toc(b)
         if h and self.kern.gather_keys:
             b = tic("halo")
@@ -565,12 +589,13 @@ class SlabTracedAdam:
                     continue
                 parts = None
                 for item in self._wrap_add[side]:
-                    if isinstance(item, tuple):
+                    if len(item) == 3:
                         parts = parts or self._split_planes(recv)
                         key, lv, first_plane = item
-                        lv.planes(self.by_key[key]["g"][0], first_plane, h).add_(parts[key])
+                        lv.planes(self.by_key[key]["h"][0], first_plane, h).add_(parts[key])
                     else:
-                        item.unpack_add(self.g, recv.reshape(-1))
+                        plist, scaled = item
+                        plist.unpack_add(self.hvec if scaled else self.g, recv.reshape(-1))
             toc(b)
         b = tic("mg_synth_adj")
         self._transpose_chain()

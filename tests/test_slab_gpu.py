@@ -133,6 +133,8 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
         sys.path.insert(0, os.path.join(root, "examples", sub))
     for sub in ("wave", "infer_constant"):
         sys.path.insert(0, os.path.join(root, "examples", sub))
+    scaled = which.endswith("-factors")
+    which = which.split("-")[0]
     ex = __import__(which)
     odil.util.set_log_file(open(os.devnull, "w"))
     nx = nx_rank * world
@@ -147,6 +149,10 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
     else:
         argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32", "--infer_k", "1", "--imposed", "stripe"]
     problem, state = ex.make_problem(ex.parse_args(argv + ["--double", str(dtype_flag)]))
+    if scaled:  # multigrid factors other than 1 (reference core.py:245-263)
+        for f in state.fields.values():
+            if isinstance(f, odil.MultigridField):
+                f.factors = [1.0, 0.5, 2.0, 1.5, 0.25][: len(f.terms)]
     gen = torch.Generator(device="cpu").manual_seed(11)
     arrays = problem.domain.arrays_from_state(state)
     new = [(torch.randn(tuple(a.shape), generator=gen, dtype=torch.float64) * 0.1).to(device=a.device, dtype=a.dtype)
@@ -159,7 +165,8 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
                                                         ("veltracer3d", 2, 1, 16), ("heat2d", 2, 1, 16),
                                                         ("veltracer", 4, 0, 16), ("veltracer", 4, 1, 8),
                                                         ("veltracer3d", 4, 1, 4), ("wave", 2, 1, 16),
-                                                        ("infer_constant", 2, 1, 16)])
+                                                        ("infer_constant", 2, 1, 16),
+                                                        ("veltracer-factors", 2, 1, 16), ("veltracer3d-factors", 4, 1, 4)])
 def test_slab_traced_emulated_ranks_equal_single_gpu(which, world, double, nx_rank):
     """The slab-decomposed Adam loop of a traced operator -- generated kernels in slab mode (global indices,
     ghost-extended sources, periodic wrap planes, ghost-writing gathers), exchange-free P^T chain, deferred

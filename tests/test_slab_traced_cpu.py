@@ -22,12 +22,17 @@ sys.path.insert(0, os.path.join(ROOT, "examples", "velocity_from_tracer"))
 sys.path.insert(0, os.path.join(ROOT, "examples", "heat"))
 
 
+FACTORS = [1.0, 0.5, 2.0]  # multigrid factors of the `-factors` cases: u = f_0 w_0 + P(f_1 w_1 + P(f_2 w_2))
+
+
 def make_problem(which, world, nx_rank=8):
     """The GLOBAL problem on CPU tensors (no kernel runs here) with a random state: (problem, state)."""
     import odil_amd as odil
 
     odil.runtime._mod = odil.ModRocm(device="cpu")
     odil.util.set_log_file(open(os.devnull, "w"))
+    scaled = which.endswith("-factors")
+    which = which.split("-")[0]
     ex = __import__(which)
     nx = nx_rank * world
     argv = ["--Nt", "8", "--Nx", str(nx), "--Ny", "8", "--double", "1"] + (["--Nz", "8"] if which == "veltracer3d" else [])
@@ -38,6 +43,11 @@ def make_problem(which, world, nx_rank=8):
         argv += ["--infer_k", "1", "--imposed", "stripe", "--keep_init", "0"]
     args = ex.parse_args(argv)
     problem, state = ex.make_problem(args)
+    if scaled:
+        for f in state.fields.values():
+            if isinstance(f, odil.MultigridField):
+                assert len(f.terms) == len(FACTORS)
+                f.factors = list(FACTORS)
     rng = np.random.default_rng(7)
     arrays = [torch.tensor(rng.standard_normal(tuple(a.shape)) * 0.1) for a in problem.domain.arrays_from_state(state)]
     problem.domain.arrays_to_state(arrays, state)
@@ -121,11 +131,14 @@ def undivided(which, world, epochs, nx_rank=8):
 
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 8), ("veltracer", 3, 8), ("veltracer3d", 2, 8),
                                                   ("veltracer", 4, 2), ("veltracer", 2, 4), ("heat2d", 2, 8),
-                                                  ("veltracer3d", 8, 4)])
+                                                  ("veltracer3d", 8, 4), ("veltracer-factors", 2, 8),
+                                                  ("veltracer-factors", 4, 2)])
 def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world, nx_rank):
     """nx_rank = 2, 4: the three multigrid levels (8 cells of t) leave 2, 1, 0.5 / 4, 2, 1 cells of x per rank: the
     coarsest levels are AGGLOMERATED (whole array on every rank, gradient shares summed by an all-reduce).  heat2d:
-    a pointwise network inside the stencil -- its parameters are replicated, their gradients summed over the ranks."""
+    a pointwise network inside the stencil -- its parameters are replicated, their gradients summed over the ranks.
+    -factors: multigrid factors other than 1 (reference core.py:245-263): scaled terms in the synthesis, unscaled
+    cotangents down the levels, every level's gradient scaled by its factor."""
     epochs = 3
     port = 29500 + (os.getpid() * 7 + world * 13 + nx_rank + len(which)) % 2000
     mp.spawn(worker, args=(world, which, epochs, port, str(tmp_path), nx_rank), nprocs=world, join=True)
