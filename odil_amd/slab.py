@@ -383,6 +383,14 @@ class TorchDistComm:
 
     def exchange(self, kind, send_lo, send_hi):
         dist = self.dist
+        if kind == "wait":  # completes a posted halo exchange: (recv_lo, recv_hi)
+            reqs, recv_lo, recv_hi, dev, keep = send_lo
+            for req in reqs:
+                req.wait()
+            if dev is not None:
+                recv_lo = recv_lo.to(dev) if recv_lo is not None else None
+                recv_hi = recv_hi.to(dev) if recv_hi is not None else None
+            return recv_lo, recv_hi
         if kind == "sum":
             t = send_lo
             if self.stage and t.is_cuda:
@@ -396,7 +404,7 @@ class TorchDistComm:
                 return send_hi, send_lo
             peer_lo = self.world - 1 if self.rank == 0 else None
             peer_hi = 0 if self.rank == self.world - 1 else None
-        else:
+        else:  # "halo" / "post" 
             peer_lo = self.rank - 1 if self.rank > 0 else None
             peer_hi = self.rank + 1 if self.rank < self.world - 1 else None
         dev = None
@@ -408,14 +416,20 @@ class TorchDistComm:
                 send_lo = send_lo.cpu() if send_lo is not None else None
                 send_hi = send_hi.cpu() if send_hi is not None else None
         ops, recv_lo, recv_hi = [], None, None
+        tag = "post-" if kind == "post" else ""  # (a posted message keeps its receive buffer until it is waited for)
         if send_lo is not None and peer_lo is not None:
             send_lo = send_lo.contiguous()
-            recv_lo = self._recv_like("lo", send_lo)
+            recv_lo = self._recv_like(tag + "lo", send_lo)
             ops += [dist.P2POp(dist.isend, send_lo, peer_lo), dist.P2POp(dist.irecv, recv_lo, peer_lo)]
         if send_hi is not None and peer_hi is not None:
             send_hi = send_hi.contiguous()
-            recv_hi = self._recv_like("hi", send_hi)
+            recv_hi = self._recv_like(tag + "hi", send_hi)
             ops += [dist.P2POp(dist.isend, send_hi, peer_hi), dist.P2POp(dist.irecv, recv_hi, peer_hi)]
+        if kind == "post":
+            # "post": the halo exchange is STARTED (RCCL orders it behind what the stream holds now and runs it on its
+            # own stream); kernels launched from here on overlap it; "wait" orders the stream behind its completion
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            return (reqs, recv_lo, recv_hi, dev, (send_lo, send_hi))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -430,6 +444,8 @@ class LocalComm:
 
     def exchange(self, kind, a, b):
         if kind == "sum":
+            return a
+        if kind == "wait":
             return a
         return (b, a) if kind == "wrap" else (None, None)
 
@@ -470,7 +486,9 @@ def run_lockstep(ranks, nepochs=1, timers=None):
             kind = msgs[0][0]
             assert all(m[0] == kind for m in msgs), "ranks out of step"
             clone = lambda t: None if t is None else t.clone()
-            if kind == "sum":
+            if kind == "wait":  # the planes of a posted exchange were moved when it was posted
+                replies = [m[1] for m in msgs]
+            elif kind == "sum":
                 total = msgs[0][1].clone()
                 for m in msgs[1:]:
                     total = total + m[1]

@@ -321,6 +321,9 @@ class SlabTracedAdam:
         self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
         send_own = dict(lo=[], hi=[])  # plane descriptors (ops.PlaneList): owned boundary planes / inner ghost planes
         recv_ghost = dict(lo=[], hi=[])
+        # the same planes split by level for the gradients' halo-add: the finest levels (97 % of the bytes) travel WHILE
+        # the transposes run down the levels, the coarser ones after them
+        own0, own1, ghost0, ghost1 = (dict(lo=[], hi=[]) for _ in range(4))
         for e in self.entries:
             shapes = [lv.shape for lv in e["levels"]] if "levels" in e else e["shapes"]
             views = dict(x=[], m=[], v=[], g=[], h=[])
@@ -341,12 +344,17 @@ class SlabTracedAdam:
                     self._rep.append((pos, cnt))
                 elif "levels" in e:
                     lv = e["levels"][k]
+                    own, ghost = (own0, ghost0) if k == 0 else (own1, ghost1)
                     if rank > 0:
                         send_own["lo"].append(lv.plane_desc(pos, 0))
                         recv_ghost["lo"].append(lv.plane_desc(pos, -1))
+                        own["lo"].append(lv.plane_desc(pos, 0))
+                        ghost["lo"].append(lv.plane_desc(pos, -1))
                     if rank < world - 1:
                         send_own["hi"].append(lv.plane_desc(pos, lv.n - 1))
                         recv_ghost["hi"].append(lv.plane_desc(pos, lv.n))
+                        own["hi"].append(lv.plane_desc(pos, lv.n - 1))
+                        ghost["hi"].append(lv.plane_desc(pos, lv.n))
                 pos += cnt
             e.update(views)
             del e["init"]
@@ -357,7 +365,9 @@ class SlabTracedAdam:
         self._ghost = {s: mk_list(recv_ghost[s]) for s in ("lo", "hi")}
         mk_buf = lambda pl: None if pl is None else torch.empty(pl.count, dtype=dtype, device=self.device)
         self._send_x = {s: mk_buf(self._own[s]) for s in ("lo", "hi")}
-        self._send_g = {s: mk_buf(self._ghost[s]) for s in ("lo", "hi")}
+        self._g_split = [({s: mk_list(o[s]) for s in ("lo", "hi")}, {s: mk_list(g_[s]) for s in ("lo", "hi")})
+                         for o, g_ in ((own0, ghost0), (own1, ghost1))]
+        self._send_g = [{s: mk_buf(ghost[s]) for s in ("lo", "hi")} for _, ghost in self._g_split]
         self.by_key = {e["key"]: e for e in self.entries}
         self.n_unknowns_local = sum(lv.n * lv.plane for e in self.entries if "levels" in e for lv in e["levels"]
                                     if not lv.replicated) + sum(
@@ -496,8 +506,6 @@ class SlabTracedAdam:
         for key in self.kern.gather_keys:
             e = self.by_key[key]
             fac = e.get("factors")
-            if fac:  # g_0 = f_0 h_0 (ghost planes included: they are this rank's share of the neighbour's gradient)
-                torch.mul(e["h"][0], fac[0], out=e["g"][0])
             for l in range(1, len(e["levels"])):
                 lv, fine = e["levels"][l], e["levels"][l - 1]
                 if lv.replicated and not fine.replicated:
@@ -597,17 +605,32 @@ class SlabTracedAdam:
                         plist, scaled = item
                         plist.unpack_add(self.hvec if scaled else self.g, recv.reshape(-1))
             toc(b)
+        for key in self.kern.gather_keys:  # g_0 = f_0 h_0 (ghost planes included: this rank's share of the neighbour's)
+            e = self.by_key[key]
+            if e.get("factors"):
+                torch.mul(e["h"][0], e["factors"][0], out=e["g"][0])
+        # the gradients' halo-add in two messages: the finest levels' ghost planes are final now -- they are POSTED and
+        # travel while the transposes run down the levels (which read this rank's partial arrays only); the coarser
+        # levels' planes follow after the chain
+        b = tic("halo")
+        (own0, ghost0), (own1, ghost1) = self._g_split
+        pack = lambda lists, bufs, side: None if lists[side] is None else lists[side].pack(self.g, bufs[side])
+        token = yield ("post", pack(ghost0, self._send_g[0], "lo"), pack(ghost0, self._send_g[0], "hi"))
+        toc(b)
         b = tic("mg_synth_adj")
         self._transpose_chain()
         toc(b)
         b = tic("halo")
-        glo, ghi = self._ghost["lo"], self._ghost["hi"]
-        recv_lo, recv_hi = yield ("halo", None if glo is None else glo.pack(self.g, self._send_g["lo"]),
-                                  None if ghi is None else ghi.pack(self.g, self._send_g["hi"]))
+        recv_lo, recv_hi = yield ("wait", token, None)
         if recv_lo is not None:
-            self._own["lo"].unpack_add(self.g, recv_lo)
+            own0["lo"].unpack_add(self.g, recv_lo)
         if recv_hi is not None:
-            self._own["hi"].unpack_add(self.g, recv_hi)
+            own0["hi"].unpack_add(self.g, recv_hi)
+        recv_lo, recv_hi = yield ("halo", pack(ghost1, self._send_g[1], "lo"), pack(ghost1, self._send_g[1], "hi"))
+        if recv_lo is not None:
+            own1["lo"].unpack_add(self.g, recv_lo)
+        if recv_hi is not None:
+            own1["hi"].unpack_add(self.g, recv_hi)
         if self._rep and world > 1:  # agglomerated levels: the ranks' shares summed (every rank then updates alike)
             total = yield ("sum", torch.cat([self.g[a:a + c] for a, c in self._rep]), None)
             off = 0
