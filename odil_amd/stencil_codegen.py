@@ -45,6 +45,22 @@ __device__ inline T block_sum(T v, T* sm) {
   for (int w = 1; w < NB / 64; ++w) r = r + sm[w];
   return r;
 }
+template <int NW>
+__device__ inline T block_sum_w(T v, T* sm) {  // NW waves per workgroup
+  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  T r = sm[0];
+  for (int w = 1; w < NW; ++w) r = r + sm[w];
+  return r;
+}
+__device__ inline void wg_barrier() {  // (one per wave, wherever it stands in its code: the tiled forward kernel)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
 // (float kernels with ODIL_TRACE_FAST_F32: the quotient of the update through v_rcp_f32, ~1 ulp, as every other
 // division of those kernels; an IEEE float division is ~10 instructions, sixteen of them per thread in a merged gather)
@@ -196,6 +212,8 @@ class _Codegen:
         self.array_slot = dict()
         self.need = self._needs_grad()
         self.partner, self.pair_first = dict(), set()
+        self.share, self.shared_A, self.shared_B = [], set(), set()
+        self._choose_shared_calls()
         if self.fast and int(os.environ.get("ODIL_TRACE_PAIR_MLP", 1)):
             self._pair_mlps()
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
@@ -214,6 +232,7 @@ class _Codegen:
         self.vw = self.vw_fwd
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
+        self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
         self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
@@ -684,6 +703,46 @@ class _Codegen:
             self.emit(line)
 
     # ---- pointwise networks: two evaluations of the same network per pair of float lanes ---------------------
+    # interior threads of a workgroup of the tiled forward kernel: rows x columns of the last two axes (ODIL_TRACE_TILE=RxC)
+    TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "8x32").split("x"))
+
+    def _choose_shared_calls(self):
+        """Network evaluations another thread's evaluation equals (stencil_share.py: k_m(i) = k_p(i - e) away from the
+        wall row) are not repeated: the forward kernel becomes a TILED kernel whose threads exchange the values -- and,
+        on the way back, the adjoints -- through LDS (_tile_forward).  Needs the last two axes to tile, frozen inputs
+        (the reverse pass of a shared evaluation runs where it was evaluated, after the exchange) and one network."""
+        from . import stencil_share
+
+        mlps = [n for n in self.order if n.op == "mlp"]
+        if (not mlps or self.slab is not None or self.ndim < 2 or not int(os.environ.get("ODIL_TRACE_SHARE", 1))
+                or self.GL != self.G):
+            return
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        if self.G[a1] % self.TILE[0] or self.G[a2] % self.TILE[1] or len({n.attr for n in mlps}) != 1:
+            return
+        if any(self.need.get(a.idx, False) for n in mlps for a in n.args):
+            return
+        try:
+            found = stencil_share.shared_network_calls(self.tr, self.order, self.G, (a1, a2))
+        except TraceUnsupported:
+            return
+        per_axis = dict()
+        for A, B, axis in found:
+            per_axis.setdefault(axis, (A, B, axis))
+        pairs = list(per_axis.values())
+        nodes = [x for A, B, _ in pairs for x in (A, B)]
+        if not pairs or len({x.idx for x in nodes}) != len(nodes):
+            return
+        # the inputs of every call involved must be computable before any shared value is known
+        outs_of = {x.idx for x in nodes}
+        for x in nodes:
+            for arg in x.args:
+                if any(m.op == "mlp_out" and m.args[0].idx in outs_of for m in stencil_grad.subdag(arg)):
+                    return
+        self.share = pairs
+        self.shared_A = {A.idx for A, _, _ in pairs}
+        self.shared_B = {B.idx for _, B, _ in pairs}
+
     def _pair_mlps(self):
         """Float kernels: evaluations of the same network (heat: the conductivity at the four faces of a cell) are
         emitted two at a time on 2-vectors, so that every multiply-add of the layers, of the reverse pass and of the
@@ -692,7 +751,7 @@ class _Codegen:
         (topologically) with the pair as one unit; pairs that would close a cycle stay single."""
         groups = dict()
         for n in self.order:
-            if n.op == "mlp":
+            if n.op == "mlp" and n.idx not in self.shared_A:  # (shared calls: evaluated by another thread)
                 groups.setdefault(n.attr, []).append(n)
         pairs = [(nodes[k], nodes[k + 1]) for nodes in groups.values() for k in range(0, len(nodes) - 1, 2)]
         while pairs:
@@ -748,22 +807,22 @@ class _Codegen:
         tanh = "odil_fast_tanh({})" if self.fast else "FN(tanh)({})"  # (network activations: see the prelude)
         return {"tanh": tanh, "relu": "({0} > (T)0 ? {0} : (T)0)", "none": "{}"}[kind].format(x)
 
-    def _emit_mlp(self, n):
-        if n.idx in self.partner and n.idx not in self.pair_first:
-            return  # emitted with its partner
-        group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
-        width = len(group)
-        V = "T2" if width == 2 else "T"
-        key, frozen, layers, act = n.attr
+    def _net_base(self, attr):
+        key, frozen, layers, act = attr
         if key not in self.net_slot:
             self.net_slot[key] = len(self.nets)
             self.nets.append((key, layers))
-        base = self.net_slot[key]
+        return self.net_slot[key]
+
+    def _mlp_forward(self, p, width, attr, inputs):
+        """Layers of one (width 1) or two packed (width 2) evaluations of a pointwise network under the name prefix p;
+        inputs: per network input the value expression (width 2: a pair)."""
+        V = "T2" if width == 2 else "T"
+        key, frozen, layers, act = attr
+        base = self._net_base(attr)
         nl = len(layers) - 1
-        p = ("mm{}" if width == 2 else "m{}").format(n.idx)
-        for i in range(len(n.args)):
-            vals = [self.r(m.args[i]) for m in group]
-            self.emit("const {} {}_h0_{} = {};".format(V, p, i, vals[0] if width == 1 else "{{{}, {}}}".format(*vals)))
+        for i, vals in enumerate(inputs):
+            self.emit("const {} {}_h0_{} = {};".format(V, p, i, vals if width == 1 else "{{{}, {}}}".format(*vals)))
         for l in range(1, nl + 1):
             ni, no = layers[l - 1], layers[l]
             for j in range(no):
@@ -771,14 +830,29 @@ class _Codegen:
                 self.emit("const {} {}_z{}_{} = ({}) + Bv({},{},{});".format(V, p, l, j, terms, base, l - 1, j))
                 if l < nl:
                     self.emit("const {0} {1}_h{2}_{3} = {4};".format(V, p, l, j, self._act(act, "{}_z{}_{}".format(p, l, j), width)))
+
+    def _emit_mlp(self, n):
+        if n.idx in self.shared_A:
+            return  # evaluated by the thread of the neighbouring point (or a halo thread): see _tile_forward
+        if n.idx in self.partner and n.idx not in self.pair_first:
+            return  # emitted with its partner
+        group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
+        width = len(group)
+        nl = len(n.attr[2]) - 1
+        p = ("mm{}" if width == 2 else "m{}").format(n.idx)
+        inputs = []
+        for i in range(len(n.args)):
+            vals = [self.r(m.args[i]) for m in group]
+            inputs.append(vals[0] if width == 1 else vals)
+        self._mlp_forward(p, width, n.attr, inputs)
         if width == 2:  # the outputs under the names the single form gives them (what mlp_out nodes read)
             for lane, m in zip("xy", group):
-                for j in range(layers[nl]):
+                for j in range(n.attr[2][nl]):
                     self.emit("const T m{}_z{}_{} = {}_z{}_{}.{};".format(m.idx, nl, j, p, nl, j, lane))
 
-    def forward(self):
+    def forward(self, only=None):
         for n in self.order:
-            if n.host:
+            if n.host or (only is not None and n.idx not in only):
                 continue
             op, A = n.op, n.args
             kt = {"r": "T", "i": "long", "b": "bool"}[n.kind]
@@ -803,6 +877,7 @@ class _Codegen:
                 self._emit_mlp(n)
             elif op == "mlp_out":
                 self.emit(v + "m{}_z{}_{};".format(A[0].idx, len(A[0].attr[2]) - 1, n.attr))
+                self.mlp_out_seen.setdefault(A[0].idx, dict())[n.attr] = n
             elif op in ("add", "sub", "mul"):
                 sym = {"add": "+", "sub": "-", "mul": "*"}[op]
                 self.emit(v + "{} {} {};".format(self.typed(A[0], n.kind), sym, self.typed(A[1], n.kind)))
@@ -963,24 +1038,41 @@ class _Codegen:
         self.cut_nodes.reverse()
 
     def _reverse_mlp(self, n, defined, acc):
+        if n.idx in self.shared_A or n.idx in self.shared_B:
+            return  # the reverse pass of shared evaluations runs after the adjoints were exchanged (_tile_forward)
         if n.idx in self.partner and n.idx not in self.pair_first:
             return  # handled when the traversal reaches its partner (the earlier node of the pair)
         group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
         if not any(self.need[m.idx] for m in group):
             return
         width = len(group)
-        V = "T2" if width == 2 else "T"
-        key, frozen, layers, act = n.attr
+        layers = n.attr[2]
         outs = [{m.attr: m for m in self.order if m.op == "mlp_out" and m.args[0] is g and m.idx in defined} for g in group]
         if not any(outs):
             return
-        base = self.net_slot[key]
         nl = len(layers) - 1
         p = ("mm{}" if width == 2 else "m{}").format(n.idx)
-        sfx = "2" if width == 2 else ""  # packed sums of two evaluations live in their own accumulators
+        dvals = []
         for j in range(layers[nl]):
             vals = ["g{}".format(o[j].idx) if j in o else "(T)0" for o in outs]
-            self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals[0] if width == 1 else "{{{}, {}}}".format(*vals)))
+            dvals.append(vals[0] if width == 1 else vals)
+        inputs_need = any(self.need[a.idx] for m in group for a in m.args)
+        self._mlp_backward(p, width, n.attr, dvals, inputs_need)
+        if inputs_need:
+            for lane, m in zip("xy", group):
+                for i, a in enumerate(m.args):
+                    acc(a, "{}_d0_{}{}".format(p, i, "" if width == 1 else "." + lane))
+
+    def _mlp_backward(self, p, width, attr, dvals, inputs_need):
+        """Reverse pass of the evaluation(s) emitted under prefix p given the adjoints of the outputs: parameter
+        gradients into the accumulators, the adjoints of the inputs (`{p}_d0_{i}`) when somebody needs them."""
+        V = "T2" if width == 2 else "T"
+        key, frozen, layers, act = attr
+        base = self.net_slot[key]
+        nl = len(layers) - 1
+        sfx = "2" if width == 2 else ""  # packed sums of two evaluations live in their own accumulators
+        for j, vals in enumerate(dvals):
+            self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals if width == 1 else "{{{}, {}}}".format(*vals)))
         if not frozen and width == 2:
             self.pg2_used.add(key)
         if not frozen and key not in self.pgrads:
@@ -992,7 +1084,6 @@ class _Codegen:
             self.pgrads[key] = names
             self.pg_offset[key] = len(self.pg_decl)
             self.pg_decl.extend(name for group in names for name in group)
-        inputs_need = any(self.need[a.idx] for m in group for a in m.args)
         for l in range(nl, 0, -1):
             ni, no = layers[l - 1], layers[l]
             if not frozen:
@@ -1004,20 +1095,16 @@ class _Codegen:
             if l == 1 and not inputs_need:
                 break
             for i in range(ni):
-                s = " + ".join("W({},{},{}) * {}_d{}_{}".format(base, l - 1, j * ni + i, p, l, j) for j in range(no))
+                s_ = " + ".join("W({},{},{}) * {}_d{}_{}".format(base, l - 1, j * ni + i, p, l, j) for j in range(no))
                 if l > 1:
                     h = "{}_h{}_{}".format(p, l - 1, i)
                     one = "(T)1" if width == 1 else "(T2)(1.0f)"
                     d = {"tanh": "({1} - {0} * {0})".format(h, one),
                          "relu": ("({} > (T)0 ? (T)1 : (T)0)" if width == 1 else "odil_step2({})").format(h),
                          "none": one}[act]
-                    self.emit("const {} {}_d{}_{} = ({}) * {};".format(V, p, l - 1, i, s, d))
+                    self.emit("const {} {}_d{}_{} = ({}) * {};".format(V, p, l - 1, i, s_, d))
                 else:
-                    self.emit("const {} {}_d0_{} = {};".format(V, p, i, s))
-        if inputs_need:
-            for lane, m in zip("xy", group):
-                for i, a in enumerate(m.args):
-                    acc(a, "{}_d0_{}{}".format(p, i, "" if width == 1 else "." + lane))
+                    self.emit("const {} {}_d0_{} = {};".format(V, p, i, s_))
 
     # ---- whole source -----------------------------------------------------------------------
     def _index_prologue(self, S, shape, names, vw, flat="l"):
@@ -1102,11 +1189,16 @@ class _Codegen:
         vw, last = self.vw, self.ndim - 1
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         self._begin()
-        self.forward()
-        fwd = self.lines
-        self.lines = []
-        self.reverse()
-        rev = self.lines
+        tiled = None
+        if self.share:
+            tiled = self._tile_parts()
+            fwd, rev = [], []
+        else:
+            self.forward()
+            fwd = self.lines
+            self.lines = []
+            self.reverse()
+            rev = self.lines
         fwd_pre = self.pre + self._group_arrays()
         nout = len(self.outputs)
         self.npar = sum(len(g) for names in self.pgrads.values() for g in names)
@@ -1136,9 +1228,12 @@ class _Codegen:
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
         # ---- k_fwd ---------------------------------------------------------------------------------------------
         occ = int(os.environ.get("ODIL_TRACE_WAVES_FWD", 0))  # register budget of k_fwd as waves per SIMD (0: the compiler's)
-        S.append('extern "C" __global__ __launch_bounds__(NB) {}void k_fwd(const Args a) {{'.format(
-            "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else ""))
-        S.append("  __shared__ T sm[NB / 64];")
+        self.fwd_threads = 256 if tiled is None else tiled["threads"]
+        if tiled is not None and self.TILE[0] * self.TILE[1] % 64:
+            raise TraceUnsupported("tile of {} x {} threads".format(*self.TILE))
+        S.append('extern "C" __global__ __launch_bounds__({}) {}void k_fwd(const Args a) {{'.format(
+            self.fwd_threads, "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else ""))
+        S.append("  __shared__ T sm[{}];".format(self.fwd_threads // 64))
         for k in range(nout):
             S.append("  T s_{} = (T)0;".format(k))
         for name in self.pg_decl:
@@ -1146,16 +1241,6 @@ class _Codegen:
         pg2 = [name for key in self.pg2_used for group in self.pgrads[key] for name in group]
         for name in pg2:  # packed partial sums of paired network evaluations
             S.append("  T2 {}2{} = (T2)(0.0f);".format(name[:2], name[2:]))
-        threads = self.total // vw
-        flat = "l4" if vw == 4 else "l"
-        if threads <= self.max_blocks * 256:  # one thread per point (or four points)
-            S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
-            S.append("  if ({} < {}) {{".format(flat, threads))
-        else:
-            S.append("  for (int {0} = blockIdx.x * NB + threadIdx.x; {0} < {1}; {0} += a.nblocks * NB) {{".format(flat, threads))
-        self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
-        if self.slab is not None:
-            S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
         esize = 8 if tdt == torch.float64 else 4
         stored = ([(n, "g{}".format(n.idx)) for n in self.cots] + [(n, "g{}".format(n.idx)) for n in self.cut_nodes]
                   + [(self.outputs[k], name) for k, name in self.jac_store])  # cut arrays follow the read cotangents
@@ -1163,44 +1248,58 @@ class _Codegen:
         for slot_k, (k, _) in enumerate(self.jac_store):
             self.pseudo_slot[self.seed_key[k]] = len(self.cots) + len(self.cut_nodes) + slot_k
         stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
-        S.extend(fwd_pre)
-        if vw == 4:
-            for slot in range(len(stored)):
-                S.append("  T O{}[4];".format(slot))
-        self._loop_open(S, vw)
-        for k, lens in enumerate(self.out_lens):
-            if lens is not None:
-                conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
-                S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
-        S.extend(fwd)
-        S.extend(rev)
-        for slot, (n, name) in enumerate(stored):
-            if vw == 4:
-                S.append("  O{}[p] = {};".format(slot, name))
-            elif stream:
-                S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
+        if tiled is not None:
+            self._tile_kernel(S, tiled, stored, stream)
+        threads = self.total // vw
+        if tiled is None:
+            flat = "l4" if vw == 4 else "l"
+            if threads <= self.max_blocks * 256:  # one thread per point (or four points)
+                S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
+                S.append("  if ({} < {}) {{".format(flat, threads))
             else:
-                S.append("  a.cot[{}][l] = {};".format(slot, name))
-        for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
-            term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
-            if self.out_lens[k] is not None:
-                term = "(inbox{} ? {} : (T)0)".format(k, term)
-            S.append("  s_{0} = s_{0} + {1};".format(k, term))
-        if vw == 4:
-            S.append("  }")  # p
-            for slot in range(len(stored)):
-                vec = "(T4){{O{0}[0], O{0}[1], O{0}[2], O{0}[3]}}".format(slot)
-                if stream:
-                    S.append("  __builtin_nontemporal_store({}, (T4*)(a.cot[{}] + l4 * 4));".format(vec, slot))
+                S.append("  for (int {0} = blockIdx.x * NB + threadIdx.x; {0} < {1}; {0} += a.nblocks * NB) {{".format(flat, threads))
+            self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
+            if self.slab is not None:
+                S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
+            S.extend(fwd_pre)
+            if vw == 4:
+                for slot in range(len(stored)):
+                    S.append("  T O{}[4];".format(slot))
+            self._loop_open(S, vw)
+            for k, lens in enumerate(self.out_lens):
+                if lens is not None:
+                    conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
+                    S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
+            S.extend(fwd)
+            S.extend(rev)
+            for slot, (n, name) in enumerate(stored):
+                if vw == 4:
+                    S.append("  O{}[p] = {};".format(slot, name))
+                elif stream:
+                    S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
                 else:
-                    S.append("  *(T4*)(a.cot[{}] + l4 * 4) = {};".format(slot, vec))
-        S.append("  }")
+                    S.append("  a.cot[{}][l] = {};".format(slot, name))
+            for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
+                term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
+                if self.out_lens[k] is not None:
+                    term = "(inbox{} ? {} : (T)0)".format(k, term)
+                S.append("  s_{0} = s_{0} + {1};".format(k, term))
+            if vw == 4:
+                S.append("  }")  # p
+                for slot in range(len(stored)):
+                    vec = "(T4){{O{0}[0], O{0}[1], O{0}[2], O{0}[3]}}".format(slot)
+                    if stream:
+                        S.append("  __builtin_nontemporal_store({}, (T4*)(a.cot[{}] + l4 * 4));".format(vec, slot))
+                    else:
+                        S.append("  *(T4*)(a.cot[{}] + l4 * 4) = {};".format(slot, vec))
+            S.append("  }")
         for name in pg2:
             S.append("  {0} = {0} + ({1}2{2}.x + {1}2{2}.y);".format(name, name[:2], name[2:]))
+        bsum = "block_sum" if self.fwd_threads == 256 else "block_sum_w<{}>".format(self.fwd_threads // 64)
         for k in range(nout):
-            S.append("  {{ const T s = block_sum(s_{0}, sm); if (threadIdx.x == 0) a.part[{0} * a.nblocks + blockIdx.x] = s; }}".format(k))
+            S.append("  {{ const T s = {1}(s_{0}, sm); if (threadIdx.x == 0) a.part[{0} * a.nblocks + blockIdx.x] = s; }}".format(k, bsum))
         for k, name in enumerate(self.pg_decl):
-            S.append("  {{ const T s = block_sum({}, sm); if (threadIdx.x == 0) a.ppart[{} * a.nblocks + blockIdx.x] = s; }}".format(name, k))
+            S.append("  {{ const T s = {}({}, sm); if (threadIdx.x == 0) a.ppart[{} * a.nblocks + blockIdx.x] = s; }}".format(bsum, name, k))
         S.append("}")
         # final reduction in two deterministic stages: k_final sums SEG segments of every row of
         # partials (one workgroup each), k_loss combines them in order: out = [loss, terms..., norms...]
@@ -1332,7 +1431,7 @@ class _Codegen:
             S.append("}")
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
-        S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3(NB), 0, (hipStream_t)stream, *a);")
+        S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3({}), 0, (hipStream_t)stream, *a);".format(self.fwd_threads))
         S.append("  hipLaunchKernelGGL(k_final, dim3({}, SEG), dim3(NB), 0, (hipStream_t)stream, *a);".format(nout + len(self.pg_decl)))
         S.append("  hipLaunchKernelGGL(k_loss, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);")
         S.append("  return (int)hipGetLastError();")
@@ -1375,6 +1474,179 @@ class _Codegen:
                         max(1, par_arrays), max(1, len(self.hs)), slab_members))
         HEAD.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
         return "\n".join(HEAD + S) + "\n"
+
+    def _tile_parts(self):
+        """Line groups of the tiled forward kernel (see _tile_kernel)."""
+        TR, TC = self.TILE
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        A_nodes = {A.idx: A for A, _, _ in self.share}
+        # nodes that need a shared value: everything downstream of the outputs of the calls evaluated elsewhere
+        late = set()
+        for n in self.order:
+            if (n.op == "mlp_out" and n.args[0].idx in A_nodes) or any(a.idx in late for a in n.args):
+                late.add(n.idx)
+        early = {n.idx for n in self.order} - late
+        self.forward(only=early)
+        fwd1, self.lines = self.lines, []
+        self.forward(only=late)
+        fwd2, self.lines = self.lines, []
+        self.reverse()
+        rev, self.lines = self.lines, []
+        attr = self.share[0][0].attr
+        nlast = len(attr[2]) - 1
+        nz = attr[2][nlast]
+        halo_rows = sum(TC if axis == a1 else TR for _, _, axis in self.share)
+        interior = 64 * ((TR * TC + 63) // 64)
+        parts = dict(fwd1=fwd1, fwd2=fwd2, rev=rev, threads=interior + 64 * ((halo_rows + 63) // 64), interior=interior,
+                     lds=[], put=[], get=[],
+                     adj_put=[], halo=[], nz=nz)
+        defined = {n.idx for n in self.order if n.op == "mlp_out"}  # (their adjoints g{idx}: defined when used)
+        rev_text = "\n".join(rev)
+        b_adj = dict()
+        for p, (A, B, axis) in enumerate(self.share):
+            row = axis == a1
+            kz = "KZ{}".format(p)
+            ga = "GA{}".format(p)
+            parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(kz, TR + (1 if row else 0), TC + (0 if row else 1), nz))
+            parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(ga, TR, TC, nz))
+            for j in range(nz):
+                parts["put"].append("  {}[{}][{}][{}] = m{}_z{}_{};".format(kz, "tr + 1" if row else "tr", "tc" if row else "tc + 1", j, B.idx, nlast, j))
+                parts["get"].append("  const T m{}_z{}_{} = {}[tr][tc][{}];".format(A.idx, nlast, j, kz, j))
+                outs_a = self.mlp_out_seen.get(A.idx, dict())
+                ga_val = "g{}".format(outs_a[j].idx) if j in outs_a and "T g{} ".format(outs_a[j].idx) in rev_text else "(T)0"
+                parts["adj_put"].append("  {}[tr][tc][{}] = {};".format(ga, j, ga_val))
+                outs_b = self.mlp_out_seen.get(B.idx, dict())
+                own = "g{}".format(outs_b[j].idx) if j in outs_b and "T g{} ".format(outs_b[j].idx) in rev_text else "(T)0"
+                nb = ("(tr + 1 < {} ? {}[tr + 1][tc][{}] : (T)0)".format(TR, ga, j) if row
+                      else "(tc + 1 < {} ? {}[tr][tc + 1][{}] : (T)0)".format(TC, ga, j))
+                b_adj.setdefault(B.idx, []).append("({} + {})".format(own, nb))
+        # reverse pass of the calls this thread evaluated, with the adjoints of both their uses
+        done = set()
+        for _, B, _ in self.share:
+            if B.idx in done:
+                continue
+            if B.idx in self.partner:
+                first = B if B.idx in self.pair_first else self.partner[B.idx]
+                second = self.partner[first.idx]
+                zero = ["(T)0"] * nz
+                dvals = list(zip(b_adj.get(first.idx, zero), b_adj.get(second.idx, zero)))
+                self._mlp_backward("mm{}".format(first.idx), 2, attr, dvals, False)
+                done.update((first.idx, second.idx))
+            else:
+                self._mlp_backward("m{}".format(B.idx), 1, attr, b_adj[B.idx], False)
+                done.add(B.idx)
+        parts["bwd"], self.lines = self.lines, []
+        # halo threads: the input of the shared call at THEIR point, one evaluation, later its reverse pass
+        saved = (self.order, self.loads, self.pre, self.groups)
+        lanes = 0
+        for p, (A, B, axis) in enumerate(self.share):
+            row = axis == a1
+            count = TC if row else TR
+            seen = dict()
+            for arg in A.args:
+                for n in stencil_grad.subdag(arg):
+                    seen[n.idx] = n
+            self.order = [seen[i] for i in sorted(seen)]
+            self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
+            self.forward()
+            inputs = [self.r(arg) for arg in A.args]
+            parts["halo"].append(dict(first=lanes, count=count, row=row, lines=self.lines, inputs=inputs, p=p))
+            lanes += count
+        self.order, self.loads, self.pre, self.groups = saved
+        self.lines = []
+        self._mlp_forward("mh", 1, attr, ["hx_{}".format(i) for i in range(len(self.share[0][0].args))])
+        parts["halo_fwd"], self.lines = self.lines, []
+        self._mlp_backward("mh", 1, attr, ["hd_{}".format(j) for j in range(nz)], False)
+        parts["halo_bwd"], self.lines = self.lines, []
+        parts["nin"] = len(self.share[0][0].args)
+        return parts
+
+    def _tile_kernel(self, S, parts, stored, stream):
+        """Body of the TILED forward kernel.  A workgroup owns an 8 x 32 tile of the last two grid axes (waves 0-3: one
+        thread per point) plus a wave of HALO threads, one per tile point whose lower neighbour lies in another tile.
+        Every thread evaluates the network for the UPPER faces of its point only (both axes as one packed evaluation);
+        halo threads evaluate the lower-face input of their point (the wall extrapolation where the tile touches the
+        wall).  Values cross to the neighbouring thread through LDS; after the reverse pass of the stencil the adjoints
+        cross back the same way, and every thread finishes the reverse pass of what IT evaluated with the sum of the
+        adjoints of both uses (the network's inputs are frozen: only parameter gradients come out of it).  Three
+        phases, two workgroup barriers; halves the network evaluations of the heat operators (+ 40 / 256 for halos)."""
+        TR, TC = self.TILE
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        n1, n2 = self.G[a1] // TR, self.G[a2] // TC
+        lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
+        ntiles = lead * n1 * n2
+        nz, nin = parts["nz"], parts["nin"]
+        S.extend(parts["lds"])
+        S.append("  const int tid = threadIdx.x;")
+        S.append("  for (int tile = blockIdx.x; tile < {}; tile += a.nblocks) {{".format(ntiles))
+        S.append("  const int tc0 = (tile % {}) * {};".format(n2, TC))
+        S.append("  const int tr0 = ((tile / {}) % {}) * {};".format(n2, n1, TR))
+        rem = "(tile / {})".format(n1 * n2)
+        for d in reversed(range(a1)):
+            if d == 0:
+                S.append("  const int i0 = {};".format(rem))
+            else:
+                S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
+                S.append("  const int q{}_ = {} / {};".format(d, rem, self.G[d]))
+                rem = "q{}_".format(d)
+        S.append("  if (tid < {}) {{".format(parts["interior"]))
+        S.append("  const int tr = tid / {0}, tc = tid % {0};".format(TC))
+        S.append("  const int i{} = tr0 + tr, i{} = tc0 + tc;".format(a1, a2))
+        S.append("  const int l = {};".format(self._offset(["i{}".format(d) for d in range(self.ndim)], self.G)))
+        for k, lens in enumerate(self.out_lens):
+            if lens is not None:
+                conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
+                S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
+        S.extend(parts["fwd1"])
+        S.extend(parts["put"])
+        S.append("  wg_barrier();")
+        S.extend(parts["get"])
+        S.extend(parts["fwd2"])
+        S.extend(parts["rev"])
+        for slot, (n, name) in enumerate(stored):
+            if stream:
+                S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
+            else:
+                S.append("  a.cot[{}][l] = {};".format(slot, name))
+        for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
+            term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
+            if self.out_lens[k] is not None:
+                term = "(inbox{} ? {} : (T)0)".format(k, term)
+            S.append("  s_{0} = s_{0} + {1};".format(k, term))
+        S.extend(parts["adj_put"])
+        S.append("  wg_barrier();")
+        S.extend(parts["bwd"])
+        S.append("  } else {")
+        S.append("  const int hl = tid - {};".format(parts["interior"]))
+        for i in range(nin):
+            S.append("  T hx_{} = (T)0;".format(i))
+        S.append("  int tr = 0, tc = 0, role = -1;")
+        for h in parts["halo"]:
+            S.append("  if (hl >= {} && hl < {}) {{".format(h["first"], h["first"] + h["count"]))
+            S.append("    role = {};".format(h["p"]))
+            S.append("    {} = hl - {};".format("tc" if h["row"] else "tr", h["first"]))
+            S.append("    const int i{} = tr0 + tr, i{} = tc0 + tc;".format(a1, a2))
+            S.extend("  " + line for line in h["lines"])
+            for i, e in enumerate(h["inputs"]):
+                S.append("    hx_{} = {};".format(i, e))
+            S.append("  }")
+        S.extend(parts["halo_fwd"])
+        nlast_name = "mh_z{}".format(len(self.share[0][0].attr[2]) - 1)
+        for h in parts["halo"]:
+            S.append("  if (role == {}) {{".format(h["p"]))
+            for j in range(nz):
+                S.append("    KZ{}[tr][tc][{}] = {}_{};".format(h["p"], j, nlast_name, j))
+            S.append("  }")
+        S.append("  wg_barrier();")
+        S.append("  wg_barrier();")
+        for j in range(nz):
+            expr = "(T)0"
+            for h in parts["halo"]:
+                expr = "(role == {} ? GA{}[tr][tc][{}] : {})".format(h["p"], h["p"], j, expr)
+            S.append("  const T hd_{} = {};".format(j, expr))
+        S.extend(parts["halo_bwd"])
+        S.append("  }")
+        S.append("  }")  # tiles
 
     def _gather_symbolic(self, S, gi, key, root):
         """The gather of ONE regular field as a pointwise kernel over its gradient expression."""

@@ -139,3 +139,40 @@ def test_symbolic_gradient_of_random_operators_equals_autograd(cpu_mod, seed, mo
             assert np.max(np.abs(got[key] - want)) <= 1e-11 * scale, (key, cg.out_mode)
         else:
             assert np.max(np.abs(want)) == 0
+
+
+@pytest.mark.parametrize("which", ["heat", "heat2d"])
+def test_shared_network_calls_are_proved_and_true(cpu_mod, which):
+    """odil_amd/stencil_share.py: the conductivity at the lower face of a cell IS the one at the upper face of its
+    neighbour, k_m(i) = k_p(i - e), wherever i has an interior lower neighbour.  The identity is PROVED on the DAG
+    (index-range simplification of the wall masks and of the periodic wrap) for every space axis of the heat
+    operators -- and evaluated numerically here: the inputs of the two network calls agree at every point with
+    i_axis >= 1 and differ somewhere on the wall row (where the generated kernel's halo threads evaluate the call)."""
+    from odil_amd import stencil_share
+
+    ex = __import__(which)
+    argv = ["--Nt", "8", "--Nx", "16", "--infer_k", "1", "--imposed", "stripe", "--double", "1", "--multigrid", "0"]
+    if which == "heat2d":
+        argv += ["--Ny", "32"]
+    problem, state = ex.make_problem(ex.parse_args(argv))
+    rng = np.random.default_rng(3)
+    arrays = problem.domain.arrays_from_state(state)
+    arrays[0] = torch.tensor(rng.random(tuple(arrays[0].shape)))
+    problem.domain.arrays_to_state(arrays, state)
+    tr, outs, raw, names, G = stencil_jit.trace_outputs(problem, state)
+    cg = _Codegen(tr, outs, raw, G, state)
+    axes = tuple(range(len(G)))[1:]
+    found = stencil_share.shared_network_calls(tr, cg.order, G, axes)
+    assert sorted(axis for _, _, axis in found) == list(axes)
+    ev = DagEval(tr, G, {"u": arrays[0].numpy()}, problem.tracers)
+    for A, B, axis in found:
+        shift = tuple(1 if d == axis else 0 for d in range(len(G)))
+        for a, b in zip(A.args, B.args):
+            va = np.asarray(ev(a), dtype=np.float64) * np.ones(G)
+            vb = np.asarray(ev(tr.roll(b, shift, virtual=True)), dtype=np.float64) * np.ones(G)
+            inner = tuple(slice(1, None) if d == axis else slice(None) for d in range(len(G)))
+            wall = tuple(slice(0, 1) if d == axis else slice(None) for d in range(len(G)))
+            assert np.array_equal(va[inner], vb[inner])
+            assert not np.array_equal(va[wall], vb[wall])
+    if which == "heat2d":  # the generator tiles the last two axes and shares both
+        assert [(a.idx, b.idx, ax) for a, b, ax in cg.share] == [(a.idx, b.idx, ax) for a, b, ax in found]
