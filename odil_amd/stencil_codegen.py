@@ -703,8 +703,7 @@ class _Codegen:
             self.emit(line)
 
     # ---- pointwise networks: two evaluations of the same network per pair of float lanes ---------------------
-    # interior threads of a workgroup of the tiled forward kernel: rows x columns of the last two axes (ODIL_TRACE_TILE=RxC)
-    TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "8x32").split("x"))
+    TILE = (8, 32)  # interior threads of a workgroup of the tiled forward kernel: rows x columns of the last two axes
 
     def _choose_shared_calls(self):
         """Network evaluations another thread's evaluation equals (stencil_share.py: k_m(i) = k_p(i - e) away from the
@@ -713,6 +712,7 @@ class _Codegen:
         (the reverse pass of a shared evaluation runs where it was evaluated, after the exchange) and one network."""
         from . import stencil_share
 
+        self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "8x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
         if (not mlps or self.slab is not None or self.ndim < 2 or not int(os.environ.get("ODIL_TRACE_SHARE", 1))
                 or self.GL != self.G):
