@@ -1,6 +1,6 @@
 """Times the P^T chain of the 512^3 f64 headline (first level + Adam) for the loaded library."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from odil_amd import ops
 from odil_amd.poisson_path import PoissonMultigridAdam
 dev = torch.device('cuda:0')
