@@ -183,7 +183,9 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
         else:
             for j in range(p + 1):
                 sub = dict()
-                zs.append(cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=sub, b=cz[j]))
+                # (p + 1 solves: without --linsolver_maxiter each is bounded well below the single-solve default)
+                zs.append(cg_normal(op_s, None, damp, dampdiag, tol=1e-14, maxiter=maxiter or min(20 * op_s.ncols, 5000),
+                                    status=sub, b=cz[j]))
                 niter = max(niter, sub.get("niter", 0))
                 worst = max(worst, sub.get("residual", 0.0))
             zs = torch.stack(zs)
