@@ -714,11 +714,18 @@ class _Codegen:
 
         self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "8x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
-        if (not mlps or self.slab is not None or self.ndim < 2 or not int(os.environ.get("ODIL_TRACE_SHARE", 1))
-                or self.GL != self.G):
+        mode = os.environ.get("ODIL_TRACE_SHARE", "auto")  # 0 / 1 / auto
+        if not mlps or self.slab is not None or self.ndim < 2 or mode == "0" or self.GL != self.G:
             return
         a1, a2 = self.ndim - 2, self.ndim - 1
         if self.G[a1] % self.TILE[0] or self.G[a2] % self.TILE[1] or len({n.attr for n in mlps}) != 1:
+            return
+        # Measured (heat, 46 parameters): on a grid of a few tiles per compute unit the tiled kernel wins (256 x 512:
+        # epoch 0.31 -> 0.23 ms -- a workgroup's serial chain holds one packed evaluation instead of two); on a large
+        # grid it LOSES (256 x 512^2: 3.5 -> 4.8 ms; 4 x 32 ... 16 x 16 tiles alike): its 5-wave workgroups fit once per
+        # compute unit at 244 VGPRs where the plain kernel keeps 8 waves, and they wait at two barriers per tile.
+        # auto: small grids only.
+        if mode == "auto" and self.total // (self.TILE[0] * self.TILE[1]) > 2048:
             return
         if any(self.need.get(a.idx, False) for n in mlps for a in n.args):
             return
