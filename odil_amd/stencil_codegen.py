@@ -712,14 +712,14 @@ class _Codegen:
         (the reverse pass of a shared evaluation runs where it was evaluated, after the exchange) and one network."""
         from . import stencil_share
 
-        self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "8x32").split("x"))  # (tests: small grids)
+        self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "7x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
         mode = os.environ.get("ODIL_TRACE_SHARE", "auto")  # 0 / 1 / auto
         if not mlps or self.slab is not None or self.ndim < 2 or mode == "0" or self.GL != self.G:
             return
         a1, a2 = self.ndim - 2, self.ndim - 1
-        if self.G[a1] % self.TILE[0] or self.G[a2] % self.TILE[1] or len({n.attr for n in mlps}) != 1:
-            return
+        if self.G[a2] % self.TILE[1] or self.G[a1] < self.TILE[0] or len({n.attr for n in mlps}) != 1 or not self.fast:
+            return  # (rows of tiles may be partial -- masked --, columns not; packed float evaluations)
         # Measured (heat, 46 parameters): on a grid of a few tiles per compute unit the tiled kernel wins (256 x 512:
         # epoch 0.31 -> 0.23 ms -- a workgroup's serial chain holds one packed evaluation instead of two); on a large
         # grid it LOSES (256 x 512^2: 3.5 -> 4.8 ms; 4 x 32 ... 16 x 16 tiles alike): its 5-wave workgroups fit once per
@@ -758,7 +758,7 @@ class _Codegen:
         (topologically) with the pair as one unit; pairs that would close a cycle stay single."""
         groups = dict()
         for n in self.order:
-            if n.op == "mlp" and n.idx not in self.shared_A:  # (shared calls: evaluated by another thread)
+            if n.op == "mlp" and n.idx not in self.shared_A and n.idx not in self.shared_B:  # (shared calls: _tile_kernel)
                 groups.setdefault(n.attr, []).append(n)
         pairs = [(nodes[k], nodes[k + 1]) for nodes in groups.values() for k in range(0, len(nodes) - 1, 2)]
         while pairs:
@@ -839,8 +839,8 @@ class _Codegen:
                     self.emit("const {0} {1}_h{2}_{3} = {4};".format(V, p, l, j, self._act(act, "{}_z{}_{}".format(p, l, j), width)))
 
     def _emit_mlp(self, n):
-        if n.idx in self.shared_A:
-            return  # evaluated by the thread of the neighbouring point (or a halo thread): see _tile_forward
+        if n.idx in self.shared_A or n.idx in self.shared_B:
+            return  # shared evaluations: the tiled kernel's unified packed evaluation (_tile_kernel)
         if n.idx in self.partner and n.idx not in self.pair_first:
             return  # emitted with its partner
         group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
@@ -1236,8 +1236,7 @@ class _Codegen:
         # ---- k_fwd ---------------------------------------------------------------------------------------------
         occ = int(os.environ.get("ODIL_TRACE_WAVES_FWD", 0))  # register budget of k_fwd as waves per SIMD (0: the compiler's)
         self.fwd_threads = 256 if tiled is None else tiled["threads"]
-        if tiled is not None and self.TILE[0] * self.TILE[1] % 64:
-            raise TraceUnsupported("tile of {} x {} threads".format(*self.TILE))
+
         S.append('extern "C" __global__ __launch_bounds__({}) {}void k_fwd(const Args a) {{'.format(
             self.fwd_threads, "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else ""))
         S.append("  __shared__ T sm[{}];".format(self.fwd_threads // 64))
@@ -1486,11 +1485,11 @@ class _Codegen:
         """Line groups of the tiled forward kernel (see _tile_kernel)."""
         TR, TC = self.TILE
         a1, a2 = self.ndim - 2, self.ndim - 1
-        A_nodes = {A.idx: A for A, _, _ in self.share}
-        # nodes that need a shared value: everything downstream of the outputs of the calls evaluated elsewhere
+        shared = {x.idx: x for A, B, _ in self.share for x in (A, B)}
+        # nodes that need a shared value: everything downstream of the outputs of the shared calls
         late = set()
         for n in self.order:
-            if (n.op == "mlp_out" and n.args[0].idx in A_nodes) or any(a.idx in late for a in n.args):
+            if (n.op == "mlp_out" and n.args[0].idx in shared) or any(a.idx in late for a in n.args):
                 late.add(n.idx)
         early = {n.idx for n in self.order} - late
         self.forward(only=early)
@@ -1501,54 +1500,42 @@ class _Codegen:
         rev, self.lines = self.lines, []
         attr = self.share[0][0].attr
         nlast = len(attr[2]) - 1
-        nz = attr[2][nlast]
-        halo_rows = sum(TC if axis == a1 else TR for _, _, axis in self.share)
-        interior = 64 * ((TR * TC + 63) // 64)
-        parts = dict(fwd1=fwd1, fwd2=fwd2, rev=rev, threads=interior + 64 * ((halo_rows + 63) // 64), interior=interior,
-                     lds=[], put=[], get=[],
-                     adj_put=[], halo=[], nz=nz)
-        defined = {n.idx for n in self.order if n.op == "mlp_out"}  # (their adjoints g{idx}: defined when used)
+        nz, nin = attr[2][nlast], len(self.share[0][0].args)
+        # the ONE packed evaluation every thread performs: lanes (0, 1) = the upper faces of the thread's point along
+        # the (first, second) shared axis -- or two halo points of one axis
+        lanes = dict()  # call idx -> lane of the unified evaluation that holds it (interior threads)
+        by_axis = {axis: (A, B) for A, B, axis in self.share}
+        for lane, axis in enumerate(sorted(by_axis)):
+            lanes[by_axis[axis][1].idx] = lane
+        parts = dict(fwd1=fwd1, fwd2=fwd2, rev=rev, threads=256, nz=nz, nin=nin, lds=[], xin=[], put=[], get=[], adj_put=[],
+                     adj_get=[], halo=[])
+        for (A, B, axis) in self.share:
+            lane = lanes[B.idx]
+            for k in range(nin):
+                parts["xin"].append("  ux{}_{} = {};".format(k, lane, self.r(B.args[k])))
         rev_text = "\n".join(rev)
-        b_adj = dict()
+
+        def adjoint_of(call, j):
+            out = self.mlp_out_seen.get(call.idx, dict()).get(j)
+            return "g{}".format(out.idx) if out is not None and "T g{} ".format(out.idx) in rev_text else "(T)0"
+
+        slot = 0
         for p, (A, B, axis) in enumerate(self.share):
             row = axis == a1
-            kz = "KZ{}".format(p)
-            ga = "GA{}".format(p)
+            lane = "xy"[lanes[B.idx]]
+            kz, ga = "KZ{}".format(p), "GA{}".format(p)
             parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(kz, TR + (1 if row else 0), TC + (0 if row else 1), nz))
             parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(ga, TR, TC, nz))
             for j in range(nz):
-                parts["put"].append("  {}[{}][{}][{}] = m{}_z{}_{};".format(kz, "tr + 1" if row else "tr", "tc" if row else "tc + 1", j, B.idx, nlast, j))
+                parts["put"].append("  {}[{}][{}][{}] = mu_z{}_{}.{};".format(kz, "tr + 1" if row else "tr", "tc" if row else "tc + 1", j, nlast, j, lane))
                 parts["get"].append("  const T m{}_z{}_{} = {}[tr][tc][{}];".format(A.idx, nlast, j, kz, j))
-                outs_a = self.mlp_out_seen.get(A.idx, dict())
-                ga_val = "g{}".format(outs_a[j].idx) if j in outs_a and "T g{} ".format(outs_a[j].idx) in rev_text else "(T)0"
-                parts["adj_put"].append("  {}[tr][tc][{}] = {};".format(ga, j, ga_val))
-                outs_b = self.mlp_out_seen.get(B.idx, dict())
-                own = "g{}".format(outs_b[j].idx) if j in outs_b and "T g{} ".format(outs_b[j].idx) in rev_text else "(T)0"
+                parts["get"].append("  const T m{}_z{}_{} = mu_z{}_{}.{};".format(B.idx, nlast, j, nlast, j, lane))
+                parts["adj_put"].append("  {}[tr][tc][{}] = valid ? {} : (T)0;".format(ga, j, adjoint_of(A, j)))
                 nb = ("(tr + 1 < {} ? {}[tr + 1][tc][{}] : (T)0)".format(TR, ga, j) if row
                       else "(tc + 1 < {} ? {}[tr][tc + 1][{}] : (T)0)".format(TC, ga, j))
-                b_adj.setdefault(B.idx, []).append("({} + {})".format(own, nb))
-        # reverse pass of the calls this thread evaluated, with the adjoints of both their uses
-        done = set()
-        for _, B, _ in self.share:
-            if B.idx in done:
-                continue
-            if B.idx in self.partner:
-                first = B if B.idx in self.pair_first else self.partner[B.idx]
-                second = self.partner[first.idx]
-                zero = ["(T)0"] * nz
-                dvals = list(zip(b_adj.get(first.idx, zero), b_adj.get(second.idx, zero)))
-                self._mlp_backward("mm{}".format(first.idx), 2, attr, dvals, False)
-                done.update((first.idx, second.idx))
-            else:
-                self._mlp_backward("m{}".format(B.idx), 1, attr, b_adj[B.idx], False)
-                done.add(B.idx)
-        parts["bwd"], self.lines = self.lines, []
-        # halo threads: the input of the shared call at THEIR point, one evaluation, later its reverse pass
-        saved = (self.order, self.loads, self.pre, self.groups)
-        lanes = 0
-        for p, (A, B, axis) in enumerate(self.share):
-            row = axis == a1
-            count = TC if row else TR
+                parts["adj_get"].append("  ud{}_{} = valid ? {} + {} : (T)0;".format(j, lanes[B.idx], adjoint_of(B, j), nb))
+            # halo points of this axis: the lower-face input at the tile's first row / column, two per thread
+            saved = (self.order, self.loads, self.pre, self.groups)
             seen = dict()
             for arg in A.args:
                 for n in stencil_grad.subdag(arg):
@@ -1557,32 +1544,39 @@ class _Codegen:
             self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
             self.forward()
             inputs = [self.r(arg) for arg in A.args]
-            parts["halo"].append(dict(first=lanes, count=count, row=row, lines=self.lines, inputs=inputs, p=p))
-            lanes += count
-        self.order, self.loads, self.pre, self.groups = saved
+            count = TC if row else TR
+            parts["halo"].append(dict(first=slot, count=count, row=row, lines=self.lines, inputs=inputs, p=p))
+            slot += count + (count % 2)  # (a thread's two points belong to one axis)
+            self.order, self.loads, self.pre, self.groups = saved
         self.lines = []
-        self._mlp_forward("mh", 1, attr, ["hx_{}".format(i) for i in range(len(self.share[0][0].args))])
-        parts["halo_fwd"], self.lines = self.lines, []
-        self._mlp_backward("mh", 1, attr, ["hd_{}".format(j) for j in range(nz)], False)
-        parts["halo_bwd"], self.lines = self.lines, []
-        parts["nin"] = len(self.share[0][0].args)
+        parts["halo_threads"] = slot // 2
+        if TR * TC + slot // 2 > 256 or (TR * TC) % 32:
+            raise TraceUnsupported("tile of {} x {} points".format(TR, TC))
+        self._mlp_forward("mu", 2, attr, [("ux{}_0".format(k), "ux{}_1".format(k)) for k in range(nin)])
+        parts["mlp_fwd"], self.lines = self.lines, []
+        self._mlp_backward("mu", 2, attr, [("ud{}_0".format(j), "ud{}_1".format(j)) for j in range(nz)], False)
+        parts["mlp_bwd"], self.lines = self.lines, []
         return parts
 
     def _tile_kernel(self, S, parts, stored, stream):
-        """Body of the TILED forward kernel.  A workgroup owns an 8 x 32 tile of the last two grid axes (waves 0-3: one
-        thread per point) plus a wave of HALO threads, one per tile point whose lower neighbour lies in another tile.
-        Every thread evaluates the network for the UPPER faces of its point only (both axes as one packed evaluation);
-        halo threads evaluate the lower-face input of their point (the wall extrapolation where the tile touches the
-        wall).  Values cross to the neighbouring thread through LDS; after the reverse pass of the stencil the adjoints
-        cross back the same way, and every thread finishes the reverse pass of what IT evaluated with the sum of the
-        adjoints of both uses (the network's inputs are frozen: only parameter gradients come out of it).  Three
-        phases, two workgroup barriers; halves the network evaluations of the heat operators (+ 40 / 256 for halos)."""
+        """Body of the TILED forward kernel.  A workgroup of 256 threads owns a 7 x 32 tile of the last two grid axes
+        (224 threads, one per point) and its HALO: the tile points whose lower neighbour along a shared axis lies in
+        another tile (or beyond the wall), two of them per halo thread (20 threads).  EVERY thread performs one packed
+        evaluation of the network: an interior thread for the upper faces of its point along the two axes, a halo
+        thread for the lower-face inputs of its two points (the wall extrapolation where the tile touches the wall) --
+        the same instruction stream for all, only the inputs differ.  Values cross to the neighbouring thread through
+        LDS; after the reverse pass of the stencil the adjoints cross back the same way, and every thread finishes
+        the reverse pass of what IT evaluated with the sum of the adjoints of both uses (the network's inputs are
+        frozen: only parameter gradients come out of it).  Two workgroup barriers per tile; 4 packed evaluations per
+        224 points where the plain kernel makes 7, at the same 8 waves per compute unit.  Halo and idle threads run
+        the stencil part too, at a point of their own, masked: no divergence outside the input selection."""
         TR, TC = self.TILE
         a1, a2 = self.ndim - 2, self.ndim - 1
-        n1, n2 = self.G[a1] // TR, self.G[a2] // TC
+        G1, G2 = self.G[a1], self.G[a2]
+        n1, n2 = (G1 + TR - 1) // TR, G2 // TC
         lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
         ntiles = lead * n1 * n2
-        nz, nin = parts["nz"], parts["nin"]
+        nz, nin, NI = parts["nz"], parts["nin"], TR * TC
         S.extend(parts["lds"])
         S.append("  const int tid = threadIdx.x;")
         S.append("  for (int tile = blockIdx.x; tile < {}; tile += a.nblocks) {{".format(ntiles))
@@ -1596,63 +1590,84 @@ class _Codegen:
                 S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
                 S.append("  const int q{}_ = {} / {};".format(d, rem, self.G[d]))
                 rem = "q{}_".format(d)
-        S.append("  if (tid < {}) {{".format(parts["interior"]))
-        S.append("  const int tr = tid / {0}, tc = tid % {0};".format(TC))
-        S.append("  const int i{} = tr0 + tr, i{} = tc0 + tc;".format(a1, a2))
+        # roles: interior thread (its point), halo thread (the first of its two points), idle (the tile's first point)
+        S.append("  const bool interior = tid < {};".format(NI))
+        S.append("  const int hs = 2 * (tid - {});".format(NI))  # first halo slot of a halo thread
+        S.append("  int tr = interior ? tid / {0} : 0, tc = interior ? tid % {0} : 0;".format(TC))
+        for h in parts["halo"]:
+            S.append("  if (!interior && hs >= {0} && hs < {1}) {2} = hs - {0};".format(h["first"], h["first"] + h["count"], "tc" if h["row"] else "tr"))
+        S.append("  const bool valid = interior && tr0 + tr < {};".format(G1))
+        S.append("  const int i{} = min(tr0 + tr, {}), i{} = tc0 + tc;".format(a1, G1 - 1, a2))
         S.append("  const int l = {};".format(self._offset(["i{}".format(d) for d in range(self.ndim)], self.G)))
         for k, lens in enumerate(self.out_lens):
             if lens is not None:
                 conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
                 S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
         S.extend(parts["fwd1"])
-        S.extend(parts["put"])
-        S.append("  wg_barrier();")
+        for k in range(nin):
+            S.append("  T ux{0}_0 = (T)0, ux{0}_1 = (T)0;".format(k))
+        S.extend(parts["xin"])
+        for h in parts["halo"]:
+            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
+            for e in range(2):
+                along = "tc" if h["row"] else "tr"
+                S.append("    if ({} + {} < {}) {{".format(along, e, h["count"]))
+                if h["row"]:
+                    S.append("      const int i{} = min(tr0, {}), i{} = tc0 + tc + {};".format(a1, G1 - 1, a2, e))
+                else:
+                    S.append("      const int i{} = min(tr0 + tr + {}, {}), i{} = tc0;".format(a1, e, G1 - 1, a2))
+                S.extend("    " + line for line in h["lines"])
+                for k, expr in enumerate(h["inputs"]):
+                    S.append("      ux{}_{} = {};".format(k, e, expr))
+                S.append("    }")
+            S.append("  }")
+        S.extend(parts["mlp_fwd"])
+        S.append("  if (interior) {")
+        S.extend("  " + line for line in parts["put"])
+        S.append("  }")
+        nl = len(self.share[0][0].attr[2]) - 1
+        for h in parts["halo"]:
+            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
+            for e, lane in enumerate("xy"):
+                idx = "[0][tc + {}]".format(e) if h["row"] else "[tr + {}][0]".format(e)
+                for j in range(nz):
+                    S.append("    if ({} + {} < {}) KZ{}{}[{}] = mu_z{}_{}.{};".format(
+                        "tc" if h["row"] else "tr", e, h["count"], h["p"], idx, j, nl, j, lane))
+            S.append("  }")
+        S.append("  __syncthreads();")
         S.extend(parts["get"])
         S.extend(parts["fwd2"])
         S.extend(parts["rev"])
+        S.append("  if (valid) {")
         for slot, (n, name) in enumerate(stored):
             if stream:
-                S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
+                S.append("    __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
             else:
-                S.append("  a.cot[{}][l] = {};".format(slot, name))
+                S.append("    a.cot[{}][l] = {};".format(slot, name))
         for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
             term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
             if self.out_lens[k] is not None:
                 term = "(inbox{} ? {} : (T)0)".format(k, term)
-            S.append("  s_{0} = s_{0} + {1};".format(k, term))
-        S.extend(parts["adj_put"])
-        S.append("  wg_barrier();")
-        S.extend(parts["bwd"])
-        S.append("  } else {")
-        S.append("  const int hl = tid - {};".format(parts["interior"]))
-        for i in range(nin):
-            S.append("  T hx_{} = (T)0;".format(i))
-        S.append("  int tr = 0, tc = 0, role = -1;")
-        for h in parts["halo"]:
-            S.append("  if (hl >= {} && hl < {}) {{".format(h["first"], h["first"] + h["count"]))
-            S.append("    role = {};".format(h["p"]))
-            S.append("    {} = hl - {};".format("tc" if h["row"] else "tr", h["first"]))
-            S.append("    const int i{} = tr0 + tr, i{} = tc0 + tc;".format(a1, a2))
-            S.extend("  " + line for line in h["lines"])
-            for i, e in enumerate(h["inputs"]):
-                S.append("    hx_{} = {};".format(i, e))
-            S.append("  }")
-        S.extend(parts["halo_fwd"])
-        nlast_name = "mh_z{}".format(len(self.share[0][0].attr[2]) - 1)
-        for h in parts["halo"]:
-            S.append("  if (role == {}) {{".format(h["p"]))
-            for j in range(nz):
-                S.append("    KZ{}[tr][tc][{}] = {}_{};".format(h["p"], j, nlast_name, j))
-            S.append("  }")
-        S.append("  wg_barrier();")
-        S.append("  wg_barrier();")
-        for j in range(nz):
-            expr = "(T)0"
-            for h in parts["halo"]:
-                expr = "(role == {} ? GA{}[tr][tc][{}] : {})".format(h["p"], h["p"], j, expr)
-            S.append("  const T hd_{} = {};".format(j, expr))
-        S.extend(parts["halo_bwd"])
+            S.append("    s_{0} = s_{0} + {1};".format(k, term))
         S.append("  }")
+        S.append("  if (interior) {")
+        S.extend("  " + line for line in parts["adj_put"])
+        S.append("  }")
+        S.append("  __syncthreads();")
+        for j in range(nz):
+            S.append("  T ud{0}_0 = (T)0, ud{0}_1 = (T)0;".format(j))
+        S.append("  if (interior) {")
+        S.extend("  " + line for line in parts["adj_get"])
+        S.append("  }")
+        for h in parts["halo"]:
+            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
+            for e in range(2):
+                idx = "[0][tc + {}]".format(e) if h["row"] else "[tr + {}][0]".format(e)
+                for j in range(nz):
+                    S.append("    if ({} + {} < {}) ud{}_{} = GA{}{}[{}];".format(
+                        "tc" if h["row"] else "tr", e, h["count"], j, e, h["p"], idx, j))
+            S.append("  }")
+        S.extend(parts["mlp_bwd"])
         S.append("  }")  # tiles
 
     def _gather_symbolic(self, S, gi, key, root):
