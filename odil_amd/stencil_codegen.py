@@ -232,6 +232,7 @@ class _Codegen:
         self.vw = self.vw_fwd
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
+        self.fwd_vblocks = None  # virtual blocks of the time-inner traversal of k_fwd (None: plain flat indexing)
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
@@ -714,19 +715,20 @@ class _Codegen:
 
         self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "7x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
-        mode = os.environ.get("ODIL_TRACE_SHARE", "auto")  # 0 / 1 / auto
+        mode = os.environ.get("ODIL_TRACE_SHARE", "0")  # 0 (default: measured slower, below) / 1
         if not mlps or self.slab is not None or self.ndim < 2 or mode == "0" or self.GL != self.G:
             return
         a1, a2 = self.ndim - 2, self.ndim - 1
         if self.G[a2] % self.TILE[1] or self.G[a1] < self.TILE[0] or len({n.attr for n in mlps}) != 1 or not self.fast:
             return  # (rows of tiles may be partial -- masked --, columns not; packed float evaluations)
-        # Measured (heat, 46 parameters): on a grid of a few tiles per compute unit the tiled kernel wins (256 x 512:
-        # epoch 0.31 -> 0.23 ms -- a workgroup's serial chain holds one packed evaluation instead of two); on a large
-        # grid it LOSES (256 x 512^2: 3.5 -> 4.8 ms; 4 x 32 ... 16 x 16 tiles alike): its 5-wave workgroups fit once per
-        # compute unit at 244 VGPRs where the plain kernel keeps 8 waves, and they wait at two barriers per tile.
-        # auto: small grids only.
-        if mode == "auto" and self.total // (self.TILE[0] * self.TILE[1]) > 2048:
-            return
+        # MEASURED, twice, and not faster (heat with two space dimensions, 256 x 512^2, 46 parameters, epoch in ms; plain
+        # kernel 3.54 - 3.56): first design -- interior threads evaluate their upper faces, a fifth wave of halo threads
+        # the tile's lower edge, 320-thread workgroups that fit once per compute unit at 244 VGPRs: 4.78 (tiles 4 x 32
+        # ... 16 x 16: 4.4 - 5.1); this design -- one packed evaluation per thread, halo points in pairs, 256 threads,
+        # 207 VGPRs, the plain kernel's 8 waves per compute unit: 4.29 (3 x 64 tiles: 4.50).  The evaluations halve
+        # (4 per 224 points instead of 7), the kernel does not get faster: two workgroup barriers per tile, the
+        # divergent input selection of the halo lanes in one of four waves, 128-byte row segments instead of the plain
+        # kernel's 1 KB rows.  Kept behind ODIL_TRACE_SHARE=1 with its parity tests; off by default.
         if any(self.need.get(a.idx, False) for n in mlps for a in n.args):
             return
         try:
@@ -1130,6 +1132,50 @@ class _Codegen:
                 S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
                 rem = "r{}_".format(d)
 
+    def _tinner(self, shape, vw):
+        """Geometry of the TIME-INNER traversal, or None.  The leading grid axis (time) is the slowest in memory: a thread
+        block that handles 1024 consecutive points of the plane t re-reads, for every stencil offset in t, rows that
+        the block of plane t - 1 read a whole plane ago -- 34 MB of traffic earlier at config 5, far beyond the 4 MB
+        of an XCD's L2 and, with a dozen arrays streaming, beyond what the last-level cache keeps: the counters
+        show 14 GB fetched by `k_fwd` where the fields are 4.3 GB, 35.6 GB by the merged gather for 21.6
+        (profiles/r03_b_cfg5_slab_pmc.txt), both kernels AT 6.1 - 6.5 TB/s on that traffic.  Here consecutive blocks
+        OF ONE XCD walk along t for a fixed chunk of the plane (block b runs on XCD b % 8): the t - 1 / t + 1 rows a
+        block needs were touched by the blocks just before / are touched by the blocks just after it, in the same L2."""
+        if not int(os.environ.get("ODIL_TRACE_TINNER", 1)) or len(shape) < 2 or shape[0] < 4:
+            return None
+        rest = int(np.prod(shape[1:])) // vw
+        ncp = (rest + 255) // 256
+        if ncp < 64:  # (a plane of a few blocks: nothing to win, and half-empty blocks to lose)
+            return None
+        ch = int(os.environ.get("ODIL_TRACE_TCHUNK", 4))
+        nsc = (ncp + ch - 1) // ch
+        nvb = 8 * ((nsc + 7) // 8) * shape[0] * ch
+        if nvb >= 2**31 - 1024:
+            return None
+        return dict(rest=rest, ch=ch, g0=shape[0], nvb=nvb)
+
+    def _tinner_prologue(self, S, shape, names, vw, geo, flat):
+        """Indices of the thread's point(s) from the virtual block index `vb` (see _tinner); opens `if (lr < rest) {`."""
+        S.append("  const int xcd_ = vb & 7, kk_ = vb >> 3;")
+        S.append("  const int tt_ = (kk_ / {}) % {};".format(geo["ch"], geo["g0"]))
+        S.append("  const int chunk_ = ((kk_ / {}) * 8 + xcd_) * {} + kk_ % {};".format(geo["ch"] * geo["g0"], geo["ch"], geo["ch"]))
+        S.append("  const int lr_ = chunk_ * NB + threadIdx.x;")
+        S.append("  if (lr_ < {}) {{".format(geo["rest"]))
+        S.append("  const int {} = tt_ * {} + lr_;".format(flat, geo["rest"]))
+        S.append("  const int {} = tt_;".format(names[0]))
+        rem = "lr_"
+        last = len(shape) - 1
+        for d in reversed(range(1, len(shape))):
+            ext = shape[d] // vw if d == last else shape[d]
+            var = "ib" if (vw == 4 and d == last) else names[d]
+            mul = " * 4" if (vw == 4 and d == last) else ""
+            if d == 1:
+                S.append("  const int {} = ({}){};".format(var, rem, mul))
+            else:
+                S.append("  const int {} = ({} % {}){};".format(var, rem, ext, mul))
+                S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
+                rem = "r{}_".format(d)
+
     def _loop_open(self, S, vw):
         last = self.ndim - 1
         if vw == 4:
@@ -1259,12 +1305,18 @@ class _Codegen:
         threads = self.total // vw
         if tiled is None:
             flat = "l4" if vw == 4 else "l"
-            if threads <= self.max_blocks * 256:  # one thread per point (or four points)
+            geo = self._tinner(self.GL, vw)
+            self.fwd_vblocks = geo["nvb"] if geo else None
+            if geo:
+                S.append("  for (int vb = blockIdx.x; vb < {}; vb += a.nblocks) {{".format(geo["nvb"]))
+                self._tinner_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, geo, flat)
+            elif threads <= self.max_blocks * 256:  # one thread per point (or four points)
                 S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
                 S.append("  if ({} < {}) {{".format(flat, threads))
             else:
                 S.append("  for (int {0} = blockIdx.x * NB + threadIdx.x; {0} < {1}; {0} += a.nblocks * NB) {{".format(flat, threads))
-            self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
+            if not geo:
+                self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
             if self.slab is not None:
                 S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
             S.extend(fwd_pre)
@@ -1299,6 +1351,8 @@ class _Codegen:
                     else:
                         S.append("  *(T4*)(a.cot[{}] + l4 * 4) = {};".format(slot, vec))
             S.append("  }")
+            if geo:
+                S.append("  }")
         for name in pg2:
             S.append("  {0} = {0} + ({1}2{2}.x + {1}2{2}.y);".format(name, name[:2], name[2:]))
         bsum = "block_sum" if self.fwd_threads == 256 else "block_sum_w<{}>".format(self.fwd_threads // 64)
@@ -1423,8 +1477,8 @@ class _Codegen:
             self.merged = sym_keys
             nk = len(sym_keys)
             S.append("struct GatAll {{ T* g[{0}]; AdamP ad[{0}]; }};".format(nk))
-            threads = self._gather_kernel(S, "k_gat_all", [(key, symbolic[key]) for key in sym_keys], "const GatAll ga",
-                                          lambda k: "ga.g[{}]".format(k), lambda k: "ga.ad[{}]".format(k))
+            nblocks_all = self._gather_kernel(S, "k_gat_all", [(key, symbolic[key]) for key in sym_keys], "const GatAll ga",
+                                              lambda k: "ga.g[{}]".format(k), lambda k: "ga.ad[{}]".format(k))
             S.append('extern "C" int jit_gather_all(const Args* a, void* const* g, void* const* x, void* const* m, void* const* v,')
             S.append('                               double alpha, double omb1, double omb2, double eps, const void* alpha_dev, void* stream) {')
             S.append("  GatAll ga;")
@@ -1432,7 +1486,7 @@ class _Codegen:
             S.append("    ga.g[k] = (T*)g[k];")
             S.append("    ga.ad[k] = AdamP{(T*)x[k], (T*)m[k], (T*)v[k], (T)alpha, (T)omb1, (T)omb2, (T)eps, (const T*)alpha_dev};")
             S.append("  }")
-            S.append("  hipLaunchKernelGGL(k_gat_all, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, ga);".format((threads + 255) // 256))
+            S.append("  hipLaunchKernelGGL(k_gat_all, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, ga);".format(nblocks_all))
             S.append("  return (int)hipGetLastError();")
             S.append("}")
         # launchers
@@ -1672,9 +1726,8 @@ class _Codegen:
 
     def _gather_symbolic(self, S, gi, key, root):
         """The gather of ONE regular field as a pointwise kernel over its gradient expression."""
-        threads = self._gather_kernel(S, "k_gat_{}".format(gi), [(key, root)], "T* __restrict__ g, const AdamP ad",
-                                      lambda k: "g", lambda k: "ad")
-        self.gather_blocks[gi] = (threads + 255) // 256
+        self.gather_blocks[gi] = self._gather_kernel(S, "k_gat_{}".format(gi), [(key, root)],
+                                                     "T* __restrict__ g, const AdamP ad", lambda k: "g", lambda k: "ad")
 
     def _gather_kernel(self, S, name, items, params, G_, AD_):
         """A pointwise kernel over the gradient expressions of `items` = [(field key, expression)] (one thread per
@@ -1683,7 +1736,7 @@ class _Codegen:
         Slab mode: threads cover planes -2 .. n + 2 of the sharded axis; planes that exist in the rank's ghost-extended
         gradient array are stored there (ghost planes: what this rank's cells contribute to the neighbour's), planes
         beyond an end of the decomposition that a periodic read reached go to the wrap buffers (as the legacy slab
-        gather).  Returns the number of threads."""
+        gather).  Returns the number of workgroups to launch."""
         self.vw = self.vw_gat
         vw, last = self.vw, self.ndim - 1
         saved = (self.order, self.lines, self.pre, self.loads, self.groups)
@@ -1717,9 +1770,15 @@ class _Codegen:
         occ = int(os.environ.get("ODIL_TRACE_WAVES_GAT", 0))
         S.append('extern "C" __global__ __launch_bounds__(NB) {}void {}(const Args a, {}) {{'.format(
             "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else "", name, params))
-        S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
-        S.append("  if ({} >= {}) return;".format(flat, threads))
-        self._index_prologue(S, shape, names, vw, flat)
+        geo = self._tinner(shape, vw)
+        if geo:
+            S.append("  const int vb = blockIdx.x;")
+            self._tinner_prologue(S, shape, names, vw, geo, flat)
+        else:
+            S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
+            S.append("  if ({} >= {}) return;".format(flat, threads))
+            self._index_prologue(S, shape, names, vw, flat)
+        nblocks = geo["nvb"] if geo else (threads + 255) // 256
         if self.slab is not None:
             S.append("  const int jo = jx - 2;")  # owned-relative position on the sharded axis
             S.append("  const int i{}g = wrap(jo + a.off, {});".format(ax, self.G[ax]))
@@ -1739,8 +1798,10 @@ class _Codegen:
             for k in range(len(items)):
                 S.append("  " + put.format(dst=G_(k), o=o, k=k))
                 S.append("  " + adam.format(ad=AD_(k), o=o, k=k))
+            if geo:
+                S.append("  }")
             S.append("}")
-            return threads
+            return nblocks
 
         def offset(along, extent):
             full = [along if d == ax else ("ib" if (vw == 4 and d == last) else "i{}".format(d)) for d in range(self.ndim)]
@@ -1766,8 +1827,10 @@ class _Codegen:
         for k, (key, _) in enumerate(items):
             S.append("    " + put.format(dst="a.gwhi[{}]".format(self.src_keys.index(key)), o="o", k=k))
         S.append("  }")
+        if geo:
+            S.append("  }")
         S.append("}")
-        return threads
+        return nblocks
 
 
 def _gather_slab(self, S, gi, key, reads, floc, fshape):
