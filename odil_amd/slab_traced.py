@@ -118,8 +118,6 @@ class HipSlabKernels:
         self.total = cg.total
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
         self.nblocks = min((self.total // cg.vw_fwd + 255) // 256, cap)
-        if cg.fwd_vblocks:  # time-inner traversal: block b and b + nblocks must run on the same XCD (b % 8)
-            self.nblocks = max(8, min(cg.fwd_vblocks, cap) // 8 * 8)
         nout = len(outs)
         self.nout = nout
         self.cot = [torch.empty(cg.GL, dtype=dt, device=device) for _ in range(cg.ncot)]

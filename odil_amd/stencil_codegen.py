@@ -232,7 +232,6 @@ class _Codegen:
         self.vw = self.vw_fwd
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
-        self.fwd_vblocks = None  # virtual blocks of the time-inner traversal of k_fwd (None: plain flat indexing)
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
@@ -1132,50 +1131,6 @@ class _Codegen:
                 S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
                 rem = "r{}_".format(d)
 
-    def _tinner(self, shape, vw):
-        """Geometry of the TIME-INNER traversal, or None.  The leading grid axis (time) is the slowest in memory: a thread
-        block that handles 1024 consecutive points of the plane t re-reads, for every stencil offset in t, rows that
-        the block of plane t - 1 read a whole plane ago -- 34 MB of traffic earlier at config 5, far beyond the 4 MB
-        of an XCD's L2 and, with a dozen arrays streaming, beyond what the last-level cache keeps: the counters
-        show 14 GB fetched by `k_fwd` where the fields are 4.3 GB, 35.6 GB by the merged gather for 21.6
-        (profiles/r03_b_cfg5_slab_pmc.txt), both kernels AT 6.1 - 6.5 TB/s on that traffic.  Here consecutive blocks
-        OF ONE XCD walk along t for a fixed chunk of the plane (block b runs on XCD b % 8): the t - 1 / t + 1 rows a
-        block needs were touched by the blocks just before / are touched by the blocks just after it, in the same L2."""
-        if not int(os.environ.get("ODIL_TRACE_TINNER", 1)) or len(shape) < 2 or shape[0] < 4:
-            return None
-        rest = int(np.prod(shape[1:])) // vw
-        ncp = (rest + 255) // 256
-        if ncp < 64:  # (a plane of a few blocks: nothing to win, and half-empty blocks to lose)
-            return None
-        ch = int(os.environ.get("ODIL_TRACE_TCHUNK", 4))
-        nsc = (ncp + ch - 1) // ch
-        nvb = 8 * ((nsc + 7) // 8) * shape[0] * ch
-        if nvb >= 2**31 - 1024:
-            return None
-        return dict(rest=rest, ch=ch, g0=shape[0], nvb=nvb)
-
-    def _tinner_prologue(self, S, shape, names, vw, geo, flat):
-        """Indices of the thread's point(s) from the virtual block index `vb` (see _tinner); opens `if (lr < rest) {`."""
-        S.append("  const int xcd_ = vb & 7, kk_ = vb >> 3;")
-        S.append("  const int tt_ = (kk_ / {}) % {};".format(geo["ch"], geo["g0"]))
-        S.append("  const int chunk_ = ((kk_ / {}) * 8 + xcd_) * {} + kk_ % {};".format(geo["ch"] * geo["g0"], geo["ch"], geo["ch"]))
-        S.append("  const int lr_ = chunk_ * NB + threadIdx.x;")
-        S.append("  if (lr_ < {}) {{".format(geo["rest"]))
-        S.append("  const int {} = tt_ * {} + lr_;".format(flat, geo["rest"]))
-        S.append("  const int {} = tt_;".format(names[0]))
-        rem = "lr_"
-        last = len(shape) - 1
-        for d in reversed(range(1, len(shape))):
-            ext = shape[d] // vw if d == last else shape[d]
-            var = "ib" if (vw == 4 and d == last) else names[d]
-            mul = " * 4" if (vw == 4 and d == last) else ""
-            if d == 1:
-                S.append("  const int {} = ({}){};".format(var, rem, mul))
-            else:
-                S.append("  const int {} = ({} % {}){};".format(var, rem, ext, mul))
-                S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
-                rem = "r{}_".format(d)
-
     def _loop_open(self, S, vw):
         last = self.ndim - 1
         if vw == 4:
@@ -1305,18 +1260,12 @@ class _Codegen:
         threads = self.total // vw
         if tiled is None:
             flat = "l4" if vw == 4 else "l"
-            geo = self._tinner(self.GL, vw)
-            self.fwd_vblocks = geo["nvb"] if geo else None
-            if geo:
-                S.append("  for (int vb = blockIdx.x; vb < {}; vb += a.nblocks) {{".format(geo["nvb"]))
-                self._tinner_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, geo, flat)
-            elif threads <= self.max_blocks * 256:  # one thread per point (or four points)
+            if threads <= self.max_blocks * 256:  # one thread per point (or four points)
                 S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
                 S.append("  if ({} < {}) {{".format(flat, threads))
             else:
                 S.append("  for (int {0} = blockIdx.x * NB + threadIdx.x; {0} < {1}; {0} += a.nblocks * NB) {{".format(flat, threads))
-            if not geo:
-                self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
+            self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
             if self.slab is not None:
                 S.append("  const int i{0}g = i{0} + a.off;".format(self.slab[0]))
             S.extend(fwd_pre)
@@ -1351,8 +1300,6 @@ class _Codegen:
                     else:
                         S.append("  *(T4*)(a.cot[{}] + l4 * 4) = {};".format(slot, vec))
             S.append("  }")
-            if geo:
-                S.append("  }")
         for name in pg2:
             S.append("  {0} = {0} + ({1}2{2}.x + {1}2{2}.y);".format(name, name[:2], name[2:]))
         bsum = "block_sum" if self.fwd_threads == 256 else "block_sum_w<{}>".format(self.fwd_threads // 64)
@@ -1770,15 +1717,10 @@ class _Codegen:
         occ = int(os.environ.get("ODIL_TRACE_WAVES_GAT", 0))
         S.append('extern "C" __global__ __launch_bounds__(NB) {}void {}(const Args a, {}) {{'.format(
             "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else "", name, params))
-        geo = self._tinner(shape, vw)
-        if geo:
-            S.append("  const int vb = blockIdx.x;")
-            self._tinner_prologue(S, shape, names, vw, geo, flat)
-        else:
-            S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
-            S.append("  if ({} >= {}) return;".format(flat, threads))
-            self._index_prologue(S, shape, names, vw, flat)
-        nblocks = geo["nvb"] if geo else (threads + 255) // 256
+        S.append("  const int {} = blockIdx.x * NB + threadIdx.x;".format(flat))
+        S.append("  if ({} >= {}) return;".format(flat, threads))
+        self._index_prologue(S, shape, names, vw, flat)
+        nblocks = (threads + 255) // 256
         if self.slab is not None:
             S.append("  const int jo = jx - 2;")  # owned-relative position on the sharded axis
             S.append("  const int i{}g = wrap(jo + a.off, {});".format(ax, self.G[ax]))
@@ -1798,8 +1740,6 @@ class _Codegen:
             for k in range(len(items)):
                 S.append("  " + put.format(dst=G_(k), o=o, k=k))
                 S.append("  " + adam.format(ad=AD_(k), o=o, k=k))
-            if geo:
-                S.append("  }")
             S.append("}")
             return nblocks
 
@@ -1827,8 +1767,6 @@ class _Codegen:
         for k, (key, _) in enumerate(items):
             S.append("    " + put.format(dst="a.gwhi[{}]".format(self.src_keys.index(key)), o="o", k=k))
         S.append("  }")
-        if geo:
-            S.append("  }")
         S.append("}")
         return nblocks
 

@@ -102,8 +102,6 @@ class TracedOperator:
         # stencils prefer many (tracer 4-D: 62.0 ms at 65536, 64.5 at 4096).
         cap = cg.max_blocks or (4096 if len(cg.pg_decl) > 8 else 65536)
         self.nblocks = min((self.total // cg.vw_fwd + 255) // 256, cap)
-        if cg.fwd_vblocks:  # time-inner traversal: block b and b + nblocks must run on the same XCD (b % 8)
-            self.nblocks = max(8, min(cg.fwd_vblocks, cap) // 8 * 8)
         nout = len(outs)
         self.cot = [torch.empty(G, dtype=dt, device=dev) for _ in range(cg.ncot)]
         self.part = torch.empty(max(1, nout * self.nblocks), dtype=dt, device=dev)
