@@ -142,7 +142,7 @@ def test_symbolic_gradient_of_random_operators_equals_autograd(cpu_mod, seed, mo
 
 
 @pytest.mark.parametrize("which", ["heat", "heat2d"])
-def test_shared_network_calls_are_proved_and_true(cpu_mod, which):
+def test_shared_network_calls_are_proved_and_true(cpu_mod, which, monkeypatch):
     """odil_amd/stencil_share.py: the conductivity at the lower face of a cell IS the one at the upper face of its
     neighbour, k_m(i) = k_p(i - e), wherever i has an interior lower neighbour.  The identity is PROVED on the DAG
     (index-range simplification of the wall masks and of the periodic wrap) for every space axis of the heat
@@ -174,5 +174,9 @@ def test_shared_network_calls_are_proved_and_true(cpu_mod, which):
             wall = tuple(slice(0, 1) if d == axis else slice(None) for d in range(len(G)))
             assert np.array_equal(va[inner], vb[inner])
             assert not np.array_equal(va[wall], vb[wall])
-    if which == "heat2d":  # the generator tiles the last two axes and shares both
-        assert [(a.idx, b.idx, ax) for a, b, ax in cg.share] == [(a.idx, b.idx, ax) for a, b, ax in found]
+    if which == "heat2d":  # on request the generator tiles the last two axes and shares both (float kernels)
+        monkeypatch.setenv("ODIL_TRACE_SHARE", "1")
+        problem, state = ex.make_problem(ex.parse_args([a if a != "1" or argv[i - 1] != "--double" else "0" for i, a in enumerate(argv)]))
+        tr, outs, raw, names, G = stencil_jit.trace_outputs(problem, state)
+        cg = _Codegen(tr, outs, raw, G, state)
+        assert sorted(axis for _, _, axis in cg.share) == [1, 2] and cg.TILE == (7, 32)
