@@ -172,6 +172,22 @@ class SlabPoissonAdam:
             t = dict(sx=cat(sx), rx=cat(rx), s_add=cat(s_add), r_add=cat(r_add), s_cp=cat(s_cp), r_cp=cat(r_cp))
             t["nx"], t["nadd"], t["ncp"] = int(t["sx"].numel()), int(t["s_add"].numel()), int(t["s_cp"].numel())
             t["send"] = torch.empty(t["nx"] + t["nadd"] + t["ncp"], dtype=self.dtype, device=dev)
+            # the same planes as strided descriptors for odil_planes_copy: one launch packs the x part, one the g part,
+            # one unpacks, one adds -- no index tables read per element (a plane of an axis-0 cut is one contiguous run)
+            def runs(level, rel):
+                lv = self.levels[level]
+                return [(int(starts[level]) + (lv.g_lo + k) * lv.plane, 1, lv.plane, lv.plane) for k in rel]
+
+            PL = getattr(self.ops, "PlaneList", None)
+            if PL is not None and t["ncp"] == 0:
+                pl = dict()
+                pl["sx"] = PL([d for l in (0, 1) for d in runs(l, first(self.levels[l], depth[l]))], dev)
+                pl["rx"] = PL([d for l in (0, 1) for d in runs(l, ghost(self.levels[l], depth[l]))], dev)
+                sa = [d for l in deep for d in runs(l, ghost(self.levels[l], 1) + first(self.levels[l], 1))]
+                ra = [d for l in deep for d in runs(l, first(self.levels[l], 1) + ghost(self.levels[l], 1))]
+                pl["s_add"] = PL(sa, dev, start=t["nx"]) if sa else None
+                pl["r_add"] = PL(ra, dev, start=t["nx"]) if ra else None
+                t["planes"] = pl
             # the initial state: V (3 on level 0) boundary planes of every level
             full_s = [planes(l, first(self.levels[l], V)) for l in range(self.nlvl)]
             full_r = [planes(l, ghost(self.levels[l], V)) for l in range(self.nlvl)]
@@ -206,6 +222,13 @@ class SlabPoissonAdam:
                 msg.append(None)
                 continue
             buf, nx, na = t["send"], t["nx"], t["nadd"]
+            pl = t.get("planes")
+            if pl is not None:
+                pl["sx"].pack(self.x, buf)
+                if pl["s_add"] is not None:
+                    pl["s_add"].pack(self.g, buf)
+                msg.append(buf)
+                continue
             torch.index_select(self.x, 0, t["sx"], out=buf[:nx])
             if na:
                 torch.index_select(self.g, 0, t["s_add"], out=buf[nx:nx + na])
@@ -217,6 +240,13 @@ class SlabPoissonAdam:
             if t is None:
                 continue
             nx, na = t["nx"], t["nadd"]
+            pl = t.get("planes")
+            if pl is not None:
+                r = r.reshape(-1)
+                pl["rx"].unpack(self.x, r)
+                if pl["r_add"] is not None:
+                    pl["r_add"].unpack_add(self.g, r)
+                continue
             self.x.index_copy_(0, t["rx"], r[:nx])
             if t["ncp"]:
                 self.g.index_copy_(0, t["r_cp"], r[nx + na:])

@@ -69,8 +69,7 @@ class PlaneList:
     """CPU double of odil_amd.ops.PlaneList (odil_planes_copy): same descriptors, index arithmetic in torch."""
 
     def __init__(self, planes, device, start=0):
-        assert start == 0, "the CPU double packs one array per message"
-        idx, self.count = [], 0
+        idx, self.start, self.count = [], int(start), int(start)
         for base, outer, ostride, inner in planes:
             o = torch.arange(outer, dtype=torch.int64).view(-1, 1) * ostride
             idx.append((base + o + torch.arange(inner, dtype=torch.int64).view(1, -1)).reshape(-1))
@@ -80,12 +79,13 @@ class PlaneList:
     def pack(self, arr, out=None):
         res = arr.index_select(0, self.index)
         if out is not None:
-            out[: self.count].copy_(res)
+            out[self.start: self.count].copy_(res)
             return out
+        assert self.start == 0
         return res
 
     def unpack(self, arr, buf):
-        arr.index_copy_(0, self.index, buf[: self.count])
+        arr.index_copy_(0, self.index, buf[self.start: self.count])
 
     def unpack_add(self, arr, buf):
-        arr.index_add_(0, self.index, buf[: self.count])
+        arr.index_add_(0, self.index, buf[self.start: self.count])
