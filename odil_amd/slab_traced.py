@@ -319,6 +319,14 @@ class SlabTracedAdam:
         self.hvec = mk() if scaled else None
         pos = 0
         self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
+        # REDUNDANT GHOST UPDATES (ODIL_SLAB_GHOST_UPDATE=0: off): every rank applies the optimizer's update to its inner
+        # ghost planes as well as to its own planes -- the gradient message carries, besides the sender's contribution to
+        # the receiver's boundary plane, the sender's own boundary plane of the partial gradient, so both ranks hold
+        # the same complete gradient of the shared planes (a + b on one side, b + a on the other: the same bits) and
+        # make the same update with the same library kernel; the exchange of the updated unknowns at the start of every
+        # epoch disappears (one initial synchronisation of the ghost planes remains).  Same bytes, one exchange fewer.
+        self.redundant = os.environ.get("ODIL_SLAB_GHOST_UPDATE", "1") != "0"
+        self._x_synced = False
         send_own = dict(lo=[], hi=[])  # plane descriptors (ops.PlaneList): owned boundary planes / inner ghost planes
         recv_ghost = dict(lo=[], hi=[])
         # the same planes split by level for the gradients' halo-add: the finest levels (97 % of the bytes) travel WHILE
@@ -345,16 +353,25 @@ class SlabTracedAdam:
                 elif "levels" in e:
                     lv = e["levels"][k]
                     own, ghost = (own0, ghost0) if k == 0 else (own1, ghost1)
+                    # `ghost`: what the gradient message to that side carries; `own`: where the message FROM that side is
+                    # added.  With redundant ghost updates the message also carries the sender's own boundary plane (its
+                    # partial gradient), which completes the receiver's copy of that plane -- its inner ghost plane
                     if rank > 0:
                         send_own["lo"].append(lv.plane_desc(pos, 0))
                         recv_ghost["lo"].append(lv.plane_desc(pos, -1))
                         own["lo"].append(lv.plane_desc(pos, 0))
                         ghost["lo"].append(lv.plane_desc(pos, -1))
+                        if self.redundant:
+                            ghost["lo"].append(lv.plane_desc(pos, 0))
+                            own["lo"].append(lv.plane_desc(pos, -1))
                     if rank < world - 1:
                         send_own["hi"].append(lv.plane_desc(pos, lv.n - 1))
                         recv_ghost["hi"].append(lv.plane_desc(pos, lv.n))
                         own["hi"].append(lv.plane_desc(pos, lv.n - 1))
                         ghost["hi"].append(lv.plane_desc(pos, lv.n))
+                        if self.redundant:
+                            ghost["hi"].append(lv.plane_desc(pos, lv.n - 1))
+                            own["hi"].append(lv.plane_desc(pos, lv.n))
                 pos += cnt
             e.update(views)
             del e["init"]
@@ -518,7 +535,10 @@ class SlabTracedAdam:
                     view = lv.inner
                 dst = view(e["h"][l])
                 best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
-                dst.copy_(best(e["h"][l - 1], e["loc"], tuple(dst.shape)))
+                if dst.is_contiguous():  # (no interface on this rank's side of the array: written in place)
+                    best(e["h"][l - 1], e["loc"], tuple(dst.shape), out=dst)
+                else:
+                    dst.copy_(best(e["h"][l - 1], e["loc"], tuple(dst.shape)))
                 if fac:
                     torch.mul(dst, fac[l], out=view(e["g"][l]))
 
@@ -538,15 +558,19 @@ class SlabTracedAdam:
             if b is not None:
                 b.record()
 
-        b = tic("halo")
-        lo, hi = self._own["lo"], self._own["hi"]
-        recv_lo, recv_hi = yield ("halo", None if lo is None else lo.pack(self.x, self._send_x["lo"]),
-                                  None if hi is None else hi.pack(self.x, self._send_x["hi"]))
-        if recv_lo is not None:
-            self._ghost["lo"].unpack(self.x, recv_lo)
-        if recv_hi is not None:
-            self._ghost["hi"].unpack(self.x, recv_hi)
-        toc(b)
+        if not (self.redundant and self._x_synced):
+            # the neighbours' boundary planes of the unknowns -> inner ghost planes: every epoch, or once at the start
+            # when the ghost planes are updated redundantly afterwards
+            b = tic("halo")
+            lo, hi = self._own["lo"], self._own["hi"]
+            recv_lo, recv_hi = yield ("halo", None if lo is None else lo.pack(self.x, self._send_x["lo"]),
+                                      None if hi is None else hi.pack(self.x, self._send_x["hi"]))
+            if recv_lo is not None:
+                self._ghost["lo"].unpack(self.x, recv_lo)
+            if recv_hi is not None:
+                self._ghost["hi"].unpack(self.x, recv_hi)
+            self._x_synced = True
+            toc(b)
         b = tic("mg_synth")
         self._synthesise()
         toc(b)

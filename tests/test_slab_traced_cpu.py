@@ -83,7 +83,17 @@ def worker(rank, world, which, epochs, port, out, nx_rank=8):
         for _ in range(epochs):
             run.epoch(comm)
             losses.append(run.last_loss(comm))
-        torch.save({"losses": losses, "owned": [a.clone().numpy() for a in run.owned_arrays()]},
+        # the planes two ranks share: the boundary planes of a rank and the inner ghost planes of its neighbours
+        shared = []
+        for e in run.entries:
+            for lv, a in zip(e.get("levels", []), e.get("x", [])):
+                if lv.replicated:
+                    continue
+                shared.append(dict(own_lo=lv.planes(a, 0).clone().numpy(), own_hi=lv.planes(a, lv.n - 1).clone().numpy(),
+                                   ghost_lo=lv.planes(a, -1).clone().numpy() if lv.g_lo else None,
+                                   ghost_hi=lv.planes(a, lv.n).clone().numpy() if lv.g_hi else None))
+        torch.save({"losses": losses, "owned": [a.clone().numpy() for a in run.owned_arrays()], "shared": shared,
+                    "redundant": run.redundant},
                    os.path.join(out, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -146,6 +156,13 @@ def test_slab_traced_ranks_equal_undivided_oracle(tmp_path, which, world, nx_ran
     results = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(world)]
     for r in range(world):
         assert np.max(np.abs(np.array(results[r]["losses"]) - np.array(losses_ref)) / np.array(losses_ref)) < 1e-12
+    # redundant ghost updates: after `epochs` updates without any exchange of the unknowns, a rank's inner ghost planes
+    # are BIT-identical to the neighbour's boundary planes (same gradient bits, same update on both sides)
+    assert all(res["redundant"] for res in results)
+    for r in range(world - 1):
+        for lo_side, hi_side in zip(results[r + 1]["shared"], results[r]["shared"]):
+            assert np.array_equal(lo_side["ghost_lo"], hi_side["own_hi"])
+            assert np.array_equal(hi_side["ghost_hi"], lo_side["own_lo"])
     for i, ref in enumerate(x_ref):
         for r in range(world):
             got = results[r]["owned"][i]
