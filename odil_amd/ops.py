@@ -139,21 +139,6 @@ def mg_synth(terms, loc, factors=None, work=None, out=None):
     return out
 
 
-_scratch_bufs = {}
-
-
-def _scratch(tag, shape, dtype, device):
-    """A work array kept per (purpose, shape, dtype, device, stream): intermediates of GB size that every epoch needs
-    again (the space part of the two-step transposed prolongation) do not pass through the allocator."""
-    key = (tag, tuple(shape), dtype, str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
-    buf = _scratch_bufs.get(key)
-    if buf is None:
-        if len(_scratch_bufs) > 64:
-            _scratch_bufs.clear()
-        buf = _scratch_bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
-    return buf
-
-
 def _two_step_adjoint(gu, shapes, loc, nontrivial):
     return (gu.dim() == 4 and loc == "nccc" and len(shapes) >= 2 and not nontrivial
             and gu.numel() * gu.element_size() >= (64 << 20) and all(s % 2 == 0 for s in gu.shape[1:]))
@@ -184,8 +169,7 @@ def mg_synth_adj(gu, shapes, loc, factors=None, grads=None):
             grads = [gu] + [torch.empty(tuple(s), dtype=dtype, device=device) for s in shapes[1:]]
         elif grads[0].data_ptr() != gu.data_ptr():
             grads[0].copy_(gu)
-        space = interp_adj(gu, "." + loc[1:], (gu.shape[0],) + tuple(shapes[1][1:]),
-                           out=_scratch("adj_space", (gu.shape[0],) + tuple(shapes[1][1:]), dtype, device))
+        space = interp_adj(gu, "." + loc[1:], (gu.shape[0],) + tuple(shapes[1][1:]))
         interp_adj(space, "n...", tuple(shapes[1]), out=grads[1])
         if nlvl > 2:
             mg_synth_adj(grads[1], shapes[1:], loc, grads=grads[1:])

@@ -286,7 +286,6 @@ class TracedOperator:
         # each runs on its own stream, the forward kernel waits for all of them
         cur = torch.cuda.current_stream()
         side = self._side_streams(len(cg.src_keys))
-        persist = not side and int(os.environ.get("ODIL_TRACE_PERSIST", 1))
         with torch.no_grad():
             for i, key in enumerate(cg.src_keys):
                 field = state.fields[key]
@@ -296,19 +295,6 @@ class TracedOperator:
                     with torch.cuda.stream(s_):
                         u = domain.get_regular_array(field).contiguous()
                     u.record_stream(cur)
-                elif persist and isinstance(field, MultigridField) and key in self.mg_meta:
-                    # the synthesised array and the chain's work arrays are kept between evaluations (GB-sized at the
-                    # configs' shapes: no allocator traffic inside the epoch)
-                    factors, loc, shapes = self.mg_meta[key]
-                    terms = [t.array.contiguous() for t in field.terms]
-                    bufs = self.__dict__.setdefault("_synth_bufs", dict())
-                    if key not in bufs or bufs[key][0].shape != terms[0].shape:
-                        bufs[key] = (torch.empty_like(terms[0]), [None] + [torch.empty_like(t) for t in terms[1:-1]] + [None])
-                    out, work = bufs[key]
-                    if len(terms) == 1 and factors is None:
-                        u = terms[0]
-                    else:
-                        u = ops.mg_synth(terms, loc, factors=factors, work=work[: len(terms)], out=out)
                 else:
                     u = domain.get_regular_array(field).contiguous()
                 keep.append(u)
