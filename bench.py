@@ -455,6 +455,7 @@ def run_api(args, dev):
     """Configs 1, 2, 3, 3b, 4b, 5b through the public operator API (bench_configs.py) on one GPU."""
     import bench_configs
 
+    spin_up(dev, args.spinup_ms)
     out = bench_configs.run_config(args.config, args.scale, epochs=args.steps, warmup=args.warmup)
     model = out.get("model_bytes_per_update")
     ms = out["ms_per_epoch"]
