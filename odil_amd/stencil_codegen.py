@@ -33,10 +33,6 @@ _PRELUDE = r"""
 #include <stdint.h>
 #define NB 256
 typedef @T@ T;
-// integer values of the operator (grid indices, masks built from them): 32 bits -- every extent is below 2^31 (checked
-// by the generator), and 64-bit compares / selects cost two vector instructions each (heat: half of k_fwd's
-// instructions are NOT the network; ODIL_TRACE_INT64=1 restores `long`)
-typedef @IT@ IT;
 #define FN(name) @FN@
 
 __device__ inline T block_sum(T v, T* sm) {
@@ -143,7 +139,7 @@ def _lit(value, kind):
     if kind == _B:
         return "true" if value else "false"
     if kind == _I:
-        return "((IT){})".format(int(value)) if abs(int(value)) < 2**31 else "{}L".format(int(value))
+        return "{}L".format(int(value))
     v = float(value)
     if math.isnan(v):
         return "((T)NAN)"
@@ -485,14 +481,14 @@ class _Codegen:
                 self.hs_slot[n.idx] = len(self.hs)
                 self.hs.append(n)
             e = "HS({})".format(self.hs_slot[n.idx])
-            return {"r": "((T){})", "i": "((IT){})", "b": "({} != 0.0)"}[n.kind].format(e)
+            return {"r": "((T){})", "i": "((long){})", "b": "({} != 0.0)"}[n.kind].format(e)
         return "v{}".format(n.idx)
 
     def r(self, n):
         return self.ex(n) if n.kind == _R else "((T){})".format(self.ex(n))
 
     def i(self, n):
-        return self.ex(n) if n.kind == _I else "((IT){})".format(self.ex(n))
+        return self.ex(n) if n.kind == _I else "((long){})".format(self.ex(n))
 
     def over(self, num, den):
         """`num / den` -- as a multiplication when `den` is a constant power of two (grid steps of 2^k cells:
@@ -689,8 +685,8 @@ class _Codegen:
                 stride *= shape[d]
         ctype = {torch.float32: "float", torch.float64: "double", torch.int32: "int", torch.int64: "long",
                  torch.bool: "unsigned char"}[t.dtype]
-        cast = {"r": "(T)", "i": "(IT)", "b": "0 != "}[n.kind]
-        ktype = {"r": "T", "i": "IT", "b": "bool"}[n.kind]
+        cast = {"r": "(T)", "i": "(long)", "b": "0 != "}[n.kind]
+        ktype = {"r": "T", "i": "long", "b": "bool"}[n.kind]
         line = "const {} v{} = {}((const {}*)a.ten[{}])[{}];".format(
             ktype, n.idx, cast, ctype, slot, " + ".join(terms) or "0")
         tdt = "float" if self.tr.torch_dtype == torch.float32 else "double"
@@ -867,16 +863,16 @@ class _Codegen:
             if n.host or (only is not None and n.idx not in only):
                 continue
             op, A = n.op, n.args
-            kt = {"r": "T", "i": "IT", "b": "bool"}[n.kind]
+            kt = {"r": "T", "i": "long", "b": "bool"}[n.kind]
             v = "const {} v{} = ".format(kt, n.idx)
             if op == "read":
                 self._emit_read(n)
             elif op in ("tensor", "rtensor"):
                 self._emit_tensor(n)
             elif op == "index":
-                self.emit(v + "(IT){};".format(self.gi(n.attr[0])))
+                self.emit(v + "(long){};".format(self.gi(n.attr[0])))
             elif op == "lindex":
-                self.emit(v + "(IT){};".format("jo" if self.in_gather else "i{}".format(n.attr[0])))
+                self.emit(v + "(long){};".format("jo" if self.in_gather else "i{}".format(n.attr[0])))
             elif op == "win":
                 self.emit(v + "{};".format(self.typed(A[0], n.kind)))
             elif op == "aparam":
@@ -1218,8 +1214,7 @@ class _Codegen:
         self.par_arrays = par_arrays
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
-        HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + _PRELUDE.replace("@T@", T).replace("@FN@", fn).replace(
-            "@IT@", "long" if int(os.environ.get("ODIL_TRACE_INT64", 0)) else "int")]
+        HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
             HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
         S = []
