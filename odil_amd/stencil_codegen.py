@@ -62,12 +62,15 @@ __device__ inline void wg_barrier() {  // (one per wave, wherever it stands in i
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
-// (float kernels with ODIL_TRACE_FAST_F32: the quotient of the update through v_rcp_f32, ~1 ulp, as every other
-// division of those kernels; an IEEE float division is ~10 instructions, sixteen of them per thread in a merged gather)
+// (float kernels with ODIL_TRACE_FAST_F32: the quotient and the square root of the update through v_rcp_f32 / v_sqrt_f32,
+// ~1 ulp each, as every other division of those kernels; the IEEE forms are ~10 instructions each, sixteen of each per
+// thread in a merged gather)
 #ifdef ODIL_FAST_F32
 #define ADAM_QUOT(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define ADAM_SQRT(a) __builtin_amdgcn_sqrtf(a)
 #else
 #define ADAM_QUOT(a, b) ((a) / (b))
+#define ADAM_SQRT(a) FN(sqrt)(a)
 #endif
 // Adam of the array a gather forms the gradient of, applied by the lane that holds g[l] (reference
 // src/odil/optimizer.py:316-318; x == NULL: gradient only).  alpha_dev != NULL: the step size is read from
@@ -79,7 +82,7 @@ __device__ inline void adam_apply(const AdamP& ad, int l, T g) {
   m = m + (g - m) * ad.omb1;
   v = v + (g * g - v) * ad.omb2;
   const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
-  x = x - ADAM_QUOT(m * alpha, FN(sqrt)(v) + ad.eps);
+  x = x - ADAM_QUOT(m * alpha, ADAM_SQRT(v) + ad.eps);
   ad.m[l] = m, ad.v[l] = v, ad.x[l] = x;
 }
 // Four consecutive points of the last axis per thread (VW == 4): 16-byte accesses (two for doubles).  The type is
@@ -95,7 +98,7 @@ __device__ inline void adam_apply4(const AdamP& ad, int l, const T* g) {
   for (int p = 0; p < 4; ++p) {
     m[p] = m[p] + (g[p] - m[p]) * ad.omb1;
     v[p] = v[p] + (g[p] * g[p] - v[p]) * ad.omb2;
-    x[p] = x[p] - ADAM_QUOT(m[p] * alpha, FN(sqrt)(v[p]) + ad.eps);
+    x[p] = x[p] - ADAM_QUOT(m[p] * alpha, ADAM_SQRT(v[p]) + ad.eps);
   }
   *(T4*)(ad.m + l) = m, *(T4*)(ad.v + l) = v, *(T4*)(ad.x + l) = x;
 }
