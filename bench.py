@@ -46,7 +46,9 @@ def parse_args():
     p.add_argument("--ndim", type=int, default=3)
     p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_N", type=int, default=256, help="grid size of the 1-core CPU-baseline sample")
+    p.add_argument("--cpu_N", type=int, default=256, help="grid size of the 1-core CPU-baseline sample (256: ~2.5 s per "
+                   "epoch; the headline 512 itself takes 160 s per epoch on one thread, most of it page faults of the "
+                   "1 GiB temporaries -- too long for the default run, available with --cpu_N 512)")
     p.add_argument("--cpu_N_all", type=int, default=128, help="grid size per core of the all-cores CPU-baseline leg")
     p.add_argument("--cpu_budget", type=float, default=10.0, help="seconds of timed CPU work per leg")
     p.add_argument("--scale", type=float, default=1.0, help="shrinks the grids of the non-default configs (smoke runs)")
@@ -110,7 +112,7 @@ def measured_traffic(kernel, ndim, N, dtype):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
     (collected separately with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied), and the
     file they come from; (None, None) when no profile of this kernel / workload is on record."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
