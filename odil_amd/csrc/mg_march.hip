@@ -209,11 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
   add = add ? add + f0 * fvol : add;
   fine += f0 * fvol;
   T v[CNT0][3][3][CX + 2];
+  auto load = [&](int q, int slot) {
 #pragma unroll
-  for (int r0 = 0; r0 < CNT0; ++r0) {
-    load_plane_shared<T, CX>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0], a.tx, jx0);
-    load_plane_shared<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1], a.tx, jx0);
-  }
+    for (int r0 = 0; r0 < CNT0; ++r0)
+      load_plane_shared<T, CX>(cb[r0], q, cnz, cplane, cnx, ty, tx, cscale, v[r0][slot], a.tx, jx0);
+  };
+  load(z0 - 1, 0);
+  load(z0, 1);
   const T rs = T(1) / T(64 * cnt0);
   for (int jz = z0; jz < z1; ++jz) {
     PackN<T, 2 * CX> ad[2][2];
@@ -222,8 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
       load_add<T, CX>(add, fbase, fnx, ad[0], a.nt);
       load_add<T, CX>(add, fbase + fplane, fnx, ad[1], a.nt);
     }
-#pragma unroll
-    for (int r0 = 0; r0 < CNT0; ++r0) load_plane_shared<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2], a.tx, jx0);
+    load(jz + 1, 2);
 #pragma unroll
     for (int sz = 0; sz < 2; ++sz) {
       T s[2][2 * CX];
@@ -236,6 +237,62 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
     }
 #pragma unroll
     for (int r0 = 0; r0 < CNT0; ++r0) shift_window<T, CX>(v[r0]);
+  }
+}
+
+// Node-centred leading axis, fine indices 2k AND 2k + 1 by one thread (blockIdx.y = k < lead_cn - 1): the window of
+// coarse volume k serves both, the window of volume k + 1 the odd one.  Same sums in the same order as the two
+// launches of k_interp_add_march_lead; the registers of the two-window launch (two waves per SIMD either way), but
+// twice the fine bytes in flight per wave and one pass less over the coarse array.
+template <typename T, int CX>
+__global__ __launch_bounds__(kBlock) void k_interp_add_march_lead_pair(const T* __restrict__ coarse,
+                                                                       const T* __restrict__ add, T* __restrict__ fine,
+                                                                       MarchArgs a, T cscale, T ascale) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)a.fn[0] * fplane;
+  const int c0 = (int)blockIdx.y;
+  int z0, z1, jy, jx0;
+  if (!march_decode<CX>(a, z0, z1, jy, jx0)) return;
+  const TapN<CX + 2> tx = tapn<CX + 2>(jx0, cnx);
+  const TapN<3> ty = tapn<3>(jy, cny);
+  const T* cb[2] = {coarse + c0 * cvol, coarse + (c0 + 1) * cvol};
+  add = add ? add + (int64_t)(2 * c0) * fvol : add;
+  fine += (int64_t)(2 * c0) * fvol;
+  T v[2][3][3][CX + 2];
+#pragma unroll
+  for (int r0 = 0; r0 < 2; ++r0) {
+    load_plane_shared<T, CX>(cb[r0], z0 - 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][0], a.tx, jx0);
+    load_plane_shared<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1], a.tx, jx0);
+  }
+  const T rs[2] = {T(1) / T(64), T(1) / T(128)};
+  for (int jz = z0; jz < z1; ++jz) {
+    PackN<T, 2 * CX> ad[2][2][2];
+    const int64_t fbase = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx0;
+    if (add) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        load_add<T, CX>(add + p * fvol, fbase, fnx, ad[p][0], a.nt);
+        load_add<T, CX>(add + p * fvol, fbase + fplane, fnx, ad[p][1], a.nt);
+      }
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 2; ++r0) load_plane_shared<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2], a.tx, jx0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int sz = 0; sz < 2; ++sz) {
+        T s[2][2 * CX];
+        zero_plane<T, CX>(s);
+#pragma unroll
+        for (int r0 = 0; r0 <= p; ++r0)
+#pragma unroll
+          for (int rz = 0; rz < 2; ++rz) acc_plane<T, CX>(s, v[r0][sz + rz], sz == rz ? 1 : 3);
+        store_plane<T, CX>(fine + p * fvol, fbase + sz * fplane, fnx, s, rs[p], ad[p][sz], add != nullptr, ascale, a.nt);
+      }
+#pragma unroll
+    for (int r0 = 0; r0 < 2; ++r0) shift_window<T, CX>(v[r0]);
   }
 }
 
@@ -1270,13 +1327,24 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
   const dim3 grid(unit_grid(m.usched), m.lead_fn);
   if (m.lead_fn != 1) {
     if (m.lead_loc == kNode) {
-      // even fine indices read one coarse volume, odd ones two: two launches, each with its window count
-      const dim3 even(unit_grid(m.usched), (m.lead_fn + 1) / 2), odd(unit_grid(m.usched), m.lead_fn / 2);
-      hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), even, dim3(kBlock), 0, stream, coarse, add, fine, m,
-                         cscale, ascale, 0, 2);
-      if (odd.y > 0)
-        hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 2>), odd, dim3(kBlock), 0, stream, coarse, add, fine, m,
-                           cscale, ascale, 1, 2);
+      // even fine indices read one coarse volume, odd ones two
+      // (ODIL_LEAD_PAIR=0: one launch per parity -- config 5 as one rank: P chain 3.25 ms against 2.70 with pairs)
+      static const bool pair = getenv("ODIL_LEAD_PAIR") ? atoi(getenv("ODIL_LEAD_PAIR")) != 0 : true;
+      if (pair && m.lead_fn == 2 * m.lead_cn - 1 && m.lead_cn >= 2) {
+        // pairs (2k, 2k + 1) by one thread, then the last (even) index alone
+        const dim3 pairs(unit_grid(m.usched), m.lead_cn - 1), last(unit_grid(m.usched), 1);
+        hipLaunchKernelGGL((k_interp_add_march_lead_pair<T, CX>), pairs, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                           cscale, ascale);
+        hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), last, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                           cscale, ascale, m.lead_fn - 1, 2);
+      } else {
+        const dim3 even(unit_grid(m.usched), (m.lead_fn + 1) / 2), odd(unit_grid(m.usched), m.lead_fn / 2);
+        hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), even, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                           cscale, ascale, 0, 2);
+        if (odd.y > 0)
+          hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 2>), odd, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                             cscale, ascale, 1, 2);
+      }
     } else {
       hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m,
                          cscale, ascale, 0, 1);
