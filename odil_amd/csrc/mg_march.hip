@@ -1359,6 +1359,247 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
   return e ? e : 1;
 }
 
+// ------------------------------------------------------------------------------------
+// P^T of float all-cell volumes whose rows hold <= 256 fine cells: ROW-marching kernel.
+//
+// out = 2 C - R, where C and R are SEPARABLE sums over the 6 x 6 x 6 fine window of a coarse cell with the per-axis
+// weight tables wc / wr of adj6 (what k_interp_adj_march evaluates; away from the walls both are (1, 3, 3, 1) / 4 per
+// axis and the result is C).  The tile kernel above stages fine planes through LDS and walks z: 235 VGPRs, 62 KB of
+// LDS, two workgroups per compute unit, 2.3 TB/s on the array in float.  Here a lane owns TWO coarse columns of ONE
+// coarse plane -- one 16 B pack of a fine row -- and walks the fine ROWS of a y chunk:
+//   x: the two fine values left and right of the pack come from the adjacent lanes' registers (wave-wide DPP shift;
+//      a row of 256 fine cells is exactly one wavefront, shorter rows share a wavefront between coarse planes);
+//   z: the lane loads its pack from the 4 fine planes of its coarse plane (6 next to a z wall) and combines them at
+//      once -- every fine value is requested by two waves of the SAME workgroup (or of the next one on the same XCD:
+//      the work items of an XCD are consecutive z groups), so the second request is a cache hit;
+//   y: the row sums slide through a 6-entry register window; a coarse row is emitted every two fine rows.
+// No LDS, no barriers, ~100 VGPRs.  The sums are formed in the order x, z, y (the tile kernel: x, y, z): same terms,
+// float rounding differs in the last bits.
+// ------------------------------------------------------------------------------------
+struct RowsArgs {
+  int cn[3], fn[3];
+  int lxlog;   // log2 of the lanes per fine row (fnx / 4)
+  int yc;      // coarse rows per work item
+  int nzg, nyc;
+  int64_t total, per_xcd;  // work items (lead x y chunks x z groups), and per XCD
+  int64_t fvol, cvol;
+};
+
+template <int NPL>
+__device__ inline void rows_load(const float* __restrict__ vol, int fy, int cz, int fny, int fnz, int64_t fplane, int fnx,
+                                 int lx4, PackN<float, 4> (&g)[NPL]) {
+  constexpr int R0 = (6 - NPL) / 2;
+  fy = fy < 0 ? 0 : (fy >= fny ? fny - 1 : fy);  // rows / planes beyond the array carry zero weights
+  const float* row = vol + (int64_t)fy * fnx + lx4;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    int fz = 2 * cz - 2 + R0 + p;
+    fz = fz < 0 ? 0 : (fz >= fnz ? fnz - 1 : fz);
+    g[p] = *reinterpret_cast<const PackN<float, 4>*>(row + (int64_t)fz * fplane);
+  }
+}
+
+// Wall corrections of one axis: the weight tables of adj6 are the interior pattern (0, 1, 3, 3, 1, 0) / 4 restricted to
+// the array, plus 1/4 on ONE tap next to a wall -- C: tap 2 for J = 0, tap 3 for J = n - 1; R: tap 0 for J = 1, tap 5
+// for J = n - 2 (the ghost weights w_cell(-1, k) / w_cell(n, k) are 1/4 at k = 0 / k = F - 1 and zero elsewhere).
+// Values beyond the array enter as zeros, so the pattern needs no range test.
+struct WallTaps {
+  float c2, c3, r0, r5;
+};
+__device__ inline WallTaps wall_taps(int J, int n) {
+  WallTaps t;
+  t.c2 = J == 0 ? 0.25f : 0.f;
+  t.c3 = J == n - 1 ? 0.25f : 0.f;
+  t.r0 = J == 1 ? 0.25f : 0.f;
+  t.r5 = J == n - 2 ? 0.25f : 0.f;
+  return t;
+}
+// (1, 3, 3, 1) / 4 of the four middle entries of a window of six
+__device__ inline float mid4(float v1, float v2, float v3, float v4) {
+  return __builtin_fmaf(0.75f, v2 + v3, 0.25f * (v1 + v4));
+}
+
+template <int NPL>
+__device__ inline void rows_reduce(const PackN<float, 4> (&g)[NPL], bool lo_edge, bool hi_edge, const WallTaps (&xw)[2],
+                                   const float (&zwc)[6], const float (&zwr)[6], float (&pc)[2], float (&pr)[2]) {
+  float xc[NPL][2], xr[NPL][2];
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    float v[8];
+    v[0] = from_prev_lane(g[p].e[2]);
+    v[1] = from_prev_lane(g[p].e[3]);
+    v[6] = from_next_lane(g[p].e[0]);
+    v[7] = from_next_lane(g[p].e[1]);
+    if (lo_edge) v[0] = v[1] = 0.f;  // beyond the row (or another row's / an undefined lane's value)
+    if (hi_edge) v[6] = v[7] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[2 + i] = g[p].e[i];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* w = v + 2 * c;
+      const float s = mid4(w[1], w[2], w[3], w[4]);
+      xc[p][c] = __builtin_fmaf(xw[c].c3, w[3], __builtin_fmaf(xw[c].c2, w[2], s));
+      xr[p][c] = __builtin_fmaf(xw[c].r5, w[5], __builtin_fmaf(xw[c].r0, w[0], s));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if constexpr (NPL == 4) {  // no lane of the wavefront is next to a z wall
+      pc[c] = mid4(xc[0][c], xc[1][c], xc[2][c], xc[3][c]);
+      pr[c] = mid4(xr[0][c], xr[1][c], xr[2][c], xr[3][c]);
+    } else {
+      float sc = 0.f, sr = 0.f;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        sc = __builtin_fmaf(zwc[p], xc[p][c], sc);
+        sr = __builtin_fmaf(zwr[p], xr[p][c], sr);
+      }
+      pc[c] = sc, pr[c] = sr;
+    }
+  }
+}
+
+template <int NPL>
+__device__ inline void rows_march(const float* __restrict__ vol, float* __restrict__ gcoarse, float* __restrict__ gscaled,
+                                  const RowsArgs& a, int cz, bool active, int y0, int y1, int lx, bool lo_edge, bool hi_edge,
+                                  int64_t cbase, float scale, const AdamArgs<float>& ad) {
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
+  const int64_t fplane = (int64_t)fny * fnx;
+  const WallTaps xw[2] = {wall_taps(2 * lx, cnx), wall_taps(2 * lx + 1, cnx)};
+  float zwc[6], zwr[6];
+  {
+    const Adj6 t = adj6(cz, cnz);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zwc[i] = t.wc[i], zwr[i] = t.wr[i];
+  }
+  float wc[2][6], wr[2][6];  // row sums of fine rows 2 cy - 2 .. 2 cy + 3
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wc[c][i] = wr[c][i] = 0.f;
+  // two steps ahead of the first coarse row: the window fills through the same loop body (a separate priming block
+  // would hold 4 rows x NPL packs in flight at once -- 256 VGPRs)
+#pragma unroll 1
+  for (int cy = y0 - 2; cy < y1; ++cy) {
+    {
+      PackN<float, 4> ga[NPL], gb[NPL];
+      rows_load<NPL>(vol, 2 * cy + 2, cz, fny, fnz, fplane, fnx, 4 * lx, ga);
+      rows_load<NPL>(vol, 2 * cy + 3, cz, fny, fnz, fplane, fnx, 4 * lx, gb);
+      float pc[2], pr[2];
+      rows_reduce<NPL>(ga, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wc[c][4] = pc[c], wr[c][4] = pr[c];
+      rows_reduce<NPL>(gb, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wc[c][5] = pc[c], wr[c][5] = pr[c];
+    }
+    if (cy >= y0) {
+      float out[2];
+      if (cy <= 1 || cy >= cny - 2) {  // next to a y wall (the whole wavefront)
+        const Adj6 ay = adj6(cy, cny);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float sc = 0.f, sr = 0.f;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            sc = __builtin_fmaf(ay.wc[i], wc[c][i], sc);
+            sr = __builtin_fmaf(ay.wr[i], wr[c][i], sr);
+          }
+          out[c] = 2.f * sc - sr;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          out[c] = 2.f * mid4(wc[c][1], wc[c][2], wc[c][3], wc[c][4]) - mid4(wr[c][1], wr[c][2], wr[c][3], wr[c][4]);
+      }
+      if (active) {
+        const int64_t ci = cbase + (int64_t)cy * cnx + 2 * lx;
+        if (gscaled || ad.x) {
+          emit_coarse<float>(gcoarse, gscaled, ci, out[0], scale, ad);
+          emit_coarse<float>(gcoarse, gscaled, ci + 1, out[1], scale, ad);
+        } else {
+          PackN<float, 2> pk;
+          pk.e[0] = out[0], pk.e[1] = out[1];
+          *reinterpret_cast<PackN<float, 2>*>(gcoarse + ci) = pk;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wc[c][i] = wc[c][i + 2], wr[c][i] = wr[c][i + 2];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_interp_adj_rows(const float* __restrict__ gfine, float* __restrict__ gcoarse,
+                                                            float* __restrict__ gscaled, RowsArgs a, float scale,
+                                                            AdamArgs<float> ad) {
+  // consecutive work items (z groups fastest, then y chunks, then volumes) on ONE XCD: the fine planes and rows that
+  // neighbouring items both read meet in that XCD's L2
+  const int xcd = blockIdx.x % kNumXcd;
+  const int64_t slot = blockIdx.x / kNumXcd, w = xcd * a.per_xcd + slot;
+  if (w >= a.total) return;
+  const int zg = (int)(w % a.nzg);
+  const int64_t r = w / a.nzg;
+  const int yc = (int)(r % a.nyc);
+  const int64_t lead = r / a.nyc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> a.lxlog, lx = lane & ((1 << a.lxlog) - 1), pw = 64 >> a.lxlog;
+  const int cz_first = (zg * (kBlock / 64) + wave) * pw;
+  if (cz_first >= a.cn[0]) return;  // the whole wavefront is beyond the last coarse plane
+  const bool active = cz_first + sub < a.cn[0];
+  const int cz = active ? cz_first + sub : a.cn[0] - 1;  // (idle lanes keep the shifts of their neighbours defined)
+  const int y0 = yc * a.yc, y1 = y0 + a.yc < a.cn[1] ? y0 + a.yc : a.cn[1];
+  const bool lo_edge = lx == 0, hi_edge = lx == (1 << a.lxlog) - 1;
+  const float* vol = gfine + lead * a.fvol;
+  const int64_t cbase = lead * a.cvol + (int64_t)cz * a.cn[1] * a.cn[2];
+  const bool z_wall = cz <= 1 || cz >= a.cn[0] - 2;
+  if (__any(z_wall))
+    rows_march<6>(vol, gcoarse, gscaled, a, cz, active, y0, y1, lx, lo_edge, hi_edge, cbase, scale, ad);
+  else
+    rows_march<4>(vol, gcoarse, gscaled, a, cz, active, y0, y1, lx, lo_edge, hi_edge, cbase, scale, ad);
+}
+
+static bool adj_rows_enabled() {
+  const char* e = getenv("ODIL_ADJ_ROWS");
+  return !e || atoi(e) != 0;
+}
+
+// Launches k_interp_adj_rows when the volumes qualify; false: the caller keeps its kernel.
+template <typename T>
+static bool adj_rows_launch(const T* gfine, T* gcoarse, T* gscaled, const MarchArgs& m, T scale, hipStream_t stream,
+                            const AdamArgs<T>& ad) {
+  if constexpr (sizeof(T) != 4) {
+    return false;
+  } else {
+    const int fnx = m.fn[2];
+    if (!adj_rows_enabled() || m.cut_lo || m.cut_hi || m.lead_loc == kNode) return false;
+    if (fnx != 64 && fnx != 128 && fnx != 256) return false;
+    for (int i = 0; i < 3; ++i)
+      if (m.fn[i] != 2 * m.cn[i] || m.cn[i] < 4) return false;
+    if (!aligned_to(gfine, 16) || !aligned_to(gcoarse, 8)) return false;
+    RowsArgs r;
+    for (int i = 0; i < 3; ++i) r.cn[i] = m.cn[i], r.fn[i] = m.fn[i];
+    r.lxlog = fnx == 256 ? 6 : (fnx == 128 ? 5 : 4);
+    const int planes_per_group = (kBlock / 64) * (64 >> r.lxlog);
+    r.nzg = (m.cn[0] + planes_per_group - 1) / planes_per_group;
+    const int64_t lead = m.lead_fn > 1 ? m.lead_fn : 1;
+    // long y chunks (every chunk loads four rows beyond its own) as long as the launch keeps >= 4096 work items
+    r.yc = 32;
+    while (r.yc > 8 && lead * r.nzg * ((m.cn[1] + r.yc - 1) / r.yc) < 4096) r.yc /= 2;
+    r.nyc = (m.cn[1] + r.yc - 1) / r.yc;
+    r.total = lead * r.nzg * r.nyc;
+    r.per_xcd = (r.total + kNumXcd - 1) / kNumXcd;
+    if (r.per_xcd * kNumXcd >= ((int64_t)1 << 31)) return false;
+    r.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
+    r.cvol = (int64_t)m.cn[0] * m.cn[1] * m.cn[2];
+    hipLaunchKernelGGL(k_interp_adj_rows, dim3((unsigned)(r.per_xcd * kNumXcd)), dim3(kBlock), 0, stream, gfine, gcoarse,
+                       gscaled, r, scale, ad);
+    return true;
+  }
+}
+
 // ODIL_ADJ_TILE=0 keeps the register-window kernel on every level (read per call: the tests compare both)
 template <typename T>
 static void launch_adj_tile(dim3 grid, bool wide, hipStream_t stream, const T* gfine, T* gcoarse, T* gscaled,
@@ -1393,7 +1634,8 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
     if (m.lead_loc == kNode)
       hipLaunchKernelGGL((k_interp_adj_march_lead<T, CX, 3>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled,
                          m, scale, ad);
-    else if (tile_ok) {
+    else if (adj_rows_launch<T>(gfine, gcoarse, gscaled, m, scale, stream, ad)) {
+    } else if (tile_ok) {
       // batch of large all-cell volumes: the LDS-staged kernel, one volume per blockIdx.y
       const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + tile_cols - 1) / tile_cols;
       m.tx = kTileX;
@@ -1408,7 +1650,8 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_adj_march_n<T, CX>), grid, dim3(kBlock), 0, stream, gfine, gcoarse, gscaled, m, scale,
                        ad);
-  else if (tile_ok) {
+  else if (adj_rows_launch<T>(gfine, gcoarse, gscaled, m, scale, stream, ad)) {
+  } else if (tile_ok) {
     // large all-cell levels: fine planes staged through LDS
     const int64_t ytiles = (m.cn[1] + kTileY - 1) / kTileY, xtiles = (m.cn[2] + tile_cols - 1) / tile_cols;
     m.tx = kTileX;

@@ -594,10 +594,14 @@ def test_tiled_transpose_is_bit_identical(dev, dtype, fine, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("fine", [(8, 32, 128), (16, 40, 136), (24, 72, 264)])
-def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine):
+def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine, monkeypatch):
     """odil_poisson_adjoint_transpose_adam == odil_poisson_adjoint(_adam) followed by the first P^T (+Adam of
-    that level), bit for bit: the gradient of the finest level, the coarse gradient, and both updated states."""
+    that level), bit for bit: the gradient of the finest level, the coarse gradient, and both updated states.
+    (The separate P^T through the kernels that sum in the same order x, y, z as the fused launch: the row-marching
+    float kernel sums x, z, y -- test_row_marching_float_transpose.)"""
     from odil_amd import ops
+
+    monkeypatch.setenv("ODIL_ADJ_ROWS", "0")
 
     rng = np.random.default_rng(43)
     coarse = tuple(n // 2 for n in fine)
@@ -630,6 +634,41 @@ def test_adjoint_and_transpose_in_one_launch(dev, dtype, fine):
     assert torch.equal(g1, gr[1])
     for a, b in zip(x + m + v, xr + mr + vr):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("loc,cshape", [("ccc", (4, 4, 32)), ("ccc", (5, 7, 32)), ("ccc", (18, 16, 64)), ("ccc", (9, 33, 128)),
+                                        ("ccc", (16, 40, 128)), (".ccc", (3, 6, 12, 32)), (".ccc", (5, 18, 20, 128)),
+                                        (".ccc", (2, 4, 5, 64)), ("ccc", (64, 64, 128)), ("nccc", (5, 4, 32, 64))])
+def test_row_marching_float_transpose(dev, loc, cshape, monkeypatch):
+    """k_interp_adj_rows (float volumes with rows of 64 / 128 / 256 fine cells: a lane owns one 16 B pack of a fine row,
+    x neighbours by wave shifts, four or six fine planes per lane, rows marched) against the float64 oracle, against
+    the kernels it replaces (same terms, other order of summation: a few ulp), with the scaled copy and with the Adam
+    update of the coarse level inside the launch; bit-reproducible."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(sum(cshape))
+    fshape = ops.fine_shape(cshape, loc)
+    g64 = rng.standard_normal(fshape)
+    g = to(g64.astype(np.float32), dev)
+    ref = onp.interp_to_finer_adj(g64.astype(np.float32).astype(np.float64), loc, cshape)
+    monkeypatch.setenv("ODIL_ADJ_ROWS", "0")
+    old = ops.interp_adj(g, loc, cshape)
+    monkeypatch.setenv("ODIL_ADJ_ROWS", "1")
+    new = ops.interp_adj(g, loc, cshape)
+    assert rel(new, ref) < 1e-6 and rel(new, old.cpu().numpy()) < 1e-6
+    assert torch.equal(new, ops.interp_adj(g, loc, cshape))
+    out, scaled = ops.interp_adj(g, loc, cshape, scale=0.5)
+    assert torch.equal(out, new) and torch.equal(scaled, 0.5 * new)
+    mk = lambda pos=False: to((np.abs(rng.standard_normal(cshape)) if pos else rng.standard_normal(cshape)).astype(np.float32), dev)
+    x, m, v = mk(), mk(), mk(True)
+    state = [t.clone() for t in (x, m, v)]
+    gout = torch.empty(cshape, dtype=torch.float32, device=dev)
+    ops.interp_adj_adam(g, loc, cshape, gout, x, m, v, 0.01, 0.1, 0.001, 1e-7)
+    assert torch.equal(gout, new)
+    xr, mr, vr = state
+    ops.adam_step(xr, mr, vr, new, 0.01, 0.1, 0.001, 1e-7)
+    for a, b in ((x, xr), (m, mr), (v, vr)):
+        assert rel(a, b.cpu().numpy()) < 1e-6
 
 
 def test_adjoint_and_transpose_in_one_launch_is_race_free(dev):
