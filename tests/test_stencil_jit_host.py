@@ -79,6 +79,40 @@ def test_slices_rolls_and_array_unknowns_trace(cpu_mod):
     assert "inbox1" in tro.source and "AP(0, 0)" in tro.source
 
 
+@pytest.mark.parametrize("shape,vw,mb", [((9, 16, 16, 16), 4, 0.004), ((9, 16, 16, 16), 1, 0.004), ((5, 12, 8), 4, 0.0002),
+                                         ((9, 16, 16, 16), 4, 5), ((33, 36, 8), 1, 0.001)])
+def test_chunked_traversal_is_a_permutation(cpu_mod, shape, vw, mb, monkeypatch):
+    """_Codegen._chunk_remap: the generated index arithmetic (chunks of axis 1 outermost, then axis 0, then axis 1 within
+    the chunk) visits every point once, walks axis 0 inside a chunk, and is the identity when a level fits the limit."""
+    import re
+
+    import veltracer
+
+    from odil_amd import stencil_codegen
+
+    monkeypatch.setenv("ODIL_TRACE_CHUNK_MB", str(mb))
+    problem, state = veltracer.make_problem(veltracer.parse_args(["--Nx", "16", "--Nt", "8"]))
+    cg = stencil_jit.TracedOperator(problem, state).cg  # (float32: 4-byte elements)
+    S = []
+    cg._chunk_remap(S, list(shape), vw, "raw", "flat")
+    total = int(np.prod(shape)) // vw
+    raw = np.arange(total)
+    env = dict(raw=raw)
+    for line in S:  # "const int a = e, b = e;": C's integer division of non-negative values is Python's //
+        for name, expr in re.findall(r"(\w+) = ([^,;]+)", line.replace("const int ", "")):
+            env[name] = eval(expr.replace("/", "//"), dict(), env)
+    flat = env["flat"]
+    assert sorted(flat.tolist()) == list(range(total))
+    row = int(np.prod(shape[2:]))
+    c1 = max([c for c in range(1, shape[1] + 1) if shape[1] % c == 0 and c * row * 4 <= mb * (1 << 20)], default=0)
+    if c1 == 0 or c1 >= shape[1]:
+        assert np.array_equal(flat, raw)
+    else:
+        per = c1 * row // vw  # threads of one chunk of one level
+        assert np.array_equal(flat[:per], raw[:per])  # the first chunk of level 0 ...
+        assert flat[per] == shape[1] * row // vw      # ... is followed by the first chunk of level 1
+
+
 def test_untraceable_operators_are_refused(cpu_mod):
     domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
     state = odil.State()
