@@ -107,6 +107,8 @@ class HipSlabKernels:
 
     def __init__(self, problem, state, axis, n, device):
         tr, outs, raw, self.names, Gshape = trace_outputs(problem, state)
+        if tr.offgrid:
+            raise TraceUnsupported("outputs in parameter space under the slab decomposition")
         self.problem, self.tr, self.raw = problem, tr, raw
         cg = _Codegen(tr, outs, raw, Gshape, state, slab=(axis, n))
         self.source = cg.source()

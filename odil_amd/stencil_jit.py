@@ -56,6 +56,19 @@ def trace_outputs(problem, state):
     # unknowns reached around ctx.field / ctx.neural_net would lose their gradient: trace on
     # differentiable leaves so that `lift` can refuse them
     leaves = [a.detach().requires_grad_(True) for a in domain.arrays_from_state(state)]
+    # ... except whole PARAMETER arrays (network weights, `Array`s): operations on them are taped, and an output built
+    # from them alone is evaluated by replaying the tape (param_tape.py)
+    from .core import Array, NeuralNet
+    from .param_tape import OffGrid, ParamTape, ParamTensor
+
+    tape, pos = ParamTape(), 0
+    for field in state.fields.values():
+        n = len(domain.arrays_from_field(field))
+        if isinstance(field, (NeuralNet, Array)):
+            for k in range(pos, pos + n):
+                if not leaves[k].is_meta:
+                    leaves[k] = tape.leaf(leaves[k], k)
+        pos += n
     ctx = TraceContext(tr, problem._shadow_state(state, leaves), problem.extra, problem.tracers)
     try:
         with torch.enable_grad():
@@ -67,6 +80,12 @@ def trace_outputs(problem, state):
         # kernels of this package): the eager path runs it, and reports genuine errors
         raise TraceUnsupported("{} under tracing: {}".format(type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
     names, values = Problem._split_outputs(res)
+    # outputs in parameter space: [(position among the outputs, expression)]
+    tr.offgrid = [(k, OffGrid.of(v)) for k, v in enumerate(values) if isinstance(v, (OffGrid, ParamTensor))]
+    tr.param_tape = tape
+    values = [v for v in values if not isinstance(v, (OffGrid, ParamTensor))]
+    if not values:
+        raise TraceUnsupported("operator has no output on the grid")
     raw = [isinstance(v, Context.Raw) for v in values]
     outs = [tr.lift(v.value if r else v) for v, r in zip(values, raw)]
     if not any(n.op == "read" for n in tr.nodes):
@@ -89,6 +108,9 @@ class TracedOperator:
         self.problem, self.domain = problem, domain
         tr, outs, raw, self.names, G = trace_outputs(problem, state)
         self.G, self.raw = G, raw
+        # outputs in parameter space (param_tape.py): [(position, expression, slice of the tape it needs)]
+        self.offgrid = [(k, e, tr.param_tape.slice_for(e.param_ids())) for k, e in tr.offgrid]
+        self.param_tape = tr.param_tape
         cg = _Codegen(tr, outs, raw, G, state)
         self.source = cg.source()
         self.lib, self.lib_path = _compile(self.source, cg.flags)
@@ -437,7 +459,41 @@ class TracedOperator:
         terms = [out[1 + k] for k in range(nout)]
         norms = [out[1 + nout + k] for k in range(nout)]
         del keep
+        if self.offgrid:
+            loss, terms, norms = self._eval_offgrid(state, loss, terms, norms)
         return loss, list(self.gviews), terms, self.names, norms
+
+    def _eval_offgrid(self, state, loss, terms, norms):
+        """The outputs that live in parameter space: the tape of their torch operations replayed on the current
+        parameter arrays, mean squares added to the loss, gradients to the parameters' gradients (autograd on a few small
+        tensors; reference core.py:1076-1100 treats them like any other output)."""
+        arrays = self.domain.arrays_from_state(state)
+        memo = dict()
+        host = lambda n: float(self._host_value(n, memo))
+        terms, norms = list(terms), list(norms)
+        with torch.enable_grad():
+            leaves = {i: arrays[i].detach().requires_grad_(True) for i in set(self.param_tape.leaves.values())}
+            total = None
+            extra = []
+            for k, expr, ops in self.offgrid:
+                env = self.param_tape.replay(ops, leaves)
+                f = expr.evaluate(env, host)
+                if not isinstance(f, torch.Tensor):
+                    f = torch.as_tensor(f, dtype=self.tr.torch_dtype, device=self.out.device)
+                term = torch.mean(torch.square(f))
+                extra.append((k, term))
+                total = term if total is None else total + term
+            used = [i for i in sorted(leaves)]
+            grads = torch.autograd.grad(total, [leaves[i] for i in used], allow_unused=True) if total.requires_grad else []
+        for i, g in zip(used, grads):
+            if g is not None:
+                self.gviews[i].add_(g.to(self.gviews[i].dtype))
+        for k, term in extra:
+            term = term.detach().to(loss.dtype)
+            terms.insert(k, term)
+            norms.insert(k, torch.sqrt(term))
+            loss = loss + term
+        return loss, terms, norms
 
 
 def _flat_range(tensors):

@@ -11,6 +11,8 @@ import math
 import numpy as np
 import torch
 
+from .param_tape import OffGrid, ParamTensor
+
 from .backend import torch_dtype
 
 
@@ -438,6 +440,12 @@ class Tracer:
         return self.node(op, (a,), shape=a.shape, kind=kind, host=a.host and op in _HOST_UNARY, win=a.win)
 
     def binary(self, op, a, b):
+        if isinstance(a, (ParamTensor, OffGrid)) or isinstance(b, (ParamTensor, OffGrid)):
+            # a whole parameter array (or an expression of such) times / plus a host scalar of the trace: an output in
+            # parameter space (param_tape.py)
+            if op not in ("add", "sub", "mul", "div"):
+                raise TraceUnsupported("operation '{}' between a symbol and a parameter array".format(op))
+            return OffGrid(op, a, b)
         a, b = self.lift(a), self.lift(b)
         if a.op == "const" and b.op == "const":
             return self.const(_HOST_BINARY[op](a.attr, b.attr))

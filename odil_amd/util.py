@@ -372,7 +372,9 @@ def make_loss_grad(problem, state):
     loss_grad.fused_adam = fused_adam
     # hipGraph replay of whole Adam epochs (optimizer._EpochGraph): possible when the evaluation is
     # made of this package's kernels only -- the generic path has its own graph (Problem(jit=True))
-    loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or getattr(problem, "_traced", None) is not None
+    # (outputs in parameter space are evaluated by torch with host scalars of the current epoch: not replayable)
+    loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or (
+        getattr(problem, "_traced", None) is not None and not getattr(problem._traced, "offgrid", None))
 
     def graph_hook(name):
         def call(*a):

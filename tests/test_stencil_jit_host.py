@@ -113,6 +113,53 @@ def test_chunked_traversal_is_a_permutation(cpu_mod, shape, vw, mb, monkeypatch)
         assert flat[per] == shape[1] * row // vw      # ... is followed by the first chunk of level 1
 
 
+def test_outputs_in_parameter_space_are_taped(cpu_mod):
+    """heat --kwreg (reference examples/heat/heat.py:131-136): `(stop_gradient(ww) - ww) * k` on the concatenated
+    network weights is an output in PARAMETER space.  The operator stays on the traced path: the torch operations on the
+    parameter arrays are taped during tracing (odil_amd/param_tape.py) and replayed on the current arrays at every
+    evaluation, with the host scalars of the current epoch."""
+    import torch
+
+    import heat
+
+    args = heat.parse_args(["--Nx", "16", "--Nt", "8", "--infer_k", "1", "--kwreg", "0.3", "--kwregdecay", "100"])
+    problem, state = heat.make_problem(args)
+    problem.tracers["epoch"] = 50
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert tro.names == ["fu", "wreg"] and [k for k, _, _ in tro.offgrid] == [1] and len(tro.raw) == 1
+    one = torch.tensor(1.0, dtype=torch.float64)
+    tro.gflat.zero_()
+    loss, terms, norms = tro._eval_offgrid(state, one, [one], [one])
+    assert float(loss) == 1.0 and [float(t) for t in terms] == [1.0, 0.0] and float(norms[1]) == 0.0
+    assert float(tro.gflat.abs().max()) == 0.0  # value and gradient of this regulariser vanish identically
+
+    # a weight decay: value k w, gradient of its mean square 2 k^2 w / n, k a function of the epoch tracer
+    base = problem.operator
+
+    def operator(ctx):
+        ww = ctx.domain.arrays_from_field(ctx.state.fields["k_net"])
+        flat = ctx.mod.concatenate([ctx.mod.flatten(w) for w in ww], axis=0)
+        return base(ctx) + [("wdecay", flat * (0.5 * 0.5 ** (ctx.tracers["epoch"] / 50)))]
+
+    problem2 = odil.Problem(operator, problem.domain, problem.extra)
+    problem2.tracers["epoch"] = 50
+    tro = stencil_jit.TracedOperator(problem2, state)
+    assert tro.names == ["fu", "wreg", "wdecay"] and [k for k, _, _ in tro.offgrid] == [1, 2]
+    arrays = problem.domain.arrays_from_state(state)
+    idx = [i for key, kind, pos, n in tro.layout if kind == "net" for i in range(pos, pos + n)]
+    w = torch.cat([arrays[i].reshape(-1) for i in idx]).double()
+    tro.gflat.zero_()
+    loss, terms, norms = tro._eval_offgrid(state, one, [one], [one])
+    k = 0.25
+    assert abs(float(terms[2]) - float((k * w).square().mean())) < 1e-6 * float(terms[2])
+    got = torch.cat([tro.gviews[i].reshape(-1) for i in idx]).double()
+    assert float((got - 2 * k * k * w / w.numel()).abs().max()) < 1e-6 * float(got.abs().max())
+    problem2.tracers["epoch"] = 100  # the host scalar follows the tracer without re-tracing
+    tro.gflat.zero_()
+    _, terms, _ = tro._eval_offgrid(state, one, [one], [one])
+    assert abs(float(terms[2]) - float((0.125 * w).square().mean())) < 1e-6 * float(terms[2])
+
+
 def test_untraceable_operators_are_refused(cpu_mod):
     domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
     state = odil.State()
