@@ -54,12 +54,27 @@ int odil_interp_add_f64(const double* coarse, const double* add, double* fine, c
                         const char* loc, double coarse_scale, double add_scale, void* stream);
 int odil_interp_add_f32(const float* coarse, const float* add, float* fine, const int64_t* cshape, int ndim,
                         const char* loc, float coarse_scale, float add_scale, void* stream);
+/* The same with the coarse operand a VIEW: `coarse_ld` elements lie between consecutive indices of its leading axis
+ * (>= the product of its other extents; a ghost-extended level array of the slab paths without its outer ghost planes --
+ * no reference counterpart).  Served by the marching kernels of the 4-D layouts ('nccc', '.ccc'); returns 1,
+ * having launched nothing, for any other layout or size (the caller then passes a contiguous copy to odil_interp_add). */
+int odil_interp_add_ld_f64(const double* coarse, int64_t coarse_ld, const double* add, double* fine, const int64_t* cshape,
+                           int ndim, const char* loc, double coarse_scale, double add_scale, void* stream);
+int odil_interp_add_ld_f32(const float* coarse, int64_t coarse_ld, const float* add, float* fine, const int64_t* cshape,
+                           int ndim, const char* loc, float coarse_scale, float add_scale, void* stream);
 /* gcoarse = P^T gfine (the cotangent autodiff produces for core.py:606-700);
  * if `gscaled` != NULL also gscaled = scale * gcoarse. */
 int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
                         const char* loc, double scale, void* stream);
 int odil_interp_adj_f32(const float* gfine, float* gcoarse, float* gscaled, const int64_t* cshape, int ndim,
                         const char* loc, float scale, void* stream);
+/* gcoarse = P^T gfine written into a VIEW with `gcoarse_ld` elements between consecutive leading indices (see
+ * odil_interp_add_ld; also the time part 'n...' of the two-step transpose of 'nccc' arrays).  Returns 1, having launched
+ * nothing, where the layout is not served. */
+int odil_interp_adj_ld_f64(const double* gfine, double* gcoarse, int64_t gcoarse_ld, const int64_t* cshape, int ndim,
+                           const char* loc, void* stream);
+int odil_interp_adj_ld_f32(const float* gfine, float* gcoarse, int64_t gcoarse_ld, const int64_t* cshape, int ndim,
+                           const char* loc, void* stream);
 /* Slab decomposition (no reference counterpart): the same transpose for an array
  * whose axis 0 is CUT at its low / high end -- that end carries ghost planes of the
  * neighbouring rank instead of being a wall, so the boundary (ghost-rule) weights are not

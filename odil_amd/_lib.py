@@ -23,6 +23,8 @@ _R = "real"
 _SIGNATURES = {
     "interp_add": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _R, _P],
     "interp_adj": [_P, _P, _P, _I64P, c_int, c_char_p, _R, _P],
+    "interp_add_ld": [_P, c_int64, _P, _P, _I64P, c_int, c_char_p, _R, _R, _P],
+    "interp_adj_ld": [_P, _P, c_int64, _I64P, c_int, c_char_p, _P],
     "interp_adj_cut": [_P, _P, _P, _I64P, c_int, c_char_p, _R, c_int, c_int, _P],
     "interp_adj_cut_adam": [_P, _P, _I64P, c_int, c_char_p, c_int, c_int, _P, _P, _P, _R, _R, _R, _R, _P, _P],
     "restrict": [_P, _P, _I64P, c_int, c_char_p, _P],
@@ -111,13 +113,17 @@ def suffix_of(dtype):
     raise TypeError("unsupported dtype {} (float32 / float64 only)".format(dtype))
 
 
-def call(name, dtype, *args):
-    """Calls odil_<name>_<f32|f64>(*args); raises OdilHipError on a non-zero status."""
+def call(name, dtype, *args, unserved_ok=False):
+    """Calls odil_<name>_<f32|f64>(*args); raises OdilHipError on a non-zero status.  unserved_ok: the entry point may
+    return 1 = "layout not served, nothing launched" (odil_interp_add_ld / _adj_ld); returns whether it served."""
     lib = load()
     fn = getattr(lib, "odil_{}_{}".format(name, suffix_of(dtype)))
     status = fn(*args)
+    if status == 1 and unserved_ok:
+        return False
     if status != 0:
         raise OdilHipError("odil_{}: {} (status {})".format(name, lib.odil_last_error().decode(), status))
+    return True
 
 
 def ptr(t):

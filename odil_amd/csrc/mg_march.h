@@ -40,6 +40,7 @@ struct MarchArgs {
   int cut_lo, cut_hi;  // z end is an interior slab interface (ghost planes), not a wall
   int nt;              // stream the fine array past the caches (it exceeds kStreamBytes)
   int lead_loc, lead_cn, lead_fn;  // 4-D layouts: leading axis kind ('.' batch or 'n') and its extents
+  int64_t lead_cstride;            // elements between leading indices of the COARSE array (its volume unless a view)
   UnitSched usched;
 };
 

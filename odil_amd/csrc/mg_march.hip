@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
-  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)a.fn[0] * fplane;
+  const int64_t cvol = a.lead_cstride, fvol = (int64_t)a.fn[0] * fplane;
   const int f0 = f0_first + f0_step * (int)blockIdx.y;
   const bool node = a.lead_loc == kNode;
   constexpr int cnt0 = CNT0;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead_pair(const T* 
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
-  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)a.fn[0] * fplane;
+  const int64_t cvol = a.lead_cstride, fvol = (int64_t)a.fn[0] * fplane;
   const int c0 = (int)blockIdx.y;
   int z0, z1, jy, jx0;
   if (!march_decode<CX>(a, z0, z1, jy, jx0)) return;
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __res
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fnz = a.fn[0], fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
-  const int64_t cvol = (int64_t)cnz * cplane, fvol = (int64_t)fnz * fplane;
+  const int64_t fvol = (int64_t)fnz * fplane;  // (the coarse volumes are a.lead_cstride apart)
   const int J0 = blockIdx.y;
   const bool node = a.lead_loc == kNode;
   int z0, z1, jy, jx0;
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_march_lead(const T* __res
         v[c] = v[c] + wv[t] * combine_z<T>(wc[t][c], wr[t][c], jz, cnz, fnz, ax[c].special || ay.special, 0, 0);
       slide<T, CX>(wc[t], wr[t]);
     }
-    const int64_t ci = J0 * cvol + (int64_t)jz * cplane + (int64_t)jy * cnx + jx0;
+    const int64_t ci = J0 * a.lead_cstride + (int64_t)jz * cplane + (int64_t)jy * cnx + jx0;
 #pragma unroll
     for (int c = 0; c < CX; ++c) emit_coarse<T>(gcoarse, gscaled, ci + c, v[c], scale, ad);
   }
@@ -1285,6 +1285,8 @@ static bool march_setup(MarchArgs& m, const InterpArgs& a, int cx, int64_t targe
   m.lead_loc = lead ? a.loc[0] : 0;
   m.lead_cn = (int)a.cn[0];
   m.lead_fn = (int)a.fn[0];
+  m.lead_cstride = a.coarse_ld ? a.coarse_ld : a.cn[1] * a.cn[2] * a.cn[3];
+  if (a.coarse_ld && !lead) return false;  // a strided coarse operand is a 4-D matter
   for (int i = 0; i < 3; ++i) {
     if (a.fn[i + 1] >= (1 << 30)) return false;
     m.cn[i] = (int)a.cn[i + 1];
@@ -1593,7 +1595,7 @@ static bool adj_rows_launch(const T* gfine, T* gcoarse, T* gscaled, const MarchA
     r.per_xcd = (r.total + kNumXcd - 1) / kNumXcd;
     if (r.per_xcd * kNumXcd >= ((int64_t)1 << 31)) return false;
     r.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
-    r.cvol = (int64_t)m.cn[0] * m.cn[1] * m.cn[2];
+    r.cvol = m.lead_cstride;
     hipLaunchKernelGGL(k_interp_adj_rows, dim3((unsigned)(r.per_xcd * kNumXcd)), dim3(kBlock), 0, stream, gfine, gcoarse,
                        gscaled, r, scale, ad);
     return true;
@@ -1626,7 +1628,9 @@ static int adj_launch(const T* gfine, T* gcoarse, T* gscaled, const InterpArgs& 
   const bool small_level = a.cn[0] * a.cn[1] * a.cn[2] * a.cn[3] <= ((int64_t)1 << 22);
   if (!march_setup(m, a, CX, small_level ? ODIL_ADJ_UNITS_SMALL : ODIL_ADJ_UNITS)) return 0;
   const dim3 grid(unit_grid(m.usched), m.lead_cn);
-  const bool tile_ok = CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled();
+  // (a strided coarse result is written by the kernels that index it through m.lead_cstride only, and never with a
+  // scaled copy / an update of arrays of another layout: the caller checks the latter)
+  const bool tile_ok = CX == 1 && m.cn[1] >= 2 * kTileY && m.cn[2] >= 2 * kTileX && adj_tile_enabled() && !a.coarse_ld;
   // float: two coarse columns per thread (16 B per lane everywhere) when the rows allow it
   const bool tile_wide = sizeof(T) == 4 && m.cn[2] % 2 == 0 && m.cn[2] >= 4 * kTileX && aligned_to(gfine, 16);
   const int tile_cols = kTileX * (tile_wide ? 2 : 1);

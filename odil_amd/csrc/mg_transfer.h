@@ -64,6 +64,9 @@ struct InterpArgs {
   // slab decomposition: array axis 0 (canonical index cut_axis) is cut at its low / high end,
   // i.e. that end is an interior interface with ghost planes, not a physical boundary
   int cut_axis, cut_lo, cut_hi;
+  // elements between consecutive LEADING indices of the coarse array when it is a view whose leading stride exceeds
+  // its volume (a ghost-extended level array of the slab paths without its outer ghost planes); 0: contiguous
+  int64_t coarse_ld;
   RowSched sched;
 };
 

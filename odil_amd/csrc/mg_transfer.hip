@@ -358,7 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_restrict_adj(const T* __restrict__ g
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_interp_adj_lead_node(const T* __restrict__ gfine, T* __restrict__ gcoarse,
                                                                 T* __restrict__ gscaled, int64_t cn0, int64_t fn0,
-                                                                int64_t vol, T scale) {
+                                                                int64_t vol, T scale, int64_t ld) {
+  // ld: elements between leading indices of gcoarse (vol unless it is a view of a larger array; no gscaled then)
   const int64_t total = cn0 * vol;
   const int64_t nthreads = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += nthreads) {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_lead_node(const T* __rest
     if (k - 1 >= 0) sides = sides + gfine[(k - 1) * vol + r];
     if (k + 1 < fn0) sides = sides + gfine[(k + 1) * vol + r];
     const T v = gfine[k * vol + r] + T(0.5) * sides;
-    gcoarse[i] = v;
+    gcoarse[J * ld + r] = v;
     if (gscaled) gscaled[i] = scale * v;
   }
 }
@@ -394,6 +395,7 @@ static int fill_interp_args(InterpArgs& a, const int64_t* cshape, int ndim, cons
   canon_shape(cshape, ndim, a.cn);
   a.cut_axis = -1;
   a.cut_lo = a.cut_hi = 0;
+  a.coarse_ld = 0;
   for (int i = 0; i < 4; ++i) {
     if (a.cn[i] < 1 || (a.loc[i] != kNone && a.cn[i] < 2)) {
       set_error("coarse extent %lld on a refined axis must be >= 2", (long long)a.cn[i]);
@@ -406,14 +408,22 @@ static int fill_interp_args(InterpArgs& a, const int64_t* cshape, int ndim, cons
 
 template <typename T>
 static int interp_add(const T* coarse, const T* add, T* fine, const int64_t* cshape, int ndim, const char* loc,
-                      T cscale, T ascale, void* stream) {
+                      T cscale, T ascale, void* stream, int64_t coarse_ld = 0) {
   InterpArgs a;
   if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
   if (!coarse || !fine) {
     set_error("interp_add: null pointer");
     return ODIL_E_INVAL;
   }
+  if (coarse_ld) {
+    if (coarse_ld < a.cn[1] * a.cn[2] * a.cn[3]) {
+      set_error("interp_add: leading stride %lld of the coarse array is less than its volume", (long long)coarse_ld);
+      return ODIL_E_INVAL;
+    }
+    a.coarse_ld = coarse_ld;
+  }
   if (int r = interp_add_march<T>(coarse, add, fine, a, cscale, ascale, (hipStream_t)stream)) return r < 0 ? r : 0;
+  if (coarse_ld) return 1;  // only the marching kernels of the 4-D layouts take a strided operand: nothing launched
   if (int r = interp_add_fast<T>(coarse, add, fine, a, cscale, ascale, (hipStream_t)stream)) return r < 0 ? r : 0;
   const int64_t npairs = (a.fn[3] + 1) / 2;
   a.sched = make_sched(a.fn[0] * a.fn[1], a.fn[2], (npairs + kBlock - 1) / kBlock);
@@ -425,9 +435,17 @@ static int interp_add(const T* coarse, const T* add, T* fine, const int64_t* csh
 template <typename T>
 static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* cshape, int ndim, const char* loc,
                       T scale, void* stream, int cut_lo = 0, int cut_hi = 0,
-                      AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0)}) {
+                      AdamArgs<T> ad = AdamArgs<T>{nullptr, nullptr, nullptr, T(0), T(0), T(0), T(0)},
+                      int64_t coarse_ld = 0) {
   InterpArgs a;
   if (int e = fill_interp_args(a, cshape, ndim, loc)) return e;
+  if (coarse_ld) {
+    if (coarse_ld < a.cn[1] * a.cn[2] * a.cn[3] || gscaled || ad.x || cut_lo || cut_hi) {
+      set_error("interp_adj: a strided result takes no scaled copy, update or cut, and a leading stride >= its volume");
+      return ODIL_E_INVAL;
+    }
+    a.coarse_ld = coarse_ld;
+  }
   if (cut_lo || cut_hi) {
     a.cut_axis = 4 - ndim;
     a.cut_lo = cut_lo;
@@ -440,7 +458,8 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
   if (a.loc[0] == kNode && a.loc[1] == kNone && a.loc[2] == kNone && a.loc[3] == kNone && a.cut_axis < 0) {
     const int64_t vol = a.cn[1] * a.cn[2] * a.cn[3];
     hipLaunchKernelGGL(k_interp_adj_lead_node<T>, dim3(grid_flat(a.cn[0] * vol, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, gfine, gcoarse, gscaled, a.cn[0], a.fn[0], vol, scale);
+                       (hipStream_t)stream, gfine, gcoarse, gscaled, a.cn[0], a.fn[0], vol, scale,
+                       coarse_ld ? coarse_ld : vol);
     if (int e = check_launch("k_interp_adj_lead_node")) return e;
     if (ad.x)
       return adam_launch<T>(ad.x, ad.m, ad.v, gscaled ? gscaled : gcoarse, prod4(a.cn), ad.alpha, ad.omb1, ad.omb2,
@@ -448,6 +467,7 @@ static int interp_adj(const T* gfine, T* gcoarse, T* gscaled, const int64_t* csh
     return 0;
   }
   if (int r = interp_adj_march<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;
+  if (coarse_ld) return 1;  // only the marching kernels of the 4-D layouts write a strided result: nothing launched
   if (int r = interp_adj_fast<T>(gfine, gcoarse, gscaled, a, scale, (hipStream_t)stream, ad)) return r < 0 ? r : 0;
   a.sched = make_sched(a.cn[0] * a.cn[1], a.cn[2], (a.cn[3] + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_interp_adj<T>, dim3(sched_grid(a.sched)), dim3(kBlock), 0, (hipStream_t)stream, gfine,
@@ -645,6 +665,24 @@ int odil_interp_add_f64(const double* coarse, const double* add, double* fine, c
 int odil_interp_add_f32(const float* coarse, const float* add, float* fine, const int64_t* cshape, int ndim,
                         const char* loc, float coarse_scale, float add_scale, void* stream) {
   return interp_add<float>(coarse, add, fine, cshape, ndim, loc, coarse_scale, add_scale, stream);
+}
+int odil_interp_add_ld_f64(const double* coarse, int64_t coarse_ld, const double* add, double* fine, const int64_t* cshape,
+                           int ndim, const char* loc, double coarse_scale, double add_scale, void* stream) {
+  return interp_add<double>(coarse, add, fine, cshape, ndim, loc, coarse_scale, add_scale, stream, coarse_ld);
+}
+int odil_interp_add_ld_f32(const float* coarse, int64_t coarse_ld, const float* add, float* fine, const int64_t* cshape,
+                           int ndim, const char* loc, float coarse_scale, float add_scale, void* stream) {
+  return interp_add<float>(coarse, add, fine, cshape, ndim, loc, coarse_scale, add_scale, stream, coarse_ld);
+}
+int odil_interp_adj_ld_f64(const double* gfine, double* gcoarse, int64_t gcoarse_ld, const int64_t* cshape, int ndim,
+                           const char* loc, void* stream) {
+  return interp_adj<double>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0, stream, 0, 0,
+                            AdamArgs<double>{nullptr, nullptr, nullptr, 0, 0, 0, 0}, gcoarse_ld);
+}
+int odil_interp_adj_ld_f32(const float* gfine, float* gcoarse, int64_t gcoarse_ld, const int64_t* cshape, int ndim,
+                           const char* loc, void* stream) {
+  return interp_adj<float>(gfine, gcoarse, nullptr, cshape, ndim, loc, 1.0f, stream, 0, 0,
+                           AdamArgs<float>{nullptr, nullptr, nullptr, 0, 0, 0, 0}, gcoarse_ld);
 }
 int odil_interp_adj_f64(const double* gfine, double* gcoarse, double* gscaled, const int64_t* cshape, int ndim,
                         const char* loc, double scale, void* stream) {

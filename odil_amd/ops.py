@@ -35,14 +35,32 @@ def coarse_shape(fshape, loc):
     return tuple((s - 2) // 2 + 1 if l == "c" else (s - 1) // 2 + 1 for s, l in zip(fshape, loc))
 
 
+def _lead_stride(t):
+    """The leading stride of a 4-D view that is contiguous but for that stride (a level array of the slab paths without
+    its outer ghost planes), else None."""
+    if t.dim() != 4 or t.is_contiguous() or t.shape[0] < 2:
+        return None
+    inner = t[0]
+    return int(t.stride(0)) if inner.is_contiguous() and t.stride(0) >= inner.numel() else None
+
+
 def interp_add(coarse, loc, add=None, coarse_scale=1.0, add_scale=1.0, out=None):
-    """out = add_scale*add + P(coarse_scale*coarse)  (reference core.py:606-700, :258-262)."""
+    """out = add_scale*add + P(coarse_scale*coarse)  (reference core.py:606-700, :258-262).  `coarse` may be a 4-D view
+    with a leading stride larger than its volume: the marching kernels read it in place, other layouts get a copy."""
     fshape = fine_shape(coarse.shape, loc)
     if out is None:
         out = torch.empty(fshape, dtype=coarse.dtype, device=coarse.device)
     assert tuple(out.shape) == fshape, (out.shape, fshape)
     if add is not None:
         assert tuple(add.shape) == fshape and add.dtype == coarse.dtype
+    if not coarse.is_contiguous():
+        ld = _lead_stride(coarse)
+        if ld is not None and call(
+            "interp_add_ld", coarse.dtype, c_void_p(coarse.data_ptr()), c_int64(ld), ptr(add), ptr(out), i64(coarse.shape),
+            c_int(coarse.dim()), loc.encode(), coarse_scale, add_scale, stream_ptr(), unserved_ok=True,
+        ):
+            return out
+        coarse = coarse.contiguous()
     call(
         "interp_add", coarse.dtype, ptr(coarse), ptr(add), ptr(out), i64(coarse.shape), c_int(coarse.dim()),
         loc.encode(), coarse_scale, add_scale, stream_ptr(),
@@ -63,6 +81,15 @@ def interp_adj(gfine, loc, cshape, scale=None, out=None, cut=(False, False)):
     assert tuple(gfine.shape) == fine_shape(cshape, loc), (gfine.shape, cshape, loc)
     if out is None:
         out = torch.empty(cshape, dtype=gfine.dtype, device=gfine.device)
+    if not out.is_contiguous():
+        # a view with a leading stride larger than its volume is written in place where the kernels can; else through
+        # a contiguous result
+        assert scale is None and not any(cut), "a strided result takes no scaled copy and no cut"
+        ld = _lead_stride(out)
+        if ld is None or not call("interp_adj_ld", gfine.dtype, ptr(gfine), c_void_p(out.data_ptr()), c_int64(ld), i64(cshape),
+                                  c_int(len(cshape)), loc.encode(), stream_ptr(), unserved_ok=True):
+            out.copy_(interp_adj(gfine, loc, cshape))
+        return out
     scaled = None
     if scale is not None:
         scaled = torch.empty_like(out)

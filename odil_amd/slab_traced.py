@@ -499,8 +499,8 @@ class SlabTracedAdam:
                     operand = coarse.narrow(self.axis, *lvc.window_of(fine))
                 else:
                     operand = lvc.inner(coarse)
-                hip_ops.interp_add(operand.contiguous(), e["loc"], add=e["x"][l], coarse_scale=cscale, add_scale=fac[l],
-                                   out=out)
+                # (a view of the level array without its outer ghost planes: read in place by the marching kernels)
+                hip_ops.interp_add(operand, e["loc"], add=e["x"][l], coarse_scale=cscale, add_scale=fac[l], out=out)
                 coarse, cscale = out, 1.0
 
     def _end_planes(self, arrays, side):
@@ -537,10 +537,7 @@ class SlabTracedAdam:
                     view = lv.inner
                 dst = view(e["h"][l])
                 best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
-                if dst.is_contiguous():  # (no interface on this rank's side of the array: written in place)
-                    best(e["h"][l - 1], e["loc"], tuple(dst.shape), out=dst)
-                else:
-                    dst.copy_(best(e["h"][l - 1], e["loc"], tuple(dst.shape)))
+                best(e["h"][l - 1], e["loc"], tuple(dst.shape), out=dst)  # (in place, also into a strided view)
                 if fac:
                     torch.mul(dst, fac[l], out=view(e["g"][l]))
 

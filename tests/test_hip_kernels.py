@@ -671,6 +671,36 @@ def test_row_marching_float_transpose(dev, loc, cshape, monkeypatch):
         assert rel(a, b.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loc,full,lo,n", [("nccc", (5, 8, 8, 16), 1, 6), ("nccc", (9, 7, 128, 128), 2, 4), (".ccc", (3, 10, 4, 8), 1, 8),
+                                          ("nccc", (3, 5, 4, 4), 1, 3), ("nccc", (33, 6, 16, 32), 0, 4)])
+def test_transfers_on_views_with_a_leading_stride(dev, dtype, loc, full, lo, n):
+    """odil_interp_add_ld / odil_interp_adj_ld: the coarse operand of P (the result of P^T) as a VIEW of a larger array
+    along axis 1 -- a ghost-extended level array of the slab paths without its outer planes.  The marching kernels of
+    the 4-D layouts read / write it in place (bit-identical to the contiguous call); layouts they do not serve (third
+    case: 3 coarse planes) take the copy inside ops.interp_add / interp_adj.  Nothing outside the view is touched."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(61)
+    big = to(rng.standard_normal(full).astype(dtype), dev)
+    view = big.narrow(1, lo, n)
+    assert not view.is_contiguous()
+    cshape = tuple(view.shape)
+    add = to(rng.standard_normal(ops.fine_shape(cshape, loc)).astype(dtype), dev)
+    want = ops.interp_add(view.contiguous(), loc, add=add, coarse_scale=0.5, add_scale=2.0)
+    got = ops.interp_add(view, loc, add=add, coarse_scale=0.5, add_scale=2.0)
+    assert torch.equal(got, want)
+    g = to(rng.standard_normal(ops.fine_shape(cshape, loc)).astype(dtype), dev)
+    for route in (ops.interp_adj, ops.interp_adj_best):
+        want = route(g, loc, cshape)
+        dst_big = torch.full(full, 7.0, dtype=big.dtype, device=dev)
+        route(g, loc, cshape, out=dst_big.narrow(1, lo, n))
+        assert torch.equal(dst_big.narrow(1, lo, n), want)
+        rest = torch.ones(full, dtype=torch.bool)
+        rest[:, lo:lo + n] = False
+        assert bool((dst_big.cpu()[rest] == 7.0).all())
+
+
 def test_adjoint_and_transpose_in_one_launch_is_race_free(dev):
     """The one-launch kernel hands g0 from the lanes that form it to the lanes that consume it through LDS, one
     plane behind: a missing barrier shows as run-to-run differences on a grid with many resident workgroups.
