@@ -417,11 +417,30 @@ class SlabTracedAdam:
             self.wrap[key] = {name: buf[woff:woff + wsizes[key]].view(wshape) for name, buf in self._wrapbuf.items()}
             woff += wsizes[key]
             if e["kind"] == "mg" and len(e["levels"]) > 1:
-                self.u[key] = torch.zeros(lv0.shape, dtype=dtype, device=self.device)
+                self.u[key] = None  # a view of ONE buffer for all synthesised arrays, below
                 self.work[key] = [None] + [torch.zeros(lv.shape, dtype=dtype, device=self.device)
                                            for lv in e["levels"][1:-1]] + [None]
             else:
                 self.u[key] = e["x"][0]
+        synth = [key for key in self.kern.src_keys if self.u[key] is None]
+        self._uflat = torch.zeros(sum(self.by_key[key]["levels"][0].size for key in synth), dtype=dtype, device=self.device)
+        uoff, ustart = 0, dict()
+        for key in synth:
+            lv0 = self.by_key[key]["levels"][0]
+            self.u[key] = self._uflat[uoff:uoff + lv0.size].view(lv0.shape)
+            ustart[key] = uoff
+            uoff += lv0.size
+        # the end planes of the synthesised arrays that close the periodic direction, as ONE message per side packed by
+        # one launch (odil_planes_copy) -- when every source field is synthesised; else slices + torch.cat
+        self._wrap_pack = None
+        if h and len(synth) == len(self.kern.src_keys):
+            self._wrap_pack = dict()
+            for side in ("lo", "hi"):
+                descs = []
+                for key in self.kern.src_keys:
+                    lv0 = self.by_key[key]["levels"][0]
+                    descs.append(lv0.plane_desc(ustart[key], 0 if side == "lo" else lv0.n - h))
+                self._wrap_pack[side] = hip_ops.PlaneList(descs, self.device)
         # where the wrap contributions of the gradients land: the first / last `h` owned planes of every gathered
         # field's finest level, in message order (odil_planes_copy, mode add)
         self._wrap_add = dict()
@@ -576,8 +595,17 @@ class SlabTracedAdam:
         if h:
             b = tic("halo")
             ufield = lambda key: self.u[key]
-            recv_lo, recv_hi = yield ("wrap", self._end_planes(ufield, "lo") if first else None,
-                                      self._end_planes(ufield, "hi") if last else None)
+            if self._wrap_pack is not None and world == 1:
+                # one rank: its high planes ARE what lies across the low end -- packed straight into place
+                self._wrap_pack["hi"].pack(self._uflat, self._wrapbuf["lo"])
+                self._wrap_pack["lo"].pack(self._uflat, self._wrapbuf["hi"])
+                recv_lo = recv_hi = None
+            elif self._wrap_pack is not None:
+                recv_lo, recv_hi = yield ("wrap", self._wrap_pack["lo"].pack(self._uflat) if first else None,
+                                          self._wrap_pack["hi"].pack(self._uflat) if last else None)
+            else:
+                recv_lo, recv_hi = yield ("wrap", self._end_planes(ufield, "lo") if first else None,
+                                          self._end_planes(ufield, "hi") if last else None)
             if recv_lo is not None:
                 self._wrapbuf["lo"].copy_(recv_lo.reshape(-1))
             if recv_hi is not None:
