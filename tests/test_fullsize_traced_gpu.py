@@ -47,6 +47,34 @@ def _randomise(problem, state, seed, scale=0.1):
     return new
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cshape", [(65, 18, 128, 128), (17, 128, 128, 128)])
+def test_float_transfers_of_the_space_time_layout_at_full_size(cshape):
+    """'nccc' float arrays at the shapes of config 5 (one rank, ghost-extended: fine (129, 36, 256, 256)) and of the
+    tracer with three space dimensions (fine (33, 256, 256, 256)): <P c, g> == <c, P^T g> in float64 accumulation --
+    the pair prolongation kernel (fine levels 2k, 2k + 1 by one thread) against the two-step transpose (row-marching
+    space part, wide node-axis stage) -- and P^T into a view with a leading stride equals P^T into a contiguous array."""
+    from odil_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    fshape = ops.fine_shape(cshape, "nccc")
+    c = torch.randn(cshape, dtype=torch.float32, device=dev, generator=gen)
+    g = torch.randn(fshape, dtype=torch.float32, device=dev, generator=gen)
+    pc = ops.interp_add(c, "nccc")
+    ptg = ops.interp_adj_best(g, "nccc", cshape)
+    dot = lambda a, b: float(torch.dot(a.reshape(-1).double(), b.reshape(-1).double()))
+    lhs, rhs = dot(pc, g), dot(c, ptg)
+    scale = (dot(pc, pc) * dot(g, g)) ** 0.5
+    assert abs(lhs - rhs) < 1e-6 * scale, (lhs, rhs, scale)
+    assert torch.equal(ptg, ops.interp_adj_best(g, "nccc", cshape))  # reproducible
+    del pc
+    big = torch.full((cshape[0], cshape[1] + 2) + cshape[2:], 3.0, dtype=torch.float32, device=dev)
+    ops.interp_adj_best(g, "nccc", cshape, out=big.narrow(1, 1, cshape[1]))
+    assert torch.equal(big.narrow(1, 1, cshape[1]), ptg)
+    assert bool((big[:, 0] == 3.0).all()) and bool((big[:, -1] == 3.0).all())
+
+
 def test_heat2d_full_size_window_vs_autograd_and_reproducible():
     """Config 3's shape, 256 x 512^2 float32, 46 network parameters inside the stencil."""
     import heat2d as ex
