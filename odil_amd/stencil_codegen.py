@@ -1134,6 +1134,26 @@ class _Codegen:
                 S.append("  const int r{}_ = {} / {};".format(d, rem, ext))
                 rem = "r{}_".format(d)
 
+    @staticmethod
+    def _block_index(shape, vw):
+        """Which slice of the index range a workgroup takes.  The hardware deals consecutive workgroups to the eight XCDs
+        in turn, so the rows two neighbouring workgroups both read (the -+ 1 rows of the second-to-last axis at their
+        common edge: a workgroup is 4 rows of 256 points) are filled into two L2s.  Here K consecutive slices go to one
+        XCD, then K to the next: the interleaving across the XCDs stays fine-grained, the shared rows of K - 1 of K edges
+        meet in one L2.  K = 8 at most, and such that the neighbours along the THIRD-to-last axis (prod(shape[-2:]) / vw /
+        256 slices away) stay on the same XCD: config 5 as one rank `k_fwd` 2.80 -> 2.72 ms, gather 8.25 -> 7.8 - 8.0 with
+        K = 8 (K = 2: 8.07; K = 16: 8.4, K = 32: 8.8 -- the x -+ 1 rows then land on another XCD; a CONTIGUOUS eighth of
+        the range per XCD: 9.05); tracer 32 x 256^3 33.85 -> 32.9 ms; heat 256 x 512^2 unchanged.  ODIL_TRACE_XCD_GROUP
+        overrides K (1: the hardware's order).  Needs a grid that is a multiple of 8 K (else the hardware's order)."""
+        k = int(os.environ.get("ODIL_TRACE_XCD_GROUP", 0))
+        if k == 0:
+            dist = (int(np.prod(shape[-2:])) // vw) // 256 if len(shape) >= 3 else 0
+            k = next((c for c in (8, 4, 2) if dist and dist % (8 * c) == 0), 1)
+        if k > 1:
+            return ("  const int bx_ = gridDim.x % {0} == 0 ? (int)((blockIdx.x / {0}) * {0} + (blockIdx.x % 8) * {1} + "
+                    "(blockIdx.x % {0}) / 8) : (int)blockIdx.x;").format(8 * k, k)
+        return "  const int bx_ = blockIdx.x;"
+
     def _chunk_remap(self, S, shape, vw, raw, flat):
         """Defines the flat index `flat` of the point(s) a thread owns from its launch index `raw`.  Plain order
         (flat = raw) walks axis 0 slowest: a stencil that reads the levels i0 - 1 / i0 + 1 (time differences of the
@@ -1288,11 +1308,12 @@ class _Codegen:
         threads = self.total // vw
         if tiled is None:
             flat = "l4" if vw == 4 else "l"
+            S.append(self._block_index(self.GL, vw))
             if threads <= self.max_blocks * 256:  # one thread per point (or four points)
-                S.append("  const int {}r = blockIdx.x * NB + threadIdx.x;".format(flat))
+                S.append("  const int {}r = bx_ * NB + threadIdx.x;".format(flat))
                 S.append("  if ({}r < {}) {{".format(flat, threads))
             else:
-                S.append("  for (int {0}r = blockIdx.x * NB + threadIdx.x; {0}r < {1}; {0}r += a.nblocks * NB) {{".format(flat, threads))
+                S.append("  for (int {0}r = bx_ * NB + threadIdx.x; {0}r < {1}; {0}r += a.nblocks * NB) {{".format(flat, threads))
             self._chunk_remap(S, self.GL, vw, flat + "r", flat)
             self._index_prologue(S, self.GL, ["i{}".format(d) for d in range(self.ndim)], vw, flat)
             if self.slab is not None:
@@ -1746,7 +1767,8 @@ class _Codegen:
         occ = int(os.environ.get("ODIL_TRACE_WAVES_GAT", 0))
         S.append('extern "C" __global__ __launch_bounds__(NB) {}void {}(const Args a, {}) {{'.format(
             "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else "", name, params))
-        S.append("  const int {}r = blockIdx.x * NB + threadIdx.x;".format(flat))
+        S.append(self._block_index(shape, vw))
+        S.append("  const int {}r = bx_ * NB + threadIdx.x;".format(flat))
         S.append("  if ({}r >= {}) return;".format(flat, threads))
         self._chunk_remap(S, shape, vw, flat + "r", flat)
         self._index_prologue(S, shape, names, vw, flat)
