@@ -92,7 +92,12 @@ typedef T T4a __attribute__((ext_vector_type(4)));
 typedef T4a T4 __attribute__((aligned(sizeof(T))));
 __device__ inline void adam_apply4(const AdamP& ad, int l, const T* g) {
   if (!ad.x) return;
+#ifdef ODIL_NT_STREAMS  // the optimizer state streams through once per epoch: kept out of the way of the rows the kernel re-reads
+  T4 m = __builtin_nontemporal_load((const T4*)(ad.m + l)), v = __builtin_nontemporal_load((const T4*)(ad.v + l));
+  T4 x = __builtin_nontemporal_load((const T4*)(ad.x + l));
+#else
   T4 m = *(const T4*)(ad.m + l), v = *(const T4*)(ad.v + l), x = *(const T4*)(ad.x + l);
+#endif
   const T alpha = ad.alpha_dev ? *ad.alpha_dev : ad.alpha;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -100,7 +105,13 @@ __device__ inline void adam_apply4(const AdamP& ad, int l, const T* g) {
     v[p] = v[p] + (g[p] * g[p] - v[p]) * ad.omb2;
     x[p] = x[p] - ADAM_QUOT(m[p] * alpha, ADAM_SQRT(v[p]) + ad.eps);
   }
+#ifdef ODIL_NT_STREAMS
+  __builtin_nontemporal_store(m, (T4*)(ad.m + l));
+  __builtin_nontemporal_store(v, (T4*)(ad.v + l));
+  __builtin_nontemporal_store(x, (T4*)(ad.x + l));
+#else
   *(T4*)(ad.m + l) = m, *(T4*)(ad.v + l) = v, *(T4*)(ad.x + l) = x;
+#endif
 }
 // Float transcendentals of the float kernels.  The library tanhf is ~30 instructions with two divergent branches;
 // a traced operator with a pointwise network evaluates it 40 times per grid point (heat with two space dimensions:
@@ -1262,7 +1273,10 @@ class _Codegen:
         self.par_arrays = par_arrays
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
-        HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
+        # the optimizer state and the gradient stream through a gather once per epoch: non-temporal accesses keep them
+        # out of the way of the rows the kernel re-reads (config 5 as one rank: gather 7.77 -> 7.47 ms; ODIL_TRACE_NT=0)
+        nt = "#define ODIL_NT_STREAMS 1\n" if int(os.environ.get("ODIL_TRACE_NT", 1)) else ""
+        HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + nt + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
             HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
         S = []
@@ -1787,6 +1801,8 @@ class _Codegen:
             S.append("  }")
         adam = "adam_apply4({ad}, {o}, acc{k});" if vw == 4 else "adam_apply({ad}, {o}, acc{k}[0]);"
         put = "*(T4*)({dst} + {o}) = (T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}};" if vw == 4 else "{dst}[{o}] = acc{k}[0];"
+        if vw == 4 and int(os.environ.get("ODIL_TRACE_NT", 1)):  # (with the optimizer state, see adam_apply4)
+            put = "__builtin_nontemporal_store((T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}}, (T4*)({dst} + {o}));"
         if self.slab is None:
             o = "l4 * 4" if vw == 4 else "l"
             for k in range(len(items)):
