@@ -1,17 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_workloads_gpu.py tests/test_fullsize_traced_gpu.py tests/test_slab_gpu.py tests/test_api_gpu.py tests/test_trajectories.py -m gpu -q 2>&1 | tail -4
-for k in 1 2; do
-timeout 300 python bench.py --config 5 --no_cpu_baseline --steps 10 --warmup 3 2>/dev/null | python -c "
+for mb in 5 2.5 1.1 0.6 5 2.5; do
+ODIL_TRACE_CHUNK_MB=$mb timeout 300 python bench.py --config 5 --no_cpu_baseline --steps 10 --warmup 3 2>/dev/null | python -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('cfg5', d['ms_per_step'], d['kernel_ms'])"
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('cfg5 chunk $mb', d['ms_per_step'], d['kernel_ms']['forward'], d['kernel_ms']['gather'])"
 done
-for k in 0 1; do
-ODIL_TRACE_NT=$k timeout 300 python bench.py --config 5b --no_cpu_baseline --steps 20 --warmup 2 2>/dev/null | python -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('cfg5b nt $k', d['ms_per_step'])"
-ODIL_TRACE_NT=$k timeout 300 python bench.py --config 3b --no_cpu_baseline --steps 20 --warmup 2 2>/dev/null | python -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('cfg3b nt $k', d['ms_per_step'])"
-done
-mkdir -p gpurun_out/jit_cache && cp odil_amd/_jit_cache/*.so gpurun_out/jit_cache/ 2>/dev/null
