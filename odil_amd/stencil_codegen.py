@@ -1943,6 +1943,10 @@ def _compile(src, flags=None):
     name = "odil_jit_{}.so".format(tag)
     for d in _cache_dirs():
         if os.path.exists(os.path.join(d, name)) and _trusted(d):
+            try:
+                os.utime(os.path.join(d, name))  # last use: lets a cache be pruned by age (tools/final_r3.sh)
+            except OSError:
+                pass
             return ctypes.CDLL(os.path.join(d, name)), os.path.join(d, name)
     last = None
     for d in _cache_dirs():
