@@ -1275,7 +1275,9 @@ class _Codegen:
         fn = "name" if T == "double" else "name##f"
         # the optimizer state and the gradient stream through a gather once per epoch: non-temporal accesses keep them
         # out of the way of the rows the kernel re-reads (config 5 as one rank: gather 7.77 -> 7.47 ms; ODIL_TRACE_NT=0)
-        nt = "#define ODIL_NT_STREAMS 1\n" if int(os.environ.get("ODIL_TRACE_NT", 1)) else ""
+        # (only where an array is beyond what the caches could hand to the next launch anyway)
+        self.nt_streams = bool(int(os.environ.get("ODIL_TRACE_NT", 1))) and self.total * (8 if T == "double" else 4) > (64 << 20)
+        nt = "#define ODIL_NT_STREAMS 1\n" if self.nt_streams else ""
         HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + nt + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
             HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
@@ -1801,7 +1803,7 @@ class _Codegen:
             S.append("  }")
         adam = "adam_apply4({ad}, {o}, acc{k});" if vw == 4 else "adam_apply({ad}, {o}, acc{k}[0]);"
         put = "*(T4*)({dst} + {o}) = (T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}};" if vw == 4 else "{dst}[{o}] = acc{k}[0];"
-        if vw == 4 and int(os.environ.get("ODIL_TRACE_NT", 1)):  # (with the optimizer state, see adam_apply4)
+        if vw == 4 and self.nt_streams:  # (with the optimizer state, see adam_apply4)
             put = "__builtin_nontemporal_store((T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}}, (T4*)({dst} + {o}));"
         if self.slab is None:
             o = "l4 * 4" if vw == 4 else "l"
