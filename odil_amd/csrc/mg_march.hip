@@ -240,6 +240,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead(const T* __res
   }
 }
 
+#ifndef ODIL_PAIR_PREFETCH
+#define ODIL_PAIR_PREFETCH 1
+#endif
 // Node-centred leading axis, fine indices 2k AND 2k + 1 by one thread (blockIdx.y = k < lead_cn - 1): the window of
 // coarse volume k serves both, the window of volume k + 1 the odd one.  Same sums in the same order as the two
 // launches of k_interp_add_march_lead; the registers of the two-window launch (two waves per SIMD either way), but
@@ -267,15 +270,35 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead_pair(const T* 
     load_plane_shared<T, CX>(cb[r0], z0, cnz, cplane, cnx, ty, tx, cscale, v[r0][1], a.tx, jx0);
   }
   const T rs[2] = {T(1) / T(64), T(1) / T(128)};
+  // the fine addend of step jz + 1 is requested before step jz is computed (ODIL_PAIR_PREFETCH): the march is a chain of
+  // dependent steps and two waves per SIMD do not cover a step's memory latency on their own
+  PackN<T, 2 * CX> nx[2][2][2];
+  auto load_step = [&](int jz, PackN<T, 2 * CX> (&dst)[2][2][2]) {
+    const int64_t fb = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      load_add<T, CX>(add + p * fvol, fb, fnx, dst[p][0], a.nt);
+      load_add<T, CX>(add + p * fvol, fb + fplane, fnx, dst[p][1], a.nt);
+    }
+  };
+#if ODIL_PAIR_PREFETCH
+  if (add) load_step(z0, nx);
+#endif
   for (int jz = z0; jz < z1; ++jz) {
     PackN<T, 2 * CX> ad[2][2][2];
     const int64_t fbase = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx0;
     if (add) {
+#if ODIL_PAIR_PREFETCH
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        load_add<T, CX>(add + p * fvol, fbase, fnx, ad[p][0], a.nt);
-        load_add<T, CX>(add + p * fvol, fbase + fplane, fnx, ad[p][1], a.nt);
-      }
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) ad[p][q][r] = nx[p][q][r];
+      if (jz + 1 < z1) load_step(jz + 1, nx);
+#else
+      load_step(jz, ad);
+#endif
     }
 #pragma unroll
     for (int r0 = 0; r0 < 2; ++r0) load_plane_shared<T, CX>(cb[r0], jz + 1, cnz, cplane, cnx, ty, tx, cscale, v[r0][2], a.tx, jx0);
