@@ -1,7 +1,11 @@
 #!/bin/bash
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_heat2d_c -- python3 $R/bench.py --config 3b --no_cpu_baseline --steps 20 --warmup 3 > $R/gpurun_out/prof_heat2d_c.log 2>&1
-cd $R
-python3 profiles/summarize.py gpurun_out/prof_heat2d_c "r03 (final) heat2d: bench.py --config 3b --steps 20 --warmup 3" | head -24 > gpurun_out/r03_c_heat2d_kernel_stats.txt
-cat gpurun_out/r03_c_heat2d_kernel_stats.txt
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_properties_gpu.py tests/test_fullsize_gpu.py -m gpu -q 2>&1 | tail -3
+for k in 1 2 3; do
+timeout 300 python bench.py --no_cpu_baseline --no_other_configs --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('poisson', d['ms_per_step'], d['kernel_ms'])"
+done
+timeout 300 python bench.py --config 3b --no_cpu_baseline --steps 20 --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('cfg3b', d['ms_per_step'])"
