@@ -246,6 +246,7 @@ class _Codegen:
         self.vw = self.vw_fwd
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
+        self.fold = None  # emitting the interior copy of a body: {predicate node idx: constant value} (_fold_plan)
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
@@ -485,6 +486,130 @@ class _Codegen:
                 if self.need.get(a.idx, False):
                     reached.add(a.idx)
         return stored
+
+    # ---- index predicates decided once per wave: an interior copy of the body -------------------------------------
+    # Wall masks (`idx == 0`, `idx == n - 1`, `it == 0`), the wrap of a shifted index and windows are functions of ONE
+    # grid index.  Evaluated over that axis they are true (or false) on a handful of values only; everywhere else --
+    # > 98 % of the points of the BASELINE grids -- every `where` they steer takes the same branch, and the ghost
+    # extrapolations, initial-row selects and their reverse pass are dead code.  The body of a kernel is therefore
+    # emitted twice: as it is, and with those predicates replaced by their majority value (the compiler folds the
+    # selects and drops what only the other branch needed, loads included); a wave takes the second copy when none of
+    # its points has an exceptional index (`__all`: one scalar branch).  Predicates of the last axis are folded only by
+    # kernels with one point per thread (a wave of a four-point kernel spans a row of 256: always at a wall).
+    _FOLD_MAX = 8
+
+    def _index_values(self, n, memo):
+        """(axis or None, values along that axis) when `n` depends on at most one grid index and literals, else None."""
+        if n.idx in memo:
+            return memo[n.idx]
+        res = None
+        op, A = n.op, n.args
+        if op == "const":
+            res = (None, np.asarray(n.attr))
+        elif op == "index":
+            res = (n.attr[0], np.arange(self.G[n.attr[0]], dtype=np.int64))
+        elif not n.host and op in ("cast", "win", "neg", "not", "abs") and len(A) == 1:
+            a = self._index_values(A[0], memo)
+            if a is not None:
+                f = {"cast": lambda x: np.asarray(x, np.float64), "win": lambda x: x, "neg": np.negative,
+                     "not": np.logical_not, "abs": np.abs}[op]
+                res = (a[0], f(a[1]))
+        elif not n.host and (op in ("add", "sub", "mul", "min", "max", "and", "or", "where") or op in _CMP):
+            parts = [self._index_values(a, memo) for a in A]
+            axes = {p[0] for p in parts if p is not None and p[0] is not None}
+            if all(p is not None for p in parts) and len(axes) <= 1:
+                f = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "min": np.minimum, "max": np.maximum,
+                     "and": np.logical_and, "or": np.logical_or, "where": np.where, "lt": np.less, "le": np.less_equal,
+                     "gt": np.greater, "ge": np.greater_equal, "eq": np.equal, "ne": np.not_equal}[op]
+                res = (axes.pop() if axes else None, f(*[p[1] for p in parts]))
+        memo[n.idx] = res
+        return res
+
+    def _fold_plan(self, nodes, vw, windows=False):
+        """(fold, exc, inbox) or None: fold = {predicate node idx: its value away from the exceptional indices},
+        exc = {axis: sorted exceptional index values}, inbox = {(output, axis)} window tests that hold in the interior."""
+        if not int(os.environ.get("ODIL_TRACE_FOLD", 1)):
+            return None
+        last, memo = self.ndim - 1, dict()
+        fold, exc, inbox = dict(), dict(), set()
+        for n in nodes:
+            if n.kind != _B or n.host or n.op == "const":
+                continue
+            r = self._index_values(n, memo)
+            if r is None or r[0] is None or (r[0] == last and vw != 1):
+                continue
+            d = r[0]
+            vals = np.broadcast_to(np.asarray(r[1], dtype=bool), (self.G[d],))
+            common = bool(2 * int(vals.sum()) > vals.size)
+            minority = np.nonzero(vals != common)[0]
+            if minority.size <= self._FOLD_MAX and 4 * minority.size <= self.G[d]:
+                fold[n.idx] = common
+                exc.setdefault(d, set()).update(int(i) for i in minority)
+        if windows:
+            for k, lens in enumerate(self.out_lens):
+                for d in range(self.ndim if lens is not None else 0):
+                    cut = self.G[d] - lens[d]
+                    if 0 < cut <= self._FOLD_MAX and 4 * cut <= self.G[d] and (d != last or vw == 1):
+                        inbox.add((k, d))
+                        exc.setdefault(d, set()).update(range(lens[d], self.G[d]))
+        if not any(exc.values()):
+            return None
+        return fold, {d: sorted(v) for d, v in exc.items() if v}, inbox
+
+    def _interior_cond(self, exc):
+        """C expression: none of the thread's indices is exceptional."""
+        conds = []
+        for d, values in sorted(exc.items()):
+            i, n, values = self.gi(d), self.G[d], list(values)
+            lo = 0
+            while values and values[0] == lo:
+                values.pop(0)
+                lo += 1
+            hi = n - 1
+            while values and values[-1] == hi:
+                values.pop()
+                hi -= 1
+            if lo > 0:
+                conds.append("{} >= {}".format(i, lo))
+            if hi < n - 1:
+                conds.append("{} <= {}".format(i, hi))
+            conds.extend("{} != {}".format(i, e) for e in values)
+        return " && ".join(conds)
+
+    def _inbox_lines(self, inbox=()):
+        out = []
+        for k, lens in enumerate(self.out_lens):
+            if lens is not None:
+                conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim)
+                         if lens[d] < self.G[d] and (k, d) not in inbox]
+                out.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
+        return out
+
+    def _interior_copy(self, nodes, vw, reverse=False):
+        """Second emission of the body whose first emission just ended (self.pre / self.groups hold its row loads), with
+        the index predicates folded: ((forward lines, reverse lines), plan) or None when nothing folds."""
+        plan = self._fold_plan(nodes, vw, windows=reverse)
+        if plan is None:
+            return None
+        keep = ("cots", "cut_nodes", "jac_store", "pg_decl", "pg_offset", "pgrads", "pg2_used")
+        saved = {k: getattr(self, k) for k in keep if hasattr(self, k)}
+        if reverse:
+            self.cots, self.cut_nodes, self.jac_store, self.pg_decl, self.pg_offset, self.pg2_used = [], [], [], [], dict(), set()
+        self.fold, self.lines, self.loads = plan[0], [], dict()
+        self.forward()
+        fwd, self.lines, rev = self.lines, [], []
+        if reverse:
+            self.reverse()
+            rev, self.lines = self.lines, []
+            same = ([n.idx for n in self.cots] == [n.idx for n in saved["cots"]] and self.pg_decl == saved["pg_decl"]
+                    and [n.idx for n in self.cut_nodes] == [n.idx for n in saved["cut_nodes"]] and self.jac_store == saved["jac_store"])
+            if not same:
+                raise RuntimeError("interior copy of the traced kernel stores other adjoints than the general one")
+        self.fold = None
+        for k, v in saved.items():
+            setattr(self, k, v)
+        self.pre = list(dict.fromkeys(self.pre))  # (row loads are requested again by the second emission)
+        return (fwd, rev), plan
 
     # ---- expressions ----------------------------------------------------------------------
     def ex(self, n):
@@ -879,7 +1004,10 @@ class _Codegen:
             op, A = n.op, n.args
             kt = {"r": "T", "i": "long", "b": "bool"}[n.kind]
             v = "const {} v{} = ".format(kt, n.idx)
-            if op == "read":
+            if self.fold is not None and n.idx in self.fold:
+                # interior copy of the body: an index predicate with the value it has away from the walls (_fold_plan)
+                self.emit(v + ("true;" if self.fold[n.idx] else "false;"))
+            elif op == "read":
                 self._emit_read(n)
             elif op in ("tensor", "rtensor"):
                 self._emit_tensor(n)
@@ -1256,7 +1384,7 @@ class _Codegen:
         vw, last = self.vw, self.ndim - 1
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         self._begin()
-        tiled = None
+        tiled, interior = None, None
         if self.share:
             tiled = self._tile_parts()
             fwd, rev = [], []
@@ -1266,6 +1394,7 @@ class _Codegen:
             self.lines = []
             self.reverse()
             rev = self.lines
+            interior = self._interior_copy(self.order, vw, reverse=True)
         fwd_pre = self.pre + self._group_arrays()
         nout = len(self.outputs)
         self.npar = sum(len(g) for names in self.pgrads.values() for g in names)
@@ -1338,27 +1467,39 @@ class _Codegen:
             if vw == 4:
                 for slot in range(len(stored)):
                     S.append("  T O{}[4];".format(slot))
-            self._loop_open(S, vw)
-            for k, lens in enumerate(self.out_lens):
-                if lens is not None:
-                    conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
-                    S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
-            S.extend(fwd)
-            S.extend(rev)
-            for slot, (n, name) in enumerate(stored):
+
+            def point_block(fwd_, rev_, inbox_):
+                B = []
+                self._loop_open(B, vw)
+                B.extend(self._inbox_lines(inbox_))
+                B.extend(fwd_)
+                B.extend(rev_)
+                for slot, (n, name) in enumerate(stored):
+                    if vw == 4:
+                        B.append("  O{}[p] = {};".format(slot, name))
+                    elif stream:
+                        B.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
+                    else:
+                        B.append("  a.cot[{}][l] = {};".format(slot, name))
+                for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
+                    term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
+                    if self.out_lens[k] is not None:
+                        term = "(inbox{} ? {} : (T)0)".format(k, term)
+                    B.append("  s_{0} = s_{0} + {1};".format(k, term))
                 if vw == 4:
-                    S.append("  O{}[p] = {};".format(slot, name))
-                elif stream:
-                    S.append("  __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
-                else:
-                    S.append("  a.cot[{}][l] = {};".format(slot, name))
-            for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
-                term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
-                if self.out_lens[k] is not None:
-                    term = "(inbox{} ? {} : (T)0)".format(k, term)
-                S.append("  s_{0} = s_{0} + {1};".format(k, term))
+                    B.append("  }")  # p
+                return B
+
+            if interior is None:
+                S.extend(point_block(fwd, rev, ()))
+            else:
+                (fwd_i, rev_i), (_, exc, inbox_i) = interior
+                S.append("  if (__all((int)({}))) {{".format(self._interior_cond(exc)))
+                S.extend(point_block(fwd_i, rev_i, inbox_i))
+                S.append("  } else {")
+                S.extend(point_block(fwd, rev, ()))
+                S.append("  }")
             if vw == 4:
-                S.append("  }")  # p
                 for slot in range(len(stored)):
                     vec = "(T4){{O{0}[0], O{0}[1], O{0}[2], O{0}[3]}}".format(slot)
                     if stream:
@@ -1762,9 +1903,11 @@ class _Codegen:
         self._begin()
         self.in_gather = True
         self.forward()
+        body = self.lines
+        interior = self._interior_copy(nodes, vw)
         self.in_gather = False
         self.vw = self.vw_fwd
-        body, pre = self.lines, self.pre + self._group_arrays()
+        pre = self.pre + self._group_arrays()
         values = [self.r(root) for _, root in items]
         sources = sorted({n.attr[0] for n in nodes if n.op == "read" and not n.attr[0].startswith("@")})
         for key, _ in items:
@@ -1795,11 +1938,24 @@ class _Codegen:
         S.extend(pre)
         for k in range(len(items)):
             S.append("  T acc{}[{}];".format(k, vw))
-        self._loop_open(S, vw)
-        S.extend(body)
-        for k, value in enumerate(values):
-            S.append("  acc{}[{}] = {};".format(k, "p" if vw == 4 else "0", value))
-        if vw == 4:
+
+        def point_block(body_):
+            B = []
+            self._loop_open(B, vw)
+            B.extend(body_)
+            for k, value in enumerate(values):
+                B.append("  acc{}[{}] = {};".format(k, "p" if vw == 4 else "0", value))
+            if vw == 4:
+                B.append("  }")
+            return B
+
+        if interior is None:
+            S.extend(point_block(body))
+        else:
+            S.append("  if (__all((int)({}))) {{".format(self._interior_cond(interior[1][1])))
+            S.extend(point_block(interior[0][0]))
+            S.append("  } else {")
+            S.extend(point_block(body))
             S.append("  }")
         adam = "adam_apply4({ad}, {o}, acc{k});" if vw == 4 else "adam_apply({ad}, {o}, acc{k}[0]);"
         put = "*(T4*)({dst} + {o}) = (T4){{acc{k}[0], acc{k}[1], acc{k}[2], acc{k}[3]}};" if vw == 4 else "{dst}[{o}] = acc{k}[0];"

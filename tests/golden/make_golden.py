@@ -76,6 +76,47 @@ def gen_interp():
     save("interp", **data)
 
 
+# ---------------------------------------------------------------- conv transfers (A3 method="conv", A5)
+def gen_conv_transfers():
+    """The reference's own `interp_to_finer(method="conv")` (core.py:645-667; the default of the tracer workload,
+    veltracer.py:150) and `restrict_to_coarser` (core.py:703-755), values and cotangents, 1-3-D, depth 1-2.  The loc
+    combinations are those of the reference's tests (test_mg_interp.py / test_mg_restrict.py: prefixes of cccc, nnnn,
+    cnnn, nccc) plus mixed ones and '.' axes -- on which the integer stride 2 of backend.py:118-119 subsamples."""
+    rng = np.random.default_rng(303)
+    locs = ["c", "n", "cc", "nn", "cn", "nc", "c.", ".n", "ccc", "nnn", "cnn", "ncc", "c.n"]
+    data, cases = dict(), []
+    for loc in locs:
+        shape = tuple(int(3 + i + (1 if l == "n" else 0)) for i, l in enumerate(loc))
+        u = rng.standard_normal(shape)
+        ut = T(u).requires_grad_(True)
+        fine = odil.core.interp_to_finer(ut, loc=loc, method="conv", mod=mod)
+        stack = odil.core.interp_to_finer(T(u), loc=loc, method="stack", mod=mod)
+        gf = rng.standard_normal(tuple(fine.shape))
+        (gu,) = torch.autograd.grad(fine, ut, T(gf))
+        cases.append(loc)
+        data[f"{loc}/u"], data[f"{loc}/fine"], data[f"{loc}/gfine"], data[f"{loc}/gu"] = u, npy(fine), gf, npy(gu)
+        data[f"{loc}/stack_minus_conv"] = np.array(float(torch.max(torch.abs(stack - fine.detach()))))
+        if len(loc) <= 2:
+            data[f"{loc}/fine2"] = npy(odil.core.interp_to_finer(T(u), loc=loc, method="conv", mod=mod, depth=2))
+    data["cases"] = np.array(cases)
+    save("interp_conv", **data)
+
+    data, cases = dict(), []
+    for loc in locs:
+        # fine arrays whose restriction exists twice: 4 m cells / 4 m + 1 nodes per axis ('.': 5, subsampled to 3, 2)
+        shape = tuple(5 if l == "." else 4 * (2 + i) + (1 if l == "n" else 0) for i, l in enumerate(loc))
+        u = rng.standard_normal(shape)
+        ut = T(u).requires_grad_(True)
+        coarse = odil.core.restrict_to_coarser(ut, loc=loc, mod=mod)
+        gc = rng.standard_normal(tuple(coarse.shape))
+        (gu,) = torch.autograd.grad(coarse, ut, T(gc))
+        cases.append(loc)
+        data[f"{loc}/u"], data[f"{loc}/coarse"], data[f"{loc}/gcoarse"], data[f"{loc}/gu"] = u, npy(coarse), gc, npy(gu)
+        data[f"{loc}/coarse2"] = npy(odil.core.restrict_to_coarser(T(u), loc=loc, mod=mod, depth=2))
+    data["cases"] = np.array(cases)
+    save("restrict", **data)
+
+
 # ---------------------------------------------------------------- multigrid synthesis (A2) + adjoint
 def gen_mg():
     rng = np.random.default_rng(202)
@@ -487,8 +528,9 @@ def gen_veltracer():
     rng = np.random.default_rng(707)
     for tag, dtype in [("f64", np.float64), ("f32", np.float32)]:
         Nt, Nx, Ny = 8, 8, 8
+        # mg_interp="conv": the workload's own default (veltracer.py:150), through the shim's conv_transpose
         domain = odil.Domain(cshape=(Nt, Nx, Ny), dimnames=("t", "x", "y"), lower=(0, 0, 0), upper=(1, 1, 1),
-                             dtype=dtype, multigrid=True, mg_interp="stack", mod=mod)
+                             dtype=dtype, multigrid=True, mg_interp="conv", mod=mod)
         args = argparse.Namespace(kxreg=0.01, ktreg=1.0, kimp=10.0)
         x, y = domain.points("x", "y", loc=".cc")
         u_init = vt.u_init_blob(npy(x), npy(y), 0).astype(dtype)
@@ -692,6 +734,7 @@ def check_reference_tests():
 if __name__ == "__main__":
     check_reference_tests()
     gen_interp()
+    gen_conv_transfers()
     gen_mg()
     gen_field_access()
     gen_poisson()

@@ -263,6 +263,39 @@ class ModShim:
     def norm(self, x):
         return torch.linalg.norm(T(x))
 
+    # strided convolutions of the multigrid transfers (reference backend.py:112-126, 165-172: jax.lax.conv /
+    # jax.lax.conv_transpose).  torch's conv{1,2,3}d is the same cross-correlation (no kernel flip) on (N, C, *spatial).
+    def convolution(self, input, filters, strides, padding):
+        input, filters = T(input), T(filters).to(T(input).dtype)
+        dim = input.dim()
+        if isinstance(strides, int):  # backend.py:118-119: an integer stride goes to EVERY axis, '.' ones included
+            strides = (strides,) * dim
+        assert padding == "VALID" and 1 <= dim <= 3, (padding, dim)
+        conv = {1: torch.nn.functional.conv1d, 2: torch.nn.functional.conv2d, 3: torch.nn.functional.conv3d}[dim]
+        res = conv(input.reshape((1, 1) + tuple(input.shape)), filters.reshape((1, 1) + tuple(filters.shape)),
+                   stride=tuple(int(s) for s in strides))
+        return res[0, 0]
+
+    def conv_transpose(self, input, filters, output_shape=None, strides=None, padding=None):
+        # called with lhs (1, *spatial, 1) and rhs (*kernel, 1, 1) (reference core.py:656-662); jax.lax.conv_transpose
+        # with its default transpose_kernel=False correlates the stride-dilated input, padded by k - 1, with the kernel
+        # as given: the scatter out[s i + k - 1 - j] += in[i] w[j], i.e. torch's conv_transpose with the kernel flipped
+        input, filters = T(input), T(filters).to(T(input).dtype)
+        dim = input.dim() - 2
+        if isinstance(strides, int):
+            strides = (strides,) * dim
+        assert padding == "VALID" and 1 <= dim <= 3, (padding, dim)
+        x = input.reshape((1, 1) + tuple(input.shape[1:-1]))
+        w = torch.flip(filters.reshape(tuple(filters.shape[:-2])), dims=tuple(range(dim))).reshape(
+            (1, 1) + tuple(filters.shape[:-2]))
+        convt = {1: torch.nn.functional.conv_transpose1d, 2: torch.nn.functional.conv_transpose2d,
+                 3: torch.nn.functional.conv_transpose3d}[dim]
+        res = convt(x, w, stride=tuple(int(s) for s in strides))
+        res = res.reshape((1,) + tuple(res.shape[2:]) + (1,))
+        if output_shape is not None:
+            assert tuple(res.shape) == tuple(int(v) for v in output_shape), (res.shape, output_shape)
+        return res
+
 
 for _name in ["abs", "cos", "sin", "exp", "square", "sqrt", "tanh", "log", "floor", "minimum", "maximum"]:
 

@@ -47,6 +47,38 @@ def test_interp_and_adjoint_vs_golden(dev, loc):
     assert rel(gu, g[f"{loc}/gu"]) < 1e-14
 
 
+@pytest.mark.parametrize("loc", [str(c) for c in load_golden("interp_conv")["cases"]])
+def test_interp_conv_reference_values(dev, loc):
+    """`interp_to_finer(method="conv")` AS THE REFERENCE COMPUTES IT (core.py:645-667; fixtures from its own function):
+    the public function with method="conv" -- the tracer workload's default -- and the cotangent kernel."""
+    import odil_amd as odil
+    from odil_amd import ops
+
+    g = load_golden("interp_conv")
+    u = g[f"{loc}/u"]
+    fine = odil.core.interp_to_finer(to(u, dev), loc=loc, method="conv", mod=odil.runtime.get_mod())
+    assert rel(fine, g[f"{loc}/fine"]) < 1e-15
+    if f"{loc}/fine2" in g:
+        fine2 = odil.core.interp_to_finer(to(u, dev), loc=loc, method="conv", mod=odil.runtime.get_mod(), depth=2)
+        assert rel(fine2, g[f"{loc}/fine2"]) < 2e-15
+    assert rel(ops.interp_adj(to(g[f"{loc}/gfine"], dev), loc, u.shape), g[f"{loc}/gu"]) < 1e-14
+
+
+@pytest.mark.parametrize("loc", [str(c) for c in load_golden("restrict")["cases"]])
+def test_restrict_reference_values(dev, loc):
+    """`restrict_to_coarser` AS THE REFERENCE COMPUTES IT (core.py:703-755 + backend.py:112-126; fixtures from its own
+    function, '.' axes subsampled by the integer stride): values, depth 2, cotangent."""
+    import odil_amd as odil
+    from odil_amd import ops
+
+    g = load_golden("restrict")
+    u = g[f"{loc}/u"]
+    mod = odil.runtime.get_mod()
+    assert rel(odil.core.restrict_to_coarser(to(u, dev), loc=loc, mod=mod), g[f"{loc}/coarse"]) < 1e-15
+    assert rel(odil.core.restrict_to_coarser(to(u, dev), loc=loc, mod=mod, depth=2), g[f"{loc}/coarse2"]) < 2e-15
+    assert rel(ops.restrict_adj(to(g[f"{loc}/gcoarse"], dev), loc, u.shape), g[f"{loc}/gu"]) < 1e-15
+
+
 @pytest.mark.parametrize(
     "loc,shape", [("ccc", (5, 6, 7)), ("ncc", (5, 4, 6)), ("cc", (33, 130)), ("c", (700,)), ("cn", (9, 300)),
                   ("ncc", (9, 16, 20)), ("ncc", (67, 8, 12)), ("ncc", (3, 6, 4)), ("ncc", (4, 2, 2)),

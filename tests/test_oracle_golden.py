@@ -34,6 +34,34 @@ def test_interp_forward_and_adjoint(loc):
     close(gu, g[f"{loc}/gu"], 1e-14)
 
 
+CONV_CASES = [str(c) for c in load_golden("interp_conv")["cases"]]
+
+
+@pytest.mark.parametrize("loc", CONV_CASES)
+def test_interp_conv_reference_values(loc):
+    """`interp_to_finer(method="conv")` of the reference itself (core.py:645-667 through the conv_transpose of
+    tests/golden/ref_shim.py; the tracer workload's default, veltracer.py:150): the oracle's one prolongation (the
+    'stack' summation order) gives the same values to rounding, and the same cotangent."""
+    g = load_golden("interp_conv")
+    u = g[f"{loc}/u"]
+    assert float(g[f"{loc}/stack_minus_conv"]) <= 16 * EPS  # the reference's two methods agree with each other
+    close(onp.interp_to_finer(u, loc), g[f"{loc}/fine"], 1e-15)
+    if f"{loc}/fine2" in g:
+        close(onp.interp_to_finer(u, loc, depth=2), g[f"{loc}/fine2"], 2e-15)
+    close(onp.interp_to_finer_adj(g[f"{loc}/gfine"], loc, u.shape), g[f"{loc}/gu"], 1e-14)
+
+
+@pytest.mark.parametrize("loc", [str(c) for c in load_golden("restrict")["cases"]])
+def test_restrict_reference_values(loc):
+    """`restrict_to_coarser` of the reference itself (core.py:703-755, the strided convolution of backend.py:112-126
+    -- integer stride on '.' axes included), values at depth 1 and 2 and the cotangent."""
+    g = load_golden("restrict")
+    u = g[f"{loc}/u"]
+    close(onp.restrict_to_coarser(u, loc), g[f"{loc}/coarse"], 1e-15)
+    close(onp.restrict_to_coarser(u, loc, depth=2), g[f"{loc}/coarse2"], 2e-15)
+    close(onp.restrict_to_coarser_adj(g[f"{loc}/gcoarse"], loc, u.shape), g[f"{loc}/gu"], 1e-15)
+
+
 def test_interp_exact_on_linear_functions():
     """reference tests/test_mg_interp.py:11-32 restated on the oracle."""
     for ndim in [1, 2, 3, 4]:
