@@ -44,6 +44,11 @@ def npy(x):
     return x.detach().numpy().copy() if isinstance(x, torch.Tensor) else np.array(x)
 
 
+# set-ups of the example workloads as the generators below build them (make_golden_traj.py runs the reference's
+# optimizers on them): name -> dict(domain, state, extra, arrays, operator, lr)
+CASES = dict()
+
+
 def save(name, **data):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **data)
@@ -519,6 +524,7 @@ def gen_heat():
             data[f"value/{n}"] = npy(v)
             data[f"term/{n}"] = npy(t)
         save(f"heat_{tag}", **data)
+        CASES[f"heat_{tag}"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=heat.operator_odil, lr=1e-3)
 
 
 def gen_veltracer():
@@ -560,6 +566,7 @@ def gen_veltracer():
             data[f"value/{i}"] = npy(v)
             data[f"term/{i}"] = npy(t)
         save(f"veltracer_{tag}", **data)
+        CASES[f"veltracer_{tag}"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=vt.operator_advection, lr=0.01)
 
 
 
@@ -684,6 +691,7 @@ def gen_generalised():
             data[f"args/{k}"] = np.array(v)
         _store(data, arrays, *_loss_grads(heat2d.operator(ctx), arrays_l))
         save(f"heat2d_{tag}", **data)
+        CASES[f"heat2d_{tag}"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=heat2d.operator, lr=1e-3)
 
         Nt, Nx = 4, 8
         domain = odil.Domain(cshape=(Nt, Nx, Nx, Nx), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
@@ -708,6 +716,7 @@ def gen_generalised():
         for i, t in enumerate(terms):
             data[f"term/{i}"] = npy(t)
         save(f"veltracer3d_{tag}", **data)
+        CASES[f"veltracer3d_{tag}"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=vt3.operator, lr=0.01)
 
 # ---------------------------------------------------------------- reference tests as known-answer checks
 def check_reference_tests():

@@ -13,6 +13,7 @@
 The reference's code runs unchanged on the torch-CPU shim (ref_shim.py), as in make_golden.py.
 """
 import numpy as np
+import torch
 
 from make_golden import T, make_poisson, mod, npy, odil, poisson, ref_loss_grad, save
 
@@ -173,6 +174,53 @@ def lbfgsb_iterates():
          rhs=npy(extra.rhs), m=np.array(50), maxls=np.array(50), shapes=np.array([a.shape for a in start]))
 
 
+def workload_adam_states(epochs=20, sample=(1, 2, 5, 10, 19)):
+    """Teacher-forcing fixtures for the TRACED workloads (heat, veltracer and their generalisations with one more space
+    dimension; f64 and f32): the reference's AdamNativeOptimizer (optimizer.py:311-336) run for `epochs` epochs on the
+    set-ups of make_golden.py (the reference's operators, its core.py, its optimizer, all on the shim; every array of
+    the state, network weights included, is an unknown), started from the fixture's random state.  Stored: the
+    optimizer's own (x, m, v) at the sampled epochs k and at k + 1, and the loss of every epoch.  `tracers["epoch"]` is
+    k at evaluation k (what the examples' callbacks set)."""
+    import sys
+
+    import make_golden as mg
+
+    mg.gen_heat()
+    mg.gen_veltracer()
+    mg.gen_generalised()
+    for name, case in mg.CASES.items():
+        smp = (1, 10) if name.startswith("veltracer3d") else sample  # (four 4-D fields: 0.2 MB per stored state)
+        want = sorted(set(smp) | {k + 1 for k in smp})
+        domain, state, extra, operator = case["domain"], case["state"], case["extra"], case["operator"]
+        dtype = domain.dtype
+        data = dict(lr=np.array(case["lr"]), epochs=np.array(epochs), sample=np.array(sorted(smp)))
+        losses = []
+
+        def loss_grad(arrays, want=want):
+            frame = sys._getframe(1)
+            assert frame.f_code.co_name == "run" and "m" in frame.f_locals and "v" in frame.f_locals
+            k = len(losses) + 1
+            if k in want:
+                for nm in ("x", "m", "v"):
+                    for i, a in enumerate(frame.f_locals[nm]):
+                        data[f"{nm}{i}_e{k}"] = npy(a).copy()
+            leaves = [a.detach().clone().requires_grad_(True) for a in arrays]
+            domain.arrays_to_state(leaves, state)
+            ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": k})
+            ff = operator(ctx)
+            values = [f[1] if isinstance(f, tuple) else f for f in ff]
+            loss = sum(mod.mean(mod.square(v)) for v in values)
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            grads = [g if g is not None else torch.zeros_like(a) for g, a in zip(grads, leaves)]
+            losses.append(float(loss))
+            return loss.detach(), grads, None
+
+        opt = odil.optimizer.AdamNativeOptimizer(dtype=dtype, mod=mod)
+        opt.run([a.detach().clone() for a in case["arrays"]], loss_grad, epochs=epochs, lr=case["lr"], jit=False)
+        data["losses"] = np.array(losses)
+        save("traj_adam_states_" + name, **data)
+
+
 def load_losses(name):
     import os
 
@@ -189,3 +237,4 @@ if __name__ == "__main__":
     adam_states(2, 32, 300, [1, 2, 3, 10, 50, 100, 124, 125, 126, 150, 200, 250, 299])
     adam_states(3, 16, 100, [1, 2, 50, 99])
     lbfgsb_iterates()
+    workload_adam_states()
