@@ -126,6 +126,13 @@ __device__ inline float odil_fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// Value held by the previous / next lane of the wavefront (wave-wide DPP shift, no LDS); lanes without a source get 0.
+__device__ inline float odil_lane_prev(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
+}
+__device__ inline float odil_lane_next(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
+}
 typedef float T2 __attribute__((ext_vector_type(2)));
 __device__ inline T2 odil_fast_tanh2(T2 x) {  // two lanes: the arithmetic packs, exp2 / rcp are per lane
   const T2 s = x * 2.88539008177792681472f;
@@ -247,6 +254,8 @@ class _Codegen:
         self.gloc = next(n.attr[2] for n in self.order if n.op == "read")
         self.in_gather = False  # emitting a gather (slab mode: threads cover the ghost planes too)
         self.fold = None  # emitting the interior copy of a body: {predicate node idx: constant value} (_fold_plan)
+        self.wregs = "mem"  # where the marching kernel keeps network parameters (source())
+        self.march_pref = None  # marching kernel: {read descriptor: (slot, load expression)} of the reads requested a step ahead
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
@@ -722,9 +731,15 @@ class _Codegen:
                 j = "({} == 0 ? 0 : {} - 1)".format(name, name)
             idx.append(j)
         if not fast:
+            e = "*({})".format(self._address(key, ptr, fshape, idx, sa))
+            if self.march_pref is not None and not zero and not pre_lines:
+                # marching kernel: the value was requested one step ahead (_march_kernel)
+                slot = self.march_pref.setdefault(desc, (len(self.march_pref), e))[0]
+                self.emit("const T v{} = ld_{};".format(n.idx, slot))
+                self.loads[desc] = "v{}".format(n.idx)
+                return
             for line in pre_lines:
                 self.emit(line)
-            e = "*({})".format(self._address(key, ptr, fshape, idx, sa))
             if zero:
                 e = "(({}) ? (T)0 : {})".format(" || ".join(zero), e)
             self.emit("const T v{} = {};".format(n.idx, e))
@@ -853,12 +868,22 @@ class _Codegen:
 
         self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "7x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
-        mode = os.environ.get("ODIL_TRACE_SHARE", "0")  # 0 (default: measured slower, below) / 1
+        # 0: every thread evaluates what its point needs; 1: the LDS-tiled kernel (measured slower, below); march: the
+        # marching kernel (_march_kernel: values carried along the second-to-last axis in registers, exchanged along the last
+        # axis by lane shifts); auto (default): march where a grid is large enough for it to pay
+        mode = os.environ.get("ODIL_TRACE_SHARE", "auto")
+        self.share_mode = None
         if not mlps or self.slab is not None or self.ndim < 2 or mode == "0" or self.GL != self.G:
             return
         a1, a2 = self.ndim - 2, self.ndim - 1
-        if self.G[a2] % self.TILE[1] or self.G[a1] < self.TILE[0] or len({n.attr for n in mlps}) != 1 or not self.fast:
-            return  # (rows of tiles may be partial -- masked --, columns not; packed float evaluations)
+        if len({n.attr for n in mlps}) != 1 or not self.fast:
+            return  # (one network; packed float evaluations)
+        if mode == "auto":
+            if self.ndim < 3 or self.G[a2] < 128 or self.G[a1] < 16:
+                return
+            mode = "march"
+        if mode == "1" and (self.G[a2] % self.TILE[1] or self.G[a1] < self.TILE[0]):
+            return  # (rows of tiles may be partial -- masked --, columns not)
         # MEASURED, twice, and not faster (heat with two space dimensions, 256 x 512^2, 46 parameters, epoch in ms; plain
         # kernel 3.54 - 3.56): first design -- interior threads evaluate their upper faces, a fifth wave of halo threads
         # the tile's lower edge, 320-thread workgroups that fit once per compute unit at 244 VGPRs: 4.78 (tiles 4 x 32
@@ -886,7 +911,10 @@ class _Codegen:
             for arg in x.args:
                 if any(m.op == "mlp_out" and m.args[0].idx in outs_of for m in stencil_grad.subdag(arg)):
                     return
+        if mode == "march" and (sorted(per_axis) != [a1, a2] or len(pairs[0][0].attr[2]) < 2):
+            return  # (the marching kernel pairs the upper faces of the last two axes in ONE packed evaluation)
         self.share = pairs
+        self.share_mode = "march" if mode == "march" else "tile"
         self.shared_A = {A.idx for A, _, _ in pairs}
         self.shared_B = {B.idx for _, B, _ in pairs}
 
@@ -961,6 +989,13 @@ class _Codegen:
             self.nets.append((key, layers))
         return self.net_slot[key]
 
+    def _launder_params(self, base, nl):
+        if getattr(self, "wregs", "mem") != "const":
+            return
+        for l in range(nl):
+            for c, ofs in (("w", "WOFS"), ("b", "BOFS")):
+                self.emit('CP {0}p_{1}_{2} = (CP)a.par[{3}_{1}_{2}]; asm volatile("" : "+s"({0}p_{1}_{2}));'.format(c, base, l, ofs))
+
     def _mlp_forward(self, p, width, attr, inputs):
         """Layers of one (width 1) or two packed (width 2) evaluations of a pointwise network under the name prefix p;
         inputs: per network input the value expression (width 2: a pair)."""
@@ -968,6 +1003,7 @@ class _Codegen:
         key, frozen, layers, act = attr
         base = self._net_base(attr)
         nl = len(layers) - 1
+        self._launder_params(base, nl)
         for i, vals in enumerate(inputs):
             self.emit("const {} {}_h0_{} = {};".format(V, p, i, vals if width == 1 else "{{{}, {}}}".format(*vals)))
         for l in range(1, nl + 1):
@@ -1221,6 +1257,7 @@ class _Codegen:
         base = self.net_slot[key]
         nl = len(layers) - 1
         sfx = "2" if width == 2 else ""  # packed sums of two evaluations live in their own accumulators
+        self._launder_params(base, nl)
         for j, vals in enumerate(dvals):
             self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals if width == 1 else "{{{}, {}}}".format(*vals)))
         if not frozen and width == 2:
@@ -1385,7 +1422,11 @@ class _Codegen:
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         self._begin()
         tiled, interior = None, None
-        if self.share:
+        march = None
+        if self.share and self.share_mode == "march":
+            march = self._march_parts()
+            fwd, rev = [], []
+        elif self.share:
             tiled = self._tile_parts()
             fwd, rev = [], []
         else:
@@ -1394,7 +1435,10 @@ class _Codegen:
             self.lines = []
             self.reverse()
             rev = self.lines
-            interior = self._interior_copy(self.order, vw, reverse=True)
+            # (not for kernels with a pointwise network: two copies of the network's forward and reverse pass cost the
+            # registers of a second resident wave -- heat 256 x 512^2: 283 + 27 spilled to AGPRs, 3.29 -> 4.36 ms / epoch)
+            has_net = any(n.op == "mlp" for n in self.order)
+            interior = None if has_net else self._interior_copy(self.order, vw, reverse=True)
         fwd_pre = self.pre + self._group_arrays()
         nout = len(self.outputs)
         self.npar = sum(len(g) for names in self.pgrads.values() for g in names)
@@ -1421,8 +1465,23 @@ class _Codegen:
             o += 2 * nl
         self.par_layout = [(key, layers) for key, layers in self.nets]
         S.append("#define AP(s, k) a.par[{} + s][k]".format(o))  # Array unknowns follow the net arrays
-        S.append("#define W(s, l, k) a.par[WOFS_##s##_##l][k]")
-        S.append("#define Bv(s, l, k) a.par[BOFS_##s##_##l][k]")
+        # the marching kernel keeps the network's parameters in registers for the whole launch (they would be re-read
+        # through the vector memory pipe -- uniform addresses, but stores to the adjoint arrays in between -- in every
+        # evaluation and every reverse pass of every step): ODIL_TRACE_MARCH_W = const (default) | vgpr | sgpr | mem
+        if self.wregs == "const":
+            # the parameter arrays read through the CONSTANT address space: the compiler may then use scalar loads, merge
+            # them across the stores of the adjoint arrays and re-load instead of spilling
+            # (scalar loads at every use instead of 46 values hoisted to the top of the kernel and spilled: the pointers
+            # are passed through an empty asm before every evaluation / reverse pass, _launder_params)
+            S.append("typedef const __attribute__((address_space(4))) T* CP;")
+            S.append("#define W(s, l, k) wp_##s##_##l[k]")
+            S.append("#define Bv(s, l, k) bp_##s##_##l[k]")
+        elif self.wregs != "mem":
+            S.append("#define W(s, l, k) wr_##s##_##l##_##k")
+            S.append("#define Bv(s, l, k) br_##s##_##l##_##k")
+        else:
+            S.append("#define W(s, l, k) a.par[WOFS_##s##_##l][k]")
+            S.append("#define Bv(s, l, k) a.par[BOFS_##s##_##l][k]")
         for (s, l), v in wofs.items():
             S.append("#define WOFS_{}_{} {}".format(s, l, v))
         for (s, l), v in bofs.items():
@@ -1450,8 +1509,10 @@ class _Codegen:
         stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
         if tiled is not None:
             self._tile_kernel(S, tiled, stored, stream)
+        if march is not None:
+            self._march_kernel(S, march, stored, stream)
         threads = self.total // vw
-        if tiled is None:
+        if tiled is None and march is None:
             flat = "l4" if vw == 4 else "l"
             S.append(self._block_index(self.GL, vw))
             if threads <= self.max_blocks * 256:  # one thread per point (or four points)
@@ -1877,6 +1938,267 @@ class _Codegen:
             S.append("  }")
         S.extend(parts["mlp_bwd"])
         S.append("  }")  # tiles
+
+    # ---- network evaluations shared by MARCHING (float kernels with a pointwise network at the faces) ---------------------
+    def _march_parts(self):
+        """Line groups of the marching forward kernel (see _march_kernel): per variant (general / interior) the forward
+        lines before and after the shared network values, and the reverse pass."""
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        self.wregs = os.environ.get("ODIL_TRACE_MARCH_W", "const")
+        by_axis = {axis: (A, B) for A, B, axis in self.share}
+        (Ax, Bx), (Ay, By) = by_axis[a1], by_axis[a2]
+        shared = {x.idx for x in (Ax, Bx, Ay, By)}
+        late = set()
+        for n in self.order:
+            if (n.op == "mlp_out" and n.args[0].idx in shared) or any(a.idx in late for a in n.args):
+                late.add(n.idx)
+        early = {n.idx for n in self.order} - late
+        attr = Bx.attr
+        nlast = len(attr[2]) - 1
+        nz, nin = attr[2][nlast], len(Bx.args)
+        parts = dict(Ax=Ax, Bx=Bx, Ay=Ay, By=By, nz=nz, nin=nin, attr=attr, variants=[])
+        plan = self._fold_plan(self.order, 1, windows=True)
+        parts["plan"] = plan
+        keep = ("cots", "cut_nodes", "jac_store", "pg_decl", "pg_offset", "pgrads", "pg2_used")
+        first = None
+        self.march_pref = dict() if int(os.environ.get("ODIL_TRACE_MARCH_PREFETCH", 1)) else None
+        for fold in ([None] if plan is None else [None, plan[0]]):
+            self.fold, self.lines, self.loads = fold, [], dict()
+            self.cots, self.cut_nodes, self.jac_store, self.pg_decl, self.pg_offset, self.pg2_used = [], [], [], [], dict(), set()
+            self.forward(only=early)
+            fwd1, self.lines = self.lines, []
+            xin = [(self.r(Bx.args[k]), self.r(By.args[k]), self.r(Ay.args[k])) for k in range(nin)]
+            self.forward(only=late)
+            fwd2, self.lines = self.lines, []
+            self.reverse()
+            rev, self.lines = self.lines, []
+            rev_text = "\n".join(rev)
+
+            def adjoint_of(call, j):
+                out = self.mlp_out_seen.get(call.idx, dict()).get(j)
+                return "g{}".format(out.idx) if out is not None and "T g{} ".format(out.idx) in rev_text else "(T)0"
+
+            adj = {name: [adjoint_of(call, j) for j in range(nz)] for name, call in (("ax", Ax), ("bx", Bx), ("ay", Ay), ("by", By))}
+            state = {k: getattr(self, k) for k in keep}
+            if first is None:
+                first = state
+            elif ([n.idx for n in state["cots"]] != [n.idx for n in first["cots"]] or state["pg_decl"] != first["pg_decl"]
+                  or [n.idx for n in state["cut_nodes"]] != [n.idx for n in first["cut_nodes"]]):
+                raise RuntimeError("interior copy of the traced kernel stores other adjoints than the general one")
+            parts["variants"].append(dict(fwd1=fwd1, fwd2=fwd2, rev=rev, xin=xin, adj=adj))
+        self.fold = None
+        parts["pref"] = sorted(self.march_pref.values()) if self.march_pref else []
+        self.march_pref = None
+        for k, v in first.items():
+            setattr(self, k, v)
+        # the pre-step of a row segment: the inputs of the LOWER face along the marching axis at the segment's first row
+        saved = (self.order, self.loads, self.pre, self.groups)
+        seen = dict()
+        for arg in Ax.args:
+            for n in stencil_grad.subdag(arg):
+                seen[n.idx] = n
+        self.order = [seen[i] for i in sorted(seen)]
+        self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
+        self.forward()
+        parts["pre_lines"], parts["pre_in"] = self.lines, [self.r(arg) for arg in Ax.args]
+        self.order, self.loads, self.pre, self.groups = saved
+        # the packed evaluation (prefix mu) and the reverse pass of the PREVIOUS step's evaluation (prefix mp)
+        self.lines = []
+        self._mlp_forward("mu", 2, attr, [("ux{}_0".format(k), "ux{}_1".format(k)) for k in range(nin)])
+        parts["mlp_fwd"], self.lines = self.lines, []
+        self._mlp_backward("mp", 2, attr, [("ud{}_0".format(j), "ud{}_1".format(j)) for j in range(nz)], False)
+        parts["mlp_bwd"], self.lines = self.lines, []
+        layers = attr[2]
+        parts["acts"] = ["h{}_{}".format(l, i) for l in range(nlast) for i in range(layers[l])]  # what the reverse pass reads
+        return parts
+
+    def _march_kernel(self, S, parts, stored, stream):
+        """Body of the MARCHING forward kernel of an operator that evaluates one pointwise network at the faces of every
+        cell (heat with two space dimensions: reference examples/heat/heat.py:86-98 per axis).  The lower face of cell i is
+        the upper face of cell i - e (stencil_share.py proves it on the DAG), so half of the evaluations of the plain
+        kernel -- and of their reverse passes, two thirds of its instructions -- are repeats.  Here a WAVE owns a strip of
+        63 columns of the last axis and marches along the second-to-last axis over a segment of rows; every lane makes ONE
+        packed evaluation per point: (upper face along the marching axis, upper face along the lane axis).
+
+        * marching axis: the value of a point's upper face is carried in registers to the next row, where it is the lower
+          face; the adjoint it collects there is added to its own before the reverse pass of the evaluation, which
+          therefore runs ONE STEP LATE, from the previous step's activations (carried as well);
+        * lane axis: lane L takes its lower face from lane L - 1 and returns the adjoint to it by wave-wide lane shifts
+          (DPP: no LDS, no barrier).  Lane 0 of every wave is a helper: it sits on lane 1's point and evaluates that point's
+          LOWER face in its second slot (the wall extrapolation where the strip starts at the wall) -- the same
+          instruction stream, one input selected;
+        * a segment starts with a pre-step that evaluates the lower face of its first row (the wall extrapolation at row 0).
+
+        Values and adjoints of lanes without a point are masked; sums of network-parameter gradients are linear in the
+        adjoints, so a face shared by two waves (or two segments) simply contributes from both sides.  The body exists
+        twice: as traced, and with every index predicate folded to its interior value (_fold_plan); the branch is scalar
+        (row index, strip and leading indices are wave-uniform)."""
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        G1, G2 = self.G[a1], self.G[a2]
+        R = max(1, min(int(os.environ.get("ODIL_TRACE_MARCH_ROWS", 64)), G1))
+        nseg, nstrip = (G1 + R - 1) // R, (G2 + 62) // 63
+        lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
+        nitems = lead * nseg * nstrip
+        nz, nin, attr = parts["nz"], parts["nin"], parts["attr"]
+        nl = len(attr[2]) - 1
+        Ax, Bx, Ay, By = parts["Ax"], parts["Bx"], parts["Ay"], parts["By"]
+        acts = parts["acts"]
+        if self.wregs not in ("mem", "const"):
+            # vgpr: an empty asm with a vector-register constraint keeps the (uniform) value out of the scalar file, whose
+            # 100-odd registers already hold the kernel's ~30 array pointers: 46 more spill to lanes of vector registers
+            # and every use costs a v_readlane
+            for s_, (key, layers) in enumerate(self.nets):
+                for l in range(len(layers) - 1):
+                    names = [("wr_{}_{}_{}".format(s_, l, k), "a.par[WOFS_{}_{}][{}]".format(s_, l, k)) for k in range(layers[l] * layers[l + 1])]
+                    names += [("br_{}_{}_{}".format(s_, l, k), "a.par[BOFS_{}_{}][{}]".format(s_, l, k)) for k in range(layers[l + 1])]
+                    for name, src in names:
+                        if self.wregs == "vgpr":
+                            S.append('  T {0} = {1}; asm volatile("" : "+v"({0}));'.format(name, src))
+                        else:
+                            S.append("  const T {} = {};".format(name, src))
+        S.append("  const int lane = threadIdx.x & 63;")
+        S.append("  const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);")
+        S.append("  for (int item = blockIdx.x * 4 + wave_; item < {}; item += a.nblocks * 4) {{".format(nitems))
+        S.append("  const int strip = item % {}, seg = (item / {}) % {};".format(nstrip, nstrip, nseg))
+        rem = "(item / {})".format(nstrip * nseg)
+        for d in reversed(range(a1)):
+            if d == 0:
+                S.append("  const int i0 = {};".format(rem))
+            else:
+                S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
+                S.append("  const int q{}_ = {} / {};".format(d, rem, self.G[d]))
+                rem = "q{}_".format(d)
+        S.append("  const int r0 = seg * {0}, r1 = min(r0 + {0}, {1});".format(R, G1))
+        S.append("  const int p2 = strip * 63 + (lane == 0 ? 0 : lane - 1);")
+        S.append("  const bool valid = lane != 0 && p2 < {};".format(G2))
+        S.append("  const int i{} = min(p2, {});".format(a2, G2 - 1))
+        # interior test, scalar: leading indices, strip range; the row is tested per step
+        plan = parts["plan"]
+        outer, rowc = [], []
+        if plan is not None:
+            _, exc, _ = plan
+            for d, values in sorted(exc.items()):
+                if d < a1:
+                    outer.append(self._interior_cond({d: values}))
+                elif d == a1:
+                    rowc.append(self._interior_cond({d: values}))
+                else:  # no exceptional column among the strip's: [s0, s0 + 62]
+                    values, lo, hi = list(values), 0, G2 - 1
+                    while values and values[0] == lo:
+                        values.pop(0)
+                        lo += 1
+                    while values and values[-1] == hi:
+                        values.pop()
+                        hi -= 1
+                    if lo > 0:
+                        outer.append("strip * 63 >= {}".format(lo))
+                    if hi < G2 - 1:
+                        outer.append("strip * 63 + 62 <= {}".format(hi))
+                    outer.extend("!(strip * 63 <= {0} && {0} <= strip * 63 + 62)".format(e) for e in values)
+            S.append("  const bool interior_ = {};".format(" && ".join(outer) or "true"))
+        # carried state
+        for j in range(nz):
+            S.append("  T kx{0} = (T)0, gbx{0} = (T)0, gy{0} = (T)0;".format(j))
+        for name in acts:
+            S.append("  T2 mp_{0} = (T2)(0.0f);".format(name))
+        # ---- pre-step: the lower face along the marching axis at row r0 -------------------------------------------
+        S.append("  {")
+        S.append("  const int i{} = r0;".format(a1))
+        S.extend(parts["pre_lines"])
+        for k in range(nin):
+            S.append("  const T ux{0}_0 = {1}, ux{0}_1 = (T)0;".format(k, parts["pre_in"][k]))
+        S.extend(parts["mlp_fwd"])
+        for j in range(nz):
+            S.append("  kx{} = mu_z{}_{}.x;".format(j, nl, j))
+        for name in acts:
+            S.append("  mp_{0} = mu_{0};".format(name))
+        S.append("  }")
+        # ---- the march ----------------------------------------------------------------------------------------------
+        # the field values a step reads are requested during the step before (the step's arithmetic covers their
+        # latency: two resident waves per SIMD cannot)
+        pref = parts["pref"]
+        if pref:
+            S.append("  T {};".format(", ".join("ldn_{}".format(k) for k, _ in pref)))
+            S.append("  {{ const int i{} = r0;".format(a1))
+            for k, e in pref:
+                S.append("    ldn_{} = {};".format(k, e))
+            S.append("  }")
+        S.append("  for (int i{0} = r0; i{0} < r1; ++i{0}) {{".format(a1))
+        S.append("  const int l = {};".format(self._offset(["i{}".format(d) for d in range(self.ndim)], self.G)))
+        if pref:
+            for k, _ in pref:
+                S.append("  const T ld_{0} = ldn_{0};".format(k))
+            S.append("  {{ const int inext_ = min(i{0} + 1, r1 - 1); {{ const int i{0} = inext_;".format(a1))
+            for k, e in pref:
+                S.append("    ldn_{} = {};".format(k, e))
+            S.append("  } }")
+        for j in range(nz):
+            S.append("  T gax{0}, gbc{0}, gay{0}, gby{0}, zx{0};".format(j))
+        for name in acts:
+            S.append("  T2 mc_{};".format(name))
+
+        def body(var, inbox):
+            B = []
+            B.extend(self._inbox_lines(inbox))
+            B.extend(var["fwd1"])
+            for k, (bx, by, ay) in enumerate(var["xin"]):
+                B.append("  const T ux{0}_0 = {1}, ux{0}_1 = lane == 0 ? {3} : {2};".format(k, bx, by, ay))
+            B.extend(parts["mlp_fwd"])
+            for name in acts:
+                B.append("  mc_{0} = mu_{0};".format(name))
+            for j in range(nz):
+                z = "mu_z{}_{}".format(nl, j)
+                B.append("  const T m{}_z{}_{} = kx{};".format(Ax.idx, nl, j, j))
+                B.append("  const T m{}_z{}_{} = {}.x;".format(Bx.idx, nl, j, z))
+                B.append("  const T m{}_z{}_{} = {}.y;".format(By.idx, nl, j, z))
+                B.append("  const T m{}_z{}_{} = odil_lane_prev({}.y);".format(Ay.idx, nl, j, z))
+                B.append("  zx{} = {}.x;".format(j, z))
+            B.extend(var["fwd2"])
+            B.extend(var["rev"])
+            B.append("  if (valid) {")
+            for slot, (n, name) in enumerate(stored):
+                if stream:
+                    B.append("    __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
+                else:
+                    B.append("    a.cot[{}][l] = {};".format(slot, name))
+            for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
+                term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
+                if self.out_lens[k] is not None:
+                    term = "(inbox{} ? {} : (T)0)".format(k, term)
+                B.append("    s_{0} = s_{0} + {1};".format(k, term))
+            B.append("  }")
+            for j in range(nz):
+                B.append("  gax{0} = valid ? {1} : (T)0; gbc{0} = valid ? {2} : (T)0;".format(j, var["adj"]["ax"][j], var["adj"]["bx"][j]))
+                B.append("  gay{0} = valid ? {1} : (T)0; gby{0} = valid ? {2} : (T)0;".format(j, var["adj"]["ay"][j], var["adj"]["by"][j]))
+            return B
+
+        variants = parts["variants"]
+        if len(variants) == 1:
+            S.extend(body(variants[0], ()))
+        else:
+            S.append("  if (interior_ && {}) {{".format(" && ".join(rowc) or "true"))
+            S.extend(body(variants[1], plan[2]))
+            S.append("  } else {")
+            S.extend(body(variants[0], ()))
+            S.append("  }")
+        # reverse pass of the PREVIOUS step's evaluation: its own adjoints + what this row found for the carried face
+        S.append("  {")
+        for j in range(nz):
+            S.append("  const T ud{0}_0 = gbx{0} + gax{0}, ud{0}_1 = gy{0};".format(j))
+        S.extend(parts["mlp_bwd"])
+        S.append("  }")
+        for j in range(nz):
+            S.append("  kx{0} = zx{0}; gbx{0} = gbc{0}; gy{0} = gby{0} + odil_lane_next(gay{0});".format(j))
+        for name in acts:
+            S.append("  mp_{0} = mc_{0};".format(name))
+        S.append("  }")  # rows
+        # flush: the last row's evaluation (its upper face along the marching axis belongs to the next segment too)
+        S.append("  {")
+        for j in range(nz):
+            S.append("  const T ud{0}_0 = gbx{0}, ud{0}_1 = gy{0};".format(j))
+        S.extend(parts["mlp_bwd"])
+        S.append("  }")
+        S.append("  }")  # items
 
     def _gather_symbolic(self, S, gi, key, root):
         """The gather of ONE regular field as a pointwise kernel over its gradient expression."""
