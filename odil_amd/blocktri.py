@@ -54,8 +54,30 @@ def normal_stencil(op, key, damp=0.0, dampdiag=0.0):
     if zero not in normal:
         return None
     if damp or dampdiag:
-        normal[zero] = normal[zero] * (1.0 + float(dampdiag) ** 2) + float(damp) ** 2
+        normal[zero] = (normal[zero] + float(damp) ** 2) * (1.0 + float(dampdiag) ** 2)  # reference linsolver.py:19-23
     return normal
+
+
+def plausible(op, key):
+    """Cheap necessary condition for `recognise` to succeed, from the shifts alone (no grid-sized array is touched):
+    some axis with at least 4 levels, blocks of at most BLOCK_MAX points, along which the shifts of every output's
+    stencil entries differ by at most one level (S^T S then couples neighbouring levels only)."""
+    field = op.key_to_field[key]
+    shape = tuple(field.array.shape)
+    by_out = dict()
+    for row0, nrows, kind, k, payload in op.blocks:
+        if kind == "stencil" and k == key:
+            by_out.setdefault(row0, []).append(tuple(_centred(a, n) for a, n in zip(payload[1], shape)))
+    if not by_out:
+        return False
+    for axis, n in enumerate(shape):
+        nb = 1
+        for d, m in enumerate(shape):
+            if d != axis:
+                nb *= m
+        if n >= 4 and nb <= BLOCK_MAX and all(max(s[axis] for s in ss) - min(s[axis] for s in ss) <= 1 for ss in by_out.values()):
+            return True
+    return False
 
 
 def recognise(normal, shape):

@@ -27,6 +27,7 @@ import pickle
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import ops
 from .backend import ModRocm, numpy_dtype, torch_dtype
@@ -98,6 +99,7 @@ class _MgSynthFn(torch.autograd.Function):
         return ops.mg_synth([t.contiguous() for t in terms], loc, factors=factors)
 
     @staticmethod
+    @once_differentiable  # (raw HIP launches: a second derivative through here must fail loudly, not vanish)
     def backward(ctx, gu):
         grads = ops.mg_synth_adj(gu.contiguous(), ctx.shapes, ctx.loc, factors=ctx.factors)
         return (None, None) + tuple(grads)
@@ -110,6 +112,7 @@ class _FieldAccessFn(torch.autograd.Function):
         return ops.field_gather(src.contiguous(), field_loc, shift, loc)
 
     @staticmethod
+    @once_differentiable  # (raw HIP launches: a second derivative through here must fail loudly, not vanish)
     def backward(ctx, g):
         shape, field_loc, shift, loc = ctx.meta
         return ops.field_scatter(g.contiguous(), shape, field_loc, shift, loc), None, None, None
@@ -126,6 +129,7 @@ class _MeanFn(torch.autograd.Function):
         return ops.mean_reduce(x, square=square)
 
     @staticmethod
+    @once_differentiable  # (raw HIP launches: a second derivative through here must fail loudly, not vanish)
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
         n = x.numel()
@@ -142,6 +146,7 @@ class _InterpFn(torch.autograd.Function):
         return ops.interp_add(u.contiguous(), loc)
 
     @staticmethod
+    @once_differentiable  # (raw HIP launches: a second derivative through here must fail loudly, not vanish)
     def backward(ctx, g):
         return ops.interp_adj(g.contiguous(), ctx.loc, ctx.shape), None
 
@@ -153,6 +158,7 @@ class _RestrictFn(torch.autograd.Function):
         return ops.restrict_to_coarser(u.contiguous(), loc)
 
     @staticmethod
+    @once_differentiable  # (raw HIP launches: a second derivative through here must fail loudly, not vanish)
     def backward(ctx, g):
         return ops.restrict_adj(g.contiguous(), ctx.loc, ctx.shape), None
 
@@ -1086,9 +1092,13 @@ class Problem:
                 gg = torch.autograd.grad(v, arrs, grad_outputs=w, create_graph=True, allow_unused=True)
                 jacs = []
                 for g, a in zip(gg, arrs):
-                    if g is None or not g.requires_grad:
+                    if g is None:  # structurally independent of this array
                         jacs.append(torch.zeros(tuple(v.shape) + tuple(a.shape), dtype=v.dtype, device=v.device))
                         continue
+                    if not g.requires_grad:
+                        # J^T w that does not depend on w: the graph of the first pass was cut on the way (a backward
+                        # without a derivative of its own) -- NOT a zero Jacobian: row by row below
+                        raise RuntimeError("first reverse pass is not differentiable")
                     gflat = g.reshape(-1)
                     cols = [torch.autograd.grad(gflat[e], w, retain_graph=True)[0] for e in range(gflat.numel())]
                     jacs.append(torch.stack(cols, dim=-1).reshape(tuple(v.shape) + tuple(a.shape)))

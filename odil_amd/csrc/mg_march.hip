@@ -1604,6 +1604,9 @@ static bool adj_rows_launch(const T* gfine, T* gcoarse, T* gscaled, const MarchA
     for (int i = 0; i < 3; ++i)
       if (m.fn[i] != 2 * m.cn[i] || m.cn[i] < 4) return false;
     if (!aligned_to(gfine, 16) || !aligned_to(gcoarse, 8)) return false;
+    // results are stored as 8-byte packs at gcoarse + lead * cvol + ...: an odd leading stride (a strided view handed
+    // to odil_interp_adj_ld) would misalign every odd leading index
+    if (m.lead_fn > 1 && (m.lead_cstride % 2) != 0) return false;
     RowsArgs r;
     for (int i = 0; i < 3; ++i) r.cn[i] = m.cn[i], r.fn[i] = m.fn[i];
     r.lxlog = fnx == 256 ? 6 : (fnx == 128 ? 5 : 4);

@@ -39,7 +39,9 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     diag = op.normal_diagonal()
     shift = None
     if damp or dampdiag:
-        shift = torch.full_like(diag, float(damp) ** 2)
+        # reference linsolver.py:19-23: damp^2 I is added FIRST, dampdiag^2 times the diagonal of the already damped
+        # matrix second: A_ii -> (A_ii + damp^2) (1 + dampdiag^2)
+        shift = torch.full_like(diag, float(damp) ** 2 * (1.0 + float(dampdiag) ** 2))
         if dampdiag:
             ops.axpy(shift, diag, float(dampdiag) ** 2)
         ops.axpy(diag, shift, 1.0)
@@ -157,7 +159,7 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
     gg = ops.dense_xty(daug[:, :p], daug)  # p x (p + 1) = [D^T D | D^T r]
     G, g = gg[:, :p].clone(), gg[:, p].clone()
     if damp or dampdiag:
-        G.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * G.diagonal().clone())
+        G.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * (G.diagonal().clone() + float(damp) ** 2))  # (as cg_normal)
     x = torch.zeros(op.ncols, dtype=dtype, device=device)
     dcols = torch.cat([torch.arange(op.key_to_offset[k], op.key_to_offset[k] + op.key_to_size[k], device=device)
                        for k in dense_keys])
@@ -224,7 +226,12 @@ def blocktri_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
         return None  # unknowns no block refers to: the general routes regularise or report them
     if key in dense_keys:
         return None
-    inner = blocktri.BlockTridiagonalNormal(op, key, damp, dampdiag)
+    if not blocktri.plausible(op, key):
+        return None  # (before any grid-sized product is formed)
+    try:
+        inner = blocktri.BlockTridiagonalNormal(op, key, damp, dampdiag)
+    except (RuntimeError, MemoryError):  # (out of memory while forming S^T S: the matrix-free routes need far less)
+        return None
     if not inner.ok:
         return None
     inner.offset, inner.size = op.key_to_offset[key], op.key_to_size[key]
@@ -330,7 +337,7 @@ def dense_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
     b = m.t() @ rhs
     if damp or dampdiag:
         d = a.diagonal().clone()
-        a.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * d)
+        a.diagonal().add_(float(damp) ** 2 + float(dampdiag) ** 2 * (d + float(damp) ** 2))  # (reference linsolver.py:19-23)
     chol, info = torch.linalg.cholesky_ex(a)
     if int(info) == 0:
         x = torch.cholesky_solve(b[:, None], chol)[:, 0]

@@ -485,8 +485,20 @@ class TracedOperator:
                 total = term if total is None else total + term
             used = [i for i in sorted(leaves)]
             grads = torch.autograd.grad(total, [leaves[i] for i in used], allow_unused=True) if total.requires_grad else []
+        # parameter arrays the grid kernels write no gradient for (an Array that appears only in a prior, a network frozen
+        # on the grid but regularised): nothing overwrites their slots of the packed gradient, so they are SET here --
+        # adding would accumulate over evaluations
+        fresh = set()
+        for key, kind, pos, n in self.layout:
+            if kind == "net" and key not in self.cg.pgrads:
+                fresh.update(range(pos, pos + n))
         for i, g in zip(used, grads):
-            if g is not None:
+            if g is None:
+                if i in fresh:
+                    self.gviews[i].zero_()
+            elif i in fresh:
+                self.gviews[i].copy_(g.to(self.gviews[i].dtype))
+            else:
                 self.gviews[i].add_(g.to(self.gviews[i].dtype))
         for k, term in extra:
             term = term.detach().to(loss.dtype)

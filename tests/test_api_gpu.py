@@ -154,7 +154,8 @@ def newton_operator(ctx):
 
 def damped_want(g, y):
     a = g["matrix"].T @ g["matrix"]
-    return np.linalg.solve(a + 0.09 * np.eye(len(a)) + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)
+    a = a + 0.09 * np.eye(len(a))  # reference linsolver.py:19-23: damp first, dampdiag on the damped diagonal
+    return np.linalg.solve(a + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)
 
 
 def make_newton_problem(mod, g):
@@ -209,7 +210,9 @@ def test_newton_linearize_and_step_vs_golden(mod):
     assert rel(odil.linsolver.schur_normal(op, rhs, damp=0.3, dampdiag=0.2), damped_want(g, y)) < 1e-9
     damped = odil.linsolver.dense_normal(op, rhs, damp=0.3, dampdiag=0.2)
     a = g["matrix"].T @ g["matrix"]
-    assert rel(damped, np.linalg.solve(a + 0.09 * np.eye(len(a)) + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)) < 1e-9
+    # reference linsolver.py:19-23: damp^2 I first, then dampdiag^2 times the diagonal of the DAMPED matrix
+    a = a + 0.09 * np.eye(len(a))
+    assert rel(damped, np.linalg.solve(a + 0.04 * np.diag(np.diag(a)), g["matrix"].T @ y)) < 1e-9
     assert rel(odil.linsolver.cg_normal(op, rhs, damp=0.3, dampdiag=0.2, tol=1e-14), damped.cpu().numpy()) < 1e-8
     # one Newton step through optimize_newton
     args = argparse.Namespace(epoch_start=0, epochs=1, linsolver="direct", linsolver_maxiter=None, linsolver_damp=0,
@@ -371,3 +374,41 @@ def test_newton_poisson_through_geometric_multigrid(mod, ndim, N):
     delta = odil.linsolver.solve(matrix, -vector, args, status, "multigrid")
     assert status["method"] == "gmg-vcycle" and status["niter"] < 25
     assert float((state2.fields["u"].array.reshape(-1) + delta - u_fast.reshape(-1)).abs().max()) < 1e-9
+
+
+def test_dense_jacobian_through_a_hip_transfer(mod):
+    """Dense Jacobian columns of network parameters (`tape.jacobian`, reference core.py:1347-1349) when the network's
+    output passes through one of this package's HIP-backed autograd functions (a prolongation): the one-pass-per-parameter
+    route needs a second derivative those functions do not have -- it must fall back to row-by-row passes, not drop the
+    block.  Checked against central differences of the operator in the weights."""
+    domain = odil.Domain(cshape=(6,), dimnames=["x"], multigrid=0, dtype=np.float64)
+    mod.random.set_seed(7)
+    state = odil.State(fields={"u": odil.Field(np.zeros(12), loc="c", cshape=(12,)),
+                               "a": odil.Array(np.linspace(-1, 1, 6)), "net": domain.make_neural_net([1, 4, 1])})
+    state = domain.init_state(state)
+
+    def operator(ctx):
+        coarse = ctx.neural_net("net")(ctx.field("a"))[0]
+        return [("f", odil.core.interp_to_finer(coarse, loc="c", mod=ctx.mod) * 3.0 - 0.5)]
+
+    problem = odil.Problem(operator, domain)
+    vector, matrix = problem.linearize(state)
+    dense = matrix.toarray()
+    arrays = domain.arrays_from_state(state)
+    sizes = [int(a.numel()) for a in arrays]
+    nfield = sizes[0]
+    assert dense.shape == (12, sum(sizes)) and np.all(dense[:, :nfield] == 0)  # u does not enter
+    h, col = 1e-6, nfield
+    for k in range(1, len(arrays)):
+        for e in range(sizes[k]):
+            vals = []
+            for sign in (1.0, -1.0):
+                pert = [a.clone() for a in arrays]
+                pert[k].view(-1)[e] += sign * h
+                domain.arrays_to_state(pert, state)
+                vals.append(npy(problem.eval_operator(state)[0][0]).reshape(-1))
+            domain.arrays_to_state(arrays, state)
+            fd = (vals[0] - vals[1]) / (2 * h)
+            assert np.max(np.abs(dense[:, col] - fd)) <= 1e-7 * max(1.0, np.max(np.abs(fd))), (k, e)
+            col += 1
+    assert np.max(np.abs(dense[:, nfield + sizes[1]:])) > 0.1  # the network block is there

@@ -43,7 +43,8 @@ HEAT = [[(0, 0), (0, 1), (0, -1), (-1, 0), (-1, 1), (-1, -1)], [(0, 0)], [(0, 0)
 def test_normal_stencil_and_blocks_equal_dense(shape):
     outputs = HEAT if len(shape) == 2 else [[(0, 0, 0), (0, 1, 0), (0, 0, -1), (-1, 0, 0), (-1, 0, 1)], [(0, 0, 0), (-1, 0, 0)]]
     op, S = fake_op(shape, outputs, 3)
-    A = S.t() @ S + 0.3**2 * torch.eye(S.shape[1], dtype=torch.float64) + 0.2**2 * torch.diag(torch.diag(S.t() @ S))
+    A = S.t() @ S + 0.3**2 * torch.eye(S.shape[1], dtype=torch.float64)
+    A = A + 0.2**2 * torch.diag(torch.diag(A))  # reference linsolver.py:19-23: dampdiag acts on the damped matrix
     normal = blocktri.normal_stencil(op, "u", damp=0.3, dampdiag=0.2)
     axis = blocktri.recognise(normal, shape)
     assert axis == 0

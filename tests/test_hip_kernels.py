@@ -733,6 +733,28 @@ def test_transfers_on_views_with_a_leading_stride(dev, dtype, loc, full, lo, n):
         assert bool((dst_big.cpu()[rest] == 7.0).all())
 
 
+def test_float_transpose_into_a_view_with_an_odd_leading_stride(dev):
+    """P^T of float '.ccc' volumes with fine rows of 64 cells is served by the row-marching kernel, which stores 8-byte
+    packs at `lead * stride + ...`: a result view whose leading stride is ODD (here 4 * 4 * 32 + 1 elements) must take
+    another route -- every odd leading index would be a misaligned vector store -- and still give the contiguous result."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(67)
+    loc, cshape = ".ccc", (3, 4, 4, 32)
+    g = to(rng.standard_normal(ops.fine_shape(cshape, loc)).astype(np.float32), dev)
+    want = ops.interp_adj(g, loc, cshape)
+    ld = 4 * 4 * 32 + 1
+    base = torch.full((3 * ld + 8,), 7.0, dtype=torch.float32, device=dev)
+    view = base.as_strided(cshape, (ld, 4 * 32, 32, 1))
+    for route in (ops.interp_adj, ops.interp_adj_best):
+        base.fill_(7.0)
+        route(g, loc, cshape, out=view)
+        assert torch.equal(view, want)
+        touched = torch.zeros_like(base, dtype=torch.bool)
+        touched.as_strided(cshape, (ld, 4 * 32, 32, 1)).fill_(True)
+        assert bool((base[~touched] == 7.0).all())
+
+
 def test_adjoint_and_transpose_in_one_launch_is_race_free(dev):
     """The one-launch kernel hands g0 from the lanes that form it to the lanes that consume it through LDS, one
     plane behind: a missing barrier shows as run-to-run differences on a grid with many resident workgroups.

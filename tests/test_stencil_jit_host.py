@@ -160,6 +160,30 @@ def test_outputs_in_parameter_space_are_taped(cpu_mod):
     assert abs(float(terms[2]) - float((0.125 * w).square().mean())) < 1e-6 * float(terms[2])
 
 
+def test_offgrid_only_parameters_do_not_accumulate(cpu_mod):
+    """An `Array` that appears ONLY in a parameter-space output (a prior) gets its gradient from the tape replay alone:
+    no grid kernel rewrites its slot of the packed gradient, so repeated evaluations must SET it, not add to it."""
+    import torch
+
+    domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
+    state = odil.State(fields={"u": odil.Field(None, loc="cc"), "p": odil.Array(np.array([1.0, -2.0, 0.5]))})
+    state = domain.init_state(state)
+
+    def operator(ctx):
+        p = ctx.domain.arrays_from_field(ctx.state.fields["p"])[0]
+        return [("fu", ctx.field("u") - 1.0), ("prior", p * 2.0)]
+
+    problem = odil.Problem(operator, domain)
+    tro = stencil_jit.TracedOperator(problem, state)
+    assert [k for k, _, _ in tro.offgrid] == [1] and "p" not in tro.cg.pgrads
+    pidx = [pos for key, kind, pos, n in tro.layout if key == "p"][0]
+    one = torch.tensor(1.0, dtype=torch.float64)
+    want = 2 * 2.0 * 2.0 * np.array([1.0, -2.0, 0.5]) / 3  # d mean((2 p)^2) / d p
+    for _ in range(3):
+        tro._eval_offgrid(state, one, [one], [one])
+        assert np.allclose(tro.gviews[pidx].numpy(), want, rtol=1e-14), tro.gviews[pidx]
+
+
 def test_untraceable_operators_are_refused(cpu_mod):
     domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
     state = odil.State()
