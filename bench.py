@@ -286,8 +286,9 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         exchanges_per_epoch=2 if world > 1 else 0)
 
 
-def run_tracer(args, rank, world, dev, comm, barrier):
-    """BASELINE config 5: velocity from tracer with three space dimensions, slab-decomposed along x."""
+def make_tracer_rank(args, rank, world, dev):
+    """One rank of BASELINE config 5 (velocity from tracer with three space dimensions, slab-decomposed along x):
+    (SlabTracedAdam, (nt, nx_rank, ny), levels, parsed example arguments)."""
     sys.path.insert(0, os.path.join(ROOT, "examples", "velocity_from_tracer"))
     import odil_amd as odil
     import veltracer3d
@@ -313,6 +314,12 @@ def run_tracer(args, rank, world, dev, comm, barrier):
     problem = odil.Problem(veltracer3d.operator, domain, extra)
     nlvl = domain.mg_nlvl
     run = SlabTracedAdam(problem, shape_state(domain, state), rank, world, lr=a.lr, device=dev)
+    return run, (nt, nx_rank, ny), nlvl, a
+
+
+def run_tracer(args, rank, world, dev, comm, barrier):
+    """BASELINE config 5: velocity from tracer with three space dimensions, slab-decomposed along x."""
+    run, (nt, nx_rank, ny), nlvl, a = make_tracer_rank(args, rank, world, dev)
     timers = Timers(only=("forward",), prealloc=args.steps + 4)
     import gc
 
@@ -473,6 +480,29 @@ def run_api(args, dev):
                 dtype=out["dtype"], exchanges_per_epoch=0, steps=out["epochs"])
 
 
+def check_parity(args, res, world):
+    """The run checks ITSELF: the (all-reduced) loss after warmup + steps epochs against profiles/expected_losses.json --
+    the same deterministic workload with its ranks emulated on one GPU (tools/expected_losses.py: device copies instead
+    of RCCL messages, the same kernels).  A wrong halo, a reused receive buffer or a missed wait on the first real
+    multi-GPU run changes the trajectory and fails here instead of printing a plausible number.  None: no reference for
+    this configuration (other sizes / more epochs than recorded)."""
+    key = {"4a": "poisson_512", "5": "tracer_cfg5"}.get(args.config)
+    if key is None or args.scale != 1.0 or (args.config == "4a" and (args.ndim, args.N, args.dtype) != (3, 512, "f64")):
+        return None
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "expected_losses.json")))
+    except OSError:
+        return None
+    ref, k = table.get(key, dict()).get(str(world)), args.warmup + args.steps
+    if not ref or not 1 <= k <= len(ref):
+        return None
+    want, got = float(ref[k - 1]), float(res["loss"])
+    tol = 1e-9 if res["dtype"] == "f64" else 1e-4  # (the trajectory is bit-identical by construction: only the order of the
+    err = abs(got - want) / abs(want)             # ranks' partial sums in the all-reduce of the LOSS differs)
+    return {"ok": bool(err <= tol), "rel_err": err, "expected": want, "tol": tol, "epoch": k,
+            "source": "profiles/expected_losses.json ({} ranks emulated on one GPU)".format(world)}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -556,14 +586,23 @@ def main():
             }
         out["kernel_ms"] = res["kernel_ms"]
         out["loss_after"] = res["loss"]
+        parity = check_parity(args, res, world)
+        out["parity_ok"] = None if parity is None else parity["ok"]
+        out["parity"] = parity
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if others is not None:
             out["other_configs"] = others
         out["spinup_ms"] = args.spinup_ms
         print(json.dumps(out))
+        failed = parity is not None and not parity["ok"]
+    else:
+        failed = False
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: loss {} after {} epochs differs from the emulated-rank reference {} (rel {:.2e})".format(
+            res["loss"], parity["epoch"], parity["expected"], parity["rel_err"]))
 
 
 if __name__ == "__main__":

@@ -139,7 +139,7 @@ class HipSlabKernels:
                 ("par", ctypes.c_void_p * max(1, cg.par_arrays)),
                 ("hs", ctypes.c_void_p), ("hsv", ctypes.c_double * max(1, len(cg.hs))),
                 ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
-                ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
+                ("pgrad", ctypes.c_void_p), ("edge", ctypes.c_void_p), ("nblocks", ctypes.c_int),
                 ("off", ctypes.c_int), ("lo", ctypes.c_int), ("ea", ctypes.c_int), ("hw", ctypes.c_int),
                 ("wlo", ctypes.c_void_p * nsrc), ("whi", ctypes.c_void_p * nsrc),
                 ("gwlo", ctypes.c_void_p * nsrc), ("gwhi", ctypes.c_void_p * nsrc),

@@ -256,6 +256,7 @@ class _Codegen:
         self.fold = None  # emitting the interior copy of a body: {predicate node idx: constant value} (_fold_plan)
         self.wregs = "mem"  # where the marching kernel keeps network parameters (source())
         self.march_pref = None  # marching kernel: {read descriptor: (slot, load expression)} of the reads requested a step ahead
+        self.march_live, self.march_used = None, set()  # ... nodes the variant being emitted really evaluates; slots it reads
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
@@ -565,6 +566,21 @@ class _Codegen:
             return None
         return fold, {d: sorted(v) for d, v in exc.items() if v}, inbox
 
+    def _live_under(self, fold):
+        """Indices of the nodes the outputs depend on once the predicates of `fold` have their constant values: a `where`
+        with a decided condition reaches only the branch it takes."""
+        live, stack = set(), list(self.outputs)
+        while stack:
+            n = stack.pop()
+            if n.idx in live:
+                continue
+            live.add(n.idx)
+            if n.op == "where" and n.args[0].idx in fold:
+                stack.append(n.args[1] if fold[n.args[0].idx] else n.args[2])
+            elif n.idx not in fold:
+                stack.extend(n.args)
+        return live
+
     def _interior_cond(self, exc):
         """C expression: none of the thread's indices is exceptional."""
         conds = []
@@ -732,9 +748,10 @@ class _Codegen:
             idx.append(j)
         if not fast:
             e = "*({})".format(self._address(key, ptr, fshape, idx, sa))
-            if self.march_pref is not None and not zero and not pre_lines:
+            if self.march_pref is not None and not zero and not pre_lines and (self.march_live is None or n.idx in self.march_live):
                 # marching kernel: the value was requested one step ahead (_march_kernel)
                 slot = self.march_pref.setdefault(desc, (len(self.march_pref), e))[0]
+                self.march_used.add(slot)
                 self.emit("const T v{} = ld_{};".format(n.idx, slot))
                 self.loads[desc] = "v{}".format(n.idx)
                 return
@@ -844,6 +861,13 @@ class _Codegen:
         line = "const {} v{} = {}((const {}*)a.ten[{}])[{}];".format(
             ktype, n.idx, cast, ctype, slot, " + ".join(terms) or "0")
         tdt = "float" if self.tr.torch_dtype == torch.float32 else "double"
+        if (self.march_pref is not None and n.kind == _R and self.vw == 1
+                and (self.march_live is None or n.idx in self.march_live)):
+            e = "{}((const {}*)a.ten[{}])[{}]".format(cast, ctype, slot, " + ".join(terms) or "0")
+            k = self.march_pref.setdefault(("@ten", n.op, n.attr), (len(self.march_pref), e))[0]
+            self.march_used.add(k)
+            self.emit("const T v{} = ld_{};".format(n.idx, k))
+            return
         if self.vw == 4 and shape[last] == 1:
             self.pre.append("  " + line)  # the same value for the thread's four points: loaded once
         elif (self.vw == 4 and shape[last] == self.G[last] and ctype == tdt and (roll is None or not roll[last])
@@ -977,6 +1001,8 @@ class _Codegen:
         return out if len(out) == len(self.order) else None
 
     def _act(self, kind, x, width=1):
+        if "tanh" in os.environ.get("ODIL_TRACE_ABLATE", "") and kind == "tanh":  # (timing experiment: wrong results)
+            return "({0} * (T)0.5)".format(x) if width == 1 else "({0} * 0.5f)".format(x)
         if width == 2:
             return {"tanh": "odil_fast_tanh2({})", "relu": "__builtin_elementwise_max({}, (T2)(0.0f))", "none": "{}"}[kind].format(x)
         tanh = "odil_fast_tanh({})" if self.fast else "FN(tanh)({})"  # (network activations: see the prelude)
@@ -1260,7 +1286,10 @@ class _Codegen:
         self._launder_params(base, nl)
         for j, vals in enumerate(dvals):
             self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals if width == 1 else "{{{}, {}}}".format(*vals)))
-        if not frozen and width == 2:
+        # (marching kernel, ODIL_TRACE_MARCH_ACC=t: the two slots of a packed evaluation summed into ONE accumulator per
+        # parameter -- two multiply-adds instead of one packed one, half the 92 accumulator registers of a [1, 5, 5, 1] net)
+        acc1 = width == 2 and getattr(self, "acc_scalar", False)
+        if not frozen and width == 2 and not acc1:
             self.pg2_used.add(key)
         if not frozen and key not in self.pgrads:
             names = []
@@ -1273,7 +1302,13 @@ class _Codegen:
             self.pg_decl.extend(name for group in names for name in group)
         for l in range(nl, 0, -1):
             ni, no = layers[l - 1], layers[l]
-            if not frozen:
+            if not frozen and acc1:
+                for j in range(no):
+                    for i in range(ni):
+                        self.emit("pw_{0}_{1}_{2} = pw_{0}_{1}_{2} + ({3}_d{4}_{5}.x * {3}_h{6}_{7}.x + {3}_d{4}_{5}.y * {3}_h{6}_{7}.y);".format(
+                            base, l - 1, j * ni + i, p, l, j, l - 1, i))
+                    self.emit("pb_{0}_{1}_{2} = pb_{0}_{1}_{2} + ({3}_d{4}_{2}.x + {3}_d{4}_{2}.y);".format(base, l - 1, j, p, l))
+            elif not frozen:
                 for j in range(no):
                     for i in range(ni):
                         self.emit("pw{8}_{0}_{1}_{2} = pw{8}_{0}_{1}_{2} + {3}_d{4}_{5} * {3}_h{6}_{7};".format(
@@ -1504,9 +1539,14 @@ class _Codegen:
         stored = ([(n, "g{}".format(n.idx)) for n in self.cots] + [(n, "g{}".format(n.idx)) for n in self.cut_nodes]
                   + [(self.outputs[k], name) for k, name in self.jac_store])  # cut arrays follow the read cotangents
         self.ncot = len(stored)
+        self.edge_numel = 0
+        mgather = march["gather"] if march is not None else None
+        if mgather is not None:  # one array per (field, leading shift) + the edge arrays (_march_gather_plan)
+            self.ncot = len(mgather["groups"])
+            self.edge_numel = self._march_edge_offsets(self.ncot)[1]
         for slot_k, (k, _) in enumerate(self.jac_store):
             self.pseudo_slot[self.seed_key[k]] = len(self.cots) + len(self.cut_nodes) + slot_k
-        stream = len(stored) * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
+        stream = self.ncot * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
         if tiled is not None:
             self._tile_kernel(S, tiled, stored, stream)
         if march is not None:
@@ -1609,6 +1649,16 @@ class _Codegen:
         S.append("  a.out[0] = loss;")
         S.append("}")
         # ---- gathers -------------------------------------------------------------------------------------------
+        if mgather is not None:
+            self._march_gather_kernels(S, mgather)
+        self.gathers_done = mgather is not None
+        self._standard_gathers(S)
+        self._launchers(S, nout, par_arrays, HEAD)
+        return "\n".join(HEAD + S) + "\n"
+
+    def _standard_gathers(self, S):
+        if self.gathers_done:
+            return
         self.gathers = []  # keys of the fields that need a gather launch
         self.gather_reads_sources = dict()  # key -> the gather reads the fields' own arrays (not only stored adjoints)
         self.direct = dict()  # key -> cot slot that already IS the gradient
@@ -1704,6 +1754,8 @@ class _Codegen:
             S.append("  hipLaunchKernelGGL(k_gat_all, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, ga);".format(nblocks_all))
             S.append("  return (int)hipGetLastError();")
             S.append("}")
+
+    def _launchers(self, S, nout, par_arrays, HEAD):
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
         S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3({}), 0, (hipStream_t)stream, *a);".format(self.fwd_threads))
@@ -1744,11 +1796,10 @@ class _Codegen:
         # copy, nothing the host rewrites later is read by a queued kernel; a launch captured into a hipGraph
         # reads them from device memory instead (hs != NULL: the row of the epoch being replayed)
         HEAD.append("struct Args {{ const T* src[{}]; const void* ten[{}]; T* cot[{}]; const T* par[{}]; const double* hs; "
-                    "double hsv[{}]; T* part; T* ppart; T* part2; T* out; T* pgrad; int nblocks;{} }};".format(
+                    "double hsv[{}]; T* part; T* ppart; T* part2; T* out; T* pgrad; T* edge; int nblocks;{} }};".format(
                         nsrc, max(1, len(self.tr.tensors)), max(1, self.ncot),
                         max(1, par_arrays), max(1, len(self.hs)), slab_members))
         HEAD.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
-        return "\n".join(HEAD + S) + "\n"
 
     def _tile_parts(self):
         """Line groups of the tiled forward kernel (see _tile_kernel)."""
@@ -1945,6 +1996,7 @@ class _Codegen:
         lines before and after the shared network values, and the reverse pass."""
         a1, a2 = self.ndim - 2, self.ndim - 1
         self.wregs = os.environ.get("ODIL_TRACE_MARCH_W", "const")
+        self.acc_scalar = os.environ.get("ODIL_TRACE_MARCH_ACC", "t2") == "t"
         by_axis = {axis: (A, B) for A, B, axis in self.share}
         (Ax, Bx), (Ay, By) = by_axis[a1], by_axis[a2]
         shared = {x.idx for x in (Ax, Bx, Ay, By)}
@@ -1964,6 +2016,7 @@ class _Codegen:
         self.march_pref = dict() if int(os.environ.get("ODIL_TRACE_MARCH_PREFETCH", 1)) else None
         for fold in ([None] if plan is None else [None, plan[0]]):
             self.fold, self.lines, self.loads = fold, [], dict()
+            self.march_live, self.march_used = (None if fold is None else self._live_under(fold)), set()
             self.cots, self.cut_nodes, self.jac_store, self.pg_decl, self.pg_offset, self.pg2_used = [], [], [], [], dict(), set()
             self.forward(only=early)
             fwd1, self.lines = self.lines, []
@@ -1985,12 +2038,13 @@ class _Codegen:
             elif ([n.idx for n in state["cots"]] != [n.idx for n in first["cots"]] or state["pg_decl"] != first["pg_decl"]
                   or [n.idx for n in state["cut_nodes"]] != [n.idx for n in first["cut_nodes"]]):
                 raise RuntimeError("interior copy of the traced kernel stores other adjoints than the general one")
-            parts["variants"].append(dict(fwd1=fwd1, fwd2=fwd2, rev=rev, xin=xin, adj=adj))
-        self.fold = None
+            parts["variants"].append(dict(fwd1=fwd1, fwd2=fwd2, rev=rev, xin=xin, adj=adj, used=set(self.march_used)))
+        self.fold, self.march_live = None, None
         parts["pref"] = sorted(self.march_pref.values()) if self.march_pref else []
         self.march_pref = None
         for k, v in first.items():
             setattr(self, k, v)
+        parts["gather"] = self._march_gather_plan()
         # the pre-step of a row segment: the inputs of the LOWER face along the marching axis at the segment's first row
         saved = (self.order, self.loads, self.pre, self.groups)
         seen = dict()
@@ -2011,6 +2065,126 @@ class _Codegen:
         layers = attr[2]
         parts["acts"] = ["h{}_{}".format(l, i) for l in range(nlast) for i in range(layers[l])]  # what the reverse pass reads
         return parts
+
+    def _march_gather_plan(self):
+        """The cotangents of the reads of a marching kernel summed IN the kernel over the marching axis (a three-row delay
+        line in registers) and over the lane axis (lane shifts) before they are stored: one array per (field, shift on the
+        leading axes) instead of one per stencil read -- heat with two space dimensions: 2 instead of 10 (32 bytes per
+        point less written by k_fwd and read again by the gather).  What crosses a segment of rows or a strip of columns
+        goes to small EDGE arrays which the final gather adds.  None when the reads do not have that shape."""
+        if not int(os.environ.get("ODIL_TRACE_MARCH_GATHER", 1)) or self.cut_nodes or self.jac_store or not self.cots:
+            return None
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        groups = dict()
+        for slot, n in enumerate(self.cots):
+            key, shift, loc, _ = n.attr
+            if not self._regular(n):
+                return None
+            cs = []
+            for d, sh in enumerate(shift):
+                ext = self.G[d]
+                v = sh % ext
+                cs.append(v - ext if v > ext // 2 else v)
+            sx, sy = cs[a1], cs[a2]
+            if abs(sx) > 1 or abs(sy) > 1 or (sx and sy):
+                return None
+            groups.setdefault((key, tuple(cs[:a1])), []).append((slot, sx, sy))
+        if any(adj is not None for adj in self.out_adj):
+            return None
+        return dict(groups=list(groups.items()))
+
+    def _march_gather_geometry(self):
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        G1, G2 = self.G[a1], self.G[a2]
+        R = max(1, min(int(os.environ.get("ODIL_TRACE_MARCH_ROWS", 64)), G1))
+        nseg, nstrip = (G1 + R - 1) // R, (G2 + 62) // 63
+        lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
+        return R, nseg, nstrip, lead
+
+    def _march_edge_offsets(self, ngroups):
+        """Element offsets into a.edge of the four edge arrays of every group: E_lo, E_hi [lead, nseg, G2] (rows that
+        cross a segment), F_lo, F_hi [lead, G1, nstrip] (columns that cross a strip); total size."""
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        R, nseg, nstrip, lead = self._march_gather_geometry()
+        esz, fsz = lead * nseg * self.G[a2], lead * self.G[a1] * nstrip
+        offs, o = [], 0
+        for _ in range(ngroups):
+            offs.append((o, o + esz, o + 2 * esz, o + 2 * esz + fsz))
+            o += 2 * esz + 2 * fsz
+        return offs, o
+
+    def _march_gather_kernels(self, S, plan):
+        """The final gathers of a marching kernel with the in-kernel partial sums (_march_gather_plan): per field
+        g[j] = sum over its groups of (P + edge terms)[j - leading shift], four points of the last axis per thread."""
+        a1, a2 = self.ndim - 2, self.ndim - 1
+        G1, G2 = self.G[a1], self.G[a2]
+        R, nseg, nstrip, lead = self._march_gather_geometry()
+        groups = plan["groups"]
+        offs, _ = self._march_edge_offsets(len(groups))
+        vw = 4 if G2 % 4 == 0 else 1
+        keys = []
+        for (key, _), _ in groups:
+            if key not in keys:
+                keys.append(key)
+        self.gathers, self.direct, self.merged, self.gather_blocks = list(keys), dict(), [], dict()
+        self.gather_reads_sources = {key: [] for key in keys}
+        for gi, key in enumerate(keys):
+            threads = self.total // vw
+            self.gather_blocks[gi] = (threads + 255) // 256
+            S.append('extern "C" __global__ __launch_bounds__(NB) void k_gat_{}(const Args a, T* __restrict__ g, const AdamP ad) {{'.format(gi))
+            S.append("  const int lr = blockIdx.x * NB + threadIdx.x;")
+            S.append("  if (lr >= {}) return;".format(threads))
+            names = ["i{}".format(d) for d in range(self.ndim)]
+            self._index_prologue(S, self.G, names, vw, "lr")
+            if vw == 1:
+                S.append("  const int ib = i{};".format(a2))
+            S.append("  T acc[{}];".format(vw))
+            S.append("  for (int p = 0; p < {}; ++p) acc[p] = (T)0;".format(vw))
+            S.append("  const int seg = i{} / {};".format(a1, R))
+            for k, ((gkey, lshift), _) in enumerate(groups):
+                if gkey != key:
+                    continue
+                e_lo, e_hi, f_lo, f_hi = offs[k]
+                S.append("  {")
+                # the point this group's sums were formed at: j - leading shift (periodic)
+                lidx = []
+                for d in range(a1):
+                    lidx.append("i{}".format(d) if lshift[d] == 0 else "wrap(i{} - ({}), {})".format(d, lshift[d], self.G[d]))
+                lflat = self._offset(lidx, self.G[:a1]) if a1 > 0 else "0"
+                S.append("  const int lf = {};".format(lflat))
+                S.append("  const T* const P = a.cot[{}] + ((long)lf * {} + i{}) * {};".format(k, G1, a1, G2))
+                if vw == 4:
+                    S.append("  { const T4 q = *(const T4*)(P + ib); acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w; }")
+                else:
+                    S.append("  acc[0] += P[ib];")
+                # rows that received a contribution from the neighbouring segment
+                S.append("  if (i{0} % {1} == {1} - 1 || i{0} == {2}) {{".format(a1, R, G1 - 1))
+                S.append("    const T* const E = a.edge + {} + ((long)lf * {} + (seg + 1 == {} ? 0 : seg + 1)) * {};".format(e_lo, nseg, nseg, G2))
+                S.append("    for (int p = 0; p < {}; ++p) acc[p] += E[ib + p];".format(vw))
+                S.append("  }")
+                S.append("  if (i{} % {} == 0) {{".format(a1, R))
+                S.append("    const T* const E = a.edge + {} + ((long)lf * {} + (seg == 0 ? {} : seg - 1)) * {};".format(e_hi, nseg, nseg - 1, G2))
+                S.append("    for (int p = 0; p < {}; ++p) acc[p] += E[ib + p];".format(vw))
+                S.append("  }")
+                # columns that received a contribution from the neighbouring strip
+                S.append("  for (int p = 0; p < {}; ++p) {{".format(vw))
+                S.append("    const int c = ib + p, st = c / 63;")
+                S.append("    const T* const F = a.edge + ((long)lf * {} + i{}) * {};".format(G1, a1, nstrip))
+                S.append("    if (c % 63 == 62 || c == {}) acc[p] += F[{} + (st + 1 == {} ? 0 : st + 1)];".format(G2 - 1, f_lo, nstrip))
+                S.append("    if (c % 63 == 0) acc[p] += F[{} + (st == 0 ? {} : st - 1)];".format(f_hi, nstrip - 1))
+                S.append("  }")
+                S.append("  }")
+            o = "lr * 4" if vw == 4 else "lr"
+            if vw == 4:
+                if self.nt_streams:
+                    S.append("  __builtin_nontemporal_store((T4){{acc[0], acc[1], acc[2], acc[3]}}, (T4*)(g + {}));".format(o))
+                else:
+                    S.append("  *(T4*)(g + {}) = (T4){{acc[0], acc[1], acc[2], acc[3]}};".format(o))
+                S.append("  adam_apply4(ad, {}, acc);".format(o))
+            else:
+                S.append("  g[{}] = acc[0];".format(o))
+                S.append("  adam_apply(ad, {}, acc[0]);".format(o))
+            S.append("}")
 
     def _march_kernel(self, S, parts, stored, stream):
         """Body of the MARCHING forward kernel of an operator that evaluates one pointwise network at the faces of every
@@ -2097,6 +2271,10 @@ class _Codegen:
                     outer.extend("!(strip * 63 <= {0} && {0} <= strip * 63 + 62)".format(e) for e in values)
             S.append("  const bool interior_ = {};".format(" && ".join(outer) or "true"))
         # carried state
+        mg = parts["gather"]
+        if mg is not None:
+            for k in range(len(mg["groups"])):
+                S.append("  T ap{0} = (T)0, ac{0} = (T)0;".format(k))  # sums of rows r - 1 and r so far
         for j in range(nz):
             S.append("  T kx{0} = (T)0, gbx{0} = (T)0, gy{0} = (T)0;".format(j))
         for name in acts:
@@ -2129,13 +2307,27 @@ class _Codegen:
             for k, _ in pref:
                 S.append("  const T ld_{0} = ldn_{0};".format(k))
             S.append("  {{ const int inext_ = min(i{0} + 1, r1 - 1); {{ const int i{0} = inext_;".format(a1))
+            always = parts["variants"][-1]["used"] if len(parts["variants"]) > 1 else {k for k, _ in pref}
             for k, e in pref:
-                S.append("    ldn_{} = {};".format(k, e))
+                if k in always:
+                    S.append("    ldn_{} = {};".format(k, e))
+            if len(always) < len(pref):  # what only the general copy of the body reads: when the next row takes that copy
+                S.append("    if (!(interior_ && {})) {{".format(" && ".join(rowc) or "true"))
+                for k, e in pref:
+                    if k not in always:
+                        S.append("      ldn_{} = {};".format(k, e))
+                S.append("    }")
             S.append("  } }")
         for j in range(nz):
             S.append("  T gax{0}, gbc{0}, gay{0}, gby{0}, zx{0};".format(j))
         for name in acts:
             S.append("  T2 mc_{};".format(name))
+        if mg is not None:
+            for k in range(len(mg["groups"])):
+                S.append("  T cm{0}, c0{0}, cp{0}, yl{0}, yr{0};".format(k))
+
+        ablate = os.environ.get("ODIL_TRACE_ABLATE", "").split(",")  # timing experiments: stores, bwd (wrong results)
+        mg = parts["gather"]
 
         def body(var, inbox):
             B = []
@@ -2155,9 +2347,24 @@ class _Codegen:
                 B.append("  zx{} = {}.x;".format(j, z))
             B.extend(var["fwd2"])
             B.extend(var["rev"])
+            if mg is not None:
+                # partial sums of the read cotangents (_march_gather_plan): per group what this row gives to the rows
+                # r - 1, r, r + 1 (cm, c0, cp; c0 with the lane neighbours' shares) and to the neighbouring strips
+                for k, (_, members) in enumerate(mg["groups"]):
+                    gsum = lambda sel: " + ".join("g{}".format(self.cots[slot].idx) for slot, sx, sy in members if sel(sx, sy)) or None
+                    term = lambda e: "(valid ? {} : (T)0)".format(e) if e else None
+                    c0, cm, cp = gsum(lambda sx, sy: sx == 0 and sy == 0), gsum(lambda sx, sy: sx == -1), gsum(lambda sx, sy: sx == 1)
+                    yl, yr = gsum(lambda sx, sy: sy == -1), gsum(lambda sx, sy: sy == 1)  # to the column left / right
+                    B.append("  cm{} = {};".format(k, term(cm) or "(T)0"))
+                    B.append("  cp{} = {};".format(k, term(cp) or "(T)0"))
+                    B.append("  yl{} = {};".format(k, term(yl) or "(T)0"))
+                    B.append("  yr{} = {};".format(k, term(yr) or "(T)0"))
+                    B.append("  c0{} = {};".format(k, term(c0) or "(T)0"))
             B.append("  if (valid) {")
-            for slot, (n, name) in enumerate(stored):
-                if stream:
+            for slot, (n, name) in enumerate(stored if mg is None else []):
+                if "stores" in ablate:  # (timing experiment: wrong results)
+                    B.append("    s_0 = s_0 + {} * (T)1e-30;".format(name))
+                elif stream:
                     B.append("    __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
                 else:
                     B.append("    a.cot[{}][l] = {};".format(slot, name))
@@ -2181,17 +2388,51 @@ class _Codegen:
             S.append("  } else {")
             S.extend(body(variants[0], ()))
             S.append("  }")
+        if mg is not None:
+            offs, _ = self._march_edge_offsets(len(mg["groups"]))
+            lead_flat = self._offset(["i{}".format(d) for d in range(a1)], self.G[:a1]) if a1 > 0 else "0"
+            S.append("  const long lf_ = {};".format(lead_flat))
+            S.append("  const int lastl_ = min(63, {} - strip * 63);".format(G2))  # the strip's last lane with a point
+            for k in range(len(mg["groups"])):
+                e_lo, e_hi, f_lo, f_hi = offs[k]
+                # the row's own sum: the lane neighbours' shares arrive by lane shifts; what leaves the strip goes to F
+                S.append("  const T fromr{0} = odil_lane_next(yl{0}), froml{0} = odil_lane_prev(yr{0});".format(k))
+                S.append("  const T row{0} = c0{0} + (valid ? froml{0} + fromr{0} : (T)0);".format(k))
+                S.append("  if (lane == 0) a.edge[{} + (lf_ * {} + i{}) * {} + strip] = fromr{};".format(f_lo, G1, a1, nstrip, k))
+                S.append("  if (lane == lastl_) a.edge[{} + (lf_ * {} + i{}) * {} + strip] = yr{};".format(f_hi, G1, a1, nstrip, k))
+                # delay line along the marching axis: row r - 1 is complete (within the segment) once row r has given its share
+                S.append("  if (i{} > r0) {{ if (valid) {}; }}".format(
+                    a1, ("__builtin_nontemporal_store(ap{0} + cm{0}, &a.cot[{0}][l - {1}])" if stream else "a.cot[{0}][l - {1}] = ap{0} + cm{0}").format(k, G2)))
+                S.append("  else if (valid) a.edge[{} + (lf_ * {} + seg) * {} + i{}] = cm{};".format(e_lo, nseg, G2, a2, k))
+                S.append("  ap{0} = ac{0} + row{0}; ac{0} = cp{0};".format(k))
         # reverse pass of the PREVIOUS step's evaluation: its own adjoints + what this row found for the carried face
         S.append("  {")
         for j in range(nz):
             S.append("  const T ud{0}_0 = gbx{0} + gax{0}, ud{0}_1 = gy{0};".format(j))
-        S.extend(parts["mlp_bwd"])
+        if "bwd" in ablate:
+            S.extend("  s_0 = s_0 + (ud{0}_0 + ud{0}_1) * (T)1e-30;".format(j) for j in range(nz))
+        else:
+            S.extend(parts["mlp_bwd"])
         S.append("  }")
         for j in range(nz):
             S.append("  kx{0} = zx{0}; gbx{0} = gbc{0}; gy{0} = gby{0} + odil_lane_next(gay{0});".format(j))
         for name in acts:
             S.append("  mp_{0} = mc_{0};".format(name))
         S.append("  }")  # rows
+        if mg is not None:
+            # the segment's last row (what the next segment's first row gives it arrives through E_lo), and what the last
+            # row gives to the next segment's first row
+            offs, _ = self._march_edge_offsets(len(mg["groups"]))
+            lead_flat = self._offset(["i{}".format(d) for d in range(a1)], self.G[:a1]) if a1 > 0 else "0"
+            S.append("  if (valid) {")
+            S.append("    const long lf_ = {};".format(lead_flat))
+            last_l = self._offset(["i{}".format(d) if d != a1 else "(r1 - 1)" for d in range(self.ndim)], self.G)
+            S.append("    const int ll_ = {};".format(last_l))
+            for k in range(len(mg["groups"])):
+                e_lo, e_hi, f_lo, f_hi = offs[k]
+                S.append("    a.cot[{0}][ll_] = ap{0};".format(k))
+                S.append("    a.edge[{} + (lf_ * {} + seg) * {} + i{}] = ac{};".format(e_hi, nseg, G2, a2, k))
+            S.append("  }")
         # flush: the last row's evaluation (its upper face along the marching axis belongs to the next segment too)
         S.append("  {")
         for j in range(nz):

@@ -140,7 +140,7 @@ class TracedOperator:
                 ("par", ctypes.c_void_p * max(1, par_arrays)),
                 ("hs", ctypes.c_void_p), ("hsv", ctypes.c_double * max(1, len(cg.hs))),
                 ("part", ctypes.c_void_p), ("ppart", ctypes.c_void_p), ("part2", ctypes.c_void_p), ("out", ctypes.c_void_p),
-                ("pgrad", ctypes.c_void_p), ("nblocks", ctypes.c_int),
+                ("pgrad", ctypes.c_void_p), ("edge", ctypes.c_void_p), ("nblocks", ctypes.c_int),
             ]
 
         self.args = Args()
@@ -152,6 +152,9 @@ class TracedOperator:
         self.args.part, self.args.ppart = self.part.data_ptr(), self.ppart.data_ptr()
         self.args.part2 = self.part2.data_ptr()
         self.args.out, self.args.pgrad = self.out.data_ptr(), self.pgrad.data_ptr()
+        # marching kernels: what their in-kernel sums of read cotangents hand across segments of rows / strips of columns
+        self.edge = torch.zeros(max(1, getattr(cg, "edge_numel", 0)), dtype=dt, device=dev)
+        self.args.edge = self.edge.data_ptr()
         self.args.nblocks = self.nblocks
         self.args.hs = None
         self._hs_rows = None  # graph replay: (pinned table, device table, device row, device row index)
