@@ -294,6 +294,23 @@ def _no_shift_for_arrays(shift):
         raise RuntimeError("Array requires an empty shift")
 
 
+def _plan_levels(cshape, axes, wanted):
+    """(axes, number of levels, cell shapes fine -> coarse) of a multigrid decomposition (what reference core.py:57-79
+    sets up): every decomposed axis halves from level to level, the depth is the smallest round(log2 n) among them --
+    so a power-of-two axis ends at 2 cells -- optionally capped by `wanted`; undecomposed axes keep their extent."""
+    ndim = len(cshape)
+    axes = list(axes) if axes else [True] * ndim
+    depths = [int(round(np.log2(n))) for n, on in zip(cshape, axes) if on]
+    depth = min(depths) if depths else max(cshape)
+    if wanted is not None:
+        if wanted < 1:
+            raise AssertionError("mg_nlvl must be at least 1")
+        depth = min(depth, wanted)
+    shapes = [tuple((int(n) >> level) if on else int(n) for n, on in zip(cshape, axes)) for level in range(depth)]
+    check_multigrid_cshapes(shapes, axes)
+    return axes, depth, shapes
+
+
 class Domain:
     def __init__(self, cshape, dimnames=None, lower=0.0, upper=1.0, dtype=None, multigrid=False,
                  mg_convert_all=True, mg_nlvl=None, mg_factors=None, mg_axes=None, mg_interp=None, mod=None):
@@ -316,22 +333,9 @@ class Domain:
         self.mod = mod
         self.multigrid = multigrid
         if multigrid:
-            self.mg_factors = mg_factors
-            mg_axes = mg_axes or [True] * ndim
-            nlvl_max = min(int(round(np.log2(n))) if ax else max(cshape) for n, ax in zip(cshape, mg_axes))
-            if mg_nlvl is not None:
-                assert mg_nlvl >= 1
-                mg_nlvl = min(mg_nlvl, nlvl_max)
-            else:
-                mg_nlvl = nlvl_max
-            self.mg_nlvl = mg_nlvl
-            self.mg_cshapes = [
-                tuple(int(n) >> lvl if ax else int(n) for n, ax in zip(cshape, mg_axes)) for lvl in range(mg_nlvl)
-            ]
-            check_multigrid_cshapes(self.mg_cshapes, mg_axes)
-            self.mg_axes = mg_axes
-            self.mg_interp = mg_interp
-            self.mg_convert_all = mg_convert_all
+            plan = _plan_levels(self.cshape, mg_axes, mg_nlvl)
+            self.mg_axes, self.mg_nlvl, self.mg_cshapes = plan
+            self.mg_factors, self.mg_interp, self.mg_convert_all = mg_factors, mg_interp, mg_convert_all
 
     # ---- geometry: host-side NumPy, results handed to the device by mod.meshgrid ----
     @staticmethod
@@ -447,110 +451,101 @@ class Domain:
         raise TypeError("Expected Field or MultigridField got {}".format(type(field).__name__))
 
     def regular_to_multigrid(self, field, cshapes=None, factors=None, method=None):
-        """Level 0 <- u / f_0, coarser levels zero (reference core.py:276-297)."""
-        mod = self.mod
+        """A regular field as a multigrid one that synthesises to the same values: the finest term carries u / f_0, every
+        coarser term starts at zero (reference core.py:276-297)."""
         if isinstance(field, (MultigridField, NeuralNet)):
             raise TypeError("Expected Field or ndarray, got type {}".format(type(field).__name__))
-        field = self.init_field(field)
-        cshapes = cshapes or self.mg_cshapes
-        factors = factors or self.mg_factors or [1] * len(cshapes)
-        assert_equal(len(cshapes), len(factors))
-        method = method or self.mg_interp
-        terms = [Field(field.array / factors[0], loc=field.loc, cshape=field.cshape)]
-        for cshape in cshapes[1:]:
-            array = mod.zeros(self._get_field_shape(cshape, loc=field.loc), dtype=self.dtype)
-            terms.append(Field(array, loc=field.loc, cshape=cshape))
-        return MultigridField(terms=terms, loc=field.loc, factors=factors, method=method)
+        fine = self.init_field(field)
+        shapes = list(cshapes or self.mg_cshapes)
+        scales = factors or self.mg_factors or [1] * len(shapes)
+        assert_equal(len(shapes), len(scales))
+        levels = [Field(fine.array / scales[0], loc=fine.loc, cshape=fine.cshape)]
+        levels += [Field(self.mod.zeros(self._get_field_shape(cs, loc=fine.loc), dtype=self.dtype), loc=fine.loc, cshape=cs)
+                   for cs in shapes[1:]]
+        return MultigridField(terms=levels, loc=fine.loc, factors=scales, method=method or self.mg_interp)
 
     # ---- state initialisation (reference core.py:299-359) -------------------------------
+    def _own(self, values, shape=None):
+        """`values` (or zeros of `shape` when None) as an unknown of this domain's dtype on its device."""
+        if values is None:
+            values = self.mod.zeros(shape, dtype=self.dtype)
+        return self.mod.variable(values, dtype=self.dtype)
+
     def init_field(self, field):
+        """Whatever a user may put into `State.fields` -- None, a bare array, a list of numbers, a `Field` without values,
+        a multigrid field, a network, an `Array` -- as an initialised object of the same kind."""
         mod = self.mod
         if field is None:
-            return self.init_field(Field(None, loc="c" * self.ndim, cshape=self.cshape))
-        elif isinstance(field, np.ndarray) or mod.is_tensor(field):
-            return self.init_field(Field(field, loc="c" * len(field.shape), cshape=tuple(field.shape)))
-        elif isinstance(field, Field):
-            cshape = field.cshape or self.cshape
-            ndim = len(cshape)
-            loc = field.loc or "c" * ndim
-            assert_equal(len(loc), ndim)
-            array = field.array
-            if array is None:
-                array = mod.zeros(self._get_field_shape(cshape, loc=loc), dtype=self.dtype)
-            array = mod.variable(array, dtype=self.dtype)
-            assert_equal(tuple(array.shape), self._get_field_shape(cshape, loc=loc))
-            return Field(array, loc=loc, cshape=cshape)
-        elif isinstance(field, MultigridField):
-            return MultigridField(
-                [self.init_field(term) for term in field.terms], loc=field.loc, factors=field.factors,
-                axes=field.axes, method=field.method,
-            )
-        elif isinstance(field, NeuralNet):
-            weights = [mod.variable(w, dtype=self.dtype) for w in field.weights]
-            biases = [mod.variable(b, dtype=self.dtype) for b in field.biases]
-            return NeuralNet(weights, biases, func_in=field.func_in, func_out=field.func_out,
-                             activation=field.activation)
+            field = Field(None, loc="c" * self.ndim, cshape=self.cshape)
         elif isinstance(field, list):
-            u = mod.cast(mod.array(np.array(field)), self.dtype)
-            return self.init_field(Array(u, shape=tuple(u.shape)))
-        elif isinstance(field, Array):
-            array = field.array
-            if array is None:
-                array = mod.zeros(field.shape, dtype=self.dtype)
-            return Array(mod.variable(array, dtype=self.dtype), field.shape)
+            values = mod.cast(mod.array(np.array(field)), self.dtype)
+            field = Array(values, shape=tuple(values.shape))
+        elif isinstance(field, np.ndarray) or mod.is_tensor(field):
+            field = Field(field, loc="c" * len(field.shape), cshape=tuple(field.shape))
+        if isinstance(field, Field):
+            cshape = field.cshape or self.cshape
+            loc = field.loc or "c" * len(cshape)
+            assert_equal(len(loc), len(cshape))
+            expect = self._get_field_shape(cshape, loc=loc)
+            values = self._own(field.array, expect)
+            assert_equal(tuple(values.shape), expect)
+            return Field(values, loc=loc, cshape=cshape)
+        if isinstance(field, MultigridField):
+            return MultigridField([self.init_field(t) for t in field.terms], loc=field.loc, factors=field.factors,
+                                  axes=field.axes, method=field.method)
+        if isinstance(field, NeuralNet):
+            return NeuralNet([self._own(w) for w in field.weights], [self._own(b) for b in field.biases],
+                             func_in=field.func_in, func_out=field.func_out, activation=field.activation)
+        if isinstance(field, Array):
+            return Array(self._own(field.array, field.shape), field.shape)
         raise TypeError("Unknown field type '{}'".format(type(field).__name__))
 
     def init_state(self, state):
-        fields = dict()
-        for key in state.fields:
-            field = self.init_field(state.fields[key])
-            if self.multigrid and self.mg_convert_all and not isinstance(field, (MultigridField, NeuralNet, Array)):
-                field = self.regular_to_multigrid(state.fields[key])
-            fields[key] = field
-        return State(fields=fields, initialized=True)
+        decompose = self.multigrid and self.mg_convert_all
+        ready = dict()
+        for key, raw in state.fields.items():
+            field = self.init_field(raw)
+            if decompose and isinstance(field, Field):
+                field = self.regular_to_multigrid(raw)
+            ready[key] = field
+        return State(fields=ready, initialized=True)
 
     # ---- flattening: defines the unknown-vector layout (reference core.py:361-469) -------
-    def arrays_from_field(self, field):
-        if isinstance(field, Field):
-            return [field.array]
-        elif isinstance(field, MultigridField):
-            return [term.array for term in field.terms]
-        elif isinstance(field, NeuralNet):
-            return field.weights + field.biases
-        elif isinstance(field, Array):
-            return [field.array]
+    # A field is a sequence of SLOTS (container, attribute or index), in the order that defines the packed vector:
+    # a field / Array: its array; a multigrid field: its terms fine -> coarse; a network: weights, then biases.
+    @staticmethod
+    def _slots(field):
+        if isinstance(field, (Field, Array)):
+            return [(field, "array")]
+        if isinstance(field, MultigridField):
+            return [(term, "array") for term in field.terms]
+        if isinstance(field, NeuralNet):
+            return [(field.weights, i) for i in range(len(field.weights))] + [(field.biases, i) for i in range(len(field.biases))]
         raise TypeError("Unknown field type '{}'".format(type(field).__name__))
 
+    def arrays_from_field(self, field):
+        return [getattr(box, at) if isinstance(at, str) else box[at] for box, at in self._slots(field)]
+
     def arrays_from_state(self, state):
-        res = []
-        for key in state.fields:
-            res += self.arrays_from_field(state.fields[key])
-        return res
+        return [a for field in state.fields.values() for a in self.arrays_from_field(field)]
 
     @staticmethod
     def arrays_to_field(arrays, field):
-        if isinstance(field, (Field, Array)):
-            field.array = arrays[0]
-            return 1
-        elif isinstance(field, MultigridField):
-            for i, term in enumerate(field.terms):
-                term.array = arrays[i]
-            return len(field.terms)
-        elif isinstance(field, NeuralNet):
-            nw, nb = len(field.weights), len(field.biases)
-            for i in range(nw):
-                field.weights[i] = arrays[i]
-            for i in range(nb):
-                field.biases[i] = arrays[nw + i]
-            return nw + nb
-        raise TypeError("Unknown field type '{}'".format(type(field).__name__))
+        """Puts the leading entries of `arrays` into the field's slots; returns how many it took."""
+        slots = Domain._slots(field)
+        for (box, at), value in zip(slots, arrays):
+            if isinstance(at, str):
+                setattr(box, at, value)
+            else:
+                box[at] = value
+        return len(slots)
 
     @staticmethod
     def arrays_to_state(arrays, state):
-        offset = 0
-        for key in state.fields:
-            offset += Domain.arrays_to_field(arrays[offset:], state.fields[key])
-        return offset
+        taken = 0
+        for field in state.fields.values():
+            taken += Domain.arrays_to_field(arrays[taken:], field)
+        return taken
 
     def pack_field(self, field):
         mod = self.mod

@@ -142,13 +142,12 @@ def setup_outdir(args, relpath_args=None):
         if getattr(args, k):
             setattr(args, k, os.path.relpath(getattr(args, k), start=outdir))
 
-    def mulint(v, k):
-        return None if v is None else max(1, round(v * k))
-
-    args.plot_every = mulint(args.plot_every, args.every_factor)
-    args.history_every = mulint(args.history_every, args.every_factor)
-    args.report_every = mulint(args.report_every, args.every_factor)
-    if args.epochs is None:
+    # the three cadences are given for every_factor = 1: stretched together, never below one epoch
+    for cadence in ("plot_every", "history_every", "report_every"):
+        value = getattr(args, cadence)
+        if value is not None:
+            setattr(args, cadence, max(1, round(value * args.every_factor)))
+    if args.epochs is None:  # as many epochs as the requested number of frames needs
         args.epochs = args.frames * args.plot_every
     if args.seed is not None:
         np.random.seed(args.seed)

@@ -243,3 +243,86 @@ def test_two_emulated_ranks_at_the_full_per_rank_shape_equal_the_undivided_path(
             # (float32, three Adam updates of size lr = 0.01 each: an entry whose gradient is at round-off level moves by
             # a rounding-dependent fraction of a step)
             assert float((got - ref).abs().max()) <= 1e-3 * scale, (r, i)
+
+
+def test_float_transfers_of_the_all_cell_layout_at_full_size():
+    """'ccc' float arrays at config 3's shape, coarse (128, 256, 256) -> fine (256, 512, 512): <P c, g> == <c, P^T g>
+    in float64 accumulation (the CX = 2 marching prolongation against the row-marching / LDS-tiled transposes that the
+    multigrid chain of heat 256 x 512^2 runs), reproducible, and the whole chain `multigrid_to_regular` against its
+    transpose over the domain's own levels."""
+    from odil_amd import ops
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(12)
+    cshape = (128, 256, 256)
+    fshape = ops.fine_shape(cshape, "ccc")
+    assert fshape == (256, 512, 512)
+    c = torch.randn(cshape, dtype=torch.float32, device=dev, generator=gen)
+    g = torch.randn(fshape, dtype=torch.float32, device=dev, generator=gen)
+    dot = lambda a, b: float(torch.dot(a.reshape(-1).double(), b.reshape(-1).double()))
+    pc = ops.interp_add(c, "ccc")
+    for route in (ops.interp_adj, ops.interp_adj_best):
+        ptg = route(g, "ccc", cshape)
+        lhs, rhs = dot(pc, g), dot(c, ptg)
+        scale = (dot(pc, pc) * dot(g, g)) ** 0.5
+        assert abs(lhs - rhs) < 1e-6 * scale, (lhs, rhs, scale)
+        assert torch.equal(ptg, route(g, "ccc", cshape))
+    del pc, ptg
+    # the chain of all levels (256 x 512^2 down to 1 x 2 x 2: 9 arrays)
+    shapes = [fshape]
+    while min(shapes[-1]) >= 2 and len(shapes) < 9:
+        shapes.append(tuple(n // 2 for n in shapes[-1]))
+    terms = [torch.randn(s, dtype=torch.float32, device=dev, generator=gen) for s in shapes]
+    u = ops.mg_synth(terms, "ccc")
+    grads = ops.mg_synth_adj(g, shapes, "ccc")
+    lhs = dot(u, g)
+    rhs = sum(dot(t, gr) for t, gr in zip(terms, grads))
+    scale = (dot(u, u) * dot(g, g)) ** 0.5
+    assert abs(lhs - rhs) < 2e-6 * scale, (lhs, rhs, scale)
+
+
+def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(monkeypatch):
+    """Config 3 as bench.py runs it -- 256 x 512^2 float32 WITH the multigrid decomposition (9 levels), the marching
+    forward kernel, Adam of the finest level inside the generated gather, the coarser levels after their transposes --
+    against the same two epochs with the optimizer's update as one separate pass over the packed vector
+    (ODIL_FUSE_ADAM0=0) and against the plain forward kernel (ODIL_TRACE_SHARE=0): loss of both epochs and the state."""
+    import heat2d as ex
+
+    odil = _quiet()
+    argv = ["--Nt", "256", "--Nx", "512", "--Ny", "512", "--infer_k", "1", "--imposed", "stripe", "--multigrid", "1"]
+    results = dict()
+    for name, env in (("fused", dict()), ("separate", dict(ODIL_FUSE_ADAM0="0")), ("plain", dict(ODIL_TRACE_SHARE="0"))):
+        for k in ("ODIL_FUSE_ADAM0", "ODIL_TRACE_SHARE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        odil.runtime.get_mod().random.set_seed(11)
+        args = ex.parse_args(argv)
+        problem, state = ex.make_problem(args)
+        assert problem.domain.mg_nlvl == 9
+        start = _randomise(problem, state, 21, scale=0.2)
+        losses = []
+        args.epoch_start, args.epochs = 0, 2
+        odil.util.optimize_grad(args, "adam", problem, state, lambda s, e, p: losses.append(float(p["loss"])))
+        assert problem._traced is not None
+        mode = problem._traced.cg.share_mode
+        assert (mode == "march") == (name != "plain"), mode
+        final = [a.clone() for a in problem.domain.arrays_from_state(state)]
+        results[name] = (losses, final)
+        del problem, state, start
+        torch.cuda.empty_cache()
+    (l0, x0) = results["fused"]
+    for other in ("separate", "plain"):
+        l1, x1 = results[other]
+        assert len(l0) == len(l1) >= 2
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 2e-5 * abs(a), (other, l0, l1)
+        lr = 1e-3
+        for i, (a, b) in enumerate(zip(x0, x1)):
+            # float32, two updates of size <= lr each.  Adam normalises the step: an entry whose gradient is at round-off
+            # level (relative to its neighbours' 1e-5) takes a rounding-dependent step of either sign -- a vanishing
+            # fraction of the 67 M entries, bounded by the two steps themselves; everything else agrees to 1 % of a step
+            d = (a - b).abs()
+            assert float(d.max()) <= 2 * 2 * lr * 1.01, (other, i, float(d.max()))
+            bad = int((d > 1e-2 * lr + 4 * 1.2e-7 * float(a.abs().max())).sum())
+            assert bad <= max(2, 1e-4 * d.numel()), (other, i, bad, d.numel())
