@@ -355,6 +355,29 @@ def run_tracer(args, rank, world, dev, comm, barrier):
         abytes=None, dtype="f32", exchanges_per_epoch=4 if world > 1 else 0)
 
 
+def pmc_traffic(path):
+    """{kernel: HBM bytes per launch} of the generated kernels from a committed rocprofv3 summary (tools/prof_cfg.sh with
+    HBM=1: TCC_EA0_RDREQ[_32B] / WRREQ[_64B] summed over the channels.  MI355X_MICROARCH.md, HBM section: on gfx950 a
+    read request of a coalesced stream is a 128-byte request tallied at 64 B -- FETCH_SIZE must be doubled -- so reads are
+    priced at 128 B per non-32-byte request; writes at 64 / 32 B per request, which the guide calls uncalibrated: they
+    reproduce the bytes these kernels store to within 15 %), or None when the file is not on record."""
+    import re
+
+    try:
+        text = open(path).read()
+    except OSError:
+        return None
+    res = dict()
+    for line in text.splitlines():
+        if "TCC_EA0_RDREQ_sum" not in line:
+            continue
+        name = line.split()[0]
+        val = lambda c: float(re.search(c + r": max ([0-9.e+]+)", line).group(1))
+        rd, rd32, wr, wr64 = val("TCC_EA0_RDREQ_sum"), val("TCC_EA0_RDREQ_32B_sum"), val("TCC_EA0_WRREQ_sum"), val("TCC_EA0_WRREQ_64B_sum")
+        res[name] = {"read_bytes": (rd - rd32) * 128 + rd32 * 32, "write_bytes": wr64 * 64 + (wr - wr64) * 32, "source": os.path.basename(path)}
+    return res or None
+
+
 def other_configs(args, dev):
     """After the timed region of the default run (N = 1 only, outside every timed window): a few epochs each of the
     other single-GPU BASELINE workloads, so that the driver's record carries them -- 3b heat inverse 256 x 512^2
@@ -451,14 +474,46 @@ def other_configs(args, dev):
 
         ms = timed(step, 1, 1)
         cells = int(np.prod(problem.domain.cshape))
+        # bytes model of one Newton step with the geometric-multigrid solve (words of 8 B per fine cell): per V-cycle
+        # four smoothing sweeps of 3 words (read x, b; write x) + residual with its restriction 2 + 1/8, over all levels
+        # (x 8/7); per step the residual (3), the update x += delta (3) and the first iterate by nested iteration (one
+        # cycle's worth); the cycle count comes from the solver's own status of one more (untimed) step
+        seen = []
+        a.epochs = 1
+        odil.util.optimize(a, "newton", problem, state, lambda s, e, p: seen.append(p.get("linsolver")))
+        cycles = next((int(st["niter"]) for st in seen if st and "niter" in st), None)
+        model = None if cycles is None else ((4 * 3 + 2.125) * 8.0 / 7.0 * (cycles + 1) + 6) * 8.0
         return {"workload": name.format(problem.domain.cshape[0], problem.domain.cshape[-1]), "ms_per_step": ms,
-                "value": cells / (ms * 1e-3), "frac_model": None, "loss_after": float(problem.eval_loss_grad(state)[0])}
+                "value": cells / (ms * 1e-3), "vcycles": cycles, "model_bytes_per_update": model,
+                "frac_model": None if model is None else cells * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "loss_after": float(problem.eval_loss_grad(state)[0])}
+
+    def api(key, epochs, warmup):
+        """Configs 1, 2, 5b through the public operator API (bench_configs.run_config), a few epochs each."""
+        def run():
+            import bench_configs
+
+            out = bench_configs.run_config(key, args.scale, epochs=epochs, warmup=warmup)
+            model = out.get("model_bytes_per_update")
+            ms = out["ms_per_epoch"]
+            return {"workload": out["name"], "ms_per_step": ms, "value": out["cells"] / (ms * 1e-3), "optimizer": out["optimizer"],
+                    "model_bytes_per_update": model,
+                    "frac_model": None if not model else out["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "loss_after": out["loss"]}
+        return run
 
     for sub in ("poisson", "heat", "velocity_from_tracer"):
         sys.path.insert(0, os.path.join(ROOT, "examples", sub))
     attempt("3b", heat)
     attempt("5_one_rank", tracer)
     attempt("4b", newton)
+    attempt("1", api("1", 400, 2))
+    attempt("2", api("2", 30, 1))
+    attempt("5b", api("5b", 10, 2))
+    # HBM traffic of the dominant generated launches from the counter passes on record (profiles/, same commands)
+    for key, fname in (("3b", "r04_heat2d_pmc.txt"), ("5_one_rank", "r04_cfg5_pmc.txt")):
+        if key in out and "error" not in out[key]:
+            out[key]["traffic"] = pmc_traffic(os.path.join(ROOT, "profiles", fname))
     return out
 
 

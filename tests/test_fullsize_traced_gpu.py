@@ -268,9 +268,9 @@ def test_float_transfers_of_the_all_cell_layout_at_full_size():
         assert abs(lhs - rhs) < 1e-6 * scale, (lhs, rhs, scale)
         assert torch.equal(ptg, route(g, "ccc", cshape))
     del pc, ptg
-    # the chain of all levels (256 x 512^2 down to 1 x 2 x 2: 9 arrays)
+    # the chain of the domain's own 8 levels (256 x 512^2 down to 2 x 4 x 4)
     shapes = [fshape]
-    while min(shapes[-1]) >= 2 and len(shapes) < 9:
+    while len(shapes) < 8:
         shapes.append(tuple(n // 2 for n in shapes[-1]))
     terms = [torch.randn(s, dtype=torch.float32, device=dev, generator=gen) for s in shapes]
     u = ops.mg_synth(terms, "ccc")
@@ -282,7 +282,7 @@ def test_float_transfers_of_the_all_cell_layout_at_full_size():
 
 
 def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(monkeypatch):
-    """Config 3 as bench.py runs it -- 256 x 512^2 float32 WITH the multigrid decomposition (9 levels), the marching
+    """Config 3 as bench.py runs it -- 256 x 512^2 float32 WITH the multigrid decomposition (8 levels), the marching
     forward kernel, Adam of the finest level inside the generated gather, the coarser levels after their transposes --
     against the same two epochs with the optimizer's update as one separate pass over the packed vector
     (ODIL_FUSE_ADAM0=0) and against the plain forward kernel (ODIL_TRACE_SHARE=0): loss of both epochs and the state."""
@@ -299,7 +299,7 @@ def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(mon
         odil.runtime.get_mod().random.set_seed(11)
         args = ex.parse_args(argv)
         problem, state = ex.make_problem(args)
-        assert problem.domain.mg_nlvl == 9
+        assert problem.domain.mg_nlvl == 8  # (min over the axes of round(log2 n): 256 -> 8)
         start = _randomise(problem, state, 21, scale=0.2)
         losses = []
         args.epoch_start, args.epochs = 0, 2

@@ -749,7 +749,8 @@ def test_float_transpose_into_a_view_with_an_odd_leading_stride(dev):
     for route in (ops.interp_adj, ops.interp_adj_best):
         base.fill_(7.0)
         route(g, loc, cshape, out=view)
-        assert torch.equal(view, want)
+        # (the kernel that takes over sums in another order than the row-marching one: float results differ in the last bits)
+        assert float((view - want).abs().max()) <= 4e-6 * float(want.abs().max())
         touched = torch.zeros_like(base, dtype=torch.bool)
         touched.as_strided(cshape, (ld, 4 * 32, 32, 1)).fill_(True)
         assert bool((base[~touched] == 7.0).all())
