@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Fills odil_amd/_jit_cache with the generated kernels of the BASELINE configurations (and of the build / smoke example)
+by tracing the example operators on CPU tensors and cross-compiling for gfx950 -- no GPU needed, nothing is launched.
+A clean clone then does not spend its first GPU minutes in hipcc.  (The kernels of the GPU test suite's small fixtures --
+a few hundred variants of a few seconds each -- are built by the suite's first run and kept in the same cache.)
+
+    python3 tools/prebuild_jit.py [--quick]
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+for sub in ("poisson", "heat", "velocity_from_tracer", "wave", "heat_tmax", "infer_constant"):
+    sys.path.insert(0, os.path.join(ROOT, "examples", sub))
+
+CONFIGS = [  # (example module, argv, slab ranks or None)
+    ("wave", ["--Nt", "8", "--Nx", "8"], None),                                                      # __graft_entry__.build()
+    ("wave", ["--Nt", "8", "--Nx", "16"], None),                                                     # __graft_entry__.smoke()
+    ("heat", ["--Nt", "256", "--Nx", "512", "--infer_k", "1", "--imposed", "stripe"], None),          # config 3
+    ("heat2d", ["--Nt", "256", "--Nx", "512", "--Ny", "512", "--infer_k", "1", "--imposed", "stripe"], None),  # config 3 at BASELINE's shape
+    ("veltracer", ["--Nt", "128", "--Nx", "256", "--Ny", "256"], None),                                # config 5, reference-native
+    ("veltracer3d", ["--Nt", "32", "--Nx", "256"], None),                                            # 5b
+    ("veltracer3d", ["--Nt", "128", "--Nx", "32", "--Ny", "256", "--Nz", "256"], 1),                  # config 5: one rank's slab, world 1
+    ("veltracer3d", ["--Nt", "128", "--Nx", "64", "--Ny", "256", "--Nz", "256"], 2),                  # ... and with interfaces (world >= 2)
+]
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--quick", action="store_true", help="the build / smoke kernels only")
+    a = p.parse_args()
+    import odil_amd
+    from odil_amd import runtime, slab_traced, stencil_jit
+
+    runtime._mod = odil_amd.ModRocm(device="cpu")
+    odil_amd.util.set_log_file(open(os.devnull, "w"))
+    for modname, argv, world in CONFIGS[:2] if a.quick else CONFIGS:
+        t0 = time.time()
+        ex = importlib.import_module(modname)
+        problem, state = ex.make_problem(ex.parse_args(argv))
+        if world is None:
+            path = stencil_jit.TracedOperator(problem, state).lib_path
+        else:
+            n = problem.domain.cshape[1] // world
+            path = slab_traced.HipSlabKernels(problem, state, 1, n, "cpu").lib_path
+        print("{:12s} {:60s} {}  {:.1f} s".format(modname, " ".join(argv), os.path.basename(path), time.time() - t0), flush=True)
+        del problem, state
+
+
+if __name__ == "__main__":
+    main()
