@@ -394,10 +394,13 @@ class TorchDistComm:
               the last rank's send_hi to the first (its recv_lo); other ranks pass (None, None);
       "sum"   all-reduce of send_lo (a few scalars); returns the tensor."""
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, self_loop=False):
         import torch.distributed as dist
 
         self.dist, self.rank, self.world = dist, rank, world
+        # self_loop (world 1 only; tests/test_rccl_selfloop_gpu.py): the rank is its own lower AND upper neighbour -- a ring
+        # of one -- so that the messages really travel through the backend's send / receive on a box with a single GPU
+        self.self_loop = bool(self_loop) and world == 1
         # gloo moves host memory: device planes are staged (tests only; RCCL sends device memory)
         self.stage = dist.get_backend() == "gloo"
         self._recv = dict()  # receive buffers, kept: (side, numel, dtype, device) -> tensor
@@ -430,13 +433,15 @@ class TorchDistComm:
             dist.all_reduce(t)
             return t
         if kind == "wrap":
-            if self.world == 1:
+            if self.world == 1 and not self.self_loop:
                 return send_hi, send_lo
             peer_lo = self.world - 1 if self.rank == 0 else None
             peer_hi = 0 if self.rank == self.world - 1 else None
         else:  # "halo" / "post" 
             peer_lo = self.rank - 1 if self.rank > 0 else None
             peer_hi = self.rank + 1 if self.rank < self.world - 1 else None
+        if self.self_loop:
+            peer_lo = peer_hi = 0
         dev = None
         if self.stage:
             for t in (send_lo, send_hi):
@@ -447,11 +452,21 @@ class TorchDistComm:
                 send_hi = send_hi.cpu() if send_hi is not None else None
         ops, recv_lo, recv_hi = [], None, None
         tag = "post-" if kind == "post" else ""  # (a posted message keeps its receive buffer until it is waited for)
-        if send_lo is not None and peer_lo is not None:
+        if self.self_loop and send_lo is not None and send_hi is not None:
+            # a ring of one: what goes down arrives from above and vice versa (messages between one pair of ranks match
+            # in the order they were issued)
+            send_lo, send_hi = send_lo.contiguous(), send_hi.contiguous()
+            recv_lo, recv_hi = self._recv_like(tag + "lo", send_hi), self._recv_like(tag + "hi", send_lo)
+            ops += [dist.P2POp(dist.isend, send_lo, 0), dist.P2POp(dist.irecv, recv_hi, 0),
+                    dist.P2POp(dist.isend, send_hi, 0), dist.P2POp(dist.irecv, recv_lo, 0)]
+            send_lo_done = send_hi_done = True
+        else:
+            send_lo_done = send_hi_done = False
+        if not send_lo_done and send_lo is not None and peer_lo is not None:
             send_lo = send_lo.contiguous()
             recv_lo = self._recv_like(tag + "lo", send_lo)
             ops += [dist.P2POp(dist.isend, send_lo, peer_lo), dist.P2POp(dist.irecv, recv_lo, peer_lo)]
-        if send_hi is not None and peer_hi is not None:
+        if not send_hi_done and send_hi is not None and peer_hi is not None:
             send_hi = send_hi.contiguous()
             recv_hi = self._recv_like(tag + "hi", send_hi)
             ops += [dist.P2POp(dist.isend, send_hi, peer_hi), dist.P2POp(dist.irecv, recv_hi, peer_hi)]
