@@ -74,15 +74,22 @@ CONFIGS = {
 def model_bytes_per_update(problem, state, optname, nout):
     """SURVEY.md 8(d) minimum-traffic model for k multigrid fields and n_out outputs under Adam:
     synthesis k (S + 1) + residual (k + 1 constant + n_out) + adjoint (n_out + k) + P^T chain k (2 S - 1) + Adam 7 k S
-    = k (10 S + 2) + 2 n_out + 1 words per grid cell; None for the other optimizers."""
-    if optname != "adam":
-        return None
+    = k (10 S + 2) + 2 n_out + 1 words per grid cell; for L-BFGS-B the evaluation + the two-loop recursion (below); None for
+    Newton (bench.py prices its V-cycles)."""
     domain = problem.domain
     k = sum(1 for f in state.fields.values() if isinstance(f, (odil.Field, odil.MultigridField)))
     nl = domain.mg_nlvl if domain.multigrid else 1
     axes = sum(1 for a in (domain.mg_axes if domain.multigrid else [])) or domain.ndim
     S = sum(2.0 ** (-axes * l) for l in range(nl))
     wordsize = np.dtype(domain.dtype).itemsize
+    if optname == "lbfgsb":
+        # per iteration: ONE loss + gradient evaluation (synthesis S + 1, residual 3, adjoint 2, P^T chain 2 S - 1 words)
+        # + the two-loop recursion over m = 50 (s, y) pairs, 4 m S words (SURVEY 8(d)) + ~6 S of vector updates; the
+        # extra evaluations of the line search (about one in ten iterations here) are not priced
+        m = 50
+        return (k * (3 * S + (4 * m + 6) * S) + 2 * nout + 1 + 2 * k) * wordsize
+    if optname != "adam":
+        return None
     return (k * (10 * S + 2) + 2 * nout + 1) * wordsize
 
 

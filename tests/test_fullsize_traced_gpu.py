@@ -285,7 +285,9 @@ def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(mon
     """Config 3 as bench.py runs it -- 256 x 512^2 float32 WITH the multigrid decomposition (8 levels), the marching
     forward kernel, Adam of the finest level inside the generated gather, the coarser levels after their transposes --
     against the same two epochs with the optimizer's update as one separate pass over the packed vector
-    (ODIL_FUSE_ADAM0=0) and against the plain forward kernel (ODIL_TRACE_SHARE=0): loss of both epochs and the state."""
+    (ODIL_FUSE_ADAM0=0: losses, gradients, states) and against the plain forward kernel (ODIL_TRACE_SHARE=0: losses of
+    both epochs and the gradient of every level and of the network at the start -- Adam's normalised steps turn round-off
+    level differences of near-zero coarse-level gradients into whole steps, so states are compared for one forward kernel)."""
     import heat2d as ex
 
     odil = _quiet()
@@ -301,6 +303,7 @@ def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(mon
         problem, state = ex.make_problem(args)
         assert problem.domain.mg_nlvl == 8  # (min over the axes of round(log2 n): 256 -> 8)
         start = _randomise(problem, state, 21, scale=0.2)
+        grads0 = [g.clone() for g in problem.eval_loss_grad(state)[1]]
         losses = []
         args.epoch_start, args.epochs = 0, 2
         odil.util.optimize_grad(args, "adam", problem, state, lambda s, e, p: losses.append(float(p["loss"])))
@@ -308,15 +311,20 @@ def test_heat2d_full_size_with_multigrid_fused_epochs_equal_separate_kernels(mon
         mode = problem._traced.cg.share_mode
         assert (mode == "march") == (name != "plain"), mode
         final = [a.clone() for a in problem.domain.arrays_from_state(state)]
-        results[name] = (losses, final)
+        results[name] = (losses, final, grads0)
         del problem, state, start
         torch.cuda.empty_cache()
-    (l0, x0) = results["fused"]
+    (l0, x0, g0) = results["fused"]
     for other in ("separate", "plain"):
-        l1, x1 = results[other]
+        l1, x1, g1 = results[other]
         assert len(l0) == len(l1) >= 2
         for a, b in zip(l0, l1):
             assert abs(a - b) <= 2e-5 * abs(a), (other, l0, l1)
+        # the gradient at the start, level by level and for the network (what the forward kernels + transposes produce)
+        for i, (a, b) in enumerate(zip(g0, g1)):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (other, i)
+        if other == "plain":
+            continue  # (the states after Adam's NORMALISED steps: compared for the same forward kernel only, below)
         lr = 1e-3
         for i, (a, b) in enumerate(zip(x0, x1)):
             # float32, two updates of size <= lr each.  Adam normalises the step: an entry whose gradient is at round-off
