@@ -616,6 +616,7 @@ def gen_examples_f2():
         data[k] = npy(getattr(extra, k))
     _store(data, arrays, *_loss_grads(wave.operator_wave(ctx), arrays_l))
     save("wave_f64", **data)
+    CASES["wave_f64"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=wave.operator_wave, lr=None)
 
     # heat_tmax.py:29-75
     ht = load_module("ref_heat_tmax", "/root/reference/examples/heat_tmax/heat_tmax.py")
@@ -634,6 +635,7 @@ def gen_examples_f2():
                 u_init=npy(extra.u_init), u_final=npy(extra.u_final))
     _store(data, arrays, *_loss_grads(ht.operator_heat(ctx), arrays_l))
     save("heat_tmax_f64", **data)
+    CASES["heat_tmax_f64"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=ht.operator_heat, lr=None)
 
     # infer_constant.py:44-74 (fields in the reference's order: coeff first)
     ic = load_module("ref_infer_constant", "/root/reference/examples/infer_constant/infer_constant.py")
@@ -651,6 +653,7 @@ def gen_examples_f2():
                 u_final=npy(extra.u_final))
     _store(data, arrays, *_loss_grads(ic.operator_adv(ctx), arrays_l))
     save("infer_constant_f64", **data)
+    CASES["infer_constant_f64"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=ic.operator_adv, lr=None)
 
 
 # ---------------------------------------------------------------- generalised workloads at BASELINE's named shapes

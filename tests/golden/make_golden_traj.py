@@ -221,6 +221,50 @@ def workload_adam_states(epochs=20, sample=(1, 2, 5, 10, 19)):
         save("traj_adam_states_" + name, **data)
 
 
+def workload_lbfgsb_pairs(iters=40):
+    """The reference's LbfgsbOptimizer (optimizer.py:54-117 -> SciPy) on the three example workloads whose default
+    optimizer it is -- wave, heat_tmax, infer_constant (reference examples/*/: `optimizer="lbfgsb"`) -- from the fixtures'
+    random states, TWICE (the second start one ulp away): loss of every iteration of both runs, so that an
+    implementation can be held to the reference for as long as the reference agrees with itself."""
+    import make_golden as mg
+    import scipy
+
+    mg.gen_examples_f2()
+    for name in ("wave_f64", "heat_tmax_f64", "infer_constant_f64"):
+        case = mg.CASES[name]
+        domain, state, extra, operator = case["domain"], case["state"], case["extra"], case["operator"]
+        data = dict(epochs=np.array(iters), m=np.array(50), maxls=np.array(50), scipy_version=np.array(scipy.__version__))
+        for tag in ("a", "b"):
+            start = [npy(a) for a in case["arrays"]]
+            if tag == "b":
+                start = [np.nextafter(a, np.inf) for a in start]
+            evals, its = [], []
+
+            def loss_grad(arrays):
+                leaves = [T(npy(a)).requires_grad_(True) for a in arrays]
+                domain.arrays_to_state(leaves, state)
+                ctx = odil.core.Context(domain, state, extra=extra, tracers={"epoch": 0})
+                values = [f[1] if isinstance(f, tuple) else f for f in operator(ctx)]
+                loss = sum(mod.mean(mod.square(v)) for v in values)
+                grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+                grads = [g if g is not None else torch.zeros_like(a) for g, a in zip(grads, leaves)]
+                evals.append(float(loss))
+                return loss.detach(), grads, None
+
+            opt = odil.optimizer.LbfgsbOptimizer(dtype=np.float64, mod=mod, m=50, maxls=50)
+            try:
+                opt.run([T(a) for a in start], loss_grad, epochs=iters, callback=lambda arrays, epoch, pinfo: its.append(evals[-1]))
+            except odil.EarlyStopError as e:
+                print("early stop", e)
+            data["iter_losses_" + tag] = np.array(its)
+        a, b = data["iter_losses_a"], data["iter_losses_b"]
+        n = min(len(a), len(b))
+        rel = np.abs(a[:n] - b[:n]) / np.abs(a[:n])
+        bad = np.nonzero(rel > 1e-6)[0]
+        print(name, "lbfgsb: reference vs reference one ulp apart agree to 1e-6 for", int(bad[0]) if len(bad) else n, "of", n, "iterations")
+        save("traj_lbfgsb_pair_" + name, **data)
+
+
 def load_losses(name):
     import os
 
@@ -238,3 +282,4 @@ if __name__ == "__main__":
     adam_states(3, 16, 100, [1, 2, 50, 99])
     lbfgsb_iterates()
     workload_adam_states()
+    workload_lbfgsb_pairs()

@@ -227,3 +227,42 @@ def test_two_emulated_slab_ranks_follow_the_reference(which, tag):
                 want = want[:, r * per:(r + 1) * per]
             bound = (1e-9 if tag == "f64" else 4 * EPS32) * max(1.0, float(want.abs().max())) + (0 if tag == "f64" else 1e-2 * lr)
             assert float((got.cpu() - want).abs().max()) <= bound, (r, i, float((got.cpu() - want).abs().max()), bound)
+
+
+@pytest.mark.parametrize("path", ["traced", "generic"])
+@pytest.mark.parametrize("which", ["wave", "heat_tmax", "infer_constant"])
+def test_lbfgsb_on_the_example_workloads_follows_the_reference(which, path, monkeypatch):
+    """The three reference examples whose default optimizer is L-BFGS-B (wave, heat_tmax, infer_constant): this package's
+    on-device L-BFGS-B (`odil.util.optimize_grad(..., "lbfgsb")`, traced operator and autograd path) from the fixtures'
+    random states against the reference's LbfgsbOptimizer -> SciPy run (fixtures traj_lbfgsb_pair_*: two reference runs one
+    ulp apart agree to 1e-6 over all 40 iterations, so every iteration is held to 1e-6)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", which))
+    ex = __import__(which if which != "wave" else "wave")
+    monkeypatch.setattr(odil.runtime, "enable_trace", path == "traced")
+    g = load_golden(which + "_f64")
+    t = load_golden("traj_lbfgsb_pair_{}_f64".format(which))
+    a, b = t["iter_losses_a"], t["iter_losses_b"]
+    n = min(len(a), len(b))
+    assert n >= 30 and np.max(np.abs(a[:n] - b[:n]) / np.abs(a[:n])) < 1e-6  # the reference agrees with itself
+    mod = odil.runtime.get_mod()
+    odil.util.set_log_file(open(os.devnull, "w"))
+    argv = ["--Nt", str(int(g["Nt"])), "--Nx", str(int(g["Nx"]))] + (["--kimp", str(float(g["kimp"]))] if "kimp" in g.files else [])
+    args = ex.parse_args(argv)
+    problem, state = ex.make_problem(args)
+    for k in ("left_u", "right_u", "init_u", "init_ut", "u_init", "u_final"):
+        if k in g.files:
+            setattr(problem.extra, k, mod.array(g[k]))
+    arrays = [mod.array(g[f"x{i}"]) for i in range(len(problem.domain.arrays_from_state(state)))]
+    problem.domain.arrays_to_state(arrays, state)
+    args.epoch_start, args.epochs = 0, int(t["epochs"])
+    args.bfgs_m, args.bfgs_maxls = int(t["m"]), int(t["maxls"])
+    losses = []
+    try:
+        odil.util.optimize_grad(args, "lbfgsb", problem, state, lambda s, e, p: losses.append(float(p["loss"])))
+    except odil.EarlyStopError:
+        pass
+    assert (problem._traced is not None) == (path == "traced")
+    got = np.array(losses[1:])  # (the callback also sees the initial evaluation)
+    k = min(len(got), n)
+    assert k >= 30, (len(got), n)
+    assert np.max(np.abs(got[:k] - a[:k]) / np.abs(a[:k])) < 1e-6, np.abs(got[:k] - a[:k]) / np.abs(a[:k])
