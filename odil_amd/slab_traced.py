@@ -108,10 +108,32 @@ class HipSlabKernels:
 
     def __init__(self, problem, state, axis, n, device):
         tr, outs, raw, self.names, Gshape = trace_outputs(problem, state)
-        if tr.offgrid:
-            raise TraceUnsupported("outputs in parameter space under the slab decomposition")
         self.problem, self.tr, self.raw = problem, tr, raw
         cg = _Codegen(tr, outs, raw, Gshape, state, slab=(axis, n))
+        # outputs in parameter space (a weight regulariser): every rank evaluates them, redundantly, with the generated
+        # kernel of param_expr.py AFTER the parameter gradients were summed over the ranks
+        self.par_outputs = None
+        if tr.offgrid:
+            from . import param_expr
+            from .core import Array, NeuralNet
+
+            domain = problem.domain
+            arrays0 = domain.arrays_from_state(state)
+            offgrid = [(k, e, tr.param_tape.slice_for(e.param_ids())) for k, e in tr.offgrid]
+            try:
+                self.par_outputs = param_expr.convert(tr.param_tape, offgrid, {i: int(a.numel()) for i, a in enumerate(arrays0)})
+            except param_expr.Unsupported as e:
+                raise TraceUnsupported("outputs in parameter space under the slab decomposition ({})".format(e))
+            cg.par_outputs, cg.par_numel, cg.par_keys, pos = self.par_outputs, dict(), dict(), 0
+            self.par_where = dict()  # global array index -> (field key, position among the field's arrays)
+            for key, field in state.fields.items():
+                cnt = len(domain.arrays_from_field(field))
+                for i in range(pos, pos + cnt):
+                    cg.par_numel[i] = int(arrays0[i].numel())
+                    if isinstance(field, (NeuralNet, Array)):
+                        cg.par_keys[i] = key
+                        self.par_where[i] = (key, i - pos)
+                pos += cnt
         self.source = cg.source()
         self.lib, self.lib_path = _compile(self.source, cg.flags)
         self.cg = cg
@@ -247,6 +269,29 @@ class HipSlabKernels:
     def partial_terms(self):
         """This rank's share of every loss term (sum over owned cells / GLOBAL count)."""
         return self.out[1:1 + self.nout]
+
+    def launch_par(self, values_of, grads_of):
+        """The parameter-space outputs: terms into self.pout, gradients added to (set in) the parameters' gradient views.
+        values_of / grads_of: field key -> list of this rank's (replicated) arrays."""
+        if self.par_outputs is None:
+            return
+        if not hasattr(self, "par_args"):
+            npar = max(1, len(self.cg.par_index))
+
+            class ParArgs(ctypes.Structure):
+                _fields_ = [("val", ctypes.c_void_p * npar), ("grad", ctypes.c_void_p * npar), ("pout", ctypes.c_void_p)]
+
+            self.par_args = ParArgs()
+            self.pout = torch.zeros(2 * len(self.par_outputs), dtype=self.dtype, device=self.out.device)
+            self.par_args.pout = self.pout.data_ptr()
+            self.lib.jit_par.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        for s_, index in enumerate(self.cg.par_index):
+            key, j = self.par_where[index]
+            self.par_args.val[s_] = values_of(key)[j].data_ptr()
+            self.par_args.grad[s_] = grads_of(key)[j].data_ptr()
+        rc = self.lib.jit_par(ctypes.byref(self.args), ctypes.byref(self.par_args), hip_ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("parameter-space kernel launch failed: hip error {}".format(rc))
 
 
 class SlabTracedAdam:
@@ -725,6 +770,8 @@ class SlabTracedAdam:
                 for view, cnt in zip(self.by_key[key]["g"], lens):
                     view.copy_(total[ofs:ofs + cnt].view(view.shape))
                     ofs += cnt
+        if getattr(self.kern, "par_outputs", None) is not None:
+            self.kern.launch_par(lambda key: self.by_key[key]["x"], lambda key: self.by_key[key]["g"])
         self.t += 1
         b = tic("adam")
         if not self._fused:
@@ -752,7 +799,13 @@ class SlabTracedAdam:
         part = self.kern.partial_terms().clone()
         if comm is not None:
             part = comm.exchange("sum", part, None)
-        return [float(v) for v in part]
+        terms = [float(v) for v in part]
+        if getattr(self.kern, "par_outputs", None) is not None and hasattr(self.kern, "pout"):
+            # parameter-space outputs are evaluated by every rank alike: counted ONCE (emulated ranks sum their
+            # last_loss(): rank 0 carries them)
+            for q, (k, _) in enumerate(self.kern.par_outputs):
+                terms.insert(k, float(self.kern.pout[2 * q]) if self.rank == 0 or comm is not None else 0.0)
+        return terms
 
     def last_loss(self, comm=None):
         return float(sum(self.last_terms(comm)))

@@ -1756,6 +1756,13 @@ class _Codegen:
             S.append("}")
 
     def _launchers(self, S, nout, par_arrays, HEAD):
+        # outputs in parameter space as one generated kernel (param_expr.py), when their tape has an elementwise form
+        self.par_index = []
+        if getattr(self, "par_outputs", None):
+            from . import param_expr
+
+            fresh = {i for i, key in self.par_keys.items() if key not in self.pgrads}
+            self.par_index = param_expr.emit(self, S, self.par_outputs, fresh)
         # launchers
         S.append('extern "C" int jit_fwd(const Args* a, void* stream) {')
         S.append("  hipLaunchKernelGGL(k_fwd, dim3(a->nblocks), dim3({}), 0, (hipStream_t)stream, *a);".format(self.fwd_threads))

@@ -112,6 +112,29 @@ class TracedOperator:
         self.offgrid = [(k, e, tr.param_tape.slice_for(e.param_ids())) for k, e in tr.offgrid]
         self.param_tape = tr.param_tape
         cg = _Codegen(tr, outs, raw, G, state)
+        # ... as ONE generated kernel when the taped operations have an elementwise form (param_expr.py); else the torch
+        # replay of _eval_offgrid
+        self.par_outputs = None
+        if self.offgrid and int(os.environ.get("ODIL_TRACE_PAR_KERNEL", 1)):
+            from . import param_expr
+            from .core import Array, NeuralNet
+
+            arrays0 = domain.arrays_from_state(state)
+            try:
+                self.par_outputs = param_expr.convert(tr.param_tape, self.offgrid, {i: int(a.numel()) for i, a in enumerate(arrays0)})
+            except param_expr.Unsupported as e:
+                from .util import printlog
+
+                printlog("odil_amd: parameter-space output evaluated by torch ({})".format(e))
+            if self.par_outputs is not None:
+                cg.par_outputs, cg.par_numel, cg.par_keys, pos = self.par_outputs, dict(), dict(), 0
+                for key, field in state.fields.items():
+                    n = len(domain.arrays_from_field(field))
+                    for i in range(pos, pos + n):
+                        cg.par_numel[i] = int(arrays0[i].numel())
+                        if isinstance(field, (NeuralNet, Array)):
+                            cg.par_keys[i] = key
+                    pos += n
         self.source = cg.source()
         self.lib, self.lib_path = _compile(self.source, cg.flags)
         self.cg, self.tr = cg, tr
@@ -159,6 +182,16 @@ class TracedOperator:
         self.args.hs = None
         self._hs_rows = None  # graph replay: (pinned table, device table, device row, device row index)
         self.lib.jit_fwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if self.par_outputs is not None:
+            npar = max(1, len(cg.par_index))
+
+            class ParArgs(ctypes.Structure):
+                _fields_ = [("val", ctypes.c_void_p * npar), ("grad", ctypes.c_void_p * npar), ("pout", ctypes.c_void_p)]
+
+            self.par_args = ParArgs()
+            self.pout = torch.zeros(2 * len(self.par_outputs), dtype=dt, device=dev)
+            self.par_args.pout = self.pout.data_ptr()
+            self.lib.jit_par.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather_adam.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 4 + [
             ctypes.c_void_p, ctypes.c_void_p]
@@ -456,13 +489,29 @@ class TracedOperator:
                 for j, group in enumerate(cg.pgrads[key]):
                     self.gviews[pos + j].copy_(self.pgrad[pofs:pofs + len(group)].view(self.gviews[pos + j].shape))
                     pofs += len(group)
+        if self.par_outputs is not None:
+            # the parameter-space outputs: one launch behind k_loss -- terms, norms, the loss and the parameters' gradients
+            arrays = self.domain.arrays_from_state(state)
+            for s_, index in enumerate(cg.par_index):
+                if not arrays[index].is_contiguous() or arrays[index].dtype != self.tr.torch_dtype:
+                    raise RuntimeError("parameter arrays must be contiguous {} tensors".format(self.tr.torch_dtype))
+                self.par_args.val[s_] = arrays[index].data_ptr()
+                self.par_args.grad[s_] = self.gviews[index].data_ptr()
+            rc = self.lib.jit_par(ctypes.byref(self.args), ctypes.byref(self.par_args), ops.stream_ptr())
+            if rc != 0:
+                raise RuntimeError("parameter-space kernel launch failed: hip error {}".format(rc))
         out = self.out.clone()
         nout = len(self.raw)
         loss = out[0]
         terms = [out[1 + k] for k in range(nout)]
         norms = [out[1 + nout + k] for k in range(nout)]
         del keep
-        if self.offgrid:
+        if self.par_outputs is not None:
+            pout = self.pout.clone()
+            for q, (k, _) in enumerate(self.par_outputs):
+                terms.insert(k, pout[2 * q])
+                norms.insert(k, pout[2 * q + 1])
+        elif self.offgrid:
             loss, terms, norms = self._eval_offgrid(state, loss, terms, norms)
         return loss, list(self.gviews), terms, self.names, norms
 

@@ -371,9 +371,11 @@ def make_loss_grad(problem, state):
     loss_grad.fused_adam = fused_adam
     # hipGraph replay of whole Adam epochs (optimizer._EpochGraph): possible when the evaluation is
     # made of this package's kernels only -- the generic path has its own graph (Problem(jit=True))
-    # (outputs in parameter space are evaluated by torch with host scalars of the current epoch: not replayable)
+    # (outputs in parameter space: replayable when they run as the generated kernel of param_expr.py; the torch replay
+    # of param_tape.py bakes the host scalars of the current epoch in)
     loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or (
-        getattr(problem, "_traced", None) is not None and not getattr(problem._traced, "offgrid", None))
+        getattr(problem, "_traced", None) is not None and (
+            not getattr(problem._traced, "offgrid", None) or getattr(problem._traced, "par_outputs", None) is not None))
 
     def graph_hook(name):
         def call(*a):

@@ -133,7 +133,7 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
         sys.path.insert(0, os.path.join(root, "examples", sub))
     for sub in ("wave", "infer_constant"):
         sys.path.insert(0, os.path.join(root, "examples", sub))
-    scaled = which.endswith("-factors")
+    scaled, decay = which.endswith("-factors"), which.endswith("-decay")
     which = which.split("-")[0]
     ex = __import__(which)
     odil.util.set_log_file(open(os.devnull, "w"))
@@ -149,6 +149,19 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
     else:
         argv = ["--Nt", "16", "--Nx", str(nx), "--Ny", "32", "--infer_k", "1", "--imposed", "stripe"]
     problem, state = ex.make_problem(ex.parse_args(argv + ["--double", str(dtype_flag)]))
+    if decay:
+        # outputs in PARAMETER space on top of the example's: the reference's weight regulariser (identically zero) and a
+        # weight decay whose value and gradient are not -- evaluated by the generated kernel of odil_amd/param_expr.py
+        base = problem.operator
+
+        def operator(ctx):
+            m = ctx.mod
+            ww = ctx.domain.arrays_from_field(ctx.state.fields["k_net"])
+            flat = m.concatenate([m.flatten(w) for w in ww], axis=0)
+            k = 0.3 * 0.5 ** (ctx.tracers["epoch"] / 4)
+            return base(ctx) + [("wreg", (m.stop_gradient(flat) - flat) * k), ("wdecay", flat * k), ("bias0", (ww[-1] - 0.25) / (1 + k))]
+
+        problem = odil.Problem(operator, problem.domain, problem.extra, tracers={"epoch": 2})
     if scaled:  # multigrid factors other than 1 (reference core.py:245-263)
         for f in state.fields.values():
             if isinstance(f, odil.MultigridField):
@@ -163,6 +176,7 @@ def _traced_problem(which, world, dtype_flag, nx_rank=16):
 
 @pytest.mark.parametrize("which,world,double,nx_rank", [("veltracer", 2, 1, 16), ("veltracer", 3, 1, 16),
                                                         ("veltracer3d", 2, 1, 16), ("heat2d", 2, 1, 16),
+                                                        ("heat2d-decay", 2, 1, 16),
                                                         ("veltracer", 4, 0, 16), ("veltracer", 4, 1, 8),
                                                         ("veltracer3d", 4, 1, 4), ("wave", 2, 1, 16),
                                                         ("infer_constant", 2, 1, 16),
