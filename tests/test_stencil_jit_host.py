@@ -160,6 +160,61 @@ def test_outputs_in_parameter_space_are_taped(cpu_mod):
     assert abs(float(terms[2]) - float((0.125 * w).square().mean())) < 1e-6 * float(terms[2])
 
 
+def test_parameter_space_outputs_have_an_elementwise_form(cpu_mod):
+    """odil_amd/param_expr.py turns the taped torch operations of a parameter-space output into segments of elementwise
+    expressions over the parameter arrays (what the generated `k_par` evaluates): interpreted here with NumPy, the
+    segments reproduce the values the torch replay gives; operations without such a form are refused."""
+    import torch
+
+    import heat
+    from odil_amd import param_expr
+
+    args = heat.parse_args(["--Nx", "16", "--Nt", "8", "--infer_k", "1", "--kwreg", "0.3", "--kwregdecay", "100", "--double", "1"])
+    problem, state = heat.make_problem(args)
+    base = problem.operator
+
+    def operator(ctx):
+        m = ctx.mod
+        ww = ctx.domain.arrays_from_field(ctx.state.fields["k_net"])
+        flat = m.concatenate([m.flatten(w) for w in ww], axis=0)
+        k = 0.5 * 0.5 ** (ctx.tracers["epoch"] / 50)
+        return base(ctx) + [("wdecay", flat * k), ("bias0", (ww[-1] - 0.25) / (1 + k) + 2 * ww[-1])]
+
+    problem2 = odil.Problem(operator, problem.domain, problem.extra)
+    problem2.tracers["epoch"] = 50
+    tro = stencil_jit.TracedOperator(problem2, state)
+    assert tro.par_outputs is not None and [k for k, _ in tro.par_outputs] == [1, 2, 3]
+    assert tro.cg.par_index and "k_par" in tro.source and "jit_par" in tro.source
+    arrays = [a.detach().double().numpy() for a in problem.domain.arrays_from_state(state)]
+    memo = dict()
+
+    def ev(e, j):
+        if e[0] == "atom":
+            return arrays[e[1]].reshape(-1)[e[2] + j]
+        if e[0] == "const":
+            return e[1]
+        if e[0] == "hs":
+            return float(tro._host_value(e[1], memo))
+        if e[0] == "neg":
+            return -ev(e[1], j)
+        a, b = ev(e[1], j), ev(e[2], j)
+        return {"add": a + b, "sub": a - b, "mul": a * b, "div": a / b}[e[0]]
+
+    one = torch.tensor(1.0, dtype=torch.float64)
+    tro.gflat.zero_()
+    _, terms, _ = tro._eval_offgrid(state, one, [one], [one])  # the torch replay
+    for q, (k, segs) in enumerate(tro.par_outputs):
+        values = np.concatenate([np.array([ev(e, j) for j in range(n)]) for n, e in segs])
+        assert abs(float(np.mean(values**2)) - float(terms[k])) <= 1e-12 * max(float(terms[k]), 1e-30), (k, float(terms[k]))
+    # a reduction of a parameter array has no elementwise form: the torch replay keeps such outputs
+    def operator3(ctx):
+        ww = ctx.domain.arrays_from_field(ctx.state.fields["k_net"])
+        return base(ctx) + [("wsum", ww[0].sum().reshape(1) * 0.1)]
+
+    tro3 = stencil_jit.TracedOperator(odil.Problem(operator3, problem.domain, problem.extra, tracers={"epoch": 0}), state)
+    assert tro3.offgrid and tro3.par_outputs is None
+
+
 def test_offgrid_only_parameters_do_not_accumulate(cpu_mod):
     """An `Array` that appears ONLY in a parameter-space output (a prior) gets its gradient from the tape replay alone:
     no grid kernel rewrites its slot of the packed gradient, so repeated evaluations must SET it, not add to it."""
