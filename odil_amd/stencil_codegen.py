@@ -881,41 +881,27 @@ class _Codegen:
             self.emit(line)
 
     # ---- pointwise networks: two evaluations of the same network per pair of float lanes ---------------------
-    TILE = (8, 32)  # interior threads of a workgroup of the tiled forward kernel: rows x columns of the last two axes
-
     def _choose_shared_calls(self):
         """Network evaluations another thread's evaluation equals (stencil_share.py: k_m(i) = k_p(i - e) away from the
-        wall row) are not repeated: the forward kernel becomes a TILED kernel whose threads exchange the values -- and,
-        on the way back, the adjoints -- through LDS (_tile_forward).  Needs the last two axes to tile, frozen inputs
-        (the reverse pass of a shared evaluation runs where it was evaluated, after the exchange) and one network."""
+        wall row) are not repeated: the forward kernel becomes the MARCHING kernel (_march_kernel: values carried along the
+        second-to-last axis in registers, exchanged along the last axis by lane shifts).  Needs frozen inputs (the reverse
+        pass of a shared evaluation runs where it was evaluated), one network, float arithmetic (packed evaluations) and
+        such pairs on both of the last two axes.  ODIL_TRACE_SHARE = auto (default: where a grid is large enough for it to
+        pay) | march (always, tests) | 0.  (An LDS-tiled variant -- interior + halo threads of a 7 x 32 tile, values and
+        adjoints through LDS, two barriers per tile -- was built in round 3, measured slower than the plain kernel, 4.29
+        against 3.55 ms at 256 x 512^2, and removed in round 4; docs/rounds/kernel_log_r01-r03.md.)"""
         from . import stencil_share
 
-        self.TILE = tuple(int(v) for v in os.environ.get("ODIL_TRACE_TILE", "7x32").split("x"))  # (tests: small grids)
         mlps = [n for n in self.order if n.op == "mlp"]
-        # 0: every thread evaluates what its point needs; 1: the LDS-tiled kernel (measured slower, below); march: the
-        # marching kernel (_march_kernel: values carried along the second-to-last axis in registers, exchanged along the last
-        # axis by lane shifts); auto (default): march where a grid is large enough for it to pay
         mode = os.environ.get("ODIL_TRACE_SHARE", "auto")
         self.share_mode = None
-        if not mlps or self.slab is not None or self.ndim < 2 or mode == "0" or self.GL != self.G:
+        if not mlps or self.slab is not None or self.ndim < 3 or mode == "0" or self.GL != self.G:
             return
         a1, a2 = self.ndim - 2, self.ndim - 1
         if len({n.attr for n in mlps}) != 1 or not self.fast:
             return  # (one network; packed float evaluations)
-        if mode == "auto":
-            if self.ndim < 3 or self.G[a2] < 128 or self.G[a1] < 16:
-                return
-            mode = "march"
-        if mode == "1" and (self.G[a2] % self.TILE[1] or self.G[a1] < self.TILE[0]):
-            return  # (rows of tiles may be partial -- masked --, columns not)
-        # MEASURED, twice, and not faster (heat with two space dimensions, 256 x 512^2, 46 parameters, epoch in ms; plain
-        # kernel 3.54 - 3.56): first design -- interior threads evaluate their upper faces, a fifth wave of halo threads
-        # the tile's lower edge, 320-thread workgroups that fit once per compute unit at 244 VGPRs: 4.78 (tiles 4 x 32
-        # ... 16 x 16: 4.4 - 5.1); this design -- one packed evaluation per thread, halo points in pairs, 256 threads,
-        # 207 VGPRs, the plain kernel's 8 waves per compute unit: 4.29 (3 x 64 tiles: 4.50).  The evaluations halve
-        # (4 per 224 points instead of 7), the kernel does not get faster: two workgroup barriers per tile, the
-        # divergent input selection of the halo lanes in one of four waves, 128-byte row segments instead of the plain
-        # kernel's 1 KB rows.  Kept behind ODIL_TRACE_SHARE=1 with its parity tests; off by default.
+        if mode == "auto" and (self.G[a2] < 128 or self.G[a1] < 16):
+            return
         if any(self.need.get(a.idx, False) for n in mlps for a in n.args):
             return
         try:
@@ -935,10 +921,10 @@ class _Codegen:
             for arg in x.args:
                 if any(m.op == "mlp_out" and m.args[0].idx in outs_of for m in stencil_grad.subdag(arg)):
                     return
-        if mode == "march" and (sorted(per_axis) != [a1, a2] or len(pairs[0][0].attr[2]) < 2):
+        if sorted(per_axis) != [a1, a2] or len(pairs[0][0].attr[2]) < 2:
             return  # (the marching kernel pairs the upper faces of the last two axes in ONE packed evaluation)
         self.share = pairs
-        self.share_mode = "march" if mode == "march" else "tile"
+        self.share_mode = "march"
         self.shared_A = {A.idx for A, _, _ in pairs}
         self.shared_B = {B.idx for _, B, _ in pairs}
 
@@ -950,7 +936,7 @@ class _Codegen:
         (topologically) with the pair as one unit; pairs that would close a cycle stay single."""
         groups = dict()
         for n in self.order:
-            if n.op == "mlp" and n.idx not in self.shared_A and n.idx not in self.shared_B:  # (shared calls: _tile_kernel)
+            if n.op == "mlp" and n.idx not in self.shared_A and n.idx not in self.shared_B:  # (shared calls: _march_kernel)
                 groups.setdefault(n.attr, []).append(n)
         pairs = [(nodes[k], nodes[k + 1]) for nodes in groups.values() for k in range(0, len(nodes) - 1, 2)]
         while pairs:
@@ -1042,7 +1028,7 @@ class _Codegen:
 
     def _emit_mlp(self, n):
         if n.idx in self.shared_A or n.idx in self.shared_B:
-            return  # shared evaluations: the tiled kernel's unified packed evaluation (_tile_kernel)
+            return  # shared evaluations: the marching kernel's unified packed evaluation (_march_kernel)
         if n.idx in self.partner and n.idx not in self.pair_first:
             return  # emitted with its partner
         group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
@@ -1251,7 +1237,7 @@ class _Codegen:
 
     def _reverse_mlp(self, n, defined, acc):
         if n.idx in self.shared_A or n.idx in self.shared_B:
-            return  # the reverse pass of shared evaluations runs after the adjoints were exchanged (_tile_forward)
+            return  # the reverse pass of shared evaluations runs one step late (_march_kernel)
         if n.idx in self.partner and n.idx not in self.pair_first:
             return  # handled when the traversal reaches its partner (the earlier node of the pair)
         group = [n, self.partner[n.idx]] if n.idx in self.pair_first else [n]
@@ -1456,13 +1442,10 @@ class _Codegen:
         vw, last = self.vw, self.ndim - 1
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         self._begin()
-        tiled, interior = None, None
+        interior = None
         march = None
-        if self.share and self.share_mode == "march":
+        if self.share:
             march = self._march_parts()
-            fwd, rev = [], []
-        elif self.share:
-            tiled = self._tile_parts()
             fwd, rev = [], []
         else:
             self.forward()
@@ -1523,7 +1506,7 @@ class _Codegen:
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
         # ---- k_fwd ---------------------------------------------------------------------------------------------
         occ = int(os.environ.get("ODIL_TRACE_WAVES_FWD", 0))  # register budget of k_fwd as waves per SIMD (0: the compiler's)
-        self.fwd_threads = 256 if tiled is None else tiled["threads"]
+        self.fwd_threads = 256
 
         S.append('extern "C" __global__ __launch_bounds__({}) {}void k_fwd(const Args a) {{'.format(
             self.fwd_threads, "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else ""))
@@ -1547,12 +1530,10 @@ class _Codegen:
         for slot_k, (k, _) in enumerate(self.jac_store):
             self.pseudo_slot[self.seed_key[k]] = len(self.cots) + len(self.cut_nodes) + slot_k
         stream = self.ncot * self.total * esize > (128 << 20)  # beyond what the last-level cache keeps
-        if tiled is not None:
-            self._tile_kernel(S, tiled, stored, stream)
         if march is not None:
             self._march_kernel(S, march, stored, stream)
         threads = self.total // vw
-        if tiled is None and march is None:
+        if march is None:
             flat = "l4" if vw == 4 else "l"
             S.append(self._block_index(self.GL, vw))
             if threads <= self.max_blocks * 256:  # one thread per point (or four points)
@@ -1807,195 +1788,6 @@ class _Codegen:
                         nsrc, max(1, len(self.tr.tensors)), max(1, self.ncot),
                         max(1, par_arrays), max(1, len(self.hs)), slab_members))
         HEAD.append("#define HS(i) (a.hs ? a.hs[i] : a.hsv[i])")
-
-    def _tile_parts(self):
-        """Line groups of the tiled forward kernel (see _tile_kernel)."""
-        TR, TC = self.TILE
-        a1, a2 = self.ndim - 2, self.ndim - 1
-        shared = {x.idx: x for A, B, _ in self.share for x in (A, B)}
-        # nodes that need a shared value: everything downstream of the outputs of the shared calls
-        late = set()
-        for n in self.order:
-            if (n.op == "mlp_out" and n.args[0].idx in shared) or any(a.idx in late for a in n.args):
-                late.add(n.idx)
-        early = {n.idx for n in self.order} - late
-        self.forward(only=early)
-        fwd1, self.lines = self.lines, []
-        self.forward(only=late)
-        fwd2, self.lines = self.lines, []
-        self.reverse()
-        rev, self.lines = self.lines, []
-        attr = self.share[0][0].attr
-        nlast = len(attr[2]) - 1
-        nz, nin = attr[2][nlast], len(self.share[0][0].args)
-        # the ONE packed evaluation every thread performs: lanes (0, 1) = the upper faces of the thread's point along
-        # the (first, second) shared axis -- or two halo points of one axis
-        lanes = dict()  # call idx -> lane of the unified evaluation that holds it (interior threads)
-        by_axis = {axis: (A, B) for A, B, axis in self.share}
-        for lane, axis in enumerate(sorted(by_axis)):
-            lanes[by_axis[axis][1].idx] = lane
-        parts = dict(fwd1=fwd1, fwd2=fwd2, rev=rev, threads=256, nz=nz, nin=nin, lds=[], xin=[], put=[], get=[], adj_put=[],
-                     adj_get=[], halo=[])
-        for (A, B, axis) in self.share:
-            lane = lanes[B.idx]
-            for k in range(nin):
-                parts["xin"].append("  ux{}_{} = {};".format(k, lane, self.r(B.args[k])))
-        rev_text = "\n".join(rev)
-
-        def adjoint_of(call, j):
-            out = self.mlp_out_seen.get(call.idx, dict()).get(j)
-            return "g{}".format(out.idx) if out is not None and "T g{} ".format(out.idx) in rev_text else "(T)0"
-
-        slot = 0
-        for p, (A, B, axis) in enumerate(self.share):
-            row = axis == a1
-            lane = "xy"[lanes[B.idx]]
-            kz, ga = "KZ{}".format(p), "GA{}".format(p)
-            parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(kz, TR + (1 if row else 0), TC + (0 if row else 1), nz))
-            parts["lds"].append("  __shared__ T {}[{}][{}][{}];".format(ga, TR, TC, nz))
-            for j in range(nz):
-                parts["put"].append("  {}[{}][{}][{}] = mu_z{}_{}.{};".format(kz, "tr + 1" if row else "tr", "tc" if row else "tc + 1", j, nlast, j, lane))
-                parts["get"].append("  const T m{}_z{}_{} = {}[tr][tc][{}];".format(A.idx, nlast, j, kz, j))
-                parts["get"].append("  const T m{}_z{}_{} = mu_z{}_{}.{};".format(B.idx, nlast, j, nlast, j, lane))
-                parts["adj_put"].append("  {}[tr][tc][{}] = valid ? {} : (T)0;".format(ga, j, adjoint_of(A, j)))
-                nb = ("(tr + 1 < {} ? {}[tr + 1][tc][{}] : (T)0)".format(TR, ga, j) if row
-                      else "(tc + 1 < {} ? {}[tr][tc + 1][{}] : (T)0)".format(TC, ga, j))
-                parts["adj_get"].append("  ud{}_{} = valid ? {} + {} : (T)0;".format(j, lanes[B.idx], adjoint_of(B, j), nb))
-            # halo points of this axis: the lower-face input at the tile's first row / column, two per thread
-            saved = (self.order, self.loads, self.pre, self.groups)
-            seen = dict()
-            for arg in A.args:
-                for n in stencil_grad.subdag(arg):
-                    seen[n.idx] = n
-            self.order = [seen[i] for i in sorted(seen)]
-            self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
-            self.forward()
-            inputs = [self.r(arg) for arg in A.args]
-            count = TC if row else TR
-            parts["halo"].append(dict(first=slot, count=count, row=row, lines=self.lines, inputs=inputs, p=p))
-            slot += count + (count % 2)  # (a thread's two points belong to one axis)
-            self.order, self.loads, self.pre, self.groups = saved
-        self.lines = []
-        parts["halo_threads"] = slot // 2
-        if TR * TC + slot // 2 > 256 or (TR * TC) % 32:
-            raise TraceUnsupported("tile of {} x {} points".format(TR, TC))
-        self._mlp_forward("mu", 2, attr, [("ux{}_0".format(k), "ux{}_1".format(k)) for k in range(nin)])
-        parts["mlp_fwd"], self.lines = self.lines, []
-        self._mlp_backward("mu", 2, attr, [("ud{}_0".format(j), "ud{}_1".format(j)) for j in range(nz)], False)
-        parts["mlp_bwd"], self.lines = self.lines, []
-        return parts
-
-    def _tile_kernel(self, S, parts, stored, stream):
-        """Body of the TILED forward kernel.  A workgroup of 256 threads owns a 7 x 32 tile of the last two grid axes
-        (224 threads, one per point) and its HALO: the tile points whose lower neighbour along a shared axis lies in
-        another tile (or beyond the wall), two of them per halo thread (20 threads).  EVERY thread performs one packed
-        evaluation of the network: an interior thread for the upper faces of its point along the two axes, a halo
-        thread for the lower-face inputs of its two points (the wall extrapolation where the tile touches the wall) --
-        the same instruction stream for all, only the inputs differ.  Values cross to the neighbouring thread through
-        LDS; after the reverse pass of the stencil the adjoints cross back the same way, and every thread finishes
-        the reverse pass of what IT evaluated with the sum of the adjoints of both uses (the network's inputs are
-        frozen: only parameter gradients come out of it).  Two workgroup barriers per tile; 4 packed evaluations per
-        224 points where the plain kernel makes 7, at the same 8 waves per compute unit.  Halo and idle threads run
-        the stencil part too, at a point of their own, masked: no divergence outside the input selection."""
-        TR, TC = self.TILE
-        a1, a2 = self.ndim - 2, self.ndim - 1
-        G1, G2 = self.G[a1], self.G[a2]
-        n1, n2 = (G1 + TR - 1) // TR, G2 // TC
-        lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
-        ntiles = lead * n1 * n2
-        nz, nin, NI = parts["nz"], parts["nin"], TR * TC
-        S.extend(parts["lds"])
-        S.append("  const int tid = threadIdx.x;")
-        S.append("  for (int tile = blockIdx.x; tile < {}; tile += a.nblocks) {{".format(ntiles))
-        S.append("  const int tc0 = (tile % {}) * {};".format(n2, TC))
-        S.append("  const int tr0 = ((tile / {}) % {}) * {};".format(n2, n1, TR))
-        rem = "(tile / {})".format(n1 * n2)
-        for d in reversed(range(a1)):
-            if d == 0:
-                S.append("  const int i0 = {};".format(rem))
-            else:
-                S.append("  const int i{} = {} % {};".format(d, rem, self.G[d]))
-                S.append("  const int q{}_ = {} / {};".format(d, rem, self.G[d]))
-                rem = "q{}_".format(d)
-        # roles: interior thread (its point), halo thread (the first of its two points), idle (the tile's first point)
-        S.append("  const bool interior = tid < {};".format(NI))
-        S.append("  const int hs = 2 * (tid - {});".format(NI))  # first halo slot of a halo thread
-        S.append("  int tr = interior ? tid / {0} : 0, tc = interior ? tid % {0} : 0;".format(TC))
-        for h in parts["halo"]:
-            S.append("  if (!interior && hs >= {0} && hs < {1}) {2} = hs - {0};".format(h["first"], h["first"] + h["count"], "tc" if h["row"] else "tr"))
-        S.append("  const bool valid = interior && tr0 + tr < {};".format(G1))
-        S.append("  const int i{} = min(tr0 + tr, {}), i{} = tc0 + tc;".format(a1, G1 - 1, a2))
-        S.append("  const int l = {};".format(self._offset(["i{}".format(d) for d in range(self.ndim)], self.G)))
-        for k, lens in enumerate(self.out_lens):
-            if lens is not None:
-                conds = ["{} < {}".format(self.gi(d), lens[d]) for d in range(self.ndim) if lens[d] < self.G[d]]
-                S.append("  const bool inbox{} = {};".format(k, " && ".join(conds) or "true"))
-        S.extend(parts["fwd1"])
-        for k in range(nin):
-            S.append("  T ux{0}_0 = (T)0, ux{0}_1 = (T)0;".format(k))
-        S.extend(parts["xin"])
-        for h in parts["halo"]:
-            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
-            for e in range(2):
-                along = "tc" if h["row"] else "tr"
-                S.append("    if ({} + {} < {}) {{".format(along, e, h["count"]))
-                if h["row"]:
-                    S.append("      const int i{} = min(tr0, {}), i{} = tc0 + tc + {};".format(a1, G1 - 1, a2, e))
-                else:
-                    S.append("      const int i{} = min(tr0 + tr + {}, {}), i{} = tc0;".format(a1, e, G1 - 1, a2))
-                S.extend("    " + line for line in h["lines"])
-                for k, expr in enumerate(h["inputs"]):
-                    S.append("      ux{}_{} = {};".format(k, e, expr))
-                S.append("    }")
-            S.append("  }")
-        S.extend(parts["mlp_fwd"])
-        S.append("  if (interior) {")
-        S.extend("  " + line for line in parts["put"])
-        S.append("  }")
-        nl = len(self.share[0][0].attr[2]) - 1
-        for h in parts["halo"]:
-            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
-            for e, lane in enumerate("xy"):
-                idx = "[0][tc + {}]".format(e) if h["row"] else "[tr + {}][0]".format(e)
-                for j in range(nz):
-                    S.append("    if ({} + {} < {}) KZ{}{}[{}] = mu_z{}_{}.{};".format(
-                        "tc" if h["row"] else "tr", e, h["count"], h["p"], idx, j, nl, j, lane))
-            S.append("  }")
-        S.append("  __syncthreads();")
-        S.extend(parts["get"])
-        S.extend(parts["fwd2"])
-        S.extend(parts["rev"])
-        S.append("  if (valid) {")
-        for slot, (n, name) in enumerate(stored):
-            if stream:
-                S.append("    __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
-            else:
-                S.append("    a.cot[{}][l] = {};".format(slot, name))
-        for k, (o_, raw) in enumerate(zip(self.outputs, self.raw)):
-            term = self.r(o_) if raw else "{0} * {0}".format(self.r(o_))
-            if self.out_lens[k] is not None:
-                term = "(inbox{} ? {} : (T)0)".format(k, term)
-            S.append("    s_{0} = s_{0} + {1};".format(k, term))
-        S.append("  }")
-        S.append("  if (interior) {")
-        S.extend("  " + line for line in parts["adj_put"])
-        S.append("  }")
-        S.append("  __syncthreads();")
-        for j in range(nz):
-            S.append("  T ud{0}_0 = (T)0, ud{0}_1 = (T)0;".format(j))
-        S.append("  if (interior) {")
-        S.extend("  " + line for line in parts["adj_get"])
-        S.append("  }")
-        for h in parts["halo"]:
-            S.append("  if (!interior && hs >= {} && hs < {}) {{".format(h["first"], h["first"] + h["count"]))
-            for e in range(2):
-                idx = "[0][tc + {}]".format(e) if h["row"] else "[tr + {}][0]".format(e)
-                for j in range(nz):
-                    S.append("    if ({} + {} < {}) ud{}_{} = GA{}{}[{}];".format(
-                        "tc" if h["row"] else "tr", e, h["count"], j, e, h["p"], idx, j))
-            S.append("  }")
-        S.extend(parts["mlp_bwd"])
-        S.append("  }")  # tiles
 
     # ---- network evaluations shared by MARCHING (float kernels with a pointwise network at the faces) ---------------------
     def _march_parts(self):

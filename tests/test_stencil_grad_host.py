@@ -174,9 +174,9 @@ def test_shared_network_calls_are_proved_and_true(cpu_mod, which, monkeypatch):
             wall = tuple(slice(0, 1) if d == axis else slice(None) for d in range(len(G)))
             assert np.array_equal(va[inner], vb[inner])
             assert not np.array_equal(va[wall], vb[wall])
-    if which == "heat2d":  # on request the generator tiles the last two axes and shares both (float kernels)
-        monkeypatch.setenv("ODIL_TRACE_SHARE", "1")
+    if which == "heat2d":  # on request the generator marches the last two axes and shares both (float kernels)
+        monkeypatch.setenv("ODIL_TRACE_SHARE", "march")
         problem, state = ex.make_problem(ex.parse_args([a if a != "1" or argv[i - 1] != "--double" else "0" for i, a in enumerate(argv)]))
         tr, outs, raw, names, G = stencil_jit.trace_outputs(problem, state)
         cg = _Codegen(tr, outs, raw, G, state)
-        assert sorted(axis for _, _, axis in cg.share) == [1, 2] and cg.TILE == (7, 32)
+        assert sorted(axis for _, _, axis in cg.share) == [1, 2] and cg.share_mode == "march"
