@@ -198,7 +198,7 @@ def test_parameter_space_outputs_have_an_elementwise_form(cpu_mod):
         if e[0] == "neg":
             return -ev(e[1], j)
         a, b = ev(e[1], j), ev(e[2], j)
-        return {"add": a + b, "sub": a - b, "mul": a * b, "div": a / b}[e[0]]
+        return a + b if e[0] == "add" else a - b if e[0] == "sub" else a * b if e[0] == "mul" else a / b
 
     one = torch.tensor(1.0, dtype=torch.float64)
     tro.gflat.zero_()
