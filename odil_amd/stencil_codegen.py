@@ -1809,11 +1809,16 @@ class _Codegen:
         nz, nin = attr[2][nlast], len(Bx.args)
         parts = dict(Ax=Ax, Bx=Bx, Ay=Ay, By=By, nz=nz, nin=nin, attr=attr, variants=[])
         plan = self._fold_plan(self.order, 1, windows=True)
-        parts["plan"] = plan
+        # a third copy for the strips that touch a wall of the LANE axis (2 of 9 at 512 columns): predicates of the other
+        # axes folded, those of the lane axis kept (ODIL_TRACE_MARCH_VARIANTS=2: general and interior only)
+        plan_w = self._fold_plan(self.order, 4, windows=True) if plan is not None and int(os.environ.get("ODIL_TRACE_MARCH_VARIANTS", 3)) >= 3 else None
+        if plan_w is not None and (plan_w[0] == plan[0] or a2 not in plan[1]):
+            plan_w = None  # (no predicate of the lane axis: the interior copy serves every strip)
+        parts["plan"], parts["plan_w"] = plan, plan_w
         keep = ("cots", "cut_nodes", "jac_store", "pg_decl", "pg_offset", "pgrads", "pg2_used")
         first = None
         self.march_pref = dict() if int(os.environ.get("ODIL_TRACE_MARCH_PREFETCH", 1)) else None
-        for fold in ([None] if plan is None else [None, plan[0]]):
+        for fold in ([None] if plan is None else ([None, plan[0]] + ([plan_w[0]] if plan_w is not None else []))):
             self.fold, self.lines, self.loads = fold, [], dict()
             self.march_live, self.march_used = (None if fold is None else self._live_under(fold)), set()
             self.cots, self.cut_nodes, self.jac_store, self.pg_decl, self.pg_offset, self.pg2_used = [], [], [], [], dict(), set()
@@ -2046,13 +2051,14 @@ class _Codegen:
         S.append("  const bool valid = lane != 0 && p2 < {};".format(G2))
         S.append("  const int i{} = min(p2, {});".format(a2, G2 - 1))
         # interior test, scalar: leading indices, strip range; the row is tested per step
-        plan = parts["plan"]
-        outer, rowc = [], []
+        plan, plan_w = parts["plan"], parts.get("plan_w")
+        outer, rowc, leadc = [], [], []
         if plan is not None:
             _, exc, _ = plan
             for d, values in sorted(exc.items()):
                 if d < a1:
                     outer.append(self._interior_cond({d: values}))
+                    leadc.append(outer[-1])
                 elif d == a1:
                     rowc.append(self._interior_cond({d: values}))
                 else:  # no exceptional column among the strip's: [s0, s0 + 62]
@@ -2069,6 +2075,7 @@ class _Codegen:
                         outer.append("strip * 63 + 62 <= {}".format(hi))
                     outer.extend("!(strip * 63 <= {0} && {0} <= strip * 63 + 62)".format(e) for e in values)
             S.append("  const bool interior_ = {};".format(" && ".join(outer) or "true"))
+            S.append("  const bool lead_ok_ = {};".format(" && ".join(leadc) or "true"))  # (the wall-strip copy's condition)
         # carried state
         mg = parts["gather"]
         if mg is not None:
@@ -2106,15 +2113,24 @@ class _Codegen:
             for k, _ in pref:
                 S.append("  const T ld_{0} = ldn_{0};".format(k))
             S.append("  {{ const int inext_ = min(i{0} + 1, r1 - 1); {{ const int i{0} = inext_;".format(a1))
-            always = parts["variants"][-1]["used"] if len(parts["variants"]) > 1 else {k for k, _ in pref}
+            vs = parts["variants"]
+            row = " && ".join(rowc) or "true"
+            always = vs[1]["used"] if len(vs) > 1 else {k for k, _ in pref}
+            wall = (vs[2]["used"] | always) if len(vs) > 2 else None
             for k, e in pref:
                 if k in always:
                     S.append("    ldn_{} = {};".format(k, e))
-            if len(always) < len(pref):  # what only the general copy of the body reads: when the next row takes that copy
-                S.append("    if (!(interior_ && {})) {{".format(" && ".join(rowc) or "true"))
+            if wall is not None and len(wall) > len(always):  # what the wall-strip copy reads beyond the interior one
+                S.append("    if (!(interior_ && {})) {{".format(row))
                 for k, e in pref:
-                    if k not in always:
+                    if k in wall and k not in always:
                         S.append("      ldn_{} = {};".format(k, e))
+                S.append("    }")
+            rest = [(k, e) for k, e in pref if k not in (wall if wall is not None else always)]
+            if rest:  # what only the general copy of the body reads: when the next row takes that copy
+                S.append("    if (!({} && {})) {{".format("lead_ok_" if wall is not None else "interior_", row))
+                for k, e in rest:
+                    S.append("      ldn_{} = {};".format(k, e))
                 S.append("    }")
             S.append("  } }")
         for j in range(nz):
@@ -2184,6 +2200,9 @@ class _Codegen:
         else:
             S.append("  if (interior_ && {}) {{".format(" && ".join(rowc) or "true"))
             S.extend(body(variants[1], plan[2]))
+            if len(variants) > 2:
+                S.append("  }} else if (lead_ok_ && {}) {{".format(" && ".join(rowc) or "true"))
+                S.extend(body(variants[2], plan_w[2]))
             S.append("  } else {")
             S.extend(body(variants[0], ()))
             S.append("  }")
