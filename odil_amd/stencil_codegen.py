@@ -1472,6 +1472,9 @@ class _Codegen:
         HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + nt + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
             HEAD.append("#define tanhf odil_tanh_f32\n#define expf odil_fast_exp")
+        if march is not None:  # (value of lane `l` -- wave-uniform -- for every lane; only the marching kernel uses it)
+            HEAD.append("__device__ inline float odil_readlane(float v, int l) {\n"
+                        "  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));\n}")
         S = []
         # parameter access macros: W(net, layer, k), Bv(net, layer, k)
         wofs, bofs, o = dict(), dict(), 0
@@ -1859,6 +1862,14 @@ class _Codegen:
         self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
         self.forward()
         parts["pre_lines"], parts["pre_in"] = self.lines, [self.r(arg) for arg in Ax.args]
+        seen = dict()
+        for arg in Ay.args:
+            for n in stencil_grad.subdag(arg):
+                seen[n.idx] = n
+        self.order = [seen[i] for i in sorted(seen)]
+        self.loads, self.pre, self.groups, self.lines = dict(), [], dict(), []
+        self.forward()
+        parts["pre_lines_y"], parts["pre_in_y"] = self.lines, [self.r(arg) for arg in Ay.args]
         self.order, self.loads, self.pre, self.groups = saved
         # the packed evaluation (prefix mu) and the reverse pass of the PREVIOUS step's evaluation (prefix mp)
         self.lines = []
@@ -1866,6 +1877,8 @@ class _Codegen:
         parts["mlp_fwd"], self.lines = self.lines, []
         self._mlp_backward("mp", 2, attr, [("ud{}_0".format(j), "ud{}_1".format(j)) for j in range(nz)], False)
         parts["mlp_bwd"], self.lines = self.lines, []
+        self._mlp_backward("mu", 2, attr, [("ud{}_0".format(j), "ud{}_1".format(j)) for j in range(nz)], False)
+        parts["mlp_bwd_mu"], self.lines = self.lines, []
         layers = attr[2]
         parts["acts"] = ["h{}_{}".format(l, i) for l in range(nlast) for i in range(layers[l])]  # what the reverse pass reads
         return parts
@@ -1900,8 +1913,8 @@ class _Codegen:
     def _march_gather_geometry(self):
         a1, a2 = self.ndim - 2, self.ndim - 1
         G1, G2 = self.G[a1], self.G[a2]
-        R = max(1, min(int(os.environ.get("ODIL_TRACE_MARCH_ROWS", 64)), G1))
-        nseg, nstrip = (G1 + R - 1) // R, (G2 + 62) // 63
+        R = max(1, min(int(os.environ.get("ODIL_TRACE_MARCH_ROWS", 64)), G1, 64))  # (<= 64: one lane of the pre-step per row)
+        nseg, nstrip = (G1 + R - 1) // R, (G2 + 63) // 64
         lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
         return R, nseg, nstrip, lead
 
@@ -1972,10 +1985,10 @@ class _Codegen:
                 S.append("  }")
                 # columns that received a contribution from the neighbouring strip
                 S.append("  for (int p = 0; p < {}; ++p) {{".format(vw))
-                S.append("    const int c = ib + p, st = c / 63;")
+                S.append("    const int c = ib + p, st = c / 64;")
                 S.append("    const T* const F = a.edge + ((long)lf * {} + i{}) * {};".format(G1, a1, nstrip))
-                S.append("    if (c % 63 == 62 || c == {}) acc[p] += F[{} + (st + 1 == {} ? 0 : st + 1)];".format(G2 - 1, f_lo, nstrip))
-                S.append("    if (c % 63 == 0) acc[p] += F[{} + (st == 0 ? {} : st - 1)];".format(f_hi, nstrip - 1))
+                S.append("    if (c % 64 == 63 || c == {}) acc[p] += F[{} + (st + 1 == {} ? 0 : st + 1)];".format(G2 - 1, f_lo, nstrip))
+                S.append("    if (c % 64 == 0) acc[p] += F[{} + (st == 0 ? {} : st - 1)];".format(f_hi, nstrip - 1))
                 S.append("  }")
                 S.append("  }")
             o = "lr * 4" if vw == 4 else "lr"
@@ -1995,17 +2008,21 @@ class _Codegen:
         cell (heat with two space dimensions: reference examples/heat/heat.py:86-98 per axis).  The lower face of cell i is
         the upper face of cell i - e (stencil_share.py proves it on the DAG), so half of the evaluations of the plain
         kernel -- and of their reverse passes, two thirds of its instructions -- are repeats.  Here a WAVE owns a strip of
-        63 columns of the last axis and marches along the second-to-last axis over a segment of rows; every lane makes ONE
+        64 columns of the last axis and marches along the second-to-last axis over a segment of rows; every lane makes ONE
         packed evaluation per point: (upper face along the marching axis, upper face along the lane axis).
 
         * marching axis: the value of a point's upper face is carried in registers to the next row, where it is the lower
           face; the adjoint it collects there is added to its own before the reverse pass of the evaluation, which
           therefore runs ONE STEP LATE, from the previous step's activations (carried as well);
         * lane axis: lane L takes its lower face from lane L - 1 and returns the adjoint to it by wave-wide lane shifts
-          (DPP: no LDS, no barrier).  Lane 0 of every wave is a helper: it sits on lane 1's point and evaluates that point's
-          LOWER face in its second slot (the wall extrapolation where the strip starts at the wall) -- the same
-          instruction stream, one input selected;
-        * a segment starts with a pre-step that evaluates the lower face of its first row (the wall extrapolation at row 0).
+          (DPP: no LDS, no barrier);
+        * a segment starts with a PRE-STEP whose packed evaluation holds the lower faces nobody hands over: slot 0 the
+          marching axis' at the segment's first row (every lane its column), slot 1 the lane axis' at the strip's FIRST
+          column -- lane j for row r0 + j (a segment has at most 64 rows).  Lane 0 fetches its row's value with
+          v_readlane as the march goes and hands the adjoint back the same way; after the march a post-step repeats the
+          pre-step's forward pass from the kept inputs and runs its reverse pass with the collected adjoints.  (Until
+          this form a HELPER lane per wave evaluated the first column's lower face every step: 63 columns per wave,
+          nine waves per row of 512 where eight suffice.)
 
         Values and adjoints of lanes without a point are masked; sums of network-parameter gradients are linear in the
         adjoints, so a face shared by two waves (or two segments) simply contributes from both sides.  The body exists
@@ -2013,9 +2030,7 @@ class _Codegen:
         (row index, strip and leading indices are wave-uniform)."""
         a1, a2 = self.ndim - 2, self.ndim - 1
         G1, G2 = self.G[a1], self.G[a2]
-        R = max(1, min(int(os.environ.get("ODIL_TRACE_MARCH_ROWS", 64)), G1))
-        nseg, nstrip = (G1 + R - 1) // R, (G2 + 62) // 63
-        lead = int(np.prod(self.G[:a1])) if a1 > 0 else 1
+        R, nseg, nstrip, lead = self._march_gather_geometry()
         nitems = lead * nseg * nstrip
         nz, nin, attr = parts["nz"], parts["nin"], parts["attr"]
         nl = len(attr[2]) - 1
@@ -2047,8 +2062,8 @@ class _Codegen:
                 S.append("  const int q{}_ = {} / {};".format(d, rem, self.G[d]))
                 rem = "q{}_".format(d)
         S.append("  const int r0 = seg * {0}, r1 = min(r0 + {0}, {1});".format(R, G1))
-        S.append("  const int p2 = strip * 63 + (lane == 0 ? 0 : lane - 1);")
-        S.append("  const bool valid = lane != 0 && p2 < {};".format(G2))
+        S.append("  const int p2 = strip * 64 + lane;")
+        S.append("  const bool valid = p2 < {};".format(G2))
         S.append("  const int i{} = min(p2, {});".format(a2, G2 - 1))
         # interior test, scalar: leading indices, strip range; the row is tested per step
         plan, plan_w = parts["plan"], parts.get("plan_w")
@@ -2061,7 +2076,7 @@ class _Codegen:
                     leadc.append(outer[-1])
                 elif d == a1:
                     rowc.append(self._interior_cond({d: values}))
-                else:  # no exceptional column among the strip's: [s0, s0 + 62]
+                else:  # no exceptional column among the strip's: [s0, s0 + 63]
                     values, lo, hi = list(values), 0, G2 - 1
                     while values and values[0] == lo:
                         values.pop(0)
@@ -2070,10 +2085,10 @@ class _Codegen:
                         values.pop()
                         hi -= 1
                     if lo > 0:
-                        outer.append("strip * 63 >= {}".format(lo))
+                        outer.append("strip * 64 >= {}".format(lo))
                     if hi < G2 - 1:
-                        outer.append("strip * 63 + 62 <= {}".format(hi))
-                    outer.extend("!(strip * 63 <= {0} && {0} <= strip * 63 + 62)".format(e) for e in values)
+                        outer.append("strip * 64 + 63 <= {}".format(hi))
+                    outer.extend("!(strip * 64 <= {0} && {0} <= strip * 64 + 63)".format(e) for e in values)
             S.append("  const bool interior_ = {};".format(" && ".join(outer) or "true"))
             S.append("  const bool lead_ok_ = {};".format(" && ".join(leadc) or "true"))  # (the wall-strip copy's condition)
         # carried state
@@ -2085,15 +2100,33 @@ class _Codegen:
             S.append("  T kx{0} = (T)0, gbx{0} = (T)0, gy{0} = (T)0;".format(j))
         for name in acts:
             S.append("  T2 mp_{0} = (T2)(0.0f);".format(name))
-        # ---- pre-step: the lower face along the marching axis at row r0 -------------------------------------------
+        # ---- pre-step: the LOWER faces the march cannot take from a neighbour -- slot 0: along the marching axis at row r0,
+        # own column; slot 1: along the lane axis at the strip's FIRST column, lane j for row r0 + j (the strip's lane 0
+        # fetches them with v_readlane as the march goes; its adjoints come back the same way and are passed through the
+        # network's reverse pass after the march, from a second forward pass over the kept inputs)
+        for k in range(nin):
+            S.append("  T axin{0}, ayin{0};".format(k))
         S.append("  {")
         S.append("  const int i{} = r0;".format(a1))
         S.extend(parts["pre_lines"])
         for k in range(nin):
-            S.append("  const T ux{0}_0 = {1}, ux{0}_1 = (T)0;".format(k, parts["pre_in"][k]))
+            S.append("  axin{} = {};".format(k, parts["pre_in"][k]))
+        S.append("  }")
+        S.append("  {")
+        S.append("  const int i{} = min(r0 + lane, r1 - 1);".format(a1))
+        S.append("  const int i{} = min(strip * 64, {});".format(a2, G2 - 1))
+        S.extend(parts["pre_lines_y"])
+        for k in range(nin):
+            S.append("  ayin{} = {};".format(k, parts["pre_in_y"][k]))
+        S.append("  }")
+        for j in range(nz):
+            S.append("  T kay{0}, gedge{0} = (T)0;".format(j))
+        S.append("  {")
+        for k in range(nin):
+            S.append("  const T ux{0}_0 = axin{0}, ux{0}_1 = ayin{0};".format(k))
         S.extend(parts["mlp_fwd"])
         for j in range(nz):
-            S.append("  kx{} = mu_z{}_{}.x;".format(j, nl, j))
+            S.append("  kx{0} = mu_z{1}_{0}.x; kay{0} = mu_z{1}_{0}.y;".format(j, nl))
         for name in acts:
             S.append("  mp_{0} = mu_{0};".format(name))
         S.append("  }")
@@ -2149,7 +2182,7 @@ class _Codegen:
             B.extend(self._inbox_lines(inbox))
             B.extend(var["fwd1"])
             for k, (bx, by, ay) in enumerate(var["xin"]):
-                B.append("  const T ux{0}_0 = {1}, ux{0}_1 = lane == 0 ? {3} : {2};".format(k, bx, by, ay))
+                B.append("  const T ux{0}_0 = {1}, ux{0}_1 = {2};".format(k, bx, by))
             B.extend(parts["mlp_fwd"])
             for name in acts:
                 B.append("  mc_{0} = mu_{0};".format(name))
@@ -2158,7 +2191,10 @@ class _Codegen:
                 B.append("  const T m{}_z{}_{} = kx{};".format(Ax.idx, nl, j, j))
                 B.append("  const T m{}_z{}_{} = {}.x;".format(Bx.idx, nl, j, z))
                 B.append("  const T m{}_z{}_{} = {}.y;".format(By.idx, nl, j, z))
-                B.append("  const T m{}_z{}_{} = odil_lane_prev({}.y);".format(Ay.idx, nl, j, z))
+                # (two statements: a lane shift inside one arm of a conditional would run with lane 0 masked off, and a DPP
+                # read from a disabled lane is invalid -- lane 1 would get 0)
+                B.append("  const T ayp{0}_ = odil_lane_prev({1}.y), ay0{0}_ = odil_readlane(kay{0}, i{2} - r0);".format(j, z, a1))
+                B.append("  const T m{0}_z{1}_{2} = lane == 0 ? ay0{2}_ : ayp{2}_;".format(Ay.idx, nl, j))
                 B.append("  zx{} = {}.x;".format(j, z))
             B.extend(var["fwd2"])
             B.extend(var["rev"])
@@ -2210,19 +2246,21 @@ class _Codegen:
             offs, _ = self._march_edge_offsets(len(mg["groups"]))
             lead_flat = self._offset(["i{}".format(d) for d in range(a1)], self.G[:a1]) if a1 > 0 else "0"
             S.append("  const long lf_ = {};".format(lead_flat))
-            S.append("  const int lastl_ = min(63, {} - strip * 63);".format(G2))  # the strip's last lane with a point
+            S.append("  const int lastl_ = min(63, {} - strip * 64);".format(G2 - 1))  # the strip's last lane with a point
             for k in range(len(mg["groups"])):
                 e_lo, e_hi, f_lo, f_hi = offs[k]
                 # the row's own sum: the lane neighbours' shares arrive by lane shifts; what leaves the strip goes to F
                 S.append("  const T fromr{0} = odil_lane_next(yl{0}), froml{0} = odil_lane_prev(yr{0});".format(k))
                 S.append("  const T row{0} = c0{0} + (valid ? froml{0} + fromr{0} : (T)0);".format(k))
-                S.append("  if (lane == 0) a.edge[{} + (lf_ * {} + i{}) * {} + strip] = fromr{};".format(f_lo, G1, a1, nstrip, k))
+                S.append("  if (lane == 0) a.edge[{} + (lf_ * {} + i{}) * {} + strip] = yl{};".format(f_lo, G1, a1, nstrip, k))
                 S.append("  if (lane == lastl_) a.edge[{} + (lf_ * {} + i{}) * {} + strip] = yr{};".format(f_hi, G1, a1, nstrip, k))
                 # delay line along the marching axis: row r - 1 is complete (within the segment) once row r has given its share
                 S.append("  if (i{} > r0) {{ if (valid) {}; }}".format(
                     a1, ("__builtin_nontemporal_store(ap{0} + cm{0}, &a.cot[{0}][l - {1}])" if stream else "a.cot[{0}][l - {1}] = ap{0} + cm{0}").format(k, G2)))
                 S.append("  else if (valid) a.edge[{} + (lf_ * {} + seg) * {} + i{}] = cm{};".format(e_lo, nseg, G2, a2, k))
                 S.append("  ap{0} = ac{0} + row{0}; ac{0} = cp{0};".format(k))
+        for j in range(nz):  # what lane 0 found for the strip's first lower face of this row: back to the lane that evaluated it
+            S.append("  {{ const T g0_ = odil_readlane(gay{0}, 0); gedge{0} = lane == i{1} - r0 ? g0_ : gedge{0}; }}".format(j, a1))
         # reverse pass of the PREVIOUS step's evaluation: its own adjoints + what this row found for the carried face
         S.append("  {")
         for j in range(nz):
@@ -2256,6 +2294,17 @@ class _Codegen:
         for j in range(nz):
             S.append("  const T ud{0}_0 = gbx{0}, ud{0}_1 = gy{0};".format(j))
         S.extend(parts["mlp_bwd"])
+        S.append("  }")
+        # post-step: the reverse pass of the pre-step's second slot (the lane axis' lower faces of the first column)
+        S.append("  {")
+        for k in range(nin):
+            S.append("  const T ux{0}_0 = axin{0}, ux{0}_1 = ayin{0};".format(k))
+        S.extend(parts["mlp_fwd"])
+        for j in range(nz):
+            S.append("  const T ud{0}_0 = (T)0, ud{0}_1 = lane < r1 - r0 ? gedge{0} : (T)0;".format(j))
+        S.append("  {")
+        S.extend(parts["mlp_bwd_mu"])
+        S.append("  }")
         S.append("  }")
         S.append("  }")  # items
 
