@@ -258,3 +258,42 @@ def test_untraceable_operators_are_refused(cpu_mod):
         with pytest.raises(stencil_jit.TraceUnsupported):
             stencil_jit.TracedOperator(odil.Problem(op, domain), state)
         assert stencil_jit.trace(odil.Problem(op, domain), state) is None, name
+
+
+def test_marching_kernel_structure(cpu_mod, monkeypatch):
+    """The code generator's round-4 machinery on heat with two space dimensions (float): index predicates that fold in an
+    interior copy of the body and their exceptional index values, the three copies of the marching kernel's body behind
+    scalar branches, the in-kernel sums of the read cotangents (one array per leading shift + edge arrays) and the final
+    gather that adds the edges.  (Numerics: tests/test_workloads_gpu.py, test_fullsize_traced_gpu.py.)"""
+    import heat2d
+
+    monkeypatch.setenv("ODIL_TRACE_SHARE", "march")
+    problem, state = heat2d.make_problem(heat2d.parse_args(["--Nt", "8", "--Nx", "16", "--Ny", "128", "--infer_k", "1",
+                                                              "--imposed", "stripe", "--multigrid", "0"]))
+    tro = stencil_jit.TracedOperator(problem, state)
+    cg = tro.cg
+    assert cg.share_mode == "march" and sorted(axis for _, _, axis in cg.share) == [1, 2]
+    fold, exc, _ = cg._fold_plan(cg.order, 1, windows=True)
+    assert exc == {0: [0], 1: [0, 15], 2: [0, 127]} and fold and all(isinstance(v, bool) for v in fold.values())
+    _, exc_w, _ = cg._fold_plan(cg.order, 4, windows=True)  # four points per thread / wall strips: the last axis stays
+    assert exc_w == {0: [0], 1: [0, 15]}
+    assert cg._interior_cond({1: [0, 15], 2: [0, 64, 127]}) == "i1 >= 1 && i1 <= 14 && i2 >= 1 && i2 <= 126 && i2 != 64"
+    live = cg._live_under(fold)
+    assert live < {n.idx for n in cg.order}  # the wall / initial-row branches are dead in the interior
+    src = tro.source
+    k_fwd = src[src.index("void k_fwd("):src.index("void k_final(")]
+    assert k_fwd.count("if (interior_ && ") == 1 and k_fwd.count("} else if (lead_ok_ && ") == 1  # three copies of the body
+    assert "if (!(lead_ok_ && " in k_fwd  # the initial-row arrays only the general copy reads: fetched when the next row takes it
+    assert "odil_readlane(kay0" in k_fwd and "odil_lane_prev(" in k_fwd and "odil_lane_next(" in k_fwd
+    assert cg.ncot == 2 and cg.edge_numel > 0 and "a.edge[" in k_fwd  # u(t) and u(t - 1): one array each + edges
+    gat = src[src.index("void k_gat_0("):]
+    assert "a.edge + " in gat and "c % 64 == 63" in gat and "adam_apply4" in gat
+    # a forward kernel WITHOUT a network gets the interior copy of its body; with one it does not (registers)
+    import veltracer
+
+    tro2 = stencil_jit.TracedOperator(*veltracer.make_problem(veltracer.parse_args(["--Nt", "8", "--Nx", "16", "--Ny", "16"])))
+    assert "__all((int)(" in tro2.source
+    monkeypatch.setenv("ODIL_TRACE_SHARE", "0")
+    tro3 = stencil_jit.TracedOperator(*heat2d.make_problem(heat2d.parse_args(["--Nt", "8", "--Nx", "16", "--Ny", "32", "--infer_k", "1"])))
+    k3 = tro3.source[tro3.source.index("void k_fwd("):tro3.source.index("void k_final(")]
+    assert "__all((int)(" not in k3
