@@ -987,8 +987,6 @@ class _Codegen:
         return out if len(out) == len(self.order) else None
 
     def _act(self, kind, x, width=1):
-        if "tanh" in os.environ.get("ODIL_TRACE_ABLATE", "") and kind == "tanh":  # (timing experiment: wrong results)
-            return "({0} * (T)0.5)".format(x) if width == 1 else "({0} * 0.5f)".format(x)
         if width == 2:
             return {"tanh": "odil_fast_tanh2({})", "relu": "__builtin_elementwise_max({}, (T2)(0.0f))", "none": "{}"}[kind].format(x)
         tanh = "odil_fast_tanh({})" if self.fast else "FN(tanh)({})"  # (network activations: see the prelude)
@@ -2174,7 +2172,6 @@ class _Codegen:
             for k in range(len(mg["groups"])):
                 S.append("  T cm{0}, c0{0}, cp{0}, yl{0}, yr{0};".format(k))
 
-        ablate = os.environ.get("ODIL_TRACE_ABLATE", "").split(",")  # timing experiments: stores, bwd (wrong results)
         mg = parts["gather"]
 
         def body(var, inbox):
@@ -2213,9 +2210,7 @@ class _Codegen:
                     B.append("  c0{} = {};".format(k, term(c0) or "(T)0"))
             B.append("  if (valid) {")
             for slot, (n, name) in enumerate(stored if mg is None else []):
-                if "stores" in ablate:  # (timing experiment: wrong results)
-                    B.append("    s_0 = s_0 + {} * (T)1e-30;".format(name))
-                elif stream:
+                if stream:
                     B.append("    __builtin_nontemporal_store({}, &a.cot[{}][l]);".format(name, slot))
                 else:
                     B.append("    a.cot[{}][l] = {};".format(slot, name))
@@ -2265,10 +2260,7 @@ class _Codegen:
         S.append("  {")
         for j in range(nz):
             S.append("  const T ud{0}_0 = gbx{0} + gax{0}, ud{0}_1 = gy{0};".format(j))
-        if "bwd" in ablate:
-            S.extend("  s_0 = s_0 + (ud{0}_0 + ud{0}_1) * (T)1e-30;".format(j) for j in range(nz))
-        else:
-            S.extend(parts["mlp_bwd"])
+        S.extend(parts["mlp_bwd"])
         S.append("  }")
         for j in range(nz):
             S.append("  kx{0} = zx{0}; gbx{0} = gbc{0}; gy{0} = gby{0} + odil_lane_next(gay{0});".format(j))
