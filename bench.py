@@ -46,9 +46,8 @@ def parse_args():
     p.add_argument("--ndim", type=int, default=3)
     p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_N", type=int, default=256, help="grid size of the 1-core CPU-baseline sample (256: ~2.5 s per "
-                   "epoch; the headline 512 itself takes 160 s per epoch on one thread, most of it page faults of the "
-                   "1 GiB temporaries -- too long for the default run, available with --cpu_N 512)")
+    p.add_argument("--cpu_N", type=int, default=512, help="grid size of the 1-core CPU-baseline sample (512 = the headline's own: ~5 s "
+                   "per epoch of the C port after ~1 min of untimed first-touch page faults of its 8.6 GB)")
     p.add_argument("--cpu_N_all", type=int, default=128, help="grid size per core of the all-cores CPU-baseline leg")
     p.add_argument("--cpu_budget", type=float, default=10.0, help="seconds of timed CPU work per leg")
     p.add_argument("--scale", type=float, default=1.0, help="shrinks the grids of the non-default configs (smoke runs)")
@@ -65,39 +64,48 @@ def algorithmic_bytes_per_update(ndim, nlvl, wordsize):
 
 
 def cpu_baseline(ndim, n_one, n_all, budget_s):
-    """The oracle (NumPy port of the reference op sequence, oracle/odil_np.py) timed on this host by
-    oracle/cpu_bench.py workers, outside the timed region and before this process touches the GPU:
-    (i) ONE thread, the reference's default (reference src/odil/runtime.py:8-12); (ii) one worker per host core,
-    concurrently, each on its own grid (what ODIL_MT / one process per core can at best deliver)."""
-    def leg(nproc, n, budget):
+    """The oracle timed on this host, outside the timed region and before this process touches the GPU.
+    3-D (the headline): oracle/poisson_epoch.c, the plain-C one-thread restatement of the epoch (pinned to the NumPy
+    oracle by tests/test_oracle_c.py), (i) ONE thread -- the reference's default (reference src/odil/runtime.py:8-12) --
+    at the headline's own grid, (ii) one worker per host core, concurrently, each on its own grid (what ODIL_MT / one
+    process per core can at best deliver); the NumPy oracle (oracle/odil_np.py, the reference's op sequence array by
+    array as TF eager runs it) is timed beside it on one thread.  Other ndim: the NumPy oracle only."""
+    def leg(cmd, nproc, n, budget):
         start = time.time() + 5.0 + 0.02 * nproc
-        cmd = [sys.executable, "-m", "oracle.cpu_bench", str(ndim), str(n), str(budget), str(start)]
+        cmd = cmd + [str(n), str(budget), str(start)]
         procs = [subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
         outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
         if any(p.returncode for p in procs):
-            raise RuntimeError("cpu_bench worker failed")
+            raise RuntimeError("cpu baseline worker failed")
         return sum(o["cells"] * o["epochs"] / o["seconds"] for o in outs), outs
 
-    v1, o1 = leg(1, n_one, budget_s)
+    numpy_cmd = [sys.executable, "-m", "oracle.cpu_bench", str(ndim)]
+    use_c = ndim == 3
+    if use_c:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+        cmd = [os.path.join(ROOT, "oracle", "_build", "poisson_epoch")]
+        per_worker, name = 16 * 8.0 * n_all**ndim, "oracle/poisson_epoch.c (plain C, -O3)"
+    else:
+        cmd, n_one = numpy_cmd, min(n_one, 4096)
+        # ~0.35 GB per 128^3 NumPy worker (f64 multigrid state, moments, gradients, temporaries)
+        per_worker, name = 0.35e9 * (n_all / 128.0) ** ndim, "oracle/odil_np.py"
+    v1, o1 = leg(cmd, 1, n_one, budget_s)
     present = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # one worker per host core, as many as memory allows: ~0.35 GB per 128^3 worker (f64 multigrid state, moments,
-    # gradients, NumPy temporaries), half of what is available at most
-    try:
+    try:  # one worker per host core, as many as half of the available memory allows
         import psutil
 
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 32 << 30
-    per_worker = 0.35e9 * (n_all / 128.0) ** ndim
     cores = max(1, min(present, int(0.5 * avail / per_worker)))
-    vall, oall = leg(cores, n_all, budget_s)
-    return {
+    vall, oall = leg(cmd, cores, n_all, budget_s)
+    out = {
         "value": v1,
         "unit": "grid-point-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": "oracle/odil_np.py, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s on one thread".format(
-            ndim, n_one, ndim, o1[0]["epochs"], o1[0]["seconds"]),
+        "sample": "{}, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s on one thread".format(
+            name, ndim, n_one, ndim, o1[0]["epochs"], o1[0]["seconds"]),
         "all_cores": {
             "value": vall,
             "cores": cores,
@@ -106,6 +114,13 @@ def cpu_baseline(ndim, n_one, n_all, budget_s):
                 cores, present, ndim, n_all, ndim, max(o["seconds"] for o in oall)),
         },
     }
+    if use_c:
+        vnp, onp_ = leg(numpy_cmd, 1, n_all, min(budget_s, 5.0))
+        out["numpy_port"] = {
+            "value": vnp, "cores": 1,
+            "sample": "oracle/odil_np.py, Poisson {}-D {}^{} f64 multigrid Adam, {} epochs in {:.1f} s on one thread".format(
+                ndim, n_all, ndim, onp_[0]["epochs"], onp_[0]["seconds"])}
+    return out
 
 
 def measured_traffic(kernel, ndim, N, dtype):
