@@ -490,9 +490,17 @@ class LbfgsVectors:
         else:
             self.scal[6:7].fill_(float(f))
 
+    # ---- hooks of a decomposed domain (slab_solvers.SlabLbfgsVectors): a rank's vectors hold its share of the unknowns,
+    # its reductions are partial until they have been combined over the ranks.  One rank: nothing to do.
+    def reduce_probes(self, scal):
+        return scal
+
+    def reduce_sums(self, t):
+        return t
+
     def read_probes(self):
         """-> (dtd, gd_direction, gd, gmax, f) with one device-to-host copy."""
-        self.scal_host.copy_(self.scal, non_blocking=True)
+        self.scal_host.copy_(self.reduce_probes(self.scal), non_blocking=True)
         torch.cuda.current_stream().synchronize()
         h = self.scal_host
         return float(h[0]), float(h[1]), float(h[3]), float(h[5]), float(h[6])
@@ -508,12 +516,12 @@ class LbfgsVectors:
         if nphys == 0:
             z = np.zeros((len(bs), 0))
             return z, z
-        out = ops.dots3(self.w[: 2 * nphys], bs).cpu().numpy()[: len(bs)]
+        out = self.reduce_sums(ops.dots3(self.w[: 2 * nphys], bs)).cpu().numpy()[: len(bs)]
         return out[:, 0::2], out[:, 1::2]
 
     def dot(self, a, b):
         """<a, b> on the host (warm start of the memory only: not on the per-iteration path)."""
-        return float(ops.dots3(a[None], [b]).cpu().numpy()[0, 0])
+        return float(self.reduce_sums(ops.dots3(a[None], [b])).cpu().numpy()[0, 0])
 
     def history_lincomb(self, y, nphys, cs, cy):
         """y += sum_k cs[k] s_k + cy[k] y_k in one pass over the history."""

@@ -89,7 +89,7 @@ class SlabPoissonAdam:
     """One rank of the slab-decomposed Poisson multigrid Adam loop (3-D, all cell-centred)."""
 
     def __init__(self, N, rank, world, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7, rhs_global=None):
+                 epsilon=1e-7, rhs_global=None, moments=True):
         self.ops = hip_ops  # the HIP kernels (tests of the exchange logic without a GPU swap this module attribute)
         self.N, self.rank, self.world = N, rank, world
         self.dtype, self.device = dtype, device
@@ -108,10 +108,11 @@ class SlabPoissonAdam:
         n = sum(sizes)
         self.n_unknowns_local = sum(lv.nz * lv.plane for lv in self.levels)
         mk = lambda: torch.zeros(n, dtype=dtype, device=device)
-        self.x, self.m, self.v, self.g = mk(), mk(), mk(), mk()
+        self.x, self.g = mk(), mk()
+        self.m, self.v = (mk(), mk()) if moments else (None, None)  # (the quasi-Newton drivers of slab_solvers.py keep none)
         split = lambda f: [t.view(lv.shape) for t, lv in zip(f.split(sizes), self.levels)]
         self.w, self.gw = split(self.x), split(self.g)
-        self.mw, self.vw = split(self.m), split(self.v)
+        self.mw, self.vw = (split(self.m), split(self.v)) if moments else (None, None)
         self.n01 = sizes[0] + sizes[1]  # levels 0 and 1: updated before the exchange; the rest after it
         self._index_tables(sizes)
         l0 = self.levels[0]
@@ -364,6 +365,54 @@ class SlabPoissonAdam:
             ops.adam_step(self.x[k:], self.m[k:], self.v[k:], self.g[k:], alpha, omb1, omb2, self.eps)
             toc(b)
 
+    # ---- loss and gradient alone (the quasi-Newton drivers of slab_solvers.py) ----------------------------
+    def loss_grad_gen(self):
+        """Generator (yields at exchanges like `epoch_gen`): from the owned planes of self.w to this rank's share of the
+        loss (self.loss_part) and the complete gradient on the owned planes of every level (self.gw).  One exchange per
+        level instead of the Adam epoch's packed one: the boundary planes of g_{l-1} travel to the neighbours' ghost
+        planes, then P^T with `cut` ends completes g_l on the owned planes."""
+        ops, lv, L = self.ops, self.levels, self.nlvl
+        yield from self._sync_state()  # the unknowns changed: their ghost planes follow (one plane per level and side)
+        coarse = lv[L - 1].inner(self.w[L - 1])
+        for l in range(L - 2, -1, -1):
+            out = self.u if l == 0 else self.work[l]
+            ops.interp_add(coarse.contiguous(), "ccc", add=self.w[l], out=out)
+            coarse = lv[l].inner(out)
+        l0 = lv[0]
+        ops.poisson_residual(self.u, self.rhs, self.h2, fu=self.fu, loss=self.loss_part,
+                             zrange=(l0.g_lo, l0.g_lo + l0.nz), denom=self.global_cells)
+        yield from self._exchange_fu(1)
+        ops.poisson_adjoint(self.fu, self.h2, self.scale, out=self.gw[0])
+        cut = (self.rank > 0, self.rank < self.world - 1)
+        for l in range(1, L):
+            f, g = lv[l - 1], self.gw[l - 1]
+            recv_lo, recv_hi = yield ("halo", g[f.g_lo] if cut[0] else None, g[f.g_lo + f.nz - 1] if cut[1] else None)
+            if recv_lo is not None:
+                g[f.g_lo - 1].copy_(recv_lo.view(f.ny, f.nx))
+            if recv_hi is not None:
+                g[f.g_lo + f.nz].copy_(recv_hi.view(f.ny, f.nx))
+            cview = lv[l].inner(self.gw[l])
+            ops.interp_adj(g, "ccc", tuple(cview.shape), out=cview, cut=cut)
+
+    def pack_owned(self, arrays, out=None):
+        """The owned planes of the level arrays `arrays` (self.w / self.gw) as ONE flat float64 vector, finest level
+        first -- the layout of the undivided unknown vector restricted to this rank (reference core.py:436-469)."""
+        if out is None:
+            out = torch.empty(self.n_unknowns_local, dtype=torch.float64, device=self.device)
+        off = 0
+        for lv, a in zip(self.levels, arrays):
+            n = lv.nz * lv.plane
+            out[off:off + n].view(lv.nz, lv.ny, lv.nx).copy_(lv.owned(a))
+            off += n
+        return out
+
+    def unpack_owned(self, flat, arrays=None):
+        off = 0
+        for lv, a in zip(self.levels, arrays or self.w):
+            n = lv.nz * lv.plane
+            lv.owned(a).copy_(flat[off:off + n].view(lv.nz, lv.ny, lv.nx))
+            off += n
+
     def epoch(self, comm, timers=None):
         gen = self.epoch_gen(timers)
         try:
@@ -392,7 +441,9 @@ class TorchDistComm:
               neighbours sent: (recv_lo, recv_hi), same sizes as the sends;
       "wrap"  the periodic closure: the FIRST rank's send_lo goes to the LAST rank (arriving as its recv_hi),
               the last rank's send_hi to the first (its recv_lo); other ranks pass (None, None);
-      "sum"   all-reduce of send_lo (a few scalars); returns the tensor."""
+      "sum"   all-reduce of send_lo (a few scalars); returns the tensor;
+      "gather" all-gather of send_lo: returns the (world, ...) stack of every rank's tensor, rank order (reductions formed
+              from it are the same bits on every rank -- the quasi-Newton drivers branch on them)."""
 
     def __init__(self, rank, world, self_loop=False):
         import torch.distributed as dist
@@ -432,6 +483,12 @@ class TorchDistComm:
                 return h.to(t.device)
             dist.all_reduce(t)
             return t
+        if kind == "gather":
+            t = send_lo.contiguous()
+            src = t.cpu() if (self.stage and t.is_cuda) else t
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src)
+            return torch.stack(parts).to(t.device)
         if kind == "wrap":
             if self.world == 1 and not self.self_loop:
                 return send_hi, send_lo
@@ -490,6 +547,8 @@ class LocalComm:
     def exchange(self, kind, a, b):
         if kind == "sum":
             return a
+        if kind == "gather":
+            return a[None]
         if kind == "wait":
             return a
         return (b, a) if kind == "wrap" else (None, None)
@@ -538,6 +597,9 @@ def run_lockstep(ranks, nepochs=1, timers=None):
                 for m in msgs[1:]:
                     total = total + m[1]
                 replies = [total.clone() for _ in range(P)]
+            elif kind == "gather":
+                stack = torch.stack([m[1] for m in msgs])
+                replies = [stack.clone() for _ in range(P)]
             elif kind == "wrap":
                 replies = [(None, None)] * P
                 replies[0] = (clone(msgs[P - 1][2]), None)

@@ -1,0 +1,253 @@
+"""Quasi-Newton and Newton drivers of the slab-decomposed Poisson path (no reference
+counterpart: the reference is single-device).  The optimizers are the single-GPU ones -- `optimizer.lbfgsb_minimize`
+(the restatement of what the reference calls, reference src/odil/optimizer.py:54-117) and the conjugate-gradient solve of
+the Newton step's normal equations (reference src/odil/linsolver.py:17-23, util.py:152-187) -- on vectors that hold ONE
+RANK's share of the unknowns:
+
+  * evaluations run the slab kernels of `slab.SlabPoissonAdam` (halo exchanges with the two neighbours, RCCL send / receive);
+  * every reduction is formed from the ranks' partial results: the probes of an L-BFGS iteration (loss, <g, d>, <d, d>,
+    max |g|) travel as ONE all-gather of eight numbers, the products of the whole (s, y) history with the new vectors
+    (the rows of S^T Y, S^T S, Y^T Y of the compact representation and S^T g, Y^T g of the next direction) as ONE
+    all-gather of 3 x 2m numbers -- two collectives per iteration instead of 2m sequential dot products; CG: two
+    scalar reductions per iteration.  The combined values are the same bits on every rank (sums over the gathered rows
+    in rank order), so the ranks take the same branches of the line search without further agreement.
+
+`ThreadComm` runs several ranks as threads of one process (one GPU, or none with the CPU doubles of the tests): the
+drivers here are ordinary loops with blocking collectives, not generators.
+"""
+
+import threading
+
+import numpy as np
+import torch
+
+from . import ops as hip_ops
+from . import slab
+from .optimizer import LbfgsVectors, lbfgsb_minimize
+
+
+def drive(gen, comm):
+    """Runs a generator of the slab path (yields (kind, send_lo, send_hi) at its exchanges) to its end over `comm`."""
+    try:
+        msg = next(gen)
+        while True:
+            msg = gen.send(comm.exchange(*msg))
+    except StopIteration:
+        pass
+
+
+class ThreadComm:
+    """The exchanges of `slab.TorchDistComm` between ranks that are THREADS of one process (tests; one GPU).  A rank
+    computes only while it holds the shared token, so the launches of two ranks never interleave (the kernels' shared
+    reduction workspaces assume one caller at a time); it hands the token over while it waits at an exchange."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.token = threading.Lock()
+            self.slots = [None] * world
+
+    def __init__(self, rank, shared):
+        self.rank, self.world, self.sh = rank, shared.world, shared
+
+    def __enter__(self):
+        self.sh.token.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        self.sh.token.release()
+        if exc[0] is not None:
+            self.sh.barrier.abort()  # the other ranks must not wait for one that died
+        return False
+
+    def exchange(self, kind, a, b):
+        sh, r, P = self.sh, self.rank, self.world
+        if kind == "wait":
+            return a
+        sh.slots[r] = (a, b)
+        sh.token.release()
+        sh.barrier.wait()
+        sh.token.acquire()
+        try:
+            clone = lambda t: None if t is None else t.clone()
+            if kind == "sum":
+                total = sh.slots[0][0].clone()
+                for i in range(1, P):
+                    total = total + sh.slots[i][0]
+                return total
+            if kind == "gather":
+                return torch.stack([sh.slots[i][0] for i in range(P)])
+            if kind == "wrap":
+                lo = clone(sh.slots[P - 1][1]) if r == 0 else None
+                hi = clone(sh.slots[0][0]) if r == P - 1 else None
+                return lo, hi
+            # "halo" / "post": what the lower neighbour sent up, what the upper one sent down
+            return (clone(sh.slots[r - 1][1]) if r > 0 else None, clone(sh.slots[r + 1][0]) if r + 1 < P else None)
+        finally:
+            sh.token.release()
+            sh.barrier.wait()  # nobody overwrites its slot before everybody has read
+            sh.token.acquire()
+
+
+def run_threads(world, body):
+    """body(rank, comm) -> result on `world` threads joined by a ThreadComm; returns the results in rank order."""
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            with ThreadComm(rank, shared) as comm:
+                results[rank] = body(rank, comm)
+        except BaseException as e:  # noqa: BLE001 (re-raised below, on the caller's thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        first = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)] or errors
+        raise first[0]
+    return results
+
+
+class SlabLbfgsVectors(LbfgsVectors):
+    """`optimizer.LbfgsVectors` over one rank's share of the unknowns: the reductions are combined over the ranks before
+    the host reads them (one all-gather each; the sum / max over its rows is formed in rank order on every rank)."""
+
+    def __init__(self, n, m, device, comm):
+        super().__init__(n, m, device)
+        self.comm = comm
+
+    def reduce_probes(self, scal):
+        rows = self.comm.exchange("gather", scal, None)  # (world, 8): dtd, gd_old, -, gd, gg, gmax, f, -
+        out = rows.sum(dim=0)
+        out[5] = rows[:, 5].max()
+        return out
+
+    def reduce_sums(self, t):
+        return self.comm.exchange("gather", t, None).sum(dim=0)
+
+
+class SlabPoissonLbfgs(slab.SlabPoissonAdam):
+    """One rank of the slab-decomposed Poisson multigrid problem under L-BFGS-B (3-D, all cell-centred): the unknown
+    vector is the undivided one restricted to this rank's planes, level after level."""
+
+    def __init__(self, N, rank, world, dtype=torch.float64, device=None, rhs_global=None):
+        super().__init__(N, rank, world, dtype=dtype, device=device, rhs_global=rhs_global, moments=False)
+        self.nfev = 0
+
+    def minimize(self, comm, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, callback=None, vectors=None):
+        """-> the dict of `lbfgsb_minimize` (task, nit, funcalls, f = GLOBAL loss); the owned planes of self.w hold the
+        result.  `vectors`: the vector backend (tests hand in a CPU double)."""
+        n = self.n_unknowns_local
+        vec = vectors or SlabLbfgsVectors(n, m, self.device, comm)
+        x = self.pack_owned(self.w)
+        gflat = torch.empty(n, dtype=torch.float64, device=self.device)
+
+        def fg(xflat):
+            self.unpack_owned(xflat)
+            drive(self.loss_grad_gen(), comm)
+            self.nfev += 1
+            return self.loss_part.to(torch.float64), self.pack_owned(self.gw, out=gflat)
+
+        res = lbfgsb_minimize(x, fg, vec, maxiter, m=m, maxls=maxls, pgtol=pgtol, factr=factr, callback=callback)
+        self.unpack_owned(x)
+        return res
+
+
+class SlabPoissonNewtonCG:
+    """One rank of a matrix-free Newton step of the slab-decomposed Poisson problem WITHOUT the multigrid decomposition
+    (the reference's `linearize` refuses multigrid unknowns, reference core.py:1208-1209): the step solves the normal
+    equations (M^T M + damp^2) dx = -M^T f of the linearisation (reference linsolver.py:17-23) by conjugate gradients;
+    M is the Laplacian stencil with the wall rows (its coefficients are the reference's `eval_operator_grad` arrays, SURVEY
+    A13), applied by the residual kernel with a zero right-hand side, M^T by the stencil-adjoint kernel.  Per CG iteration:
+    one plane of p and one plane of M p to each neighbour (the same halo pattern as an epoch), two scalar reductions."""
+
+    def __init__(self, N, rank, world, dtype=torch.float64, device=None, rhs_global=None, nz=None):
+        """The box (world * nz, N, N) with spacing 1 / N, nz (default N) planes per rank."""
+        self.ops = hip_ops
+        self.N, self.rank, self.world, self.dtype, self.device = N, rank, world, dtype, device
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        nz = nz or N
+        self.lv = slab.SlabLevel(nz, N, N, rank, world)
+        self.h2 = [npdt(1.0 / N) ** 2] * 3
+        self.global_cells = world * nz * N * N
+        mk = lambda: torch.zeros(self.lv.shape, dtype=dtype, device=device)
+        self.u, self.f, self.p, self.q, self.r, self.z = mk(), mk(), mk(), mk(), mk(), mk()
+        self.zero = mk()
+        self.part = torch.zeros((), dtype=dtype, device=device)
+        lv = self.lv
+        if rhs_global is not None:
+            lo = rank * nz - lv.g_lo
+            self.rhs = rhs_global[lo: lo + lv.shape[0]].to(device=device, dtype=dtype).contiguous()
+        else:
+            assert nz == N, "the built-in reference solution is that of the cubic slabs"
+            ref_u = slab.hat_reference_slab(lv, N, rank, world, dtype, device)
+            self.rhs, _ = self.ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)
+        self.status = dict()
+
+    def owned(self, a):
+        return self.lv.owned(a)
+
+    def _halo(self, comm, a):
+        """One boundary plane of `a` to each neighbour's inner ghost plane."""
+        lv = self.lv
+        lo = a[lv.g_lo] if self.rank > 0 else None
+        hi = a[lv.g_lo + lv.nz - 1] if self.rank < self.world - 1 else None
+        recv_lo, recv_hi = comm.exchange("halo", lo, hi)
+        if recv_lo is not None:
+            a[lv.g_lo - 1].copy_(recv_lo.view(lv.ny, lv.nx))
+        if recv_hi is not None:
+            a[lv.g_lo + lv.nz].copy_(recv_hi.view(lv.ny, lv.nx))
+
+    def _dot(self, comm, a, b):
+        part = (self.owned(a).to(torch.float64) * self.owned(b).to(torch.float64)).sum().reshape(1)
+        return float(comm.exchange("gather", part, None).sum())
+
+    def residual(self, comm, u, out):
+        """out = f(u) = Lap(u) - rhs on the owned planes; -> global mean of its squares."""
+        self._halo(comm, u)
+        lv = self.lv
+        self.ops.poisson_residual(u, self.rhs, self.h2, fu=out, loss=self.part, zrange=(lv.g_lo, lv.g_lo + lv.nz),
+                                  denom=self.global_cells)
+        return float(comm.exchange("gather", self.part.to(torch.float64).reshape(1), None).sum())
+
+    def normal_apply(self, comm, p, out, damp2=0.0):
+        """out = M^T M p + damp2 p on the owned planes (ghost planes of p and of M p refreshed on the way)."""
+        self._halo(comm, p)
+        self.ops.poisson_residual(p, self.zero, self.h2, fu=self.q, loss=self.part)
+        self._halo(comm, self.q)
+        self.ops.poisson_adjoint(self.q, self.h2, 1.0, out=out)
+        if damp2:
+            out.add_(p, alpha=damp2)
+
+    def step(self, comm, maxiter=100, tol=1e-10, damp=0.0):
+        """One Newton step u <- u + dx; -> (loss before, loss after).  self.status: CG iterations and relative residual."""
+        loss0 = self.residual(comm, self.u, self.f)
+        # b = -M^T f
+        self._halo(comm, self.f)
+        b = self.z
+        self.ops.poisson_adjoint(self.f, self.h2, -1.0, out=b)
+        dx = torch.zeros_like(self.u)
+        r, p, ap = self.r, self.p, torch.zeros_like(self.u)
+        r.copy_(b)
+        p.copy_(b)
+        rr = self._dot(comm, r, r)
+        bb, it = rr, 0
+        while it < maxiter and rr > tol * tol * bb and rr > 0.0:
+            self.normal_apply(comm, p, ap, damp * damp)
+            alpha = rr / self._dot(comm, p, ap)
+            self.owned(dx).add_(self.owned(p), alpha=alpha)
+            self.owned(r).add_(self.owned(ap), alpha=-alpha)
+            rr_new = self._dot(comm, r, r)
+            beta = rr_new / rr
+            self.owned(p).mul_(beta).add_(self.owned(r))
+            rr = rr_new
+            it += 1
+        self.owned(self.u).add_(self.owned(dx))
+        loss1 = self.residual(comm, self.u, self.f)
+        self.status = dict(niter=it, residual=float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
+        return loss0, loss1

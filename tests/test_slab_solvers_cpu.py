@@ -1,0 +1,130 @@
+"""The quasi-Newton / Newton drivers of the slab path (odil_amd/slab_solvers.py) on CPU: ranks as threads of one process
+and as gloo processes, kernels replaced by their NumPy-oracle doubles.  L-BFGS-B on the decomposed domain must follow
+the undivided run of the same `lbfgsb_minimize` iterate for iterate (the reductions differ in summation order only); the
+matrix-free CG Newton step must reproduce the undivided solve."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import odil_np as onp  # noqa: E402
+
+
+def make_rhs(N, world):
+    return np.random.default_rng(7).standard_normal((N * world, N, N))
+
+
+def undivided_lbfgs(N, world, rhs, maxiter, m):
+    from test_lbfgs_host_logic import NumpyVectors
+
+    from odil_amd.optimizer import lbfgsb_minimize
+
+    cshape = (N * world, N, N)
+    shapes = onp.mg_cshapes(cshape)
+    sizes = [int(np.prod(s)) for s in shapes]
+    dw = (1.0 / N,) * 3
+
+    def fun(x):
+        terms = [t.reshape(s) for t, s in zip(np.split(x, np.cumsum(sizes)[:-1]), shapes)]
+        loss, grads, _ = onp.poisson_loss_grad(terms, rhs, dw)
+        return float(loss), np.concatenate([g.ravel() for g in grads])
+
+    x = np.zeros(sum(sizes))
+    res = lbfgsb_minimize(x, fun, NumpyVectors(x.size, m), maxiter, m=m)
+    return res, [t.reshape(s) for t, s in zip(np.split(x, np.cumsum(sizes)[:-1]), shapes)]
+
+
+def lbfgs_rank(rank, world, comm, N, rhs, maxiter, m):
+    import slab_oracle_ops
+    from slab_oracle_vectors import TorchCpuSlabVectors
+
+    from odil_amd import slab
+    from odil_amd.slab_solvers import SlabPoissonLbfgs
+
+    slab.hip_ops = slab_oracle_ops
+    run = SlabPoissonLbfgs(N, rank, world, dtype=torch.float64, device=torch.device("cpu"), rhs_global=torch.from_numpy(rhs))
+    res = run.minimize(comm, maxiter, m=m, vectors=TorchCpuSlabVectors(run.n_unknowns_local, m, comm))
+    return res, [w.clone().numpy() for w in run.owned_levels()]
+
+
+def check_lbfgs(results, ref, world):
+    res_ref, x_ref = ref
+    for r, (res, owned) in enumerate(results):
+        assert res["nit"] == res_ref["nit"] and res["funcalls"] == res_ref["funcalls"]
+        assert abs(res["f"] - res_ref["f"]) <= 1e-9 * abs(res_ref["f"])
+        for lvl, want in enumerate(x_ref):
+            nz = want.shape[0] // world
+            np.testing.assert_allclose(owned[lvl], want[r * nz:(r + 1) * nz], rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_lbfgs_thread_ranks_follow_the_undivided_run(world):
+    from odil_amd.slab_solvers import run_threads
+
+    N, maxiter, m = 8, 8, 5
+    rhs = make_rhs(N, world)
+    results = run_threads(world, lambda rank, comm: lbfgs_rank(rank, world, comm, N, rhs, maxiter, m))
+    check_lbfgs(results, undivided_lbfgs(N, world, rhs, maxiter, m), world)
+
+
+def gloo_worker(rank, world, N, maxiter, m, port, out):
+    from odil_amd.slab import TorchDistComm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = lbfgs_rank(rank, world, TorchDistComm(rank, world), N, make_rhs(N, world), maxiter, m)
+        torch.save(res, os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_lbfgs_two_gloo_ranks_follow_the_undivided_run(tmp_path):
+    world, N, maxiter, m = 2, 8, 6, 4
+    port = 29500 + (os.getpid() + 77) % 2000
+    mp.spawn(gloo_worker, args=(world, N, maxiter, m, port, str(tmp_path)), nprocs=world, join=True)
+    results = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    check_lbfgs(results, undivided_lbfgs(N, world, make_rhs(N, world), maxiter, m), world)
+
+
+def newton_rank(rank, world, comm, N, rhs, maxiter, nz=None):
+    import slab_oracle_ops
+
+    from odil_amd import slab_solvers
+
+    slab_solvers.hip_ops = slab_oracle_ops
+    run = slab_solvers.SlabPoissonNewtonCG(N, rank, world, dtype=torch.float64, device=torch.device("cpu"),
+                                           rhs_global=torch.from_numpy(rhs), nz=nz)
+    loss0, loss1 = run.step(comm, maxiter=maxiter, tol=1e-13)
+    return loss0, loss1, dict(run.status), run.owned(run.u).clone().numpy()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_newton_cg_step_solves_the_undivided_problem(world):
+    from odil_amd.slab import LocalComm
+    from odil_amd.slab_solvers import run_threads
+
+    N = 4
+    cshape = (N * world, N, N)
+    dw = (1.0 / N,) * 3
+    ref_u = np.random.default_rng(3).standard_normal(cshape)
+    rhs = onp.poisson_discrete_rhs(ref_u, dw)  # f(u) = Lap(u) - rhs is linear: one exact step lands on ref_u
+    results = run_threads(world, lambda rank, comm: newton_rank(rank, world, comm, N, rhs, 400))
+    for r, (loss0, loss1, status, u) in enumerate(results):
+        assert abs(loss0 - np.mean(rhs**2)) <= 1e-12 * np.mean(rhs**2)
+        assert loss1 < 1e-16 * loss0 and status["niter"] < 400
+        np.testing.assert_allclose(u, ref_u[r * N:(r + 1) * N], rtol=0, atol=1e-8)
+    # the undivided box through the same class (one rank holding every plane): the same iteration count and solution
+    loss0, loss1, status, u = newton_rank(0, 1, LocalComm(), N, rhs, 400, nz=N * world)
+    assert status["niter"] == results[0][2]["niter"]
+    np.testing.assert_allclose(u, np.concatenate([res[3] for res in results]), rtol=0, atol=1e-10)

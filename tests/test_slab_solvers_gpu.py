@@ -1,0 +1,114 @@
+"""The quasi-Newton / Newton drivers of the slab path (odil_amd/slab_solvers.py) on the HIP kernels, ranks emulated as
+threads on one GPU: L-BFGS-B on the decomposed domain follows the undivided oracle run iterate for iterate; the matrix-free
+CG Newton step solves the undivided problem."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import odil_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def make_rhs(N, world):
+    return np.random.default_rng(7).standard_normal((N * world, N, N))
+
+
+def undivided_lbfgs(N, world, rhs, maxiter, m):
+    from test_lbfgs_host_logic import NumpyVectors
+
+    from odil_amd.optimizer import lbfgsb_minimize
+
+    cshape = (N * world, N, N)
+    shapes = onp.mg_cshapes(cshape)
+    sizes = [int(np.prod(s)) for s in shapes]
+    dw = (1.0 / N,) * 3
+
+    def fun(x):
+        terms = [t.reshape(s) for t, s in zip(np.split(x, np.cumsum(sizes)[:-1]), shapes)]
+        loss, grads, _ = onp.poisson_loss_grad(terms, rhs, dw)
+        return float(loss), np.concatenate([g.ravel() for g in grads])
+
+    x = np.zeros(sum(sizes))
+    res = lbfgsb_minimize(x, fun, NumpyVectors(x.size, m), maxiter, m=m)
+    return res, [t.reshape(s) for t, s in zip(np.split(x, np.cumsum(sizes)[:-1]), shapes)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_lbfgs_emulated_ranks_follow_the_undivided_oracle_run(world):
+    from odil_amd.slab_solvers import SlabPoissonLbfgs, run_threads
+
+    N, maxiter, m = 16, 10, 6
+    dev = torch.device("cuda:0")
+    rhs = make_rhs(N, world)
+
+    def body(rank, comm):
+        torch.cuda.set_device(dev)
+        run = SlabPoissonLbfgs(N, rank, world, dtype=torch.float64, device=dev, rhs_global=torch.from_numpy(rhs))
+        res = run.minimize(comm, maxiter, m=m)
+        return res, [w.cpu().numpy() for w in run.owned_levels()]
+
+    results = run_threads(world, body)
+    res_ref, x_ref = undivided_lbfgs(N, world, rhs, maxiter, m)
+    for r, (res, owned) in enumerate(results):
+        assert res["nit"] == res_ref["nit"] and res["funcalls"] == res_ref["funcalls"]
+        assert abs(res["f"] - res_ref["f"]) <= 1e-9 * abs(res_ref["f"])
+        for lvl, want in enumerate(x_ref):
+            nz = want.shape[0] // world
+            np.testing.assert_allclose(owned[lvl], want[r * nz:(r + 1) * nz], rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+def test_slab_lbfgs_one_rank_equals_the_single_gpu_optimizer():
+    """World 1 through the slab driver == `LbfgsVectors` + the undivided kernels (the reductions are the same launches)."""
+    from odil_amd import ops
+    from odil_amd.optimizer import LbfgsVectors, lbfgsb_minimize
+    from odil_amd.slab import LocalComm
+    from odil_amd.slab_solvers import SlabPoissonLbfgs
+
+    N, maxiter, m = 16, 8, 5
+    dev = torch.device("cuda:0")
+    rhs = make_rhs(N, 1)
+    run = SlabPoissonLbfgs(N, 0, 1, dtype=torch.float64, device=dev, rhs_global=torch.from_numpy(rhs))
+    res = run.minimize(LocalComm(), maxiter, m=m)
+    shapes = onp.mg_cshapes((N, N, N))
+    sizes = [int(np.prod(s)) for s in shapes]
+    h2 = [(1.0 / N) ** 2] * 3
+    trhs = torch.from_numpy(rhs).to(dev)
+    x = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
+
+    def fg(xflat):
+        terms = [t.view(s) for t, s in zip(xflat.split(sizes), shapes)]
+        u = ops.mg_synth(terms, "ccc")
+        fu, loss = ops.poisson_residual(u, trhs, h2)
+        gu = ops.poisson_adjoint(fu, h2, 2.0 / fu.numel())
+        return loss, torch.cat([g.reshape(-1) for g in ops.mg_synth_adj(gu, shapes, "ccc")])
+
+    ref = lbfgsb_minimize(x, fg, LbfgsVectors(x.numel(), m, dev), maxiter, m=m)
+    assert res["nit"] == ref["nit"] and res["funcalls"] == ref["funcalls"]
+    assert abs(res["f"] - ref["f"]) <= 1e-10 * abs(ref["f"])
+    got = torch.cat([w.reshape(-1) for w in run.owned_levels()])
+    assert float((got - x).abs().max()) <= 1e-9 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_newton_cg_emulated_ranks_solve_the_undivided_problem(world):
+    from odil_amd.slab_solvers import SlabPoissonNewtonCG, run_threads
+
+    N = 8
+    dev = torch.device("cuda:0")
+    cshape = (N * world, N, N)
+    dw = (1.0 / N,) * 3
+    ref_u = np.random.default_rng(3).standard_normal(cshape)
+    rhs = onp.poisson_discrete_rhs(ref_u, dw)
+
+    def body(rank, comm):
+        torch.cuda.set_device(dev)
+        run = SlabPoissonNewtonCG(N, rank, world, dtype=torch.float64, device=dev, rhs_global=torch.from_numpy(rhs))
+        loss0, loss1 = run.step(comm, maxiter=3000, tol=1e-13)
+        return loss0, loss1, dict(run.status), run.owned(run.u).cpu().numpy()
+
+    for r, (loss0, loss1, status, u) in enumerate(run_threads(world, body)):
+        assert abs(loss0 - np.mean(rhs**2)) <= 1e-12 * np.mean(rhs**2)
+        assert loss1 < 1e-14 * loss0 and status["niter"] < 3000
+        np.testing.assert_allclose(u, ref_u[r * N:(r + 1) * N], rtol=0, atol=1e-7)

@@ -6,7 +6,7 @@ RCCL's send / receive kernels to itself, so that what the multi-GPU epochs rely 
   * device tensors through `batch_isend_irecv`, `req.wait()` ordering the compute stream behind the transfer;
   * a POSTED exchange overlapping kernels on the compute stream, receive buffers that are reused every epoch,
     send buffers rewritten right after the wait (a stale or torn plane shows as a wrong checksum);
-  * the scalar all-reduce;
+  * the scalar all-reduce and the all-gather of the quasi-Newton drivers' partial reductions;
   * a Poisson slab epoch whose exchanges run through this comm equals the one with the local closure bit for bit.
 
 Prints one line `rccl self-loop ok ...` and exits 0, or raises.
@@ -57,9 +57,24 @@ def main():
     assert torch.equal(total.cpu(), torch.arange(5, dtype=torch.float64))
     rl, rh = comm.exchange("wrap", lo_src, hi_src)
     assert torch.equal(rl, hi_src) and torch.equal(rh, lo_src)
+    rows = comm.exchange("gather", torch.arange(8, dtype=torch.float64, device=dev), None)
+    assert tuple(rows.shape) == (1, 8) and torch.equal(rows[0].cpu(), torch.arange(8, dtype=torch.float64))
+    # the quasi-Newton driver of the slab path, its reductions through RCCL's all-gather: the same iterates as with the
+    # local closure
+    from odil_amd.slab import LocalComm
+    from odil_amd.slab_solvers import SlabPoissonLbfgs
+
+    plain = TorchDistComm(0, 1)  # (no self-loop: a single rank of this driver has no neighbour planes to send)
+    outs = []
+    for c in (plain, LocalComm()):
+        run = SlabPoissonLbfgs(32, 0, 1, dtype=torch.float64, device=dev)
+        res = run.minimize(c, 6, m=4)
+        outs.append((res["f"], res["funcalls"], run.x.clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
     torch.cuda.synchronize()
     dist.destroy_process_group()
-    print("rccl self-loop ok: 200 exchanges of 2 x {} MB (halo / post + wait), all-reduce, wrap".format(4 * n >> 20))
+    print("rccl self-loop ok: 200 exchanges of 2 x {} MB (halo / post + wait), all-reduce, all-gather, wrap, "
+          "6 L-BFGS iterations".format(4 * n >> 20))
 
 
 if __name__ == "__main__":
