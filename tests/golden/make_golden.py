@@ -722,6 +722,35 @@ def gen_generalised():
         CASES[f"veltracer3d_{tag}"] = dict(domain=domain, state=state, extra=extra, arrays=arrays, operator=vt3.operator, lr=0.01)
 
 # ---------------------------------------------------------------- reference tests as known-answer checks
+# ---------------------------------------------------------------- examples/basic/fields.py: one field per location
+def gen_basic_fields():
+    """The reference's tutorial example on fields centred in cells, nodes and faces (examples/basic/fields.py:16-40):
+    four multigrid fields of four different shapes, four outputs of four different shapes, and a network in the state
+    that the operator never evaluates (its gradient is absent: zeros)."""
+    rng = np.random.default_rng(909)
+    bf = load_module("ref_basic_fields", "/root/reference/examples/basic/fields.py")
+    Nx, Ny = 8, 4
+    for tag, dtype in (("f64", np.float64), ("f32", np.float32)):
+        domain = odil.Domain(cshape=(Nx, Ny), dimnames=["x", "y"], lower=(0, 0), upper=(2, 1), dtype=dtype, multigrid=1,
+                             mg_axes=[True, True], mod=mod)
+        state = odil.State(fields={
+            "uc": odil.Field(np.zeros(domain.size(loc="cc")), loc="cc"),
+            "un": odil.Field(np.zeros(domain.size(loc="nn")), loc="nn"),
+            "ufx": odil.Field(np.zeros(domain.size(loc="nc")), loc="nc"),
+            "ufy": odil.Field(np.zeros(domain.size(loc="cn")), loc="cn"),
+            "net": domain.make_neural_net([2, 4, 2]),
+        })
+        state = domain.init_state(state)
+        arrays = [T(rng.standard_normal(tuple(a.shape)) * 0.3).to(torch.float64 if dtype == np.float64 else torch.float32)
+                  for a in domain.arrays_from_state(state)]
+        arrays_l = [a.detach().clone().requires_grad_(True) for a in arrays]
+        domain.arrays_to_state(arrays_l, state)
+        ctx = odil.core.Context(domain, state, extra=None, tracers={"epoch": 0})
+        data = dict(Nx=np.array(Nx), Ny=np.array(Ny), nlvl=np.array(domain.mg_nlvl))
+        _store(data, arrays, *_loss_grads(bf.operator(ctx), arrays_l))
+        save("basic_fields_" + tag, **data)
+
+
 def check_reference_tests():
     """tests/test_mg_interp.py:11-32 on the shim: exact on linear functions."""
     for ndim in [1, 2, 3, 4]:
@@ -756,4 +785,5 @@ if __name__ == "__main__":
     gen_heat()
     gen_veltracer()
     gen_examples_f2()
+    gen_basic_fields()
     gen_generalised()

@@ -84,3 +84,20 @@ def test_generic_oracle_heat_vs_reference(which):
     loss, grads, terms, names, values = og.eval_loss_grad(ex.operator, geom, fields, extra, tracers={"epoch": int(g["epoch"])})
     assert names == [str(n) for n in g["names"]]
     check(g, loss, grads, terms, values, nlvl + 6, named=True)
+
+
+@pytest.mark.parametrize("tag,tol", [("f64", 1e-12), ("f32", 2e-6)])
+def test_generic_oracle_basic_fields_vs_reference(tag, tol):
+    """One multigrid field per location, four output shapes (reference examples/basic/fields.py:16-40)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", "basic"))
+    import fields as ex
+
+    g = load_golden("basic_fields_" + tag)
+    nlvl = int(g["nlvl"])
+    dtype = np.float64 if tag == "f64" else np.float32
+    geom = og.Geometry((int(g["Nx"]), int(g["Ny"])), ("x", "y"), (0, 0), (2, 1), dtype)
+    fields = {key: dict(kind="mg", loc=loc, terms=[g[f"x{i * nlvl + l}"] for l in range(nlvl)])
+              for i, (key, loc) in enumerate(ex.FIELDS)}
+    loss, grads, terms, names, values = og.eval_loss_grad(ex.operator, geom, fields)
+    assert names == [str(n) for n in g["names"]]
+    check(g, loss, grads, terms, values, 4 * nlvl, tol=tol)
