@@ -46,9 +46,20 @@ from .stencil_trace import (  # noqa: F401  (re-exported: the public names of th
 # ======================================================================================
 # Traced evaluator
 # ======================================================================================
-def trace_outputs(problem, state):
+class TraceGroups(TraceUnsupported):
+    """The operator's outputs live on grids of DIFFERENT shapes (a field per location: cell centres, nodes, faces --
+    reference examples/basic/fields.py:16-40): no single kernel set covers them, one per shape does (`TracedGroups`).
+    `groups`: positions of the outputs, grouped by shape, in order of first appearance."""
+
+    def __init__(self, groups):
+        super().__init__("outputs on {} grids of different shapes".format(len(groups)))
+        self.groups = groups
+
+
+def trace_outputs(problem, state, only=None):
     """Runs `problem.operator` once on symbolic values: (tracer, output nodes, raw flags, names, grid shape).
-    Only the STRUCTURE of `state` matters (array shapes; 'meta' tensors do)."""
+    Only the STRUCTURE of `state` matters (array shapes; 'meta' tensors do).  `only`: positions of the outputs to keep
+    (one shape group of an operator whose outputs have several, see TraceGroups)."""
     from .core import Context, Problem
 
     domain = problem.domain
@@ -91,6 +102,16 @@ def trace_outputs(problem, state):
     if not any(n.op == "read" for n in tr.nodes):
         raise TraceUnsupported("operator reads no field")
     G = tuple(tr.grid_shape())
+    if only is not None:
+        assert not tr.offgrid
+        names, raw, outs = [names[k] for k in only], [raw[k] for k in only], [outs[k] for k in only]
+        G = tuple(outs[0].shape)
+    elif not tr.offgrid and all(not o.host and o.win is None for o in outs) and len({tuple(o.shape) for o in outs}) > 1:
+        shapes = []
+        for o in outs:
+            if tuple(o.shape) not in shapes:
+                shapes.append(tuple(o.shape))
+        raise TraceGroups([[k for k, o in enumerate(outs) if tuple(o.shape) == shape] for shape in shapes])
     for o in outs:  # every output lives on the grid of the reads, all of it or a window of it
         if o.host or (o.win is None and tuple(o.shape) != G):
             raise TraceUnsupported("output of shape {} on grid {}".format(tuple(o.shape), G))
@@ -101,12 +122,12 @@ def trace_outputs(problem, state):
 class TracedOperator:
     """loss / gradient of one user operator through its generated kernels."""
 
-    def __init__(self, problem, state):
+    def __init__(self, problem, state, only=None):
         from .core import Field, MultigridField
 
         domain = problem.domain
         self.problem, self.domain = problem, domain
-        tr, outs, raw, self.names, G = trace_outputs(problem, state)
+        tr, outs, raw, self.names, G = trace_outputs(problem, state, only)
         self.G, self.raw = G, raw
         # outputs in parameter space (param_tape.py): [(position, expression, slice of the tape it needs)]
         self.offgrid = [(k, e, tr.param_tape.slice_for(e.param_ids())) for k, e in tr.offgrid]
@@ -576,13 +597,65 @@ def _flat_range(tensors):
         first.untyped_storage(), first.storage_offset(), (off - first.storage_offset(),), (1,))
 
 
+class TracedGroups:
+    """The evaluator of an operator whose outputs live on grids of different shapes: one `TracedOperator` (one generated
+    kernel set) per shape, every one over the whole state; losses and gradients are summed, terms and norms returned in
+    the operator's order.  (The optimizer's update is applied by the plain kernel: a field may receive gradient from
+    several groups; epochs are not replayed as a graph.)"""
+
+    graph_ok = False
+    offgrid, par_outputs = (), None
+
+    def __init__(self, problem, state, groups):
+        self.problem, self.domain, self.groups = problem, problem.domain, groups
+        self.parts = [TracedOperator(problem, state, only=positions) for positions in groups]
+        for part in self.parts:
+            if part.offgrid:
+                raise TraceUnsupported("outputs in parameter space beside outputs on several grids")
+        self.names = [None] * sum(len(g) for g in groups)
+        for positions, part in zip(groups, self.parts):
+            for k, name in zip(positions, part.names):
+                self.names[k] = name
+        from .optimizer import pack_like
+
+        self.gflat, self.gviews = pack_like(self.domain.arrays_from_state(state))
+        self.lib_path = [part.lib_path for part in self.parts]
+        self.cg = self.parts[0].cg
+
+    def matches(self, state):
+        return all(part.matches(state) for part in self.parts)
+
+    def graph_begin(self, nrows):
+        raise RuntimeError("epochs of an operator traced as several kernel sets are not replayed as a graph")
+
+    graph_upload = graph_end = graph_begin
+
+    def eval_loss_grad(self, state, adam=None):
+        """loss, grads (views of one packed buffer, overwritten by the next call), terms, names, norms."""
+        n = len(self.names)
+        terms, norms, loss = [None] * n, [None] * n, None
+        for j, (positions, part) in enumerate(zip(self.groups, self.parts)):
+            l, _, t, _, r = part.eval_loss_grad(state)
+            loss = l if loss is None else loss + l
+            if j == 0:
+                self.gflat.copy_(part.gflat)
+            else:
+                self.gflat.add_(part.gflat)
+            for k, tk, rk in zip(positions, t, r):
+                terms[k], norms[k] = tk, rk
+        return loss, list(self.gviews), terms, self.names, norms
+
+
 def trace(problem, state):
-    """A TracedOperator for `problem`, or None (with the reason logged) when the operator cannot be
-    expressed as one pointwise stencil kernel."""
+    """A TracedOperator for `problem` (a TracedGroups when its outputs live on grids of several shapes), or None (with
+    the reason logged) when the operator cannot be expressed as pointwise stencil kernels."""
     from .util import printlog
 
     try:
-        return TracedOperator(problem, state)
+        try:
+            return TracedOperator(problem, state)
+        except TraceGroups as e:
+            return TracedGroups(problem, state, e.groups)
     except TraceUnsupported as e:
         printlog("odil_amd: operator not traced ({}); using the generic autograd path".format(e))
     except FileNotFoundError as e:

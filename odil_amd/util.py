@@ -374,7 +374,7 @@ def make_loss_grad(problem, state):
     # (outputs in parameter space: replayable when they run as the generated kernel of param_expr.py; the torch replay
     # of param_tape.py bakes the host scalars of the current epoch in)
     loss_grad.graph_safe = lambda: getattr(problem, "_fused", None) is not None or (
-        getattr(problem, "_traced", None) is not None and (
+        getattr(problem, "_traced", None) is not None and getattr(problem._traced, "graph_ok", True) and (
             not getattr(problem._traced, "offgrid", None) or getattr(problem._traced, "par_outputs", None) is not None))
 
     def graph_hook(name):

@@ -297,3 +297,31 @@ def test_marching_kernel_structure(cpu_mod, monkeypatch):
     tro3 = stencil_jit.TracedOperator(*heat2d.make_problem(heat2d.parse_args(["--Nt", "8", "--Nx", "16", "--Ny", "32", "--infer_k", "1"])))
     k3 = tro3.source[tro3.source.index("void k_fwd("):tro3.source.index("void k_final(")]
     assert "__all((int)(" not in k3
+
+
+def test_outputs_on_grids_of_different_shapes_become_one_kernel_set_per_shape(cpu_mod):
+    """A field per location (reference examples/basic/fields.py:16-40) plus a second output on one of the grids: the
+    outputs are grouped by shape in order of first appearance, every group is traced over the whole state."""
+    domain = odil.Domain(cshape=(8, 4), dtype=np.float64, multigrid=True)
+    state = odil.State()
+    for key, loc in (("a", "cc"), ("b", "nn"), ("c", "nc")):
+        state.fields[key] = odil.Field(None, loc=loc)
+    state = domain.init_state(state)
+
+    def op(ctx):
+        x, y = ctx.points(loc="nn")
+        a, b, c = ctx.field("a"), ctx.field("b"), ctx.field("c")
+        return [("fa", a - ctx.field("a", frozen=True) * 0.5), ("fb", b - x), ("fc", c * c), ("fa2", (ctx.field("a", 1, 0) - a) * 2.0),
+                ("fb2", b * y)]
+
+    with pytest.raises(stencil_jit.TraceGroups) as e:
+        stencil_jit.TracedOperator(odil.Problem(op, domain), state)
+    assert e.value.groups == [[0, 3], [1, 4], [2]]
+    traced = stencil_jit.trace(odil.Problem(op, domain), state)
+    assert isinstance(traced, stencil_jit.TracedGroups) and not traced.graph_ok
+    assert traced.names == ["fa", "fb", "fc", "fa2", "fb2"]
+    assert [tuple(p.G) for p in traced.parts] == [(8, 4), (9, 5), (9, 4)]
+    assert [p.names for p in traced.parts] == [["fa", "fa2"], ["fb", "fb2"], ["fc"]]
+    # an output that mixes two grids stays untraceable
+    bad = lambda ctx: [ctx.field("a"), ctx.field("b")[1:, 1:] + ctx.field("a")]
+    assert stencil_jit.trace(odil.Problem(bad, domain), state) is None
