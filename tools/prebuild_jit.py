@@ -14,12 +14,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-for sub in ("poisson", "heat", "velocity_from_tracer", "wave", "heat_tmax", "infer_constant"):
+for sub in ("poisson", "heat", "velocity_from_tracer", "wave", "heat_tmax", "infer_constant", "basic"):
     sys.path.insert(0, os.path.join(ROOT, "examples", sub))
 
 CONFIGS = [  # (example module, argv, slab ranks or None)
     ("wave", ["--Nt", "8", "--Nx", "8"], None),                                                      # __graft_entry__.build()
     ("wave", ["--Nt", "8", "--Nx", "16"], None),                                                     # __graft_entry__.smoke()
+    ("fields", [], None),                                                                            # one kernel set per field location
     ("heat", ["--Nt", "256", "--Nx", "512", "--infer_k", "1", "--imposed", "stripe"], None),          # config 3
     ("heat2d", ["--Nt", "256", "--Nx", "512", "--Ny", "512", "--infer_k", "1", "--imposed", "stripe"], None),  # config 3 at BASELINE's shape
     ("veltracer", ["--Nt", "128", "--Nx", "256", "--Ny", "256"], None),                                # config 5, reference-native
@@ -43,7 +44,8 @@ def main():
         ex = importlib.import_module(modname)
         problem, state = ex.make_problem(ex.parse_args(argv))
         if world is None:
-            path = stencil_jit.TracedOperator(problem, state).lib_path
+            path = stencil_jit.trace(problem, state).lib_path
+            path = path[0] if isinstance(path, list) else path
         else:
             n = problem.domain.cshape[1] // world
             path = slab_traced.HipSlabKernels(problem, state, 1, n, "cpu").lib_path
