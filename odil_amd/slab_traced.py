@@ -616,24 +616,23 @@ class SlabTracedAdam:
         join()
 
     def _transpose_field(self, key):
-        if True:
-            e = self.by_key[key]
-            fac = e.get("factors")
-            for l in range(1, len(e["levels"])):
-                lv, fine = e["levels"][l], e["levels"][l - 1]
-                if lv.replicated and not fine.replicated:
-                    # this rank's share of the replicated level: zero but for the window its planes reach
-                    e["h"][l].zero_()
-                    if fac:
-                        e["g"][l].zero_()
-                    view = lambda a: a.narrow(self.axis, *lv.window_of(fine))
-                else:
-                    view = lv.inner
-                dst = view(e["h"][l])
-                best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
-                best(e["h"][l - 1], e["loc"], tuple(dst.shape), out=dst)  # (in place, also into a strided view)
+        e = self.by_key[key]
+        fac = e.get("factors")
+        for l in range(1, len(e["levels"])):
+            lv, fine = e["levels"][l], e["levels"][l - 1]
+            if lv.replicated and not fine.replicated:
+                # this rank's share of the replicated level: zero but for the window its planes reach
+                e["h"][l].zero_()
                 if fac:
-                    torch.mul(dst, fac[l], out=view(e["g"][l]))
+                    e["g"][l].zero_()
+                view = lambda a: a.narrow(self.axis, *lv.window_of(fine))
+            else:
+                view = lv.inner
+            dst = view(e["h"][l])
+            best = getattr(hip_ops, "interp_adj_best", hip_ops.interp_adj)
+            best(e["h"][l - 1], e["loc"], tuple(dst.shape), out=dst)  # (in place, also into a strided view)
+            if fac:
+                torch.mul(dst, fac[l], out=view(e["g"][l]))
 
     # ---- one epoch -------------------------------------------------------------------------------------
     def epoch_gen(self, timers=None):
