@@ -61,14 +61,21 @@ class ThreadComm:
             self.sh.barrier.abort()  # the other ranks must not wait for one that died
         return False
 
+    def _wait(self):
+        """The barrier, with the token handed over meanwhile (and held again afterwards even when another rank died and
+        the barrier broke: __exit__ releases it)."""
+        self.sh.token.release()
+        try:
+            self.sh.barrier.wait()
+        finally:
+            self.sh.token.acquire()
+
     def exchange(self, kind, a, b):
         sh, r, P = self.sh, self.rank, self.world
         if kind == "wait":
             return a
         sh.slots[r] = (a, b)
-        sh.token.release()
-        sh.barrier.wait()
-        sh.token.acquire()
+        self._wait()
         try:
             clone = lambda t: None if t is None else t.clone()
             if kind == "sum":
@@ -85,9 +92,7 @@ class ThreadComm:
             # "halo" / "post": what the lower neighbour sent up, what the upper one sent down
             return (clone(sh.slots[r - 1][1]) if r > 0 else None, clone(sh.slots[r + 1][0]) if r + 1 < P else None)
         finally:
-            sh.token.release()
-            sh.barrier.wait()  # nobody overwrites its slot before everybody has read
-            sh.token.acquire()
+            self._wait()  # nobody overwrites its slot before everybody has read
 
 
 def run_threads(world, body):

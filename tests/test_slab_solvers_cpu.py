@@ -128,3 +128,17 @@ def test_slab_newton_cg_step_solves_the_undivided_problem(world):
     loss0, loss1, status, u = newton_rank(0, 1, LocalComm(), N, rhs, 400, nz=N * world)
     assert status["niter"] == results[0][2]["niter"]
     np.testing.assert_allclose(u, np.concatenate([res[3] for res in results]), rtol=0, atol=1e-10)
+
+
+def test_thread_ranks_report_the_first_error_and_do_not_hang():
+    from odil_amd.slab_solvers import run_threads
+
+    def body(rank, comm):
+        comm.exchange("gather", torch.zeros(1), None)
+        if rank == 1:
+            raise ValueError("rank 1 failed")
+        comm.exchange("gather", torch.zeros(1), None)  # the others wait here: the broken barrier releases them
+        return rank
+
+    with pytest.raises(ValueError, match="rank 1 failed"):
+        run_threads(3, body)
