@@ -256,3 +256,115 @@ class SlabPoissonNewtonCG:
         loss1 = self.residual(comm, self.u, self.f)
         self.status = dict(niter=it, residual=float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
         return loss0, loss1
+
+
+class ReplicatedTailVectors(SlabLbfgsVectors):
+    """`SlabLbfgsVectors` for a local vector [owned entries | entries EVERY rank holds] (coarse levels agglomerated on
+    every rank, network parameters): the tail takes part in every rank's vector algebra -- all ranks then update it alike,
+    from the same combined scalars -- but must count ONCE in the reductions: every rank enters its tail products with
+    the weight 1 / world (whole-vector product minus (1 - 1 / world) of the tail's, two launches instead of one)."""
+
+    def __init__(self, n, m, device, comm, n_own, world):
+        super().__init__(n, m, device, comm)
+        self.n_own, self.excess = n_own, 1.0 - 1.0 / world
+        self.tail = n > n_own and world > 1
+        self.tscal = torch.zeros(8, dtype=torch.float64, device=device)
+
+    def probe_direction(self, d, g):
+        super().probe_direction(d, g)
+        if self.tail:
+            k = self.n_own
+            hip_ops.dots3(d[None, k:], [d[k:], g[k:]], out=self.tscal[0:3].view(3, 1))
+
+    def probe_eval(self, f, g, d):
+        super().probe_eval(f, g, d)
+        if self.tail:
+            k = self.n_own
+            hip_ops.dots3(g[None, k:], [d[k:], g[k:]], out=self.tscal[3:6].view(3, 1))  # <g, d>, <g, g> of the tail
+
+    def reduce_probes(self, scal):
+        if self.tail:
+            fixed = scal.clone()
+            fixed[0:2] -= self.excess * self.tscal[0:2]
+            fixed[3:5] -= self.excess * self.tscal[3:5]
+            scal = fixed
+        return super().reduce_probes(scal)
+
+    def history_products(self, nphys, bs):
+        if nphys == 0 or not self.tail:
+            return super().history_products(nphys, bs)
+        k = self.n_own
+        whole = hip_ops.dots3(self.w[: 2 * nphys], bs)
+        tail = hip_ops.dots3(self.w[: 2 * nphys, k:], [b[k:] for b in bs])
+        out = self.reduce_sums(whole - self.excess * tail).cpu().numpy()[: len(bs)]
+        return out[:, 0::2], out[:, 1::2]
+
+    def dot(self, a, b):
+        k = self.n_own
+        whole = hip_ops.dots3(a[None], [b])
+        if self.tail:
+            whole = whole - self.excess * hip_ops.dots3(a[None, k:], [b[k:]])
+        return float(self.reduce_sums(whole).cpu().numpy()[0, 0])
+
+
+class SlabTracedLbfgs:
+    """L-BFGS-B for ANY traced operator on the slab decomposition of `slab_traced.SlabTracedAdam` (whose evaluation it
+    borrows: `epoch_gen(update=False)`).  The local vector: this rank's owned planes of every level of every field,
+    then what every rank holds whole (agglomerated coarse levels, network / `Array` parameters)."""
+
+    def __init__(self, run):
+        self.run = run
+        own, rep = [], []
+        dev = run.device
+        for e in run.entries:
+            shapes = [lv.shape for lv in e["levels"]] if "levels" in e else e["shapes"]
+            pos = e["start"]
+            for k, shape in enumerate(shapes):
+                cnt = int(np.prod(shape)) if len(shape) else 1
+                index = torch.arange(pos, pos + cnt, dtype=torch.int64, device=dev).view(tuple(shape))
+                if "levels" in e and not e["levels"][k].replicated:
+                    own.append(e["levels"][k].owned(index).reshape(-1))
+                else:
+                    rep.append(index.reshape(-1))
+                pos += cnt
+        self.n_own = int(sum(t.numel() for t in own))
+        self.index = torch.cat(own + rep) if own or rep else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.n = int(self.index.numel())
+        self.nfev = 0
+
+    def pack(self, flat, out=None):
+        res = flat.index_select(0, self.index).to(torch.float64)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
+
+    def unpack(self, vec, flat):
+        flat.index_copy_(0, self.index, vec.to(flat.dtype))
+
+    def local_loss(self):
+        """This rank's share of the loss of the last evaluation (the ranks' shares add up to the loss)."""
+        run = self.run
+        part = run.kern.partial_terms().to(torch.float64).sum()
+        if getattr(run.kern, "par_outputs", None) is not None and hasattr(run.kern, "pout") and run.rank == 0:
+            for q in range(len(run.kern.par_outputs)):  # evaluated by every rank alike: counted once
+                part = part + run.kern.pout[2 * q].to(torch.float64)
+        return part
+
+    def minimize(self, comm, maxiter, m=50, maxls=50, pgtol=1e-16, factr=0.0, callback=None, vectors=None):
+        """-> the dict of `lbfgsb_minimize` (f = GLOBAL loss); the unknowns of `self.run` hold the result."""
+        run = self.run
+        vec = vectors or ReplicatedTailVectors(self.n, m, run.device, comm, self.n_own, run.world)
+        x = self.pack(run.x)
+        gflat = torch.empty(self.n, dtype=torch.float64, device=run.device)
+
+        def fg(xflat):
+            self.unpack(xflat, run.x)
+            drive(run.epoch_gen(update=False), comm)
+            self.nfev += 1
+            return self.local_loss(), self.pack(run.g, out=gflat)
+
+        res = lbfgsb_minimize(x, fg, vec, maxiter, m=m, maxls=maxls, pgtol=pgtol, factr=factr, callback=callback)
+        self.unpack(x, run.x)
+        run._x_synced = False  # the ghost planes of the unknowns are refreshed by whoever evaluates next
+        return res

@@ -635,9 +635,14 @@ class SlabTracedAdam:
                 torch.mul(dst, fac[l], out=view(e["g"][l]))
 
     # ---- one epoch -------------------------------------------------------------------------------------
-    def epoch_gen(self, timers=None):
+    def epoch_gen(self, timers=None, update=True):
+        """One Adam epoch as a generator that yields at its exchanges.  update=False: loss and gradient only (the
+        quasi-Newton driver of slab_solvers.py) -- the ghost planes of the unknowns are refreshed first (somebody else
+        changed the unknowns), no launch applies an update, and self.g is left complete on the owned planes, on the
+        replicated levels and on the parameters."""
         rank, world, h = self.rank, self.world, self.h
         first, last = rank == 0, rank == world - 1
+        fused = self._fused if update else dict()
 
         def tic(name):
             if timers is None:
@@ -650,7 +655,7 @@ class SlabTracedAdam:
             if b is not None:
                 b.record()
 
-        if not (self.redundant and self._x_synced):
+        if not (update and self.redundant and self._x_synced):
             # the neighbours' boundary planes of the unknowns -> inner ghost planes: every epoch, or once at the start
             # when the ghost planes are updated redundantly afterwards
             b = tic("halo")
@@ -693,23 +698,23 @@ class SlabTracedAdam:
         hyper = (alpha, 1 - self.b1, 1 - self.b2, self.eps)
         b = tic("gather")
         merged = list(getattr(self.kern, "merged", []))
-        spans = {self._fused[key] for key in merged if key in self._fused}
+        spans = {fused[key] for key in merged if key in fused}
         if merged and len(spans) <= 1:  # one launch for all of them (the fused planes are the same for every field)
             items = []
             for key in merged:
                 w, e = self.wrap[key], self.by_key[key]
                 items.append((key, e["h"][0], w["glo"], w["ghi"],
-                              (e["x"][0], e["m"][0], e["v"][0]) if key in self._fused else None))
-            self.kern.gather_all(items, hyper, spans.pop() if spans else (0, 0))
+                              (e["x"][0], e["m"][0], e["v"][0]) if key in fused else None))
+            self.kern.gather_all(items, hyper if update else None, spans.pop() if spans else (0, 0))
         else:
             merged = []
         for key in self.kern.gather_keys:
             if key in merged:
                 continue
             w, e = self.wrap[key], self.by_key[key]
-            if key in self._fused:
+            if key in fused:
                 self.kern.gather(key, e["h"][0], w["glo"], w["ghi"],
-                                 adam=(e["x"][0], e["m"][0], e["v"][0]) + hyper + self._fused[key])
+                                 adam=(e["x"][0], e["m"][0], e["v"][0]) + hyper + fused[key])
             else:
                 self.kern.gather(key, e["h"][0], w["glo"], w["ghi"])
         toc(b)
@@ -771,6 +776,8 @@ class SlabTracedAdam:
                     ofs += cnt
         if getattr(self.kern, "par_outputs", None) is not None:
             self.kern.launch_par(lambda key: self.by_key[key]["x"], lambda key: self.by_key[key]["g"])
+        if not update:
+            return
         self.t += 1
         b = tic("adam")
         if not self._fused:

@@ -60,3 +60,29 @@ class TorchCpuSlabVectors:
             c = torch.zeros(2 * nphys, dtype=torch.float64)
             c[0::2], c[1::2] = torch.as_tensor(cs), torch.as_tensor(cy)
             y += c @ self.w[: 2 * nphys]
+
+
+class TorchCpuTailVectors(TorchCpuSlabVectors):
+    """Double of `odil_amd.slab_solvers.ReplicatedTailVectors`: the tail [n_own:] is held by every rank and enters the
+    reductions with the weight 1 / world."""
+
+    def __init__(self, n, m, comm, n_own, world):
+        super().__init__(n, m, comm)
+        self.weight = torch.ones(n, dtype=torch.float64)
+        self.weight[n_own:] = 1.0 / world
+
+    def probe_direction(self, d, g):
+        self.scal[0], self.scal[1] = (self.weight * d) @ d, (self.weight * g) @ d
+
+    def probe_eval(self, f, g, d):
+        self.scal[3], self.scal[4], self.scal[5], self.scal[6] = (self.weight * g) @ d, (self.weight * g) @ g, g.abs().max(), float(f)
+
+    def history_products(self, nphys, bs):
+        if nphys == 0:
+            z = np.zeros((len(bs), 0))
+            return z, z
+        out = self._sums(torch.stack([self.w[: 2 * nphys] @ (self.weight * b) for b in bs])).numpy()
+        return out[:, 0::2], out[:, 1::2]
+
+    def dot(self, a, b):
+        return float(self._sums(((self.weight * a) @ b).reshape(1)))

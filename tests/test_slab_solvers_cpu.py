@@ -142,3 +142,94 @@ def test_thread_ranks_report_the_first_error_and_do_not_hang():
 
     with pytest.raises(ValueError, match="rank 1 failed"):
         run_threads(3, body)
+
+
+def undivided_traced_lbfgs(which, world, nx_rank, maxiter, m):
+    """L-BFGS-B (the same `lbfgsb_minimize`, NumPy vectors) on the UNDIVIDED problem evaluated by the generic oracle."""
+    from test_lbfgs_host_logic import NumpyVectors
+    from test_slab_traced_cpu import make_problem
+
+    from odil_amd.optimizer import lbfgsb_minimize
+    from oracle import odil_generic as og
+
+    problem, state = make_problem(which, world, nx_rank)
+    geom = og.Geometry.of(problem.domain)
+    fields = og.fields_of_state(problem.domain, state)
+
+    def get():
+        out = []
+        for f in fields.values():
+            out += list(f["terms"]) if f["kind"] == "mg" else (
+                [f["array"]] if f["kind"] in ("field", "array") else list(f["weights"]) + list(f["biases"]))
+        return out
+
+    def put(x):
+        k = 0
+        for f in fields.values():
+            if f["kind"] == "mg":
+                f["terms"] = x[k:k + len(f["terms"])]
+                k += len(f["terms"])
+            elif f["kind"] in ("field", "array"):
+                f["array"] = x[k]
+                k += 1
+            else:
+                nw, nb = len(f["weights"]), len(f["biases"])
+                f["weights"], f["biases"] = x[k:k + nw], x[k + nw:k + nw + nb]
+                k += nw + nb
+
+    x0 = [np.asarray(a, dtype=np.float64) for a in get()]
+    shapes, sizes = [a.shape for a in x0], [a.size for a in x0]
+    split = lambda v: [p.reshape(s) for p, s in zip(np.split(v, np.cumsum(sizes)[:-1]), shapes)]
+
+    def fun(v):
+        put(split(v))
+        loss, grads = og.eval_loss_grad(problem.operator, geom, fields, problem.extra, tracers=problem.tracers)[:2]
+        return float(loss), np.concatenate([np.asarray(g).ravel() for g in grads])
+
+    x = np.concatenate([a.ravel() for a in x0])
+    res = lbfgsb_minimize(x, fun, NumpyVectors(x.size, m), maxiter, m=m)
+    return res, split(x)
+
+
+def traced_lbfgs_rank(rank, world, comm, which, nx_rank, maxiter, m):
+    import slab_oracle_ops
+    import slab_traced_double
+    from slab_oracle_vectors import TorchCpuTailVectors
+    from test_slab_traced_cpu import local_extra, make_problem
+
+    from odil_amd import slab_traced
+    from odil_amd.slab_solvers import SlabTracedLbfgs
+
+    slab_traced.hip_ops = slab_oracle_ops
+    problem, state = make_problem(which, world, nx_rank)
+    run = slab_traced.SlabTracedAdam(problem, state, rank, world, axis=1, lr=0.01, device=torch.device("cpu"),
+                                     kernels=slab_traced_double.make_kernels(local_extra))
+    drv = SlabTracedLbfgs(run)
+    res = drv.minimize(comm, maxiter, m=m, vectors=TorchCpuTailVectors(drv.n, m, comm, drv.n_own, world))
+    return res, [a.clone().numpy() for a in run.owned_arrays()], drv.n_own, drv.n
+
+
+@pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 8), ("veltracer", 4, 2), ("heat2d", 2, 8),
+                                                  ("veltracer-factors", 2, 8)])
+def test_slab_traced_lbfgs_thread_ranks_follow_the_undivided_run(which, world, nx_rank):
+    """Any traced operator under L-BFGS-B on the slabs: (4, 2) leaves 2, 1, 0.5 cells of x per rank on the three levels --
+    the coarser two are held whole by every rank and count once in the reductions; heat2d: network parameters likewise."""
+    from odil_amd.slab_solvers import run_threads
+
+    maxiter, m = 6, 4
+    results = run_threads(world, lambda rank, comm: traced_lbfgs_rank(rank, world, comm, which, nx_rank, maxiter, m))
+    res_ref, x_ref = undivided_traced_lbfgs(which, world, nx_rank, maxiter, m)
+    for r, (res, owned, n_own, n) in enumerate(results):
+        assert res["nit"] == res_ref["nit"] and res["funcalls"] == res_ref["funcalls"]
+        assert abs(res["f"] - res_ref["f"]) <= 1e-9 * abs(res_ref["f"])
+        if (world, nx_rank) == (4, 2) or which == "heat2d":
+            assert n > n_own  # a replicated tail exists
+        for i, ref in enumerate(x_ref):
+            got = owned[i]
+            if got.shape == ref.shape:
+                want = ref
+            else:
+                k = ref.shape[1] // world
+                want = ref[:, r * k:(r + 1) * k]
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want))), (i, r)

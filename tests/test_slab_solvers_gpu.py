@@ -2,6 +2,8 @@
 threads on one GPU: L-BFGS-B on the decomposed domain follows the undivided oracle run iterate for iterate; the matrix-free
 CG Newton step solves the undivided problem."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -112,3 +114,47 @@ def test_slab_newton_cg_emulated_ranks_solve_the_undivided_problem(world):
         assert abs(loss0 - np.mean(rhs**2)) <= 1e-12 * np.mean(rhs**2)
         assert loss1 < 1e-14 * loss0 and status["niter"] < 3000
         np.testing.assert_allclose(u, ref_u[r * N:(r + 1) * N], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 16), ("veltracer3d", 4, 4), ("heat2d", 2, 16)])
+def test_slab_traced_lbfgs_emulated_ranks_follow_the_single_gpu_optimizer(which, world, nx_rank):
+    """L-BFGS-B of a traced operator on the slabs (generated kernels in slab mode, ranks as threads on one GPU; (4, 4):
+    the coarsest level is held whole by every rank; heat2d: network parameters) against `LbfgsbOptimizer` on the
+    undivided traced path: the same iteration / evaluation counts, the unknowns to 1e-8."""
+    import argparse
+
+    import odil_amd as odil
+    from odil_amd.slab_solvers import SlabTracedLbfgs, run_threads
+    from odil_amd.slab_traced import SlabTracedAdam
+    from test_slab_gpu import _traced_problem
+
+    maxiter, m = 8, 5
+    problem, state = _traced_problem(which, world, 1, nx_rank)
+    dev = torch.device("cuda:0")
+
+    def body(rank, comm):
+        torch.cuda.set_device(dev)
+        run = SlabTracedAdam(problem, state, rank, world, axis=1, lr=0.01)
+        drv = SlabTracedLbfgs(run)
+        res = drv.minimize(comm, maxiter, m=m)
+        return res, [a.clone() for a in run.owned_arrays()], drv.n - drv.n_own
+
+    results = run_threads(world, body)
+    a = argparse.Namespace(epoch_start=0, epochs=maxiter, lr=0.01, bfgs_m=m, bfgs_pgtol=None, bfgs_maxls=None,
+                           adam_epsilon=None, adam_beta_1=None, adam_beta_2=None, callback_update_state=0)
+    odil.util.set_log_file(open(os.devnull, "w"))
+    _, optinfo = None, None
+    odil.util.optimize_grad(a, "lbfgsb", problem, state, None)
+    assert problem._traced is not None
+    want = problem.domain.arrays_from_state(state)
+    want_loss = float(problem.eval_loss_grad(state)[0])
+    for r, (res, owned, ntail) in enumerate(results):
+        assert res["nit"] == maxiter
+        assert abs(res["f"] - want_loss) <= 1e-9 * abs(want_loss), (res["f"], want_loss)
+        if which == "heat2d" or (world, nx_rank) == (4, 4):
+            assert ntail > 0
+        for i, (got, ref) in enumerate(zip(owned, want)):
+            if got.shape != ref.shape:
+                n = ref.shape[1] // world
+                ref = ref[:, r * n:(r + 1) * n]
+            assert float((got - ref).abs().max()) <= 1e-8 * max(1.0, float(ref.abs().max())), (r, i)
