@@ -830,7 +830,8 @@ class SlabTracedAdam:
 def optimize_slab(args, problem, state, callback=None, axis=None):
     """`odil.util.optimize(args, "adam", ...)` for a run started with one process per GPU (e.g. `python -m
     torch.distributed.run --nproc-per-node 8 examples/velocity_from_tracer/veltracer3d.py --slab 1`): every rank
-    builds the same GLOBAL problem, owns a slab of it (this module) and runs `args.epochs` Adam epochs; the loss
+    builds the same GLOBAL problem, owns a slab of it (this module) and runs `args.epochs` Adam epochs (or, with
+    `--optimizer lbfgsb`, that many L-BFGS-B iterations: slab_solvers.SlabTracedLbfgs); the loss
     terms are all-reduced and logged by rank 0 every `args.report_every` epochs (the quantity the reference's
     callback reports, src/odil/util.py:337-467).  `callback(run, epoch, terms)` is called on every rank at those
     epochs.  Returns the rank's SlabTracedAdam (its `owned_arrays()` are the rank's part of the solution; dump
@@ -844,15 +845,37 @@ def optimize_slab(args, problem, state, callback=None, axis=None):
     run = SlabTracedAdam(problem, state, rank, world, axis=axis, lr=args.lr, **kw)
     every = getattr(args, "report_every", 0) or 0
     start = getattr(args, "epoch_start", 0)
+
+    def report(epoch):
+        terms = run.last_terms(comm)  # of the last evaluation
+        if rank == 0:
+            printlog("epoch={:05d} ranks={} loss={:.8g} terms={}".format(
+                epoch, world, sum(terms), " ".join("{:.6g}".format(t) for t in terms)))
+        if callback is not None:
+            callback(run, epoch, terms)
+
+    optname = getattr(args, "optimizer", "adam") or "adam"
+    if optname == "lbfgsb":
+        # L-BFGS-B on the slabs (slab_solvers.SlabTracedLbfgs): an "epoch" is an iteration, as in the undivided driver
+        from .slab_solvers import SlabTracedLbfgs
+
+        opts = {dst: getattr(args, src) for src, dst in (("bfgs_m", "m"), ("bfgs_pgtol", "pgtol"), ("bfgs_maxls", "maxls"))
+                if getattr(args, src, None) is not None}
+        count = [start]
+
+        def each(_x):
+            count[0] += 1
+            if every and (count[0] % every == 0 or count[0] == args.epochs):
+                report(count[0])
+
+        SlabTracedLbfgs(run).minimize(comm, args.epochs - start, callback=each, **opts)
+        return run
+    if optname != "adam":
+        raise NotImplementedError("optimizer '{}' on the slab decomposition (adam, lbfgsb)".format(optname))
     for epoch in range(start + 1, args.epochs + 1):
         run.epoch(comm)
         if every and (epoch % every == 0 or epoch == args.epochs):
-            terms = run.last_terms(comm)  # of the evaluation at the start of this epoch
-            if rank == 0:
-                printlog("epoch={:05d} ranks={} loss={:.8g} terms={}".format(
-                    epoch, world, sum(terms), " ".join("{:.6g}".format(t) for t in terms)))
-            if callback is not None:
-                callback(run, epoch, terms)
+            report(epoch)  # (the evaluation at the start of this epoch)
     return run
 
 

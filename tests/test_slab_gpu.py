@@ -277,7 +277,8 @@ def test_bench_config5_two_ranks_over_torch_distributed(tmp_path):
     assert abs(d["value"] - 2 * cells * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
 
 
-def test_example_runs_slab_decomposed_under_torch_distributed(tmp_path):
+@pytest.mark.parametrize("optimizer", ["adam", "lbfgsb"])
+def test_example_runs_slab_decomposed_under_torch_distributed(tmp_path, optimizer):
     """`python -m torch.distributed.run --nproc-per-node 2 examples/velocity_from_tracer/veltracer3d.py --slab 1`
     (gloo, both ranks on this box's GPU): the user-level entry of the slab path -- rank 0 logs the all-reduced loss,
     both ranks write their planes of the final tracer field into one raw + XDMF2 file -- against the same example
@@ -292,7 +293,8 @@ def test_example_runs_slab_decomposed_under_torch_distributed(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "examples", "velocity_from_tracer", "veltracer3d.py")
     common = ["--Nt", "8", "--Nx", "32", "--Ny", "16", "--Nz", "16", "--double", "1", "--epochs", "6", "--report_every", "3",
-              "--plot_every", "100", "--history_every", "0", "--checkpoint_every", "0", "--frames", "1"]
+              "--plot_every", "100", "--history_every", "0", "--checkpoint_every", "0", "--frames", "1",
+              "--optimizer", optimizer]
     env = dict(os.environ, ODIL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(key, None)
