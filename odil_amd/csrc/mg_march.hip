@@ -320,6 +320,168 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead_pair(const T* 
 }
 
 // ------------------------------------------------------------------------------------
+// P with a node-centred leading axis, float: the fine volumes 2k and 2k + 1 of a TILE of coarse cells, staged through LDS.
+//
+// The marching pair kernel above keeps two 3 x 3 x (CX + 2) coarse windows in registers (244 VGPRs, two waves per
+// SIMD) and walks the z axis of the array -- 18 coarse planes on one rank of the tracer workload, two of them spent
+// priming: 3.5 - 3.9 TB/s on the arrays where a device copy moves 4.75.  Here a workgroup stages the ghosted coarse
+// neighbourhood of its tile for the volumes k and k + 1 ONCE (the joint ghost rule applied while staging:
+// 2 c[clamp] - c[reflect] over all three cell axes, as load_plane forms it), then every thread forms 16-byte packs of
+// fine values from LDS reads and streams them out: no dependent steps, ~70 registers, the fine addend in flight while
+// the tile is staged.  The sums are formed in the order of acc_plane / store_plane (leading tap, z tap, then (ry, rx);
+// weight * value added term by term; scaled by 1 / 64 or 1 / 128; addend last): bit-identical to the marching kernels.
+// Tiles: whole fine rows where they fit (TX coarse columns = 2 TX fine cells), 8 packs per thread.
+// ------------------------------------------------------------------------------------
+struct LeadTileArgs {
+  int cn[3], fn[3];      // (z, y, x) coarse / fine extents of one volume
+  int nty, ntx;          // tiles along y and x (z tiles = gridDim.x / (nty ntx))
+  int nt;                // stream the fine arrays past the caches
+  int64_t cvol, fvol;    // elements between leading indices of the coarse / fine arrays
+};
+
+template <int TX, int TY, int TZ>
+__global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const float* __restrict__ coarse,
+                                                                 const float* __restrict__ add, float* __restrict__ fine,
+                                                                 LeadTileArgs a, float cscale, float ascale) {
+  static_assert((TX / 2) * TY * TZ == kBlock, "one thread per pair of coarse columns of the tile");
+  constexpr int LX = TX + 2, LY = TY + 2, LZ = TZ + 2, LVOL = LZ * LY * LX;
+  __shared__ float sv[2 * LVOL];
+  const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
+  const int fny = a.fn[1], fnx = a.fn[2];
+  const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
+  const int k = (int)blockIdx.y;
+  int tile = (int)blockIdx.x;
+  const int tx_ = tile % a.ntx;
+  tile /= a.ntx;
+  const int ty_ = tile % a.nty, tz_ = tile / a.nty;
+  const int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
+  const float* cb = coarse + (int64_t)k * a.cvol;
+  add = add ? add + (int64_t)(2 * k) * a.fvol : add;
+  fine += (int64_t)(2 * k) * a.fvol;
+  // the thread's coarse cell pair (jz, jy, 2 xp .. 2 xp + 1): its 2 x 2 fine rows of 4 values, in both fine volumes --
+  // eight 16-byte packs; consecutive lanes hold consecutive packs of a fine row
+  const int xp = threadIdx.x % (TX / 2), jyl = (threadIdx.x / (TX / 2)) % TY, jzl = threadIdx.x / ((TX / 2) * TY);
+  const int jz = z0 + jzl, jy = y0 + jyl, jx = x0 + 2 * xp;
+  const bool own = jz < cnz && jy < cny && jx < cnx;
+  const int64_t base = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx;
+  PackN<float, 4> ad[2][2][2];
+  if (add && own) {
+#pragma unroll
+    for (int pv = 0; pv < 2; ++pv)
+#pragma unroll
+      for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+          ad[pv][sz][sy] = stream_ld<float, 4>(add + pv * a.fvol + base + sz * fplane + sy * fnx, a.nt != 0);
+  }
+  // the ghosted coarse neighbourhood of the tile, volumes k and k + 1
+  const bool inner = z0 >= 1 && z0 + TZ < cnz && y0 >= 1 && y0 + TY < cny && x0 >= 1 && x0 + TX < cnx;
+  if (inner) {  // no wall (and no overhang) within reach: every staged position is a cell of the array
+    for (int i = threadIdx.x; i < 2 * LVOL; i += kBlock) {
+      const int lv = i / LVOL, j = i - lv * LVOL;
+      const int dx = j % LX, dy = (j / LX) % LY, dz = j / (LX * LY);
+      sv[i] = cscale * cb[(int64_t)lv * a.cvol + (int64_t)(z0 - 1 + dz) * cplane + (int64_t)(y0 - 1 + dy) * cnx + (x0 - 1 + dx)];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2 * LVOL; i += kBlock) {
+      const int lv = i / LVOL, j = i - lv * LVOL;
+      const int dx = j % LX, dy = (j / LX) % LY, dz = j / (LX * LY);
+      const int qz = z0 - 1 + dz, qy = y0 - 1 + dy, qx = x0 - 1 + dx;
+      const bool out = qz < 0 || qz >= cnz || qy < 0 || qy >= cny || qx < 0 || qx >= cnx;
+      const int zc = qz < 0 ? 0 : (qz >= cnz ? cnz - 1 : qz), zr = qz < 0 ? 1 : (qz >= cnz ? cnz - 2 : qz);
+      const int yc = qy < 0 ? 0 : (qy >= cny ? cny - 1 : qy), yr = qy < 0 ? 1 : (qy >= cny ? cny - 2 : qy);
+      const int xc = qx < 0 ? 0 : (qx >= cnx ? cnx - 1 : qx), xr = qx < 0 ? 1 : (qx >= cnx ? cnx - 2 : qx);
+      const float* vol = cb + (int64_t)lv * a.cvol;
+      const float val = cscale * vol[(int64_t)zc * cplane + (int64_t)yc * cnx + xc];
+      float res = val;
+      if (out) res = 2.0f * val - cscale * vol[(int64_t)zr * cplane + (int64_t)yr * cnx + xr];
+      sv[i] = res;
+    }
+  }
+  __syncthreads();
+  if (!own) return;
+  // the 3 x 3 x 4 window of the thread's cell pair, per volume (index 0 <-> coarse j - 1)
+  float v[2][3][3][4];
+#pragma unroll
+  for (int lv = 0; lv < 2; ++lv)
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* row = sv + lv * LVOL + ((jzl + dz) * LY + (jyl + dy)) * LX + 2 * xp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[lv][dz][dy][c] = row[c];
+      }
+  const float rs[2] = {1.0f / 64.0f, 1.0f / 128.0f};
+#pragma unroll
+  for (int pv = 0; pv < 2; ++pv)
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy) {
+        PackN<float, 4> pk;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+          float t = 0.f;
+#pragma unroll
+          for (int r0 = 0; r0 <= pv; ++r0)
+#pragma unroll
+            for (int rz = 0; rz < 2; ++rz)
+#pragma unroll
+              for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+                for (int rx = 0; rx < 2; ++rx) {
+                  const int w = (sz == rz ? 1 : 3) * (sy == ry ? 1 : 3) * ((sx & 1) == rx ? 1 : 3);
+                  t = t + (float)w * v[r0][sz + rz][sy + ry][(sx >> 1) + (sx & 1) + rx];
+                }
+          float o = t * rs[pv];
+          if (add) o = ascale * ad[pv][sz][sy].e[sx] + o;
+          pk.e[sx] = o;
+        }
+        stream_st<float, 4>(fine + pv * a.fvol + base + sz * fplane + sy * fnx, pk, a.nt != 0);
+      }
+}
+
+static bool lead_tile_enabled() {
+  const char* e = getenv("ODIL_LEAD_TILE");
+  return !e || atoi(e) != 0;
+}
+
+// Launches the tiled pair kernel for the lead.cn - 1 pairs of fine volumes; false: the caller keeps the marching kernel.
+template <typename T>
+static bool lead_tile_launch(const T* coarse, const T* add, T* fine, const MarchArgs& m, T cscale, T ascale,
+                             hipStream_t stream) {
+  if constexpr (sizeof(T) != 4) {
+    return false;
+  } else {
+    if (!lead_tile_enabled() || m.cut_lo || m.cut_hi) return false;
+    for (int i = 0; i < 3; ++i)
+      if (m.fn[i] != 2 * m.cn[i] || m.cn[i] < 2) return false;
+    if (m.cn[2] % 2 || m.cn[2] < 32) return false;
+    if (reinterpret_cast<uintptr_t>(fine) % 16 || (add && reinterpret_cast<uintptr_t>(add) % 16)) return false;
+    LeadTileArgs a;
+    for (int i = 0; i < 3; ++i) a.cn[i] = m.cn[i], a.fn[i] = m.fn[i];
+    a.nt = m.nt;
+    a.cvol = m.lead_cstride;
+    a.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
+    if (a.fvol % 4) return false;  // every fine volume starts on 16 bytes
+    const int tx = m.cn[2] >= 128 ? 128 : (m.cn[2] >= 64 ? 64 : 32), ty = 256 / tx, tz = 2;
+    a.ntx = (m.cn[2] + tx - 1) / tx;
+    a.nty = (m.cn[1] + ty - 1) / ty;
+    const int64_t tiles = (int64_t)a.ntx * a.nty * ((m.cn[0] + tz - 1) / tz);
+    if (tiles >= ((int64_t)1 << 31) || m.lead_cn - 1 > 65535) return false;
+    const dim3 grid((unsigned)tiles, (unsigned)(m.lead_cn - 1));
+    if (tx == 128)
+      hipLaunchKernelGGL((k_interp_add_lead_tile<128, 2, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
+    else if (tx == 64)
+      hipLaunchKernelGGL((k_interp_add_lead_tile<64, 4, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
+    else
+      hipLaunchKernelGGL((k_interp_add_lead_tile<32, 8, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
+    return true;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // P^T
 // ------------------------------------------------------------------------------------
 // 1-D adjoint weights on a 'c' axis for coarse index J: window of 6 fine indices from 2J-2.
@@ -1358,8 +1520,9 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
       if (pair && m.lead_fn == 2 * m.lead_cn - 1 && m.lead_cn >= 2) {
         // pairs (2k, 2k + 1) by one thread, then the last (even) index alone
         const dim3 pairs(unit_grid(m.usched), m.lead_cn - 1), last(unit_grid(m.usched), 1);
-        hipLaunchKernelGGL((k_interp_add_march_lead_pair<T, CX>), pairs, dim3(kBlock), 0, stream, coarse, add, fine, m,
-                           cscale, ascale);
+        if (!(CX == 2 && lead_tile_launch<T>(coarse, add, fine, m, cscale, ascale, stream)))
+          hipLaunchKernelGGL((k_interp_add_march_lead_pair<T, CX>), pairs, dim3(kBlock), 0, stream, coarse, add, fine, m,
+                             cscale, ascale);
         hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), last, dim3(kBlock), 0, stream, coarse, add, fine, m,
                            cscale, ascale, m.lead_fn - 1, 2);
       } else {
