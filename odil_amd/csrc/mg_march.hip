@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_march_lead_pair(const T* 
 // fine values from LDS reads and streams them out: no dependent steps, ~70 registers, the fine addend in flight while
 // the tile is staged.  The sums are formed in the order of acc_plane / store_plane (leading tap, z tap, then (ry, rx);
 // weight * value added term by term; scaled by 1 / 64 or 1 / 128; addend last): bit-identical to the marching kernels.
-// Tiles: whole fine rows where they fit (TX coarse columns = 2 TX fine cells), 8 packs per thread.
+// One thread per pair of coarse columns of the tile: its 2 x 2 x 4 fine values in both volumes, eight 16-byte packs.
 // ------------------------------------------------------------------------------------
 struct LeadTileArgs {
   int cn[3], fn[3];      // (z, y, x) coarse / fine extents of one volume
@@ -465,19 +465,27 @@ static bool lead_tile_launch(const T* coarse, const T* add, T* fine, const March
     a.cvol = m.lead_cstride;
     a.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
     if (a.fvol % 4) return false;  // every fine volume starts on 16 bytes
-    const int tx = m.cn[2] >= 128 ? 128 : (m.cn[2] >= 64 ? 64 : 32), ty = 256 / tx, tz = 2;
+    // 32 x 8 x 2 coarse cells per workgroup: measured on the tracer rank's arrays (four fields, tools/mb_transfers_cfg5.py)
+    // 1.92 ms against 1.99 (64 x 4 x 2), 1.97 (32 x 4 x 4), 2.24 (128 x 2 x 2: whole fine rows) and 2.41 (marching kernel)
+    int tx = 32, ty = 8, tz = 2;
+    if (const char* e = getenv("ODIL_LEAD_TILE_SHAPE")) {  // "64,4,2", "128,2,2", "32,4,4"
+      int ex = 0, ey = 0, ez = 0;
+      if (sscanf(e, "%d,%d,%d", &ex, &ey, &ez) == 3 && ex <= m.cn[2]) tx = ex, ty = ey, tz = ez;
+    }
     a.ntx = (m.cn[2] + tx - 1) / tx;
     a.nty = (m.cn[1] + ty - 1) / ty;
     const int64_t tiles = (int64_t)a.ntx * a.nty * ((m.cn[0] + tz - 1) / tz);
     if (tiles >= ((int64_t)1 << 31) || m.lead_cn - 1 > 65535) return false;
     const dim3 grid((unsigned)tiles, (unsigned)(m.lead_cn - 1));
-    if (tx == 128)
-      hipLaunchKernelGGL((k_interp_add_lead_tile<128, 2, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
-    else if (tx == 64)
-      hipLaunchKernelGGL((k_interp_add_lead_tile<64, 4, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
-    else
-      hipLaunchKernelGGL((k_interp_add_lead_tile<32, 8, 2>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, ascale);
-    return true;
+#define ODIL_LT(X, Y, Z)                                                                                             \
+  if (tx == X && ty == Y && tz == Z) {                                                                               \
+    hipLaunchKernelGGL((k_interp_add_lead_tile<X, Y, Z>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, \
+                       ascale);                                                                                      \
+    return true;                                                                                                     \
+  }
+    ODIL_LT(32, 8, 2) ODIL_LT(64, 4, 2) ODIL_LT(128, 2, 2) ODIL_LT(32, 4, 4)
+#undef ODIL_LT
+    return false;
   }
 }
 
