@@ -339,13 +339,14 @@ struct LeadTileArgs {
   int64_t cvol, fvol;    // elements between leading indices of the coarse / fine arrays
 };
 
-template <int TX, int TY, int TZ>
-__global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const float* __restrict__ coarse,
-                                                                 const float* __restrict__ add, float* __restrict__ fine,
-                                                                 LeadTileArgs a, float cscale, float ascale) {
+// NV = 2: a node-centred leading axis (coarse volumes k, k + 1 -> fine volumes 2k, 2k + 1); NV = 1: one volume per
+// leading index (a 3-D array, or a batch '.ccc'): coarse volume k -> fine volume k.
+template <typename T, int NV, int TX, int TY, int TZ>
+__global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const T* __restrict__ coarse, const T* __restrict__ add,
+                                                                 T* __restrict__ fine, LeadTileArgs a, T cscale, T ascale) {
   static_assert((TX / 2) * TY * TZ == kBlock, "one thread per pair of coarse columns of the tile");
   constexpr int LX = TX + 2, LY = TY + 2, LZ = TZ + 2, LVOL = LZ * LY * LX;
-  __shared__ float sv[2 * LVOL];
+  __shared__ T sv[NV * LVOL];
   const int cnz = a.cn[0], cny = a.cn[1], cnx = a.cn[2];
   const int fny = a.fn[1], fnx = a.fn[2];
   const int64_t cplane = (int64_t)cny * cnx, fplane = (int64_t)fny * fnx;
@@ -355,35 +356,35 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const float* __
   tile /= a.ntx;
   const int ty_ = tile % a.nty, tz_ = tile / a.nty;
   const int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
-  const float* cb = coarse + (int64_t)k * a.cvol;
-  add = add ? add + (int64_t)(2 * k) * a.fvol : add;
-  fine += (int64_t)(2 * k) * a.fvol;
+  const T* cb = coarse + (int64_t)k * a.cvol;
+  add = add ? add + (int64_t)(NV * k) * a.fvol : add;
+  fine += (int64_t)(NV * k) * a.fvol;
   // the thread's coarse cell pair (jz, jy, 2 xp .. 2 xp + 1): its 2 x 2 fine rows of 4 values, in both fine volumes --
   // eight 16-byte packs; consecutive lanes hold consecutive packs of a fine row
   const int xp = threadIdx.x % (TX / 2), jyl = (threadIdx.x / (TX / 2)) % TY, jzl = threadIdx.x / ((TX / 2) * TY);
   const int jz = z0 + jzl, jy = y0 + jyl, jx = x0 + 2 * xp;
   const bool own = jz < cnz && jy < cny && jx < cnx;
   const int64_t base = (int64_t)(2 * jz) * fplane + (int64_t)(2 * jy) * fnx + 2 * jx;
-  PackN<float, 4> ad[2][2][2];
+  PackN<T, 4> ad[NV][2][2];
   if (add && own) {
 #pragma unroll
-    for (int pv = 0; pv < 2; ++pv)
+    for (int pv = 0; pv < NV; ++pv)
 #pragma unroll
       for (int sz = 0; sz < 2; ++sz)
 #pragma unroll
         for (int sy = 0; sy < 2; ++sy)
-          ad[pv][sz][sy] = stream_ld<float, 4>(add + pv * a.fvol + base + sz * fplane + sy * fnx, a.nt != 0);
+          ad[pv][sz][sy] = stream_ld<T, 4>(add + pv * a.fvol + base + sz * fplane + sy * fnx, a.nt != 0);
   }
   // the ghosted coarse neighbourhood of the tile, volumes k and k + 1
   const bool inner = z0 >= 1 && z0 + TZ < cnz && y0 >= 1 && y0 + TY < cny && x0 >= 1 && x0 + TX < cnx;
   if (inner) {  // no wall (and no overhang) within reach: every staged position is a cell of the array
-    for (int i = threadIdx.x; i < 2 * LVOL; i += kBlock) {
+    for (int i = threadIdx.x; i < NV * LVOL; i += kBlock) {
       const int lv = i / LVOL, j = i - lv * LVOL;
       const int dx = j % LX, dy = (j / LX) % LY, dz = j / (LX * LY);
       sv[i] = cscale * cb[(int64_t)lv * a.cvol + (int64_t)(z0 - 1 + dz) * cplane + (int64_t)(y0 - 1 + dy) * cnx + (x0 - 1 + dx)];
     }
   } else {
-    for (int i = threadIdx.x; i < 2 * LVOL; i += kBlock) {
+    for (int i = threadIdx.x; i < NV * LVOL; i += kBlock) {
       const int lv = i / LVOL, j = i - lv * LVOL;
       const int dx = j % LX, dy = (j / LX) % LY, dz = j / (LX * LY);
       const int qz = z0 - 1 + dz, qy = y0 - 1 + dy, qx = x0 - 1 + dx;
@@ -391,38 +392,38 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const float* __
       const int zc = qz < 0 ? 0 : (qz >= cnz ? cnz - 1 : qz), zr = qz < 0 ? 1 : (qz >= cnz ? cnz - 2 : qz);
       const int yc = qy < 0 ? 0 : (qy >= cny ? cny - 1 : qy), yr = qy < 0 ? 1 : (qy >= cny ? cny - 2 : qy);
       const int xc = qx < 0 ? 0 : (qx >= cnx ? cnx - 1 : qx), xr = qx < 0 ? 1 : (qx >= cnx ? cnx - 2 : qx);
-      const float* vol = cb + (int64_t)lv * a.cvol;
-      const float val = cscale * vol[(int64_t)zc * cplane + (int64_t)yc * cnx + xc];
-      float res = val;
-      if (out) res = 2.0f * val - cscale * vol[(int64_t)zr * cplane + (int64_t)yr * cnx + xr];
+      const T* vol = cb + (int64_t)lv * a.cvol;
+      const T val = cscale * vol[(int64_t)zc * cplane + (int64_t)yc * cnx + xc];
+      T res = val;
+      if (out) res = T(2) * val - cscale * vol[(int64_t)zr * cplane + (int64_t)yr * cnx + xr];
       sv[i] = res;
     }
   }
   __syncthreads();
   if (!own) return;
   // the 3 x 3 x 4 window of the thread's cell pair, per volume (index 0 <-> coarse j - 1)
-  float v[2][3][3][4];
+  T v[NV][3][3][4];
 #pragma unroll
-  for (int lv = 0; lv < 2; ++lv)
+  for (int lv = 0; lv < NV; ++lv)
 #pragma unroll
     for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const float* row = sv + lv * LVOL + ((jzl + dz) * LY + (jyl + dy)) * LX + 2 * xp;
+        const T* row = sv + lv * LVOL + ((jzl + dz) * LY + (jyl + dy)) * LX + 2 * xp;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[lv][dz][dy][c] = row[c];
       }
-  const float rs[2] = {1.0f / 64.0f, 1.0f / 128.0f};
+  const T rs[2] = {T(1) / T(64), T(1) / T(128)};
 #pragma unroll
-  for (int pv = 0; pv < 2; ++pv)
+  for (int pv = 0; pv < NV; ++pv)
 #pragma unroll
     for (int sz = 0; sz < 2; ++sz)
 #pragma unroll
       for (int sy = 0; sy < 2; ++sy) {
-        PackN<float, 4> pk;
+        PackN<T, 4> pk;
 #pragma unroll
         for (int sx = 0; sx < 4; ++sx) {
-          float t = 0.f;
+          T t = T(0);
 #pragma unroll
           for (int r0 = 0; r0 <= pv; ++r0)
 #pragma unroll
@@ -432,13 +433,13 @@ __global__ __launch_bounds__(kBlock) void k_interp_add_lead_tile(const float* __
 #pragma unroll
                 for (int rx = 0; rx < 2; ++rx) {
                   const int w = (sz == rz ? 1 : 3) * (sy == ry ? 1 : 3) * ((sx & 1) == rx ? 1 : 3);
-                  t = t + (float)w * v[r0][sz + rz][sy + ry][(sx >> 1) + (sx & 1) + rx];
+                  t = t + T(w) * v[r0][sz + rz][sy + ry][(sx >> 1) + (sx & 1) + rx];
                 }
-          float o = t * rs[pv];
+          T o = t * rs[pv];
           if (add) o = ascale * ad[pv][sz][sy].e[sx] + o;
           pk.e[sx] = o;
         }
-        stream_st<float, 4>(fine + pv * a.fvol + base + sz * fplane + sy * fnx, pk, a.nt != 0);
+        stream_st<T, 4>(fine + pv * a.fvol + base + sz * fplane + sy * fnx, pk, a.nt != 0);
       }
 }
 
@@ -447,46 +448,45 @@ static bool lead_tile_enabled() {
   return !e || atoi(e) != 0;
 }
 
-// Launches the tiled pair kernel for the lead.cn - 1 pairs of fine volumes; false: the caller keeps the marching kernel.
-template <typename T>
+// Launches the tiled kernel -- NV = 2: for the lead_cn - 1 pairs of fine volumes of a node-centred leading axis; NV = 1: for
+// every volume of a 3-D array / a batch; false: the caller keeps its marching kernel.
+template <typename T, int NV>
 static bool lead_tile_launch(const T* coarse, const T* add, T* fine, const MarchArgs& m, T cscale, T ascale,
                              hipStream_t stream) {
-  if constexpr (sizeof(T) != 4) {
-    return false;
-  } else {
-    if (!lead_tile_enabled() || m.cut_lo || m.cut_hi) return false;
-    for (int i = 0; i < 3; ++i)
-      if (m.fn[i] != 2 * m.cn[i] || m.cn[i] < 2) return false;
-    if (m.cn[2] % 2 || m.cn[2] < 32) return false;
-    if (reinterpret_cast<uintptr_t>(fine) % 16 || (add && reinterpret_cast<uintptr_t>(add) % 16)) return false;
-    LeadTileArgs a;
-    for (int i = 0; i < 3; ++i) a.cn[i] = m.cn[i], a.fn[i] = m.fn[i];
-    a.nt = m.nt;
-    a.cvol = m.lead_cstride;
-    a.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
-    if (a.fvol % 4) return false;  // every fine volume starts on 16 bytes
-    // 32 x 8 x 2 coarse cells per workgroup: measured on the tracer rank's arrays (four fields, tools/mb_transfers_cfg5.py)
-    // 1.92 ms against 1.99 (64 x 4 x 2), 1.97 (32 x 4 x 4), 2.24 (128 x 2 x 2: whole fine rows) and 2.41 (marching kernel)
-    int tx = 32, ty = 8, tz = 2;
-    if (const char* e = getenv("ODIL_LEAD_TILE_SHAPE")) {  // "64,4,2", "128,2,2", "32,4,4"
-      int ex = 0, ey = 0, ez = 0;
-      if (sscanf(e, "%d,%d,%d", &ex, &ey, &ez) == 3 && ex <= m.cn[2]) tx = ex, ty = ey, tz = ez;
-    }
-    a.ntx = (m.cn[2] + tx - 1) / tx;
-    a.nty = (m.cn[1] + ty - 1) / ty;
-    const int64_t tiles = (int64_t)a.ntx * a.nty * ((m.cn[0] + tz - 1) / tz);
-    if (tiles >= ((int64_t)1 << 31) || m.lead_cn - 1 > 65535) return false;
-    const dim3 grid((unsigned)tiles, (unsigned)(m.lead_cn - 1));
-#define ODIL_LT(X, Y, Z)                                                                                             \
-  if (tx == X && ty == Y && tz == Z) {                                                                               \
-    hipLaunchKernelGGL((k_interp_add_lead_tile<X, Y, Z>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, \
-                       ascale);                                                                                      \
-    return true;                                                                                                     \
+  if (!lead_tile_enabled()) return false;
+  for (int i = 0; i < 3; ++i)
+    if (m.fn[i] != 2 * m.cn[i] || m.cn[i] < 2) return false;
+  if (m.cn[2] % 2 || m.cn[2] < 32) return false;
+  const uintptr_t pack = 4 * sizeof(T);  // the fine arrays are accessed in packs of four values
+  if (reinterpret_cast<uintptr_t>(fine) % pack || (add && reinterpret_cast<uintptr_t>(add) % pack)) return false;
+  LeadTileArgs a;
+  for (int i = 0; i < 3; ++i) a.cn[i] = m.cn[i], a.fn[i] = m.fn[i];
+  a.nt = m.nt;
+  a.cvol = m.lead_cstride;
+  a.fvol = (int64_t)m.fn[0] * m.fn[1] * m.fn[2];
+  const int nlead = NV == 2 ? m.lead_cn - 1 : (m.lead_fn > 1 ? m.lead_fn : 1);
+  if ((nlead > 1 || NV == 2) && a.fvol % 4) return false;  // every fine volume starts on a pack boundary
+  // 32 x 8 x 2 coarse cells per workgroup: measured on the tracer rank's arrays (four fields, tools/mb_transfers_cfg5.py)
+  // 1.92 ms against 1.99 (64 x 4 x 2), 1.97 (32 x 4 x 4), 2.24 (128 x 2 x 2: whole fine rows) and 2.41 (marching kernel)
+  int tx = 32, ty = 8, tz = 2;
+  if (const char* e = getenv("ODIL_LEAD_TILE_SHAPE")) {  // "64,4,2", "128,2,2", "32,4,4"
+    int ex = 0, ey = 0, ez = 0;
+    if (sscanf(e, "%d,%d,%d", &ex, &ey, &ez) == 3 && ex <= m.cn[2]) tx = ex, ty = ey, tz = ez;
   }
-    ODIL_LT(32, 8, 2) ODIL_LT(64, 4, 2) ODIL_LT(128, 2, 2) ODIL_LT(32, 4, 4)
+  a.ntx = (m.cn[2] + tx - 1) / tx;
+  a.nty = (m.cn[1] + ty - 1) / ty;
+  const int64_t tiles = (int64_t)a.ntx * a.nty * ((m.cn[0] + tz - 1) / tz);
+  if (tiles >= ((int64_t)1 << 31) || nlead > 65535 || nlead < 1) return false;
+  const dim3 grid((unsigned)tiles, (unsigned)nlead);
+#define ODIL_LT(X, Y, Z)                                                                                                 \
+  if (tx == X && ty == Y && tz == Z) {                                                                                   \
+    hipLaunchKernelGGL((k_interp_add_lead_tile<T, NV, X, Y, Z>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, \
+                       ascale);                                                                                          \
+    return true;                                                                                                         \
+  }
+  ODIL_LT(32, 8, 2) ODIL_LT(64, 4, 2) ODIL_LT(128, 2, 2) ODIL_LT(32, 4, 4)
 #undef ODIL_LT
-    return false;
-  }
+  return false;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1528,7 +1528,7 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
       if (pair && m.lead_fn == 2 * m.lead_cn - 1 && m.lead_cn >= 2) {
         // pairs (2k, 2k + 1) by one thread, then the last (even) index alone
         const dim3 pairs(unit_grid(m.usched), m.lead_cn - 1), last(unit_grid(m.usched), 1);
-        if (!(CX == 2 && lead_tile_launch<T>(coarse, add, fine, m, cscale, ascale, stream)))
+        if (!lead_tile_launch<T, 2>(coarse, add, fine, m, cscale, ascale, stream))
           hipLaunchKernelGGL((k_interp_add_march_lead_pair<T, CX>), pairs, dim3(kBlock), 0, stream, coarse, add, fine, m,
                              cscale, ascale);
         hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), last, dim3(kBlock), 0, stream, coarse, add, fine, m,
@@ -1541,14 +1541,14 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
           hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 2>), odd, dim3(kBlock), 0, stream, coarse, add, fine, m,
                              cscale, ascale, 1, 2);
       }
-    } else {
+    } else if (!lead_tile_launch<T, 1>(coarse, add, fine, m, cscale, ascale, stream)) {
       hipLaunchKernelGGL((k_interp_add_march_lead<T, CX, 1>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m,
                          cscale, ascale, 0, 1);
     }
   } else if (a.loc[1] == kNode)
     hipLaunchKernelGGL((k_interp_add_march_n<T, CX>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m, cscale,
                        ascale);
-  else
+  else if (!lead_tile_launch<T, 1>(coarse, add, fine, m, cscale, ascale, stream))
     hipLaunchKernelGGL((k_interp_add_march<T, CX>), grid, dim3(kBlock), 0, stream, coarse, add, fine, m, cscale,
                        ascale);
   const int e = check_launch("k_interp_add_march");

@@ -897,3 +897,23 @@ def test_tiled_float_prolongation_of_a_node_leading_axis_equals_the_marching_ker
     if with_add:
         ref = ref + 2.0 * add.cpu().numpy().astype(np.float64)
     assert rel(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("loc,cshape", [("ccc", (6, 8, 32)), ("ccc", (3, 5, 64)), ("ccc", (4, 3, 160)), ("ccc", (16, 16, 128)),
+                                         (".ccc", (3, 4, 6, 32)), ("nccc", (4, 3, 8, 64))])
+def test_tiled_prolongation_of_volumes_and_batches_equals_the_marching_kernels(dev, dtype, loc, cshape, monkeypatch):
+    """The LDS-tiled prolongation with ONE fine volume per leading index (3-D 'ccc', batches '.ccc') and, in float64, the
+    pairs of a node-centred leading axis: the same bits as the marching kernels (ODIL_LEAD_TILE=0), the oracle to rounding."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(5)
+    c = to(rng.standard_normal(cshape).astype(dtype), dev)
+    add = to(rng.standard_normal(ops.fine_shape(cshape, loc)).astype(dtype), dev)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ODIL_LEAD_TILE", flag)
+        res.append((ops.interp_add(c, loc, add=add, coarse_scale=0.5, add_scale=2.0), ops.interp_add(c, loc)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = onp.interp_to_finer(c.cpu().numpy().astype(np.float64), loc)
+    assert rel(res[0][1], ref) < (2e-6 if dtype == np.float32 else 1e-14)
