@@ -51,6 +51,29 @@ def main():
             path = slab_traced.HipSlabKernels(problem, state, 1, n, "cpu").lib_path
         print("{:12s} {:60s} {}  {:.1f} s".format(modname, " ".join(argv), os.path.basename(path), time.time() - t0), flush=True)
         del problem, state
+    if not a.quick:
+        # config 5 with 4 and 8 ranks: the GLOBAL grid would not fit on the host -- the shape-only state bench.py builds
+        import argparse as ap
+        import numpy as np
+        import veltracer3d
+
+        for world in (4, 8):
+            t0 = time.time()
+            va = veltracer3d.parse_args(["--Nt", "128", "--Nx", str(32 * world), "--Ny", "256", "--Nz", "256"])
+            domain = odil_amd.Domain(cshape=(va.Nt, va.Nx, va.Ny, va.Nz), dimnames=("t", "x", "y", "z"), lower=(0, 0, 0, 0),
+                                     upper=(1, 1, 1, 1), dtype=np.float32, multigrid=va.multigrid, mg_interp=va.mg_interp,
+                                     mg_nlvl=va.nlvl)
+            x, y, z = np.meshgrid(*domain.points_1d("x", "y", "z"), indexing="ij")
+            extra = ap.Namespace(args=va, u_init=domain.mod.cast(veltracer3d.blob(x, y, z, 0), np.float32),
+                                 u_final=domain.mod.cast(veltracer3d.blob(x, y, z, 1), np.float32))
+            del x, y, z
+            state = odil_amd.State()
+            for key in ("u",) + veltracer3d.VEL:
+                state.fields[key] = odil_amd.Field(None, loc=veltracer3d.LOC)
+            problem = odil_amd.Problem(veltracer3d.operator, domain, extra)
+            path = slab_traced.HipSlabKernels(problem, slab_traced.shape_state(domain, state), 1, 32, "cpu").lib_path
+            print("{:12s} {:60s} {}  {:.1f} s".format("veltracer3d", "config 5, {} ranks".format(world), os.path.basename(path),
+                                                        time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":
