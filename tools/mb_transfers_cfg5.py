@@ -55,7 +55,17 @@ ms = t(lambda: four(lambda i: ops.interp_adj_best(w0[i], LOC, CS, out=g1[i])))
 print("P^T 4 fields, 4 streams: %.3f ms  %.2f TB/s" % (ms, K * (fb + cb) / ms / 1e9))
 ms = t(lambda: [ops.interp_add(c1[i], LOC, add=w0[i], out=u[i]) for i in range(K)])
 print("P   4 fields, 1 stream : %.3f ms  %.2f TB/s" % (ms, K * (2 * fb + cb) / ms / 1e9))
-ms = t(lambda: [ops.interp_adj_best(w0[i], LOC, CS, out=g1[i]) for i in range(K)])
+# (every field with its OWN intermediate: four calls that reuse one scratch buffer -- written, read, overwritten right away --
+# run 3.4x slower, docs/rounds/kernel_log_r04.md)
+space = [torch.empty((FS[0],) + CS[1:], dtype=torch.float32, device=dev) for _ in range(K)]
+
+
+def adj_split(i):
+    ops.interp_adj(w0[i], "." + LOC[1:], (FS[0],) + CS[1:], out=space[i])
+    ops.interp_adj(space[i], "n...", CS, out=g1[i])
+
+
+ms = t(lambda: [adj_split(i) for i in range(K)])
 print("P^T 4 fields, 1 stream : %.3f ms  %.2f TB/s" % (ms, K * (fb + cb) / ms / 1e9))
 # reference points: a plain copy and a read-only reduction of the same bytes
 ms = t(lambda: u[0].copy_(w0[0]))
