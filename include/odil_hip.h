@@ -107,6 +107,19 @@ int odil_restrict_adj_f64(const double* gcoarse, double* gfine, const int64_t* f
 int odil_restrict_adj_f32(const float* gcoarse, float* gfine, const int64_t* fshape, int ndim, const char* loc,
                           void* stream);
 
+/* Strided VALID correlations with a small dense kernel: `mod.convolution` (backend.py:112-126 -> jax.lax.conv; called by
+ * restrict_to_coarser, core.py:744-751) and `mod.conv_transpose` (backend.py:165-172 -> jax.lax.conv_transpose; called
+ * by interp_to_finer(method="conv"), core.py:656-662) for user operators that call them directly (the framework's own
+ * transfers use the dedicated kernels above).  Kernel extents and strides 1..4 per axis, ndim <= 4, taps summed in C
+ * order of the kernel.
+ *   transposed == 0:  out[o] = sum_k w[k] in[o * s + k],                 oshape = (ishape - wshape) / s + 1
+ *   transposed != 0:  out[p] = sum_k w[k] in[(p - k) / s] over the taps with s | (p - k) and the quotient inside `in`
+ *                     (the transpose of the above; oshape >= (ishape - 1) s + wshape, zeros beyond). */
+int odil_conv_valid_f64(const double* in, const double* w, double* out, const int64_t* ishape, const int64_t* wshape,
+                        const int64_t* strides, const int64_t* oshape, int ndim, int transposed, void* stream);
+int odil_conv_valid_f32(const float* in, const float* w, float* out, const int64_t* ishape, const int64_t* wshape,
+                        const int64_t* strides, const int64_t* oshape, int ndim, int transposed, void* stream);
+
 /* u = sum_l P^l (factor_l * w_l): `Domain.multigrid_to_regular` (core.py:245-263).
  * terms / work / grads are HOST arrays of device pointers, factors / shapes HOST arrays.
  * terms[l]: level arrays fine->coarse, shapes[l*ndim..]: their array shapes,

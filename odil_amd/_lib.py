@@ -29,6 +29,7 @@ _SIGNATURES = {
     "interp_adj_cut_adam": [_P, _P, _I64P, c_int, c_char_p, c_int, c_int, _P, _P, _P, _R, _R, _R, _R, _P, _P],
     "restrict": [_P, _P, _I64P, c_int, c_char_p, _P],
     "restrict_adj": [_P, _P, _I64P, c_int, c_char_p, _P],
+    "conv_valid": [_P, _P, _P, _I64P, _I64P, _I64P, _I64P, c_int, c_int, _P],
     "mg_synth": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
     "mg_synth_adj": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P],
     "mg_synth_adj_adam": [_P, _P, _P, _P, _I64P, c_int, c_int, c_char_p, _P, _P, _P, _R, _R, _R, _R, _P, _P],

@@ -41,6 +41,32 @@ def numpy_dtype(dtype):
     return np.dtype(dtype)
 
 
+class _ConvValidFn(torch.autograd.Function):
+    """y = corr(x, w, s) (VALID) or its transpose, through `odil_conv_valid`; the cotangent is the other of the two with
+    the same kernel.  (The framework's own transfers -- `core.restrict_to_coarser`, `core.interp_to_finer` -- use the
+    dedicated packed / marching kernels, not this one.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, strides, transposed, out_shape):
+        from . import ops
+
+        ctx.save_for_backward(w)
+        ctx.strides, ctx.transposed, ctx.xshape = strides, transposed, tuple(x.shape)
+        return ops.conv_valid(x, w, strides, transposed=transposed, out_shape=out_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.transposed:
+            # y = C^T x (possibly zero-extended): dx = C g restricted to the VALID extent that maps back onto x
+            gx = _ConvValidFn.apply(g, w, ctx.strides, False, None)
+            gx = gx[tuple(slice(0, n) for n in ctx.xshape)]
+        else:
+            gx = _ConvValidFn.apply(g, w, ctx.strides, True, ctx.xshape)
+        return gx, None, None, None, None
+
+
 class ModRocm:
     """NumPy-flavoured namespace over torch tensors living on one HIP device."""
 
@@ -277,10 +303,51 @@ class ModRocm:
         return lambda f: f
 
     def convolution(self, input, filters, strides, padding):
-        raise NotImplementedError("use odil_amd.core.restrict_to_coarser (HIP kernel) instead of mod.convolution")
+        """n-dimensional VALID cross-correlation of `input` with `filters` (same rank), integer stride or one per axis
+        (reference backend.py:112-126: jax.lax.conv on (1, 1) + shape; the call of `restrict_to_coarser`,
+        core.py:744-751) through the tap kernel `odil_conv_valid`; differentiable in `input`."""
+        input = self._t(input)
+        filters = self._t(filters, input.dtype)
+        dim = input.dim()
+        if isinstance(strides, (int, np.integer)):
+            strides = (int(strides),) * dim
+        strides = tuple(int(v) for v in strides)
+        if padding != "VALID":
+            raise NotImplementedError("mod.convolution: padding='{}' (the reference only uses 'VALID')".format(padding))
+        if filters.dim() != dim or len(strides) != dim or dim > 4:
+            raise ValueError("mod.convolution: input {}, filters {}, strides {}".format(tuple(input.shape), tuple(filters.shape), strides))
+        if filters.requires_grad:
+            raise NotImplementedError("mod.convolution: gradients with respect to the filters")
+        return _ConvValidFn.apply(input.contiguous(), filters.contiguous(), strides, False, None)
 
-    def conv_transpose(self, *args, **kwargs):
-        raise NotImplementedError("use odil_amd.core.interp_to_finer (HIP kernel) instead of mod.conv_transpose")
+    def conv_transpose(self, input, filters, output_shape=None, strides=None, padding=None):
+        """Transposed VALID convolution in the layout the reference calls it with (backend.py:165-172 ->
+        jax.lax.conv_transpose; core.py:656-662): input (1, *spatial, 1), filters (*kernel, 1, 1); the stride-dilated
+        input is correlated with the kernel AS GIVEN (transpose_kernel=False), i.e. out[s i + K - 1 - j] += in[i] w[j].
+        Result (1, *((n - 1) s + K), 1); differentiable in `input`."""
+        input = self._t(input)
+        filters = self._t(filters, input.dtype)
+        dim = input.dim() - 2
+        if dim < 1 or dim > 4 or input.shape[0] != 1 or input.shape[-1] != 1 or filters.dim() != dim + 2 \
+                or tuple(filters.shape[-2:]) != (1, 1):
+            raise NotImplementedError("mod.conv_transpose: expected input (1, *spatial, 1) and filters (*kernel, 1, 1), got {} "
+                                      "and {}".format(tuple(input.shape), tuple(filters.shape)))
+        if padding != "VALID":
+            raise NotImplementedError("mod.conv_transpose: padding='{}' (the reference only uses 'VALID')".format(padding))
+        if strides is None:
+            strides = 1
+        if isinstance(strides, (int, np.integer)):
+            strides = (int(strides),) * dim
+        strides = tuple(int(v) for v in strides)
+        if filters.requires_grad:
+            raise NotImplementedError("mod.conv_transpose: gradients with respect to the filters")
+        x = input.reshape(tuple(input.shape[1:-1])).contiguous()
+        w = torch.flip(filters.reshape(tuple(filters.shape[:-2])), dims=tuple(range(dim))).contiguous()
+        res = _ConvValidFn.apply(x, w, strides, True, None)
+        res = res.reshape((1,) + tuple(res.shape) + (1,))
+        if output_shape is not None and tuple(int(v) for v in output_shape) != tuple(res.shape):
+            raise ValueError("mod.conv_transpose: output_shape {} but the VALID result is {}".format(tuple(output_shape), tuple(res.shape)))
+        return res
 
     # -- random (host generator: reproducible across devices) -----------------------
     def _set_seed(self, seed):

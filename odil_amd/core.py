@@ -224,48 +224,50 @@ def check_multigrid_cshapes(cshapes, axes=None):
 # ======================================================================================
 # Neural networks (reference core.py:779-862) -- only as used inside stencils
 # ======================================================================================
-def make_neural_net(layers, dtype, mod, initializer="lecun", func_in=None, func_out=None, activation=None):
-    def get_scale(ni, no):
-        if initializer == "legacy":
-            return np.sqrt(1.0 / ni)
-        elif initializer == "glorot":
-            return np.sqrt(6.0 / (ni + no))
-        elif initializer == "lecun":
-            return np.sqrt(3.0 / ni)
-        elif initializer == "he":
-            return np.sqrt(6.0 / ni)
-        raise ValueError("Unknown initializer=" + initializer)
+# uniform(-a, a) with a^2 = numerator / fan; fan counted over the inputs, or inputs + outputs for 'glorot'
+# (the four schemes of reference core.py:779-803)
+_NET_INIT = {"legacy": (1.0, False), "glorot": (6.0, True), "lecun": (3.0, False), "he": (6.0, False)}
 
+
+def make_neural_net(layers, dtype, mod, initializer="lecun", func_in=None, func_out=None, activation=None):
+    """Dense network with `layers[k]` units per layer: uniform weights by `initializer`, zero biases (the API of
+    reference core.py:779-803)."""
+    if initializer not in _NET_INIT:
+        raise ValueError("Unknown initializer=" + initializer)
+    numerator, both = _NET_INIT[initializer]
     weights, biases = [], []
-    for ni, no in zip(layers[:-1], layers[1:]):
-        scale = get_scale(ni, no)
-        weights.append(mod.random.uniform(shape=(no, ni), minval=-scale, maxval=scale, dtype=dtype))
-        biases.append(mod.zeros(no, dtype=dtype))
+    for fan_in, fan_out in zip(layers, layers[1:]):
+        bound = np.sqrt(numerator / (fan_in + fan_out if both else fan_in))
+        weights.append(mod.random.uniform(shape=(fan_out, fan_in), minval=-bound, maxval=bound, dtype=dtype))
+        biases.append(mod.zeros(fan_out, dtype=dtype))
     return NeuralNet(weights, biases, func_in=func_in, func_out=func_out, activation=activation)
 
 
 def eval_neural_net(net, inputs, mod, frozen=False):
-    """Dense MLP applied pointwise to grid arrays (reference core.py:807-862)."""
-    weights, biases = net.weights, net.biases
-    assert_equal(len(weights), len(biases), "Weights and biases do not match")
-    assert_equal(weights[0].shape[1], len(inputs), "Weights and inputs do not match")
-    for w, b in zip(weights, biases):
-        assert_equal(w.shape[0], b.shape[0])
-    if frozen:
-        weights = [mod.stop_gradient(w) for w in weights]
-        biases = [mod.stop_gradient(b) for b in biases]
-    func_act = {"tanh": mod.tanh, "relu": mod.relu, "none": lambda x: x}[net.activation]
+    """The network applied pointwise to grid arrays (what reference core.py:807-862 computes): every grid point is a
+    column, a layer is one batched product  h <- act(W h + b)  with the activation on all layers but the last.  This is
+    the GENERIC path; a traced operator inlines the network into its generated kernel (stencil_codegen)."""
+    layers = list(zip(net.weights, net.biases))
+    if len(net.weights) != len(net.biases):
+        assert_equal(len(net.weights), len(net.biases), "Weights and biases do not match")
+    assert_equal(layers[0][0].shape[1], len(inputs), "Weights and inputs do not match")
+    if net.activation not in ("tanh", "relu", "none"):
+        raise KeyError(net.activation)
+    act = None if net.activation == "none" else getattr(mod, net.activation)
     if net.func_in is not None:
         inputs = net.func_in(*inputs)
-    tmp = mod.stack([mod.cast(v, weights[0].dtype) for v in inputs], axis=0)
-    tmp = torch.movedim(tmp, 0, -1)[..., None]  # (..., ni, 1): columns of inputs
-    n = len(weights)
-    for i in range(n):
-        tmp = mod.matmul(weights[i], tmp) + biases[i][:, None]
-        if i < n - 1:
-            tmp = func_act(tmp)
-    tmp = torch.movedim(tmp[..., 0], -1, 0)
-    outputs = [tmp[i] for i in range(tmp.shape[0])]
+    wdtype = layers[0][0].dtype
+    h = torch.stack(torch.broadcast_tensors(*[mod.cast(v, wdtype) for v in inputs]), dim=0)
+    grid = tuple(h.shape[1:])
+    h = h.reshape(h.shape[0], -1)  # (units, points)
+    for k, (w, b) in enumerate(layers):
+        assert_equal(w.shape[0], b.shape[0])
+        if frozen:
+            w, b = mod.stop_gradient(w), mod.stop_gradient(b)
+        h = torch.addmm(b[:, None], w, h)
+        if act is not None and k < len(layers) - 1:
+            h = act(h)
+    outputs = list(h.reshape((h.shape[0],) + grid).unbind(0))
     if net.func_out is not None:
         outputs = net.func_out(*outputs)
     return outputs

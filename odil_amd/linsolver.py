@@ -230,7 +230,14 @@ def blocktri_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
         return None  # (before any grid-sized product is formed)
     try:
         inner = blocktri.BlockTridiagonalNormal(op, key, damp, dampdiag)
-    except (RuntimeError, MemoryError):  # (out of memory while forming S^T S: the matrix-free routes need far less)
+    except (RuntimeError, MemoryError) as e:
+        # ONLY out of memory while forming S^T S falls through to the matrix-free routes (they need far less); a launch
+        # error, a shape bug or an assertion is a defect and must not hide behind a slower solver
+        if not (isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError)) or "out of memory" in str(e).lower()):
+            raise
+        from .util import printlog
+
+        printlog("odil_amd: block cyclic reduction ran out of memory ({}); using the matrix-free routes".format(str(e).splitlines()[0]))
         return None
     if not inner.ok:
         return None

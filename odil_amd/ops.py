@@ -132,6 +132,25 @@ def restrict_to_coarser(u, loc, depth=1):
     return u
 
 
+def conv_valid(x, w, strides, transposed=False, out_shape=None):
+    """Strided VALID correlation of `x` with the small dense kernel `w` (same rank), or its transpose (see
+    include/odil_hip.h: odil_conv_valid).  `out_shape` only for the transpose: a longer output than (n - 1) s + K."""
+    dim = x.dim()
+    strides = [int(s) for s in strides]
+    assert w.dim() == dim and len(strides) == dim and w.dtype == x.dtype
+    if transposed:
+        oshape = [(n - 1) * s + k for n, s, k in zip(x.shape, strides, w.shape)]
+        if out_shape is not None:
+            assert all(a >= b for a, b in zip(out_shape, oshape)), (out_shape, oshape)
+            oshape = [int(v) for v in out_shape]
+    else:
+        oshape = [(n - k) // s + 1 for n, s, k in zip(x.shape, strides, w.shape)]
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    call("conv_valid", x.dtype, ptr(x), ptr(w), ptr(out), i64(x.shape), i64(w.shape), i64(strides), i64(oshape), c_int(dim),
+         c_int(1 if transposed else 0), stream_ptr())
+    return out
+
+
 def restrict_adj(gcoarse, loc, fshape):
     """R^T gcoarse (cotangent of restrict_to_coarser) for a fine array of shape `fshape`."""
     fshape = tuple(int(s) for s in fshape)

@@ -36,6 +36,13 @@ _BIN = {"add": "add", "__add__": "add", "__radd__": "radd", "sub": "sub", "subtr
         "divide": "div", "__truediv__": "div", "__rtruediv__": "rdiv"}
 
 
+def _numel(shape):
+    n = 1
+    for s in shape or ():
+        n *= int(s)
+    return n
+
+
 def _shift(expr, by):
     """The expression with every atom's offset advanced by `by` elements."""
     if expr[0] == "atom":
@@ -78,12 +85,27 @@ def _combine(op, a, b):
 
 
 class Symbolic:
-    """Tape values as segment lists.  `leaves`: {tape id: array index in arrays_from_state order}, `numel`: {index: size}."""
+    """Tape values as segment lists IN C ORDER of the value's shape.  `leaves`: {tape id: array index in
+    arrays_from_state order}, `numel`: {index: size}.  Every value carries the shape it had when the operator was traced
+    (`tape.shapes`): a segment list only says how the elements lie end to end, so an operation is accepted only when its
+    torch result is that same end-to-end order -- elementwise operations between EQUAL shapes (or with a scalar),
+    concatenation of 1-D pieces or along axis 0; anything that broadcasts, or interleaves rows, raises Unsupported and the
+    torch replay of param_tape.py (which is exact for any tape) evaluates the output."""
 
     def __init__(self, tape, numel):
         self.tape, self.numel, self.env = tape, numel, dict()
         for ident, index in tape.leaves.items():
             self.env[ident] = [(numel[index], ("atom", index, 0, False))]
+
+    def shape(self, x):
+        """Shape of a tape value at trace time; None for scalars (numbers, host symbols)."""
+        if isinstance(x, ParamTensor):
+            x = _Ref(x._id)
+        if isinstance(x, _Ref):
+            if x.id not in self.tape.shapes:
+                raise Unsupported("value of the tape without a recorded shape")
+            return tuple(self.tape.shapes[x.id])
+        return None
 
     def value(self, x):
         from .stencil_trace import Sym
@@ -100,9 +122,17 @@ class Symbolic:
             return ("hs", x) if x.op != "const" else ("const", float(x.attr))
         if isinstance(x, (bool, int, float)):
             return ("const", float(x))
-        if isinstance(x, torch.Tensor) and x.dim() == 0 and not x.requires_grad:
-            return ("const", float(x))
+        # (a plain tensor operand -- even 0-dim -- is NOT baked in: the operator may rebuild it between epochs, and
+        # reading it here would synchronise with the device; the torch replay re-reads it every evaluation)
         raise Unsupported("operand of type {}".format(type(x).__name__))
+
+    def binary(self, op, x, y):
+        """`x op y` of two operands as they appear on the tape / in an OffGrid expression."""
+        a, b = self.value(x), self.value(y)
+        sa, sb = self.shape(x), self.shape(y)
+        if isinstance(a, list) and isinstance(b, list) and sa != sb:
+            raise Unsupported("elementwise '{}' between shapes {} and {} (broadcast)".format(op, sa, sb))
+        return _combine(op, a, b)
 
     def run(self, ops):
         for func, args, kwargs, outs in ops:
@@ -111,27 +141,34 @@ class Symbolic:
                 raise Unsupported("operation '{}' with several results".format(name))
             if name in _PASS:
                 res = self.value(args[0])
+                # (these keep the C order of the elements; the NEW shape is on the tape for the operations that follow)
+                if isinstance(res, list) and sum(n for n, _ in res) != _numel(self.tape.shapes.get(outs[0])):
+                    raise Unsupported("operation '{}' changes the number of elements".format(name))
             elif name == "detach":
                 res = [(n, _detach(e)) for n, e in self.value(args[0])]
             elif name in _CAT:
                 pieces = args[0]
                 axis = kwargs.get("dim", kwargs.get("axis", args[1] if len(args) > 1 else 0))
-                if axis not in (0, -1):
-                    raise Unsupported("concatenation along axis {}".format(axis))
                 res = []
                 for p in pieces:
                     v = self.value(p)
-                    if not isinstance(v, list):
+                    shape = self.shape(p)
+                    if not isinstance(v, list) or shape is None:
                         raise Unsupported("scalar in a concatenation")
+                    # end-to-end order of the result == pieces laid end to end: 1-D pieces, or axis 0 of C-ordered ones
+                    if not (len(shape) == 1 and axis in (0, -1)) and not (len(shape) > 1 and axis in (0, -len(shape))):
+                        raise Unsupported("concatenation of pieces of shape {} along axis {}".format(shape, axis))
                     res += v
             elif name in _BIN and len(args) == 2 and not {k for k in kwargs if k != "alpha"}:
                 op = _BIN[name]
-                a, b = self.value(args[0]), self.value(args[1])
                 if kwargs.get("alpha", 1) != 1:
                     raise Unsupported("alpha argument")
+                x, y = args
                 if op.startswith("r"):
-                    op, a, b = op[1:], b, a
-                res = _combine(op, a, b)
+                    op, x, y = op[1:], y, x
+                res = self.binary(op, x, y)
+                if isinstance(res, list) and sum(n for n, _ in res) != _numel(self.tape.shapes.get(outs[0])):
+                    raise Unsupported("operation '{}' broadcasts".format(name))
             elif name in ("neg", "__neg__", "negative"):
                 v = self.value(args[0])
                 res = [(n, ("neg", e)) for n, e in v] if isinstance(v, list) else ("neg", v)
@@ -141,14 +178,21 @@ class Symbolic:
 
     def offgrid(self, expr):
         """Segment list of an OffGrid expression (param_tape.OffGrid) whose tape slice has been run."""
+        return self._offgrid(expr)[0]
+
+    def _offgrid(self, expr):
+        """(segments or scalar expression, shape or None)."""
         if not isinstance(expr, OffGrid):
-            return self.value(expr)
-        a = self.offgrid(expr.a)
+            return self.value(expr), self.shape(expr)
+        a, sa = self._offgrid(expr.a)
         if expr.op == "leaf":
-            return a
+            return a, sa
         if expr.op == "neg":
-            return [(n, ("neg", e)) for n, e in a] if isinstance(a, list) else ("neg", a)
-        return _combine(expr.op, a, self.offgrid(expr.b))
+            return ([(n, ("neg", e)) for n, e in a] if isinstance(a, list) else ("neg", a)), sa
+        b, sb = self._offgrid(expr.b)
+        if isinstance(a, list) and isinstance(b, list) and sa != sb:
+            raise Unsupported("elementwise '{}' between shapes {} and {} (broadcast)".format(expr.op, sa, sb))
+        return _combine(expr.op, a, b), (sa if isinstance(a, list) else sb)
 
 
 def convert(tape, offgrid, numel):

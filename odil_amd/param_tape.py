@@ -30,6 +30,7 @@ class ParamTape:
     def __init__(self):
         self.ops = []      # (func, args, kwargs, out ids) with ParamTensors replaced by _Ref
         self.leaves = {}   # tape id -> index of the array in `Domain.arrays_from_state` order
+        self.shapes = {}   # tape id -> shape of the value when the operator was traced (param_expr.py checks broadcasts)
         self.count = 0
 
     def new_id(self):
@@ -39,6 +40,7 @@ class ParamTape:
     def leaf(self, tensor, index):
         ident = self.new_id()
         self.leaves[ident] = index
+        self.shapes[ident] = tuple(tensor.shape)
         return ParamTensor.wrap(tensor, self, ident)
 
     def slice_for(self, ids):
@@ -103,6 +105,8 @@ class ParamTensor(torch.Tensor):
             return res  # shapes, dtypes, Python numbers: not part of the tape
         ref = lambda a: _Ref(a._id) if isinstance(a, ParamTensor) else a
         outs = [tape.new_id() for _ in tensors]
+        for ident, t in zip(outs, tensors):
+            tape.shapes[ident] = tuple(t.shape)
         tape.ops.append((func, tree_map(ref, args), tree_map(ref, kwargs), outs))
         wrapped = [ParamTensor.wrap(t, tape, i) for t, i in zip(tensors, outs)]
         return wrapped[0] if isinstance(res, torch.Tensor) else type(res)(wrapped)

@@ -620,7 +620,7 @@ class TracedGroups:
 
         self.gflat, self.gviews = pack_like(self.domain.arrays_from_state(state))
         self.lib_path = [part.lib_path for part in self.parts]
-        self.cg = self.parts[0].cg
+        self.cgs = [part.cg for part in self.parts]  # one code generator per shape group (there is no single `cg`)
 
     def matches(self, state):
         return all(part.matches(state) for part in self.parts)
@@ -659,5 +659,13 @@ def trace(problem, state):
     except TraceUnsupported as e:
         printlog("odil_amd: operator not traced ({}); using the generic autograd path".format(e))
     except FileNotFoundError as e:
-        printlog("odil_amd: no hipcc for traced operators ({}); using the generic autograd path".format(e))
+        # no hipcc / no writable cache: the operator COULD run on generated kernels but this installation cannot build
+        # them.  Falling back silently would leave a ~20x slower evaluation behind a log line, so this is an error
+        # unless the fallback is asked for (ODIL_TRACE_FALLBACK=1).
+        if not int(os.environ.get("ODIL_TRACE_FALLBACK", 0)):
+            raise RuntimeError(
+                "odil_amd: the operator traces to generated HIP kernels but they cannot be built here ({}). Install hipcc / "
+                "prebuild the cache (tools/prebuild_jit.py, ODIL_JIT_CACHE), or set ODIL_TRACE_FALLBACK=1 to accept the "
+                "generic autograd path (about 20x slower), or ODIL_TRACE=0 to choose it explicitly.".format(e)) from e
+        printlog("odil_amd: no hipcc for traced operators ({}); ODIL_TRACE_FALLBACK=1: using the generic autograd path".format(e))
     return None

@@ -640,6 +640,23 @@ class ParamArray:
     __array_ufunc__ = None
 
 
+class _TraceDomain:
+    """The domain as an operator sees it WHILE IT IS TRACED: every attribute is the real Domain's, except `mod`, which is
+    the tracing namespace -- reference operators take their backend from the domain (`mod = ctx.domain.mod`,
+    reference examples/poisson/poisson.py:90-93), and arithmetic on symbols through the real backend would fail (and the
+    operator would silently keep the autograd path)."""
+
+    def __init__(self, domain, mod):
+        object.__setattr__(self, "_domain", domain)
+        object.__setattr__(self, "mod", mod)
+
+    def __getattr__(self, name):
+        return getattr(self._domain, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._domain, name, value)
+
+
 class TraceContext:
     """`Context` (reference core.py:865-990) whose reads return symbols."""
 
@@ -652,11 +669,11 @@ class TraceContext:
 
         self.Raw = Context.Raw
         self._tr = tr
-        self.domain = tr.domain
         self.state = state
         self.extra = extra
         self.dtype = tr.domain.dtype
         self.mod = ModTrace(tr)
+        self.domain = _TraceDomain(tr.domain, self.mod)
         self.distinct_shift = False
         self.step = tr.domain.step
         self.size = tr.domain.size
@@ -682,7 +699,7 @@ class TraceContext:
         return self.mod.cast(value, dtype or self.dtype)
 
     def indices(self, *dims, loc=None):
-        domain = self.domain
+        domain = self._tr.domain
         loc = loc or "c" * domain.ndim
         if any(c not in "cn" for c in loc) or len(loc) != domain.ndim:
             return domain.indices(*dims, loc=loc)
@@ -692,7 +709,7 @@ class TraceContext:
         return res[0] if len(dims) == 1 else res
 
     def points(self, *dims, loc=None):
-        domain = self.domain
+        domain = self._tr.domain
         loc = loc or "c" * domain.ndim
         if any(c not in "cn" for c in loc) or len(loc) != domain.ndim:
             return domain.points(*dims, loc=loc)
@@ -710,7 +727,7 @@ class TraceContext:
     def field(self, key, *shift, loc=None, frozen=False):
         from .core import Array, Field, MultigridField
 
-        domain = self.domain
+        domain = self._tr.domain
         field = self.state.fields[key]
         if isinstance(field, Array):
             if len(shift):

@@ -17,9 +17,11 @@ _BIN = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide,
 
 
 class DagEval:
-    def __init__(self, tr, G, arrays, tracers=None):
-        """arrays: key -> ndarray of shape G (fields and '@...' stored adjoints)."""
+    def __init__(self, tr, G, arrays, tracers=None, nets=None):
+        """arrays: key -> ndarray of shape G (fields and '@...' stored adjoints); nets: key -> (weights, biases) as
+        lists of ndarrays, for operators with a pointwise network (`mlp` nodes)."""
         self.tr, self.G, self.arrays, self.tracers = tr, tuple(G), arrays, tracers or dict()
+        self.nets = nets or dict()
         self.memo = dict()
 
     def __call__(self, n):
@@ -58,6 +60,19 @@ class DagEval:
             return np.asarray(self(A[0]), dtype=np.float64)
         if op == "where":
             return np.where(self(A[0]), self(A[1]), self(A[2]))
+        if op == "mlp":  # all outputs of the pointwise network (reference core.py:807-862): (n_out,) + broadcast shape
+            key, _, layers, activation = n.attr
+            weights, biases = self.nets[key]
+            act = {"tanh": np.tanh, "relu": lambda a: np.maximum(a, 0), "none": lambda a: a}[activation]
+            vals = np.broadcast_arrays(*[np.asarray(self(a), dtype=np.float64) for a in A])
+            h = np.stack(vals).reshape(len(vals), -1)
+            for k, (w, b) in enumerate(zip(weights, biases)):
+                h = np.asarray(w, dtype=np.float64) @ h + np.asarray(b, dtype=np.float64)[:, None]
+                if k < len(weights) - 1:
+                    h = act(h)
+            return h.reshape((h.shape[0],) + vals[0].shape)
+        if op == "mlp_out":
+            return self(A[0])[n.attr]
         if op in _UN:
             return _UN[op](self(A[0]))
         if op in _BIN:

@@ -215,6 +215,66 @@ def test_parameter_space_outputs_have_an_elementwise_form(cpu_mod):
     assert tro3.offgrid and tro3.par_outputs is None
 
 
+def test_parameter_space_expressions_that_broadcast_or_interleave_keep_the_torch_replay(cpu_mod):
+    """The segment form of param_expr.py only says how elements lie end to end, so it must refuse what torch evaluates in
+    another order: an outer product by broadcasting (n^2 elements, not n), a concatenation of 2-D pieces along the last
+    axis (rows interleave), a tensor operand that is not part of the tape.  Such outputs stay with the torch replay
+    (`_eval_offgrid`), which is exact -- and whose value for the accepted forms equals the segments' (cross-check)."""
+    import torch
+
+    from odil_amd import param_expr
+
+    domain = odil.Domain(cshape=(8, 8), dtype=np.float64)
+    state = odil.State(fields={"u": odil.Field(None, loc="cc"), "p": odil.Array(np.array([1.0, -2.0, 0.5, 3.0])),
+                               "q": odil.Array(np.arange(6.0).reshape(2, 3) + 1)})
+    state = domain.init_state(state)
+    par = lambda ctx, key: ctx.domain.arrays_from_field(ctx.state.fields[key])[0]  # noqa: E731
+    cases = {
+        # name: (operator tail, converts to a kernel?)
+        "outer product": (lambda ctx: par(ctx, "p").reshape(-1, 1) * par(ctx, "p").reshape(1, -1), False),
+        "row-interleaving cat": (lambda ctx: ctx.mod.concatenate([par(ctx, "q"), 2 * par(ctx, "q")], axis=-1), False),
+        "column plus row": (lambda ctx: par(ctx, "q") + par(ctx, "q")[0], None),  # indexing: not on the supported list
+        "tensor operand": (lambda ctx: par(ctx, "p") * torch.tensor(2.0, dtype=torch.float64), False),
+        "flatten + cat(axis=0)": (lambda ctx: ctx.mod.concatenate([ctx.mod.flatten(par(ctx, "q")), par(ctx, "p")], axis=0) * 0.5, True),
+        "cat of 2-D pieces along axis 0": (lambda ctx: ctx.mod.concatenate([par(ctx, "q"), 2 * par(ctx, "q")], axis=0), True),
+        "same shapes": (lambda ctx: par(ctx, "q") * par(ctx, "q") - 1.0, True),
+    }
+    one = torch.tensor(1.0, dtype=torch.float64)
+    for name, (tail, converts) in cases.items():
+        problem = odil.Problem(lambda ctx, tail=tail: [("fu", ctx.field("u") - 1.0), ("par", tail(ctx))], domain)
+        tro = stencil_jit.TracedOperator(problem, state)
+        assert tro.offgrid, name
+        if converts is not None:
+            assert (tro.par_outputs is not None) == converts, name
+        # the value the evaluation will use is torch's in every case
+        arrays = {"p": state.fields["p"].array.double().numpy(), "q": state.fields["q"].array.double().numpy()}
+        want = {"outer product": np.outer(arrays["p"], arrays["p"]),
+                "row-interleaving cat": np.concatenate([arrays["q"], 2 * arrays["q"]], axis=-1),
+                "column plus row": arrays["q"] + arrays["q"][0], "tensor operand": 2 * arrays["p"],
+                "flatten + cat(axis=0)": 0.5 * np.concatenate([arrays["q"].reshape(-1), arrays["p"]]),
+                "cat of 2-D pieces along axis 0": np.concatenate([arrays["q"], 2 * arrays["q"]], axis=0),
+                "same shapes": arrays["q"] ** 2 - 1.0}[name]
+        tro.gflat.zero_()
+        _, terms, _ = tro._eval_offgrid(state, one, [one], [one])
+        assert abs(float(terms[1]) - float(np.mean(want**2))) <= 1e-13 * float(np.mean(want**2)), name
+        if tro.par_outputs is not None:  # ... and the generated kernel's segments give the same elements in the same order
+            flat = [a.detach().double().numpy().reshape(-1) for a in domain.arrays_from_state(state)]
+
+            def ev(e, j):
+                if e[0] == "atom":
+                    return flat[e[1]][e[2] + j]
+                if e[0] == "const":
+                    return e[1]
+                if e[0] == "neg":
+                    return -ev(e[1], j)
+                a, b = ev(e[1], j), ev(e[2], j)
+                return a + b if e[0] == "add" else a - b if e[0] == "sub" else a * b if e[0] == "mul" else a / b
+
+            (k, segs), = tro.par_outputs
+            values = np.concatenate([np.array([ev(e, j) for j in range(n)]) for n, e in segs])
+            assert values.shape == want.reshape(-1).shape and np.allclose(values, want.reshape(-1), rtol=1e-15, atol=0), name
+
+
 def test_offgrid_only_parameters_do_not_accumulate(cpu_mod):
     """An `Array` that appears ONLY in a parameter-space output (a prior) gets its gradient from the tape replay alone:
     no grid kernel rewrites its slot of the packed gradient, so repeated evaluations must SET it, not add to it."""
