@@ -244,7 +244,15 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         run = SlabPoissonAdam(N, rank, world, dtype=dtype, device=dev)
         step = lambda timers=None: run.epoch(comm, timers)
     else:
-        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev)
+        ref_u = None
+        if (ndim, N, args.dtype) == (3, 512, "f64"):
+            # the headline at N = 1 starts from the inputs of the value-level fixture, bit for bit (reference solution by
+            # NumPy on the host, right-hand side from it by the residual kernel): its first epochs are then comparable
+            # with the C oracle's (oracle_values_check) -- a last-bit change of the inputs is amplified to O(1) within
+            # three epochs of this problem
+            ref_u = torch.as_tensor(hat_reference_host(N)).to(dev)
+        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev, ref_u=ref_u)
+        del ref_u
         step = lambda timers=None: run.epoch(timers)
     # (created and primed before the warm-up: growing the runtime's event pool stalls the queue, see Timers)
     timers = Timers(only=("adjoint_transpose", "adjoint", "adam"), prealloc=2 * args.steps + 8)
@@ -311,13 +319,30 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         exchanges_per_epoch=2 if world > 1 else 0, oracle=oracle)
 
 
+def hat_reference_host(N):
+    """The reference solution 'hat' (reference examples/poisson/poisson.py:18-24) on the cell centres of the unit cube,
+    float64, NumPy on the host -- the SAME arithmetic as tests/golden/make_golden_fullsize.py:reference_u (same image,
+    same libm: same bits), so that this run's inputs are the fixture's."""
+    import numpy as np
+
+    x = (np.arange(N, dtype=np.float64) + 0.5) / N
+    p = (1 - x) * x * 5
+    u = np.ones((N, N, N))
+    u *= p[:, None, None]
+    u *= p[None, :, None]
+    u *= p[None, None, :]
+    u5 = u**5
+    return (u5 / (1 + u5)) ** (1 / 5)
+
+
 def oracle_values_check(run, epoch, acc, key):
     """VALUE-level parity inside the bench run (N = 1, headline size only): the losses of the first epochs (untimed warm-up;
     zero start) and 64 sampled unknowns per level after the last recorded epoch against tests/golden/fullsize_poisson_N512.npz
     -- three epochs of the plain-C oracle at 512^3 (tests/golden/make_golden_fullsize.py; the oracle itself is NOT run
-    here).  The right-hand side is formed on the device here and on the host there (pow of two math libraries: last-bit
-    differences of rhs), hence 1e-9 where tests/test_fullsize_values_gpu.py, which feeds the generator's own bits, holds
-    1e-12.  Returns the accumulated record (None when no fixture applies)."""
+    here).  Inputs are the fixture's bit for bit (checked on its sampled entries).  Tolerances: loss 1e-10; unknowns 1e-6
+    of a level's largest sample (tests/test_fullsize_values_gpu.py explains what the problem's conditioning leaves of
+    two correct float64 implementations after epoch 1: observed 7e-10).  Returns the accumulated record (None when no
+    fixture applies)."""
     if key != (3, 512, "f64"):
         return None
     path = os.path.join(ROOT, "tests", "golden", "fullsize_poisson_N512.npz")
@@ -327,8 +352,13 @@ def oracle_values_check(run, epoch, acc, key):
         import numpy as np
 
         fx = np.load(path)
-        acc = {"source": "tests/golden/fullsize_poisson_N512.npz (oracle/poisson_epoch.c, 3 epochs at 512^3)", "tol": 1e-9,
+        acc = {"source": "tests/golden/fullsize_poisson_N512.npz (oracle/poisson_epoch.c, 3 epochs at 512^3)", "tol": 1e-10,
                "loss_rel_err": [], "ok": True, "_fx": {k: fx[k] for k in fx.files}}
+        i0 = torch.as_tensor(fx["sample_index"][: int(fx["sample_count"][0])], device=run.ref_u.device)
+        acc["inputs_bit_identical"] = bool(
+            np.array_equal(run.ref_u.reshape(-1)[i0].cpu().numpy(), fx["ref_u_samples"])
+            and np.array_equal(run.ev.rhs.reshape(-1)[i0].cpu().numpy(), fx["rhs_samples"]))
+        acc["ok"] = acc["inputs_bit_identical"]
     fx = acc.get("_fx")
     if fx is None or epoch > int(fx["epochs"]):
         return acc
@@ -341,12 +371,14 @@ def oracle_values_check(run, epoch, acc, key):
     if epoch == int(fx["epochs"]):
         idx = np.split(fx["sample_index"], np.cumsum(fx["sample_count"])[:-1])
         ref = np.split(fx["x_samples_e{}".format(epoch)], np.cumsum(fx["sample_count"])[:-1])
-        worst = 0.0
+        by_level = []
         for w, i, r in zip(run.w, idx, ref):
             g = w.reshape(-1)[torch.as_tensor(i, device=w.device)].cpu().numpy()
-            worst = max(worst, float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)))
+            by_level.append(float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-300)))
+        worst = max(by_level)
         acc["x_sample_rel_err_after_epoch_{}".format(epoch)] = worst
-        acc["ok"] = bool(acc["ok"] and worst <= 1e-8)
+        acc["x_sample_rel_err_by_level"] = by_level
+        acc["ok"] = bool(acc["ok"] and worst <= 1e-6)
         acc["epochs"] = epoch
         del acc["_fx"]
     return acc
@@ -519,40 +551,62 @@ def other_configs(args, dev):
         S = sum(2.0 ** (-4 * l) for l in range(res["config"]["levels"]))
         model = (4 * (10 * S + 2) + 2 * 8 + 1) * 4
         return {"workload": res["workload"], "ms_per_step": ms, "value": res["cells"] / (ms * 1e-3),
-                "frac_model": res["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": res["kernel_ms"]}
+                "frac_model": res["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": res["kernel_ms"],
+                "traced": True}  # (SlabTracedAdam runs generated kernels only: it has no autograd path)
 
-    def newton():
-        import bench_configs
-        import importlib
+    def newton(modname="poisson", argv=None, env=None, name=None, words_per_cycle=(4 * 3 + 2.125), words_setup=0.0):
+        """One Newton step (the SECOND of two: work buffers exist) of a 3-D problem through `odil.util.optimize`.
+        env: switches for the step (ODIL_NEWTON_SHORTCUT=0: the general route eval_operator_grad -> linearize ->
+        linsolver.solve instead of the recognised-Poisson shortcut; ODIL_GMG=stencil: the variable-coefficient cycle)."""
+        def run():
+            import importlib
 
-        import odil_amd as odil
+            import bench_configs
+            import odil_amd as odil
 
-        modname, argv, _, _, _, name = bench_configs.CONFIGS["4b"]
-        sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
-        ex = importlib.import_module(modname)
-        a = ex.parse_args(argv(sc))
-        odil.util.set_log_file(open(os.devnull, "w"))
-        problem, state = ex.make_problem(a)
-        a.epoch_start, a.epochs = 0, 1
+            sc = lambda n: max(8, int(round(n * args.scale)) // 8 * 8)
+            av = argv(sc) if argv is not None else bench_configs.CONFIGS["4b"][1](sc)
+            saved = {k: os.environ.get(k) for k in (env or {})}
+            os.environ.update(env or {})
+            try:
+                ex = importlib.import_module(modname)
+                a = ex.parse_args(av)
+                odil.util.set_log_file(open(os.devnull, "w"))
+                problem, state = ex.make_problem(a)
+                a.epoch_start, a.epochs = 0, 1
 
-        def step():
-            odil.util.optimize(a, "newton", problem, state, None)
+                def step():
+                    odil.util.optimize(a, "newton", problem, state, None)
 
-        ms = timed(step, 1, 1)
-        cells = int(np.prod(problem.domain.cshape))
-        # bytes model of one Newton step with the geometric-multigrid solve (words of 8 B per fine cell): per V-cycle
-        # four smoothing sweeps of 3 words (read x, b; write x) + residual with its restriction 2 + 1/8, over all levels
-        # (x 8/7); per step the residual (3), the update x += delta (3) and the first iterate by nested iteration (one
-        # cycle's worth); the cycle count comes from the solver's own status of one more (untimed) step
-        seen = []
-        a.epochs = 1
-        odil.util.optimize(a, "newton", problem, state, lambda s, e, p: seen.append(p.get("linsolver")))
-        cycles = next((int(st["niter"]) for st in seen if st and "niter" in st), None)
-        model = None if cycles is None else ((4 * 3 + 2.125) * 8.0 / 7.0 * (cycles + 1) + 6) * 8.0
-        return {"workload": name.format(problem.domain.cshape[0], problem.domain.cshape[-1]), "ms_per_step": ms,
-                "value": cells / (ms * 1e-3), "vcycles": cycles, "model_bytes_per_update": model,
-                "frac_model": None if model is None else cells * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "loss_after": float(problem.eval_loss_grad(state)[0])}
+                ms = timed(step, 1, 1)
+                cells = int(np.prod(problem.domain.cshape))
+                # bytes model of one Newton step with a geometric-multigrid solve (words per fine cell): per V-cycle four
+                # smoothing sweeps + the residual with its restriction, over all levels (x 8/7) -- 3 and 2 1/8 words for
+                # the constant-coefficient Poisson cycle, 10 and 9 1/8 with seven coefficient arrays --; per step the
+                # residual (3), the update x += delta (3), the first iterate by nested iteration (one cycle's worth) and
+                # `words_setup` (general route: the seven coefficient arrays written by eval_operator_grad, read by
+                # linearize / recognition, the coarse operators formed); the cycle count comes from the solver's own
+                # status of one more (untimed) step
+                seen = []
+                a.epochs = 1
+                odil.util.optimize(a, "newton", problem, state, lambda s, e, p: seen.append(p.get("linsolver")))
+                st = next((st for st in seen if st and "niter" in st), None)
+                cycles = None if st is None else int(st["niter"])
+                wsize = 8.0 if np.dtype(problem.domain.dtype) == np.float64 else 4.0
+                model = None if cycles is None else (words_per_cycle * 8.0 / 7.0 * (cycles + 1) + 6 + words_setup) * wsize
+                return {"workload": (name or bench_configs.CONFIGS["4b"][5]).format(problem.domain.cshape[0], problem.domain.cshape[-1]),
+                        "ms_per_step": ms, "value": cells / (ms * 1e-3), "vcycles": cycles,
+                        "solver": None if st is None else st.get("method"), "model_bytes_per_update": model,
+                        "frac_model": None if model is None else cells * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "loss_after": float(problem.eval_loss_grad(state)[0]), "env": env or {},
+                        "vram_peak_gb": torch.cuda.max_memory_allocated() / 1e9}
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return run
 
     def api(key, epochs, warmup):
         """Configs 1, 2, 5b through the public operator API (bench_configs.run_config), a few epochs each."""
@@ -565,14 +619,31 @@ def other_configs(args, dev):
             return {"workload": out["name"], "ms_per_step": ms, "value": out["cells"] / (ms * 1e-3), "optimizer": out["optimizer"],
                     "model_bytes_per_update": model,
                     "frac_model": None if not model else out["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "loss_after": out["loss"]}
+                    "loss_after": out["loss"], "timing": "median of {} epochs, HIP events in the driver's per-epoch callback".format(out["epochs"]),
+                    "ms_mean": out["ms_mean"], "ms_max": out["ms_max"], "ms_min": out["ms_min"], "setup_s": out["setup_s"],
+                    "traced": out["traced"], "fused": out["fused"], "vram_peak_gb": out["vram_peak_gb"],
+                    "vram_reserved_gb": out["vram_reserved_gb"]}
         return run
 
     for sub in ("poisson", "heat", "velocity_from_tracer"):
         sys.path.insert(0, os.path.join(ROOT, "examples", sub))
+    for sub in ("diffusion",):
+        sys.path.insert(0, os.path.join(ROOT, "examples", sub))
     attempt("3b", heat)
     attempt("5_one_rank", tracer)
-    attempt("4b", newton)
+    attempt("4a_api", api("4a", 20, 3))  # the headline workload through odil.util.optimize(args, "adam", problem, state, cb)
+    attempt("4b", newton())
+    # the same Newton step WITHOUT the recognised-Poisson shortcut: eval_operator_grad (seven coefficient arrays) ->
+    # linearize_device -> linsolver.solve -> recognise -> V-cycles; then with the constant-coefficient cycle switched off
+    # as well (the cycle any (2 d + 1)-point operator gets), and that cycle on a genuinely variable operator at 256^3
+    attempt("4b_general", newton(env={"ODIL_NEWTON_SHORTCUT": "0"}, name="poisson 3D {0}^3 newton, general route (linearize + solve) f64",
+                                 words_setup=7 * 3))
+    attempt("4b_varcoef", newton(env={"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil"}, words_per_cycle=4 * 10 + 9.125,
+                                 words_setup=7 * 3 + 8, name="poisson 3D {0}^3 newton, variable-coefficient multigrid f64"))
+    attempt("4c_diffusion", newton("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver",
+                                                             "multigrid", "--linsolver_tol", "1e-10"],
+                                   words_per_cycle=4 * 10 + 9.125, words_setup=7 * 3 + 8,
+                                   name="diffusion div(k grad u), k jumps 1 : 1000, 3D {0}^3 newton + variable-coefficient multigrid f64"))
     attempt("1", api("1", 400, 2))
     attempt("2", api("2", 30, 1))
     attempt("5b", api("5b", 10, 2))
@@ -595,7 +666,7 @@ def run_api(args, dev):
     if model:
         rl = roofline("whole epoch (all launches; SURVEY 8(d) model bytes -- no single dominant launch timed)",
                       model * out["cells"], model * out["cells"], ms, None, None)
-    return dict(elapsed=out["wall_s"], cells=out["cells"], loss=out["loss"], kernel_ms={},
+    return dict(elapsed=1e-3 * out["ms_mean"] * out["epochs"], cells=out["cells"], loss=out["loss"], kernel_ms={},
                 metric="grid-point-updates/s, " + out["name"], workload=out["name"] + ", 1xMI355X, public operator API",
                 config=dict(cells_per_gpu=out["cells"], optimizer=out["optimizer"]), roofline=rl, abytes=model,
                 dtype=out["dtype"], exchanges_per_epoch=0, steps=out["epochs"])
@@ -610,6 +681,8 @@ def check_parity(args, res, world):
     key = {"4a": "poisson_512", "5": "tracer_cfg5"}.get(args.config)
     if key is None or args.scale != 1.0 or (args.config == "4a" and (args.ndim, args.N, args.dtype) != (3, 512, "f64")):
         return None
+    if args.config == "4a" and world == 1:
+        return None  # N = 1 is held to the C oracle's VALUES instead (oracle_values_check); the table is these kernels' own
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "expected_losses.json")))
     except OSError:

@@ -344,6 +344,30 @@ int odil_stencil_march_f64(const double* coeffs, const int64_t* shifts, int nshi
                            const int64_t* shape, int ndim, int axis, int direction, void* stream);
 int odil_stencil_march_f32(const float* coeffs, const int64_t* shifts, int nshift, int diag, const float* b, float* x,
                            const int64_t* shape, int ndim, int axis, int direction, void* stream);
+/* Geometric multigrid for a (2 ndim + 1)-point operator with VARIABLE coefficients on a cell-centred grid, ndim <= 3 (the
+ * Newton system of any single-field operator whose Jacobian `Problem.linearize` delivers as per-shift coefficient arrays,
+ * core.py:1113-1217; the reference hands M^T M to SuperLU / pyamg, linsolver.py:17-26, 61-72).  `coeffs`: the 2 ndim + 1
+ * arrays one after another in the order (0, -e_0, +e_0, -e_1, +e_1, ...), each of `shape`; neighbours wrap periodically
+ * (core.py:962-963), a wall row carries a zero coefficient towards the wall.
+ *   smooth, mode 0:  out = x - omega (A x - b) / c0   (one damped-Jacobi sweep; out != x)
+ *           mode 1:  out = b - A x
+ *   residual_restrict: coarse = scale * sum over the 2^ndim children of (b - A x), loss = mean((A x - b)^2)
+ *           (deterministic two-stage sum; `partials`: odil_reduce_workspace_bytes()); even extents
+ *   coarsen: the coarse-grid operator as 2 ndim + 1 arrays of shape / 2: aggregates of 2^ndim cells, piecewise-constant
+ *           Galerkin products of the second-order part (x 1/2), the matrix-antisymmetric part and the row sums
+ *           (csrc/stencil_mg.hip). */
+int odil_stencil_var_smooth_f64(const double* coeffs, const double* x, const double* b, double* out, const int64_t* shape,
+                                int ndim, double omega, int mode, void* stream);
+int odil_stencil_var_smooth_f32(const float* coeffs, const float* x, const float* b, float* out, const int64_t* shape,
+                                int ndim, float omega, int mode, void* stream);
+int odil_stencil_var_residual_restrict_f64(const double* coeffs, const double* x, const double* b, double* coarse,
+                                           const int64_t* shape, int ndim, double scale, double* partials, double* loss,
+                                           void* stream);
+int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, const float* b, float* coarse,
+                                           const int64_t* shape, int ndim, float scale, double* partials, float* loss,
+                                           void* stream);
+int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream);
+int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream);
 /* CSR assembly of the same matrix (core.py:1144-1171, :1214): indptr[n+1], indices,
  * data of nnz = nshift*n entries, columns offset by `col_offset`; rows keep ODIL's
  * order (ascending shift index within a row, not sorted by column). */

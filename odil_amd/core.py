@@ -257,17 +257,16 @@ def eval_neural_net(net, inputs, mod, frozen=False):
     if net.func_in is not None:
         inputs = net.func_in(*inputs)
     wdtype = layers[0][0].dtype
-    h = torch.stack(torch.broadcast_tensors(*[mod.cast(v, wdtype) for v in inputs]), dim=0)
-    grid = tuple(h.shape[1:])
-    h = h.reshape(h.shape[0], -1)  # (units, points)
+    # every grid point a column vector: (grid..., units, 1); a layer is one batched product W h + b
+    h = torch.stack(torch.broadcast_tensors(*[mod.cast(v, wdtype) for v in inputs]), dim=-1).unsqueeze(-1)
     for k, (w, b) in enumerate(layers):
         assert_equal(w.shape[0], b.shape[0])
         if frozen:
             w, b = mod.stop_gradient(w), mod.stop_gradient(b)
-        h = torch.addmm(b[:, None], w, h)
+        h = torch.matmul(w, h) + b.unsqueeze(-1)
         if act is not None and k < len(layers) - 1:
             h = act(h)
-    outputs = list(h.reshape((h.shape[0],) + grid).unbind(0))
+    outputs = list(h.squeeze(-1).unbind(-1))
     if net.func_out is not None:
         outputs = net.func_out(*outputs)
     return outputs

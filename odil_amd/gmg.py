@@ -200,6 +200,130 @@ class PoissonGMG:
         return x.clone() if copy else x
 
 
+class StencilGMG(PoissonGMG):
+    """V-cycles for ANY (2 d + 1)-point operator with variable coefficients on a cell-centred grid (d <= 3): the Newton
+    system M delta = -r of a single-field operator as `Problem.linearize` delivers it (reference core.py:1113-1217) --
+    variable-coefficient diffusion, reaction and convection terms, any wall closure, periodic axes.  Same cycle as
+    PoissonGMG (Chebyshev-weighted Jacobi sweeps, full-weighting restriction, the multigrid decomposition's P for the
+    corrections, nested-iteration start); what differs is where the operators come from:
+
+      fine level     the Jacobian's own coefficient arrays                    `coeffs` [(2 d + 1), *shape]
+      coarse levels  odil_stencil_var_coarsen (csrc/stencil_mg.hip): aggregates of 2^d cells, piecewise-constant Galerkin
+                     products of the second-order part (x 1/2), the antisymmetric part and the row sums -- formed once
+                     per solve (the coefficients change with the state), 8/7 of one pass over the fine arrays
+      sweeps         odil_stencil_var_smooth            (2 d + 1) + 3 words per cell (Poisson: 3)
+      coarse rhs     odil_stencil_var_residual_restrict (2 d + 1) + 2 + 1 / 2^d words, the residual norm on the way
+
+    M need not be symmetric; the cycle is a stationary iteration on M delta = -r itself (for a square nonsingular M the
+    solution of the normal equations the reference forms, linsolver.py:17-23).  `solve` reports `converged`; the caller
+    (linsolver.solve) falls back to the normal-equation routes when the cycles do not contract."""
+
+    def __init__(self, coeffs, nu1=2, nu2=2, min_size=2):
+        shape = tuple(coeffs.shape[1:])
+        self.ndim = len(shape)
+        assert coeffs.shape[0] == 2 * self.ndim + 1 and self.ndim <= 3 and coeffs.is_contiguous()
+        self.loc = "c" * self.ndim
+        self.dtype, self.device = coeffs.dtype, coeffs.device
+        self.omega = {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
+        self.nu1, self.nu2 = nu1, nu2
+        self.coeffs, self.shapes = [coeffs], [shape]
+        while all(s % 2 == 0 and s // 2 >= min_size for s in self.shapes[-1]):
+            self.coeffs.append(ops.stencil_var_coarsen(self.coeffs[-1]))
+            self.shapes.append(tuple(s // 2 for s in self.shapes[-1]))
+        self.nlvl = len(self.shapes)
+        mk = lambda s: torch.zeros(s, dtype=self.dtype, device=self.device)
+        self.x = [None] + [mk(s) for s in self.shapes[1:]]
+        self.b = [None] + [mk(s) for s in self.shapes[1:]]
+        self._r = [None] * self.nlvl
+        self.spare = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.shapes]
+        self.loss = mk(())
+        self._coarse_inv = None
+
+    def coarse_inverse(self):
+        """(Pseudo-)inverse of the coarsest operator, from the residual kernel applied to unit vectors; a singular
+        coarsest operator (all-periodic or all-Neumann problems: constants in the null space) gets the minimum-norm
+        solution."""
+        if self._coarse_inv is None:
+            shape = self.shapes[-1]
+            n = math.prod(shape)
+            eye = torch.eye(n, dtype=self.dtype, device=self.device)
+            zero = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            cols = [-ops.stencil_var_residual(self.coeffs[-1], eye[j].view(shape).contiguous(), zero).reshape(-1) for j in range(n)]
+            amat = torch.stack(cols, dim=1).cpu().numpy().astype(np.float64)  # column j = A e_j
+            inv = np.linalg.pinv(amat, rcond=1e-12)
+            self._coarse_inv = torch.as_tensor(inv, dtype=self.dtype).to(self.device).contiguous()
+        return self._coarse_inv
+
+    def residual(self, lvl, x, b, out):
+        """out = A x - b, mean square in self.loss."""
+        ops.stencil_var_residual(self.coeffs[lvl], x, b, out=out)
+        ops.scale(out, -1.0, out=out)
+        ops.mean_reduce(out.reshape(-1), square=True, out=self.loss)
+        return out
+
+    def sweeps(self, lvl, x, b, weights):
+        for w in weights:
+            y = self.spare[lvl]
+            ops.stencil_var_smooth(self.coeffs[lvl], x, b, w, out=y)
+            self.spare[lvl] = x
+            x = y
+        return x
+
+    def coarse_rhs(self, lvl, x, b):
+        bc = self.b[lvl + 1]
+        ops.stencil_var_residual_restrict(self.coeffs[lvl], x, b, 1.0 / 2**self.ndim, bc, self.loss)
+        return bc
+
+    def finish_cycle(self, lvl, x, b):
+        xc = self.x[lvl + 1]
+        xc.zero_()
+        xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1])
+        if xc_new is not xc:
+            self.x[lvl + 1] = xc_new
+        out = self.spare[lvl]
+        ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
+        self.spare[lvl] = x
+        return self.sweeps(lvl, out, b, self.weights(self.nu2))
+
+
+def recognise_stencil(op):
+    """The coefficient tensor [(2 d + 1), *shape] (order 0, -e_0, +e_0, -e_1, ...) when the LinearizedOperator is square,
+    acts on ONE cell-centred `Field` (d <= 3, even extents) and every stencil block's shift is 0 or a unit vector --
+    the structure StencilGMG needs; None otherwise.  Shifts that do not occur are zero arrays, duplicates are summed."""
+    from .core import Field
+
+    if len(op.key_to_field) != 1 or op.nrows != op.ncols:
+        return None
+    (key, field), = op.key_to_field.items()
+    if not isinstance(field, Field):
+        return None
+    shape = tuple(field.array.shape)
+    ndim = len(shape)
+    if ndim > 3 or field.loc != "c" * ndim or any(s < 4 or s % 2 for s in shape):
+        return None
+    want = [(0,) * ndim]
+    for i in range(ndim):
+        want += [tuple(-1 if j == i else 0 for j in range(ndim)), tuple(1 if j == i else 0 for j in range(ndim))]
+    coeffs = torch.zeros((len(want),) + shape, dtype=op.dtype, device=op.device)
+    seen = set()
+    for row0, nrows, kind, k, payload in op.blocks:
+        if kind != "stencil" or row0 != 0 or nrows != op.ncols:
+            return None
+        coeff, shift, loc, vshape = payload
+        norm = tuple(((s + n // 2) % n) - n // 2 for s, n in zip(shift, shape))  # periodic roll: |shift| <= n / 2
+        if loc != field.loc or tuple(vshape) != shape or norm not in want:
+            return None
+        slot = want.index(norm)
+        if slot in seen:
+            ops.axpy(coeffs[slot].view(-1), coeff.reshape(-1).contiguous(), 1.0)
+        else:
+            coeffs[slot].view(-1).copy_(coeff.reshape(-1))
+            seen.add(slot)
+    if 0 not in seen:
+        return None
+    return coeffs
+
+
 def recognise_poisson(op):
     """(shape, h2) if the LinearizedOperator is exactly the zero-Dirichlet Laplacian stencil of one
     cell-centred field, else None."""

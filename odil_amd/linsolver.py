@@ -387,15 +387,38 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
     # and is solved by geometric multigrid V-cycles (gmg.py) -- the only option that scales to
     # 512^3.  `multigrid` always takes it when it applies, `direct` above 2e5 unknowns.
     if not damp and not dampdiag and (linsolver == "multigrid" or (linsolver == "direct" and matr.ncols > 200000)):
+        import os
+
         from . import gmg
 
-        rec = gmg.recognise_poisson(matr)
+        # ODIL_GMG = auto (default) | poisson | stencil: `stencil` sends even the constant-coefficient Laplacian through
+        # the variable-coefficient cycle (measurement, tests), `poisson` switches that cycle off
+        mode = os.environ.get("ODIL_GMG", "auto")
+        gtol = 1e-12 if linsolver == "direct" else tol
+        rec = gmg.recognise_poisson(matr) if mode != "stencil" else None
         if rec is not None:
             shape, h2 = rec
             solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
-            gtol = 1e-12 if linsolver == "direct" else tol
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
+        # Any other square (2 d + 1)-point operator on one cell-centred field (variable-coefficient diffusion, reaction,
+        # convection, other wall closures): V-cycles on its own coefficient arrays.  M d = rhs is solved, which for a
+        # nonsingular square M is the solution of the normal equations; cycles that do not contract hand over to the
+        # normal-equation routes below.
+        coeffs = gmg.recognise_stencil(matr) if mode != "poisson" else None
+        if coeffs is not None:
+            sub = dict()
+            solver = gmg.StencilGMG(coeffs)
+            x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+            if sub.get("converged") and bool(torch.isfinite(x).all()):
+                sub["method"] = "gmg-vcycle (variable coefficients, {} levels)".format(solver.nlvl)
+                status.update(sub)
+                return x.reshape(-1)
+            from .util import printlog
+
+            printlog("odil_amd: variable-coefficient multigrid did not converge (relative residual {:.1e} after {} cycles); "
+                     "using the normal-equation routes".format(sub.get("residual", float("nan")), sub.get("niter", 0)))
+            del solver, coeffs, x
     # Square and triangular along one axis (time-explicit operators): M d = rhs by substitution is exact and has the
     # solution of the normal equations
     if not damp and not dampdiag and linsolver in ("direct", "directsq", "multigrid"):

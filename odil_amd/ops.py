@@ -151,6 +151,40 @@ def conv_valid(x, w, strides, transposed=False, out_shape=None):
     return out
 
 
+def stencil_var_smooth(coeffs, x, b, omega, out):
+    """out = x - omega (A x - b) / c0 for the (2 d + 1)-point operator with coefficient arrays `coeffs` [(2 d + 1), *shape]
+    (include/odil_hip.h: odil_stencil_var_smooth, mode 0)."""
+    assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape) and out is not x
+    call("stencil_var_smooth", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()), float(omega),
+         c_int(0), stream_ptr())
+    return out
+
+
+def stencil_var_residual(coeffs, x, b, out=None):
+    """b - A x (mode 1 of odil_stencil_var_smooth)."""
+    assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape)
+    out = torch.empty_like(x) if out is None else out
+    call("stencil_var_smooth", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()), 0.0, c_int(1),
+         stream_ptr())
+    return out
+
+
+def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss):
+    """out = scale * (sum over the 2^d children of b - A x), loss <- mean((A x - b)^2), one pass."""
+    assert tuple(out.shape) == tuple(s // 2 for s in x.shape) and out.is_contiguous()
+    call("stencil_var_residual_restrict", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()),
+         float(scale), ptr(reduce_workspace(x.device)), ptr(loss), stream_ptr())
+    return out
+
+
+def stencil_var_coarsen(coeffs):
+    """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip)."""
+    shape = tuple(coeffs.shape[1:])
+    out = torch.empty((coeffs.shape[0],) + tuple(s // 2 for s in shape), dtype=coeffs.dtype, device=coeffs.device)
+    call("stencil_var_coarsen", coeffs.dtype, ptr(coeffs), ptr(out), i64(shape), c_int(len(shape)), stream_ptr())
+    return out
+
+
 def restrict_adj(gcoarse, loc, fshape):
     """R^T gcoarse (cotangent of restrict_to_coarser) for a fine array of shape `fshape`."""
     fshape = tuple(int(s) for s in fshape)

@@ -55,7 +55,9 @@ def hat_reference(cshape, dtype, device):
 
 class PoissonMultigridAdam:
     def __init__(self, ndim, N, dtype=torch.float64, device=None, lr=0.005, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7, multigrid=True, rhs=None):
+                 epsilon=1e-7, multigrid=True, rhs=None, ref_u=None):
+        """ref_u: the reference solution as a device tensor (default: 'hat' formed on the device); rhs: the right-hand
+        side (default: the discrete Laplacian of ref_u by the residual kernel, reference poisson.py:71-86)."""
         self.ndim, self.N, self.dtype, self.device = ndim, N, dtype, device
         self.loc = "c" * ndim
         cshape = (N,) * ndim
@@ -78,7 +80,9 @@ class PoissonMultigridAdam:
         self.mw = [t.view(s) for t, s in zip(self.m.split(self.sizes), self.shapes)]
         self.vw = [t.view(s) for t, s in zip(self.v.split(self.sizes), self.shapes)]
         # rhs = discrete Laplacian of the reference solution (poisson.py:71-86): same kernel, rhs = 0
-        ref_u = hat_reference(cshape, dtype, device)
+        if ref_u is None:
+            ref_u = hat_reference(cshape, dtype, device)
+        assert tuple(ref_u.shape) == tuple(cshape) and ref_u.dtype == dtype
         self.ref_u = ref_u
         if rhs is None:
             rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), self.h2)

@@ -283,8 +283,8 @@ def _poisson_newton_step(problem, state, args, status):
 
     ev = getattr(problem, "_fused", None)
     linsolver = getattr(args, "linsolver", "direct")
-    if ev is None or ev.nlvl != 1 or len(state.fields) != 1:
-        return None
+    if ev is None or ev.nlvl != 1 or len(state.fields) != 1 or not int(os.environ.get("ODIL_NEWTON_SHORTCUT", 1)):
+        return None  # (ODIL_NEWTON_SHORTCUT=0: the general route eval_operator_grad -> linearize -> linsolver.solve)
     (field,) = state.fields.values()
     if not isinstance(field, Field) or getattr(args, "linsolver_damp", 0) or getattr(args, "linsolver_dampdiag", 0):
         return None

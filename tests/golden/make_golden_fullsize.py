@@ -7,9 +7,9 @@
 Runs EPOCHS epochs of `oracle/poisson_epoch.c` (the plain-C restatement of the epoch, pinned to the NumPy oracle by
 tests/test_oracle_c.py, which is pinned on the reference's golden vectors by tests/test_oracle_golden.py) and stores,
 per epoch: the loss; per level: sum, sum of squares and NSAMPLE sampled entries of x, m, v (and of the gradient).
-The inputs are NOT stored (1 GB): `reference_inputs` below regenerates ref_u and rhs with the same C library on the
-host the test runs on (same image => same libm), and the fixture carries their checksums so that a drifted input is
-reported as such.  tests/test_fullsize_values_gpu.py compares the HIP epoch (bespoke driver AND public API) with it.
+The inputs are NOT stored (1 GB): `reference_u` below regenerates ref_u with NumPy on the host the test runs on (same
+image => same libm), the device forms rhs from it, and the fixture carries samples and checksums of both so that a drifted
+input is reported as such.  tests/test_fullsize_values_gpu.py compares the HIP epoch (bespoke driver AND public API) with it.
 
 Reference arithmetic restated by the C file: src/odil/core.py:245-263, 606-700 (synthesis), examples/poisson/poisson.py:57-113
 (residual), core.py:1093-1100 (loss, reverse mode), optimizer.py:311-319 (Adam).
@@ -52,9 +52,11 @@ def levels(N):
     return [(N >> l,) * 3 for l in range(nlvl)]
 
 
-def reference_inputs(lib, N):
-    """ref_u = 'hat' on the cell centres (reference examples/poisson/poisson.py:18-24), rhs = its discrete Laplacian
-    (:71-86), both float64 (N, N, N); NumPy arithmetic for ref_u, the C residual for rhs."""
+def reference_u(N):
+    """ref_u = 'hat' on the cell centres of the unit cube (reference examples/poisson/poisson.py:18-24), float64
+    (N, N, N), plain NumPy on the host: the SAME function gives the same bits in the generator, in the GPU test and in
+    bench.py (one image, one libm) -- which matters: Adam from the zero state on this problem amplifies a last-bit change
+    of the inputs by (1 / h^2)^2 lr / eps ~ 1e14 within two epochs (see tests/test_fullsize_values_gpu.py)."""
     x = (np.arange(N, dtype=np.float64) + 0.5) / N
     p = (1 - x) * x * 5
     u = np.ones((N, N, N))
@@ -62,12 +64,18 @@ def reference_inputs(lib, N):
     u *= p[None, :, None]
     u *= p[None, None, :]
     u5 = u**5
-    u = (u5 / (1 + u5)) ** (1 / 5)
-    del u5
-    rhs = np.empty((N, N, N))
-    h2 = np.full(3, (1.0 / N) ** 2)
-    lib.odil_c_residual(ptr(u), None, N, N, N, ptr(h2), ptr(rhs))
-    return u, rhs
+    return (u5 / (1 + u5)) ** (1 / 5)
+
+
+def reference_inputs(N):
+    """(ref_u, rhs): rhs = the discrete Laplacian of ref_u (poisson.py:71-86) by the NumPy oracle, whose operation order
+    the HIP residual kernel reproduces bit for bit (asserted at full size by the GPU test: the device forms ITS rhs from
+    ref_u with `odil_poisson_residual` and must find the fixture's sampled entries exactly)."""
+    sys.path.insert(0, ROOT)
+    from oracle import odil_np as onp
+
+    u = reference_u(N)
+    return u, onp.poisson_discrete_rhs(u, onp.step((N,) * 3))
 
 
 def sample_indices(N):
@@ -89,7 +97,7 @@ def stats(arrs, idx):
 def make(N):
     lib = load_lib()
     shapes = levels(N)
-    ref_u, rhs = reference_inputs(lib, N)
+    ref_u, rhs = reference_inputs(N)
     x, m, v, g = ([np.zeros(s) for s in shapes] for _ in range(4))
     arr = lambda arrs: (P * len(arrs))(*[ptr(a) for a in arrs])  # noqa: E731
     half = N // 2
@@ -104,6 +112,10 @@ def make(N):
     for epoch in range(1, EPOCHS + 1):
         loss = lib.odil_c_epoch(N, len(shapes), arr(x), arr(m), arr(v), arr(g), ptr(rhs), ptr(u), ptr(fu), ptr(work),
                                 ptr(la), ptr(lb), epoch, LR)
+        # the C epoch sums its 1.3e8 squares one after the other (rounding ~ sqrt(n) eps = 1e-12 of the sum): the fixture
+        # holds the mean square of the epoch's OWN residual array summed in extended precision instead
+        loss_seq, loss = loss, float(np.sum(np.square(fu, dtype=np.longdouble)) / fu.size)
+        assert abs(loss - loss_seq) <= 1e-10 * abs(loss)
         losses.append(loss)
         for name, arrs in (("x", x), ("m", m), ("v", v), ("g", g)):
             s, smp = stats(arrs, idx)

@@ -1,0 +1,151 @@
+"""The variable-coefficient geometric multigrid of the general Newton route (odil_amd/gmg.py: StencilGMG;
+csrc/stencil_mg.hip; SURVEY 8 A14 / A15: `Problem.linearize` -> `linsolver.solve`, reference src/odil/core.py:1113-1217,
+linsolver.py:4-87) on the GPU:
+
+  * every kernel against the NumPy restatement tests/stencil_gmg_np.py (operator application, Jacobi sweep, restricted
+    residual with its norm, coarse-operator construction) in 1 - 3 dimensions, f64 1e-13 / f32 1e-5;
+  * V-cycles contract as the restatement's do (tests/test_stencil_gmg_host.py);
+  * through the public API: one Newton step of the variable-coefficient diffusion example with `--linsolver multigrid`
+    lands on the iterate of `--linsolver direct` (dense Cholesky of M^T M: the reference's SuperLU solve) -- the parity the
+    reference's linsolver defines; and the constant-coefficient Poisson operator sent through the SAME general cycle
+    (ODIL_GMG=stencil, ODIL_NEWTON_SHORTCUT=0) reaches the Newton iterate of the dedicated Poisson cycle."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import stencil_gmg_np as sg
+import torch
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def random_coeffs(shape, rng, walls=True):
+    """a diagonally dominant operator with random positive couplings, a reaction part and (optionally) wall rows"""
+    nd = len(shape)
+    off = [rng.uniform(0.5, 2.0, shape) * rng.choice([1.0, 50.0]) for _ in range(2 * nd)]
+    if walls:
+        for a in range(nd):
+            idx = np.arange(shape[a]).reshape([-1 if j == a else 1 for j in range(nd)])
+            off[2 * a] = np.where(idx == 0, 0.0, off[2 * a])
+            off[2 * a + 1] = np.where(idx == shape[a] - 1, 0.0, off[2 * a + 1])
+    c0 = -(sum(off) + rng.uniform(0.0, 1.0, shape))
+    return [c0] + off
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
+@pytest.mark.parametrize("shape,walls", [((64,), True), ((12, 20), True), ((8, 6, 10), True), ((4, 4, 4), False),
+                                         ((16, 32, 64), True), ((6, 10), False)])
+def test_kernels_equal_the_numpy_restatement(dev, shape, walls, dtype, tol):
+    from odil_amd import ops
+
+    rng = np.random.default_rng(3)
+    coeffs = [c.astype(dtype) for c in random_coeffs(shape, rng, walls)]
+    x, b = rng.standard_normal(shape).astype(dtype), rng.standard_normal(shape).astype(dtype)
+    c64 = [c.astype(np.float64) for c in coeffs]
+    x64, b64 = x.astype(np.float64), b.astype(np.float64)
+    ct = torch.as_tensor(np.stack(coeffs)).to(dev)
+    xt, bt = torch.as_tensor(x).to(dev), torch.as_tensor(b).to(dev)
+    assert rel(ops.stencil_var_residual(ct, xt, bt), b64 - sg.apply(c64, x64)) < tol
+    assert rel(ops.stencil_var_smooth(ct, xt, bt, 0.8, out=torch.empty_like(xt)), sg.jacobi(c64, x64, b64, 0.8)) < tol
+    cshape = tuple(s // 2 for s in shape)
+    out, loss = torch.empty(cshape, dtype=xt.dtype, device=dev), torch.zeros((), dtype=xt.dtype, device=dev)
+    ops.stencil_var_residual_restrict(ct, xt, bt, 1.0 / 2 ** len(shape), out, loss)
+    r = b64 - sg.apply(c64, x64)
+    assert rel(out, sg.restrict_mean(r)) < tol
+    assert abs(float(loss) - np.mean(r**2)) <= 10 * tol * np.mean(r**2)
+    coarse = ops.stencil_var_coarsen(ct)
+    want = np.stack(sg.coarsen(c64))
+    assert tuple(coarse.shape) == want.shape
+    assert rel(coarse, want) < 10 * tol
+
+
+smooth = lambda *x: 1 + 10 * np.prod([np.sin(np.pi * v) ** 2 for v in x], axis=0)  # noqa: E731
+jump = lambda *x: np.where(np.abs(x[0] - 0.5) < 0.25, 1000.0, 1.0) * np.ones_like(x[0])  # noqa: E731
+
+
+@pytest.mark.parametrize("name,make,limit", [
+    ("poisson 64^3", lambda: sg.poisson_coeffs((64, 64, 64)), 12),
+    ("k jumps 1 : 1000, 64^3", lambda: sg.diffusion_coeffs((64, 64, 64), jump), 13),
+    ("smooth k + reaction, 256^2", lambda: sg.diffusion_coeffs((256, 256), smooth, sigma=5000.0), 12),
+    ("upwind convection 128^2", lambda: sg.add_upwind_convection(sg.poisson_coeffs((128, 128)), 200.0), 24),
+])
+def test_vcycles_contract_on_the_device(dev, name, make, limit):
+    from odil_amd import gmg
+
+    coeffs = torch.as_tensor(np.stack(make())).to(dev)
+    rng = np.random.default_rng(0)
+    xt = torch.as_tensor(rng.standard_normal(tuple(coeffs.shape[1:]))).to(dev)
+    from odil_amd import ops
+
+    b = ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)  # A x_true
+    status = dict()
+    solver = gmg.StencilGMG(coeffs)
+    x = solver.solve(b, tol=1e-10, maxiter=40, status=status)
+    assert status["converged"] and status["niter"] <= limit, (name, status)
+    assert float((x - xt).abs().max()) <= 1e-6 * float(xt.abs().max()), name
+
+
+def newton_step(modname, argv, env):
+    import importlib
+
+    import odil_amd as odil
+
+    for sub in ("poisson", "diffusion"):
+        p = os.path.join(ROOT, "examples", sub)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    ex = importlib.import_module(modname)
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        odil.util.set_log_file(open(os.devnull, "w"))
+        args = ex.parse_args(argv)
+        problem, state = ex.make_problem(args)
+        args.epoch_start, args.epochs = 0, 1
+        seen = []
+        odil.util.optimize(args, "newton", problem, state, lambda s, e, p: seen.append(p.get("linsolver") if hasattr(p, "get") else None))
+        u = state.fields["u"].array.clone()
+        err = ex.error_rms(problem.domain, problem.extra, state, "u")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return u, err, [s for s in seen if s]
+
+
+@pytest.mark.parametrize("kind,ndim,N", [("smooth", 3, 32), ("jump", 3, 32), ("jump", 2, 128)])
+def test_newton_step_with_multigrid_equals_direct_solve(dev, kind, ndim, N):
+    """<= 49152 unknowns: `direct` is the dense Cholesky of M^T M (what the reference's SuperLU computes)."""
+    argv = ["--ndim", str(ndim), "--N", str(N), "--kind", kind]
+    ud, errd, _ = newton_step("diffusion", argv + ["--linsolver", "direct"], {})
+    um, errm, stat = newton_step("diffusion", argv + ["--linsolver", "multigrid", "--linsolver_tol", "1e-12"], {})
+    assert stat and "variable coefficients" in stat[-1]["method"] and stat[-1]["niter"] <= 15, stat
+    scale = float(ud.abs().max())
+    assert float((um - ud).abs().max()) <= 1e-9 * scale, (kind, float((um - ud).abs().max()) / scale)
+    assert errm < 1e-9 and errd < 1e-7  # the problem is linear: one step solves it (rhs = the operator on ref_u)
+
+
+def test_poisson_through_the_general_cycle_equals_the_dedicated_one(dev):
+    argv = ["--ndim", "3", "--N", "64", "--multigrid", "0", "--linsolver", "multigrid", "--linsolver_tol", "1e-11"]
+    ua, _, sa = newton_step("poisson", argv, {})
+    ub, _, sb = newton_step("poisson", argv, {"ODIL_NEWTON_SHORTCUT": "0"})
+    uc, _, sc = newton_step("poisson", argv, {"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil"})
+    assert sb[-1]["method"] == "gmg-vcycle" and "variable coefficients" in sc[-1]["method"], (sb, sc)
+    scale = float(ua.abs().max())
+    assert float((ub - ua).abs().max()) <= 1e-9 * scale and float((uc - ua).abs().max()) <= 1e-9 * scale
+    assert sc[-1]["niter"] <= 13

@@ -15,5 +15,6 @@ if [ -n "$HBM" ]; then
 ( cd /tmp && timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/C -- $CMD > /dev/null 2>&1 )
 ( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/D -- $CMD > /dev/null 2>&1 )
 fi
-python3 profiles/summarize.py $OUT "$TAG: bench.py --config $CFG $*" | grep -v "^at::\|elementwise\|copyBuffer" | cut -c1-900 > $R/gpurun_out/${TAG}_pmc.txt
+# (every kernel of the run is listed, torch's `at::` elementwise / copy kernels included: they are part of what ran)
+python3 profiles/summarize.py $OUT "$TAG: bench.py --config $CFG $*" | cut -c1-900 > $R/gpurun_out/${TAG}_pmc.txt
 grep -E "^k_fwd|^k_gat|^kernel" $R/gpurun_out/${TAG}_pmc.txt | cut -c1-600
