@@ -368,6 +368,11 @@ int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, 
                                            void* stream);
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream);
 int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream);
+/* out[0] = max |a - b|, out[1] = max |b| over n entries in one pass (NaN differences propagate): the comparison by which
+ * a linearised operator's coefficient arrays are recognised as a known stencil (gmg.recognise_poisson) -- no reference
+ * counterpart.  `partials`: odil_reduce_workspace_bytes(). */
+int odil_max_abs_diff_f64(const double* a, const double* b, int64_t n, double* partials, double* out, void* stream);
+int odil_max_abs_diff_f32(const float* a, const float* b, int64_t n, double* partials, float* out, void* stream);
 /* CSR assembly of the same matrix (core.py:1144-1171, :1214): indptr[n+1], indices,
  * data of nnz = nshift*n entries, columns offset by `col_offset`; rows keep ODIL's
  * order (ascending shift index within a row, not sorted by column). */

@@ -23,6 +23,7 @@ bookkeeping over device tensors; there is no CPU path.
 """
 
 import math
+import os
 import pickle
 
 import numpy as np
@@ -871,6 +872,7 @@ class Problem:
         self._fused = None  # fused evaluator (fused.py) once the operator has been recognised
         self._fused_checked = False
         self._traced = None  # generated per-operator kernels (stencil_jit.py)
+        self._jac_traced = None  # ... with the Jacobian kernel of eval_operator_grad (None: not tried, False: not expressible)
         if not isinstance(domain.mod, ModRocm):
             raise NotImplementedError("Unsupported mod={:}".format(domain.mod))
 
@@ -1046,6 +1048,18 @@ class Problem:
         if not state.initialized:
             raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
         domain = self.domain
+        # the generated Jacobian kernel (stencil_codegen._jacobian_kernel): values and every per-shift coefficient array in
+        # ONE pointwise launch from the symbolic derivative of the traced operator; operators it cannot express (dense
+        # columns of parameter arrays, windows, untraceable code) take the autograd evaluation below
+        from . import runtime
+
+        if runtime.enable_trace and int(os.environ.get("ODIL_TRACE_JAC", 1)) and torch.cuda.is_available():
+            if self._jac_traced is None or (self._jac_traced and not self._jac_traced.matches(state)):
+                from . import stencil_jit
+
+                self._jac_traced = stencil_jit.trace_jacobian(self, state) or False
+            if self._jac_traced:
+                return self._jac_traced.eval_operator_grad(state)
         arrays = domain.arrays_from_state(state)
         leaves = [a.detach().requires_grad_(True) for a in arrays]
         shadow = self._shadow_state(state, leaves)
@@ -1119,7 +1133,7 @@ class Problem:
         op = LinearizedOperator(self.domain, state)
         for value, grad in zip(values, grads):
             op.add_output(tuple(value.shape), grad)
-        vector = torch.cat([v.reshape(-1) for v in values])
+        vector = values[0].reshape(-1) if len(values) == 1 else torch.cat([v.reshape(-1) for v in values])
         return vector, op
 
     def linearize(self, state, modsp=None):

@@ -216,6 +216,65 @@ __global__ __launch_bounds__(kBlock) void k_svar_coarsen(const T* __restrict__ c
   cc[I] = diag2 + diag10;
 }
 
+// max |a - b| and max |b| over n entries (recognition of a known operator from its coefficient arrays: one pass over
+// both instead of several elementwise launches); one partial pair per workgroup, combined by a second tiny launch
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_max_abs_diff(const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                                        double* __restrict__ partials) {
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double md = 0.0, mb = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const double vb = (double)b[i], vd = fabs((double)a[i] - vb);
+    md = vd > md || vd != vd ? vd : md;  // (a NaN difference must not pass for a match)
+    mb = fabs(vb) > mb ? fabs(vb) : mb;
+  }
+  __shared__ double sd[kBlock], sb[kBlock];
+  sd[threadIdx.x] = md;
+  sb[threadIdx.x] = mb;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double od = sd[threadIdx.x + off], ob = sb[threadIdx.x + off];
+      if (od > sd[threadIdx.x] || od != od) sd[threadIdx.x] = od;
+      if (ob > sb[threadIdx.x]) sb[threadIdx.x] = ob;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = sd[0];
+    partials[2 * blockIdx.x + 1] = sb[0];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_max_abs_final(const double* __restrict__ partials, int count, T* __restrict__ out) {
+  double md = 0.0, mb = 0.0;
+  for (int i = 0; i < count; ++i) {  // (a few thousand entries at most: one lane, fixed order)
+    const double vd = partials[2 * i], vb = partials[2 * i + 1];
+    md = vd > md || vd != vd ? vd : md;
+    mb = vb > mb ? vb : mb;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (T)md;
+    out[1] = (T)mb;
+  }
+}
+
+template <typename T>
+static int max_abs_diff(const T* a, const T* b, int64_t n, double* partials, T* out, void* stream) {
+  if (!a || !b || !partials || !out || n < 1) {
+    set_error("max_abs_diff: null pointer or n < 1");
+    return ODIL_E_INVAL;
+  }
+  int grid = grid_for(n, kBlock * 8);
+  if (2 * grid > kMaxPartials) grid = kMaxPartials / 2;
+  hipLaunchKernelGGL((k_max_abs_diff<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, b, n, partials);
+  if (int e = check_launch("k_max_abs_diff")) return e;
+  hipLaunchKernelGGL((k_max_abs_final<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, partials, grid, out);
+  return check_launch("k_max_abs_final");
+}
+
 static int svar_fill(SvarArgs& a, const int64_t* shape, int ndim, const char* what) {
   if (ndim < 1 || ndim > 3 || !shape) {
     set_error("%s: ndim %d (1..3 supported)", what, ndim);
@@ -326,6 +385,12 @@ int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, 
                                            const int64_t* shape, int ndim, float scale, double* partials, float* loss,
                                            void* stream) {
   return svar_residual_restrict<float>(coeffs, x, b, coarse, shape, ndim, scale, partials, loss, stream);
+}
+int odil_max_abs_diff_f64(const double* a, const double* b, int64_t n, double* partials, double* out, void* stream) {
+  return max_abs_diff<double>(a, b, n, partials, out, stream);
+}
+int odil_max_abs_diff_f32(const float* a, const float* b, int64_t n, double* partials, float* out, void* stream) {
+  return max_abs_diff<float>(a, b, n, partials, out, stream);
 }
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream) {
   return svar_coarsen<double>(coeffs, coarse, shape, ndim, stream);

@@ -177,6 +177,14 @@ def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss):
     return out
 
 
+def max_abs_diff(a, b):
+    """2-element device tensor (max |a - b|, max |b|), one pass over both arrays."""
+    assert a.numel() == b.numel() and a.dtype == b.dtype
+    out = torch.empty(2, dtype=a.dtype, device=a.device)
+    call("max_abs_diff", a.dtype, ptr(a), ptr(b), c_int64(a.numel()), ptr(reduce_workspace(a.device)), ptr(out), stream_ptr())
+    return out
+
+
 def stencil_var_coarsen(coeffs):
     """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip)."""
     shape = tuple(coeffs.shape[1:])

@@ -1646,8 +1646,43 @@ class _Codegen:
             self._march_gather_kernels(S, mgather)
         self.gathers_done = mgather is not None
         self._standard_gathers(S)
+        if getattr(self, "want_jac", False):
+            self._jacobian_kernel(S)
         self._launchers(S, nout, par_arrays, HEAD)
         return "\n".join(HEAD + S) + "\n"
+
+    def _jacobian_kernel(self, S):
+        """`k_jac`: what `Problem.eval_operator_grad` returns (reference core.py:1313-1361, the input of `linearize`,
+        core.py:1113-1217) as ONE pointwise kernel -- the value of every output and d output / d read for every distinct
+        read (key, shift, loc), i.e. the per-shift coefficient arrays of the Jacobian -- from the SYMBOLIC derivative of the
+        traced DAG (stencil_grad.GradBuilder with the unit seed), instead of one autograd pass per output over a graph
+        of torch elementwise kernels.  Operators whose outputs are windows of the grid, or that differentiate through
+        parameter arrays (dense Jacobian columns), keep the autograd route (TraceUnsupported)."""
+        tr = self.tr
+        items, self.jac_items = [], []  # jac_items[j] = (output position, None for its value | the read's attr)
+        for k, o in enumerate(self.outputs):
+            if o.win is not None or tuple(o.shape) != self.G or self.raw[k]:
+                raise TraceUnsupported("Jacobian kernel: output {} is not a plain residual on the whole grid".format(k))
+            nodes = stencil_grad.subdag(o)
+            if not stencil_grad.differentiable(nodes, self.need):
+                raise TraceUnsupported("Jacobian kernel: parameters below output {} (dense columns)".format(k))
+            gb = stencil_grad.GradBuilder(tr, self.G, self.need, stop=())
+            items.append(("@jv{}".format(k), gb.real(o)))
+            self.jac_items.append((k, None))
+            adj = gb.adjoints(o, gb.const(1.0), nodes) if self.need.get(o.idx, False) else dict()
+            for ridx in sorted(adj):
+                expr = adj[ridx]
+                if expr is None:
+                    continue
+                items.append(("@jd{}_{}".format(k, ridx), expr))
+                self.jac_items.append((k, tuple(tr.nodes[ridx].attr)))
+        if len(items) > 96:
+            raise TraceUnsupported("Jacobian kernel: {} arrays".format(len(items)))
+        saved = dict(self.gather_reads_sources)
+        S.append("struct JacP {{ T* p[{}]; }};".format(len(items)))
+        self.jac_blocks = self._gather_kernel(S, "k_jac", items, "const JacP jp, const AdamP ad", lambda k: "jp.p[{}]".format(k),
+                                              lambda k: "ad")
+        self.gather_reads_sources = saved  # (bookkeeping of the optimizer fusion: the Jacobian kernel is not a gather)
 
     def _standard_gathers(self, S):
         if self.gathers_done:
@@ -1784,6 +1819,14 @@ class _Codegen:
         S.append("  }")
         S.append("  return (int)hipGetLastError();")
         S.append("}")
+        if getattr(self, "jac_items", None):
+            S.append('extern "C" int jit_jac(const Args* a, void* const* ptrs, void* stream) {')
+            S.append("  JacP jp;")
+            S.append("  for (int k = 0; k < {}; ++k) jp.p[k] = (T*)ptrs[k];".format(len(self.jac_items)))
+            S.append("  const AdamP ad = {nullptr, nullptr, nullptr, (T)0, (T)0, (T)0, (T)0, nullptr};")
+            S.append("  hipLaunchKernelGGL(k_jac, dim3({}), dim3(NB), 0, (hipStream_t)stream, *a, jp, ad);".format(self.jac_blocks))
+            S.append("  return (int)hipGetLastError();")
+            S.append("}")
         # the argument block: sized last (the gradient expressions add host scalars of their own)
         nsrc = max(1, len(self.src_keys))
         slab_members = ""

@@ -122,7 +122,9 @@ def trace_outputs(problem, state, only=None):
 class TracedOperator:
     """loss / gradient of one user operator through its generated kernels."""
 
-    def __init__(self, problem, state, only=None):
+    def __init__(self, problem, state, only=None, jac=False):
+        """jac: also generate `k_jac`, the Jacobian coefficient arrays of `Problem.eval_operator_grad` (a library of its own:
+        the Newton driver asks for it, the gradient optimizers never pay for it)."""
         from .core import Field, MultigridField
 
         domain = problem.domain
@@ -133,6 +135,7 @@ class TracedOperator:
         self.offgrid = [(k, e, tr.param_tape.slice_for(e.param_ids())) for k, e in tr.offgrid]
         self.param_tape = tr.param_tape
         cg = _Codegen(tr, outs, raw, G, state)
+        cg.want_jac = bool(jac)
         # ... as ONE generated kernel when the taped operations have an elementwise form (param_expr.py); else the torch
         # replay of _eval_offgrid
         self.par_outputs = None
@@ -216,6 +219,8 @@ class TracedOperator:
         self.lib.jit_gather.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.jit_gather_adam.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 4 + [
             ctypes.c_void_p, ctypes.c_void_p]
+        if getattr(cg, "jac_items", None):
+            self.lib.jit_jac.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
         if cg.merged:
             self.lib.jit_gather_all.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [
                 ctypes.c_double] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
@@ -344,6 +349,40 @@ class TracedOperator:
 
     # ---- evaluation ---------------------------------------------------------------------------
     def _launch(self, state):
+        keep = self._bind(state)
+        rc = self.lib.jit_fwd(ctypes.byref(self.args), ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("traced operator launch failed: hip error {}".format(rc))
+        return keep
+
+    def eval_operator_grad(self, state):
+        """values, grads, names of `Problem.eval_operator_grad` (reference core.py:1313-1361) from the generated `k_jac`:
+        per output its value array and {(key, shift, loc): d output / d read}, one launch, no autograd graph."""
+        cg = self.cg
+        if not getattr(cg, "jac_items", None):
+            raise RuntimeError("this operator was traced without its Jacobian kernel")
+        keep = self._bind(state)
+        dev, dt = self.out.device, self.tr.torch_dtype
+        n = len(cg.jac_items)
+        arrays = [torch.empty(self.G, dtype=dt, device=dev) for _ in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[a.data_ptr() for a in arrays])
+        rc = self.lib.jit_jac(ctypes.byref(self.args), ptrs, ops.stream_ptr())
+        if rc != 0:
+            raise RuntimeError("traced Jacobian launch failed: hip error {}".format(rc))
+        del keep
+        nout = len(self.raw)
+        values, grads = [None] * nout, [dict() for _ in range(nout)]
+        for (k, attr), a in zip(cg.jac_items, arrays):
+            if attr is None:
+                values[k] = a
+            else:
+                key, shift, loc, _ = attr
+                grads[k][(key, tuple(int(v) for v in shift), loc)] = a
+        return values, grads, list(self.names)
+
+    def _bind(self, state):
+        """The argument block filled for `state`: regular arrays of the fields (multigrid syntheses launched), parameter
+        pointers, host scalars.  Returns the tensors that must stay alive until the launch that follows is queued."""
         from .core import MultigridField
 
         domain, cg = self.domain, self.cg
@@ -394,10 +433,6 @@ class TracedOperator:
                 raise RuntimeError("Array unknown '{}' must be a contiguous {} tensor".format(key, self.tr.torch_dtype))
             self.args.par[i] = arr.data_ptr()
             i += 1
-        stream = ops.stream_ptr()
-        rc = self.lib.jit_fwd(ctypes.byref(self.args), stream)
-        if rc != 0:
-            raise RuntimeError("traced operator launch failed: hip error {}".format(rc))
         return keep
 
     def eval_loss_grad_adam(self, state, m, v, alpha, omb1, omb2, eps):
@@ -644,6 +679,25 @@ class TracedGroups:
             for k, tk, rk in zip(positions, t, r):
                 terms[k], norms[k] = tk, rk
         return loss, list(self.gviews), terms, self.names, norms
+
+
+def trace_jacobian(problem, state):
+    """A TracedOperator with the Jacobian kernel for `Problem.eval_operator_grad`, or None (reason logged) when the operator
+    has no pointwise form or its Jacobian needs dense columns / windows (the autograd route then stays)."""
+    from .core import Field
+    from .util import printlog
+
+    if not all(isinstance(f, Field) for f in state.fields.values()):
+        return None  # (`linearize` takes plain fields; parameter arrays mean dense Jacobian columns)
+    try:
+        return TracedOperator(problem, state, jac=True)
+    except TraceUnsupported as e:
+        printlog("odil_amd: Jacobian not generated ({}); eval_operator_grad uses autograd".format(e))
+    except FileNotFoundError as e:
+        if not int(os.environ.get("ODIL_TRACE_FALLBACK", 0)):
+            raise RuntimeError("odil_amd: the Jacobian kernel cannot be built here ({}); set ODIL_TRACE_FALLBACK=1 to accept the "
+                               "autograd evaluation".format(e)) from e
+    return None
 
 
 def trace(problem, state):

@@ -323,7 +323,9 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         delta = _poisson_newton_step(problem, state, args, linstatus)
         if delta is None:
             vector, matrix = problem.linearize_device(state)
-            delta = solve(matrix, -vector, args, linstatus, getattr(args, "linsolver", "direct"))
+            from . import ops as _ops
+
+            delta = solve(matrix, _ops.scale(vector.contiguous(), -1.0), args, linstatus, getattr(args, "linsolver", "direct"))
         if getattr(args, "linsolver_verbose", 0):
             printlog(linstatus)
         from . import ops

@@ -66,7 +66,7 @@ def interp_by_mod(u, loc, mod, depth=1):
 
 
 def locs_of(g):
-    return sorted({k.split("/")[0] for k in g.files})
+    return sorted({k.split("/")[0] for k in g.files if k.endswith("/u")})
 
 
 def test_restriction_written_on_mod_convolution_gives_the_reference_values(dev, mod):
@@ -77,7 +77,8 @@ def test_restriction_written_on_mod_convolution_gives_the_reference_values(dev, 
         assert rel(coarse, g[f"{loc}/coarse"]) < 2e-15, loc
         (gu,) = torch.autograd.grad(coarse, u, torch.as_tensor(g[f"{loc}/gcoarse"], device=dev))
         assert rel(gu, g[f"{loc}/gu"]) < 2e-15, loc
-        assert rel(restrict_by_mod(u.detach(), loc, mod, depth=2), g[f"{loc}/coarse2"]) < 4e-15, loc
+        if f"{loc}/coarse2" in g.files:
+            assert rel(restrict_by_mod(u.detach(), loc, mod, depth=2), g[f"{loc}/coarse2"]) < 4e-15, loc
 
 
 def test_prolongation_written_on_mod_conv_transpose_gives_the_reference_values(dev, mod):
@@ -88,7 +89,8 @@ def test_prolongation_written_on_mod_conv_transpose_gives_the_reference_values(d
         assert rel(fine, g[f"{loc}/fine"]) < 4e-15, loc
         (gu,) = torch.autograd.grad(fine, u, torch.as_tensor(g[f"{loc}/gfine"], device=dev))
         assert rel(gu, g[f"{loc}/gu"]) < 4e-15, loc
-        assert rel(interp_by_mod(u.detach(), loc, mod, depth=2), g[f"{loc}/fine2"]) < 8e-15, loc
+        if f"{loc}/fine2" in g.files:
+            assert rel(interp_by_mod(u.detach(), loc, mod, depth=2), g[f"{loc}/fine2"]) < 8e-15, loc
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-14), (torch.float32, 2e-6)])
