@@ -39,8 +39,8 @@ def run(problem, state, args, optname, epochs, warmup=2):
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     odil.util.set_log_file(open(os.devnull, "w"))
-    if optname != "newton" and warmup:
-        args.epoch_start, args.epochs = 0, warmup
+    if warmup:  # (Newton too: the first step builds its Jacobian kernel and the solver's work buffers)
+        args.epoch_start, args.epochs = 0, warmup if optname != "newton" else 1
         try:
             odil.util.optimize(args, optname, problem, state, None)
         except odil.EarlyStopError:

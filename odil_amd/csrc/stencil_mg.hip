@@ -90,34 +90,63 @@ __global__ __launch_bounds__(kBlock) void k_svar_smooth(const T* __restrict__ c,
   }
 }
 
-// one thread per COARSE cell; children (2 I + k) of every present axis
+// one thread per COARSE cell; its two children along x are one 16-byte (f64) pack of every stream: the coefficient
+// arrays, b and x are read once, fully coalesced (adjacent threads, adjacent packs); the y / z neighbour rows of x come
+// as packs too (cache hits of the neighbouring threads' own rows), the two x neighbours outside the pack as scalars
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_svar_residual_restrict(const T* __restrict__ c, const T* __restrict__ x,
                                                                   const T* __restrict__ b, T* __restrict__ coarse,
                                                                   SvarArgs a, SvarArgs ca, T scale,
                                                                   double* __restrict__ partials) {
+  typedef typename Vec2<T>::type T2;
   // a contiguous chunk of coarse cells per workgroup: the order of the partial sums does not depend on the grid
   const int64_t per = (ca.size + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per;
   const int64_t hi = lo + per < ca.size ? lo + per : ca.size;
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
   double local = 0.0;
   for (int64_t I = lo + threadIdx.x; I < hi; I += kBlock) {
     int64_t cid[3];
     svar_decode(I, ca, cid);
     T sum = T(0);
-    const int k0 = a.has[0] ? 2 : 1, k1 = a.has[1] ? 2 : 1, k2 = a.has[2] ? 2 : 1;
+    const int k0 = a.has[0] ? 2 : 1, k1 = a.has[1] ? 2 : 1;
+    const int64_t x0 = 2 * cid[2];
+    const int64_t xl = x0 == 0 ? X - 1 : x0 - 1, xr = x0 + 2 >= X ? 0 : x0 + 2;
     for (int p = 0; p < k0; ++p)
-      for (int q = 0; q < k1; ++q)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s >= k2) continue;
-          const int64_t id[3] = {a.has[0] ? 2 * cid[0] + p : 0, a.has[1] ? 2 * cid[1] + q : 0,
-                                 a.has[2] ? 2 * cid[2] + s : 0};
-          const int64_t i = (id[0] * a.n[1] + id[1]) * a.n[2] + id[2];
-          const T r = b[i] - svar_apply<T>(c, x, a, i, id);
-          local += (double)(r * r);
-          sum = sum + r;
+      for (int q = 0; q < k1; ++q) {
+        const int64_t z = a.has[0] ? 2 * cid[0] + p : 0, y = a.has[1] ? 2 * cid[1] + q : 0;
+        const int64_t row = z * sz + y * sy, i = row + x0;
+        const T2 xc = *(const T2*)(x + i);
+        const T2 c0 = *(const T2*)(c + i);
+        const T2 bb = *(const T2*)(b + i);
+        const T2 cxm = *(const T2*)(c + (int64_t)a.slot[2] * a.size + i);
+        const T2 cxp = *(const T2*)(c + (int64_t)(a.slot[2] + 1) * a.size + i);
+        const T wl = x[row + xl], er = x[row + xr];
+        T2 ax = c0 * xc;
+        ax.x = ax.x + cxm.x * wl;
+        ax.x = ax.x + cxp.x * xc.y;
+        ax.y = ax.y + cxm.y * xc.x;
+        ax.y = ax.y + cxp.y * er;
+        if (a.has[1]) {
+          const int64_t ym = (y == 0 ? Y - 1 : y - 1) * sy + z * sz + x0, yp = (y == Y - 1 ? 0 : y + 1) * sy + z * sz + x0;
+          const T2 cm = *(const T2*)(c + (int64_t)a.slot[1] * a.size + i);
+          const T2 cp = *(const T2*)(c + (int64_t)(a.slot[1] + 1) * a.size + i);
+          ax = ax + cm * *(const T2*)(x + ym);
+          ax = ax + cp * *(const T2*)(x + yp);
         }
+        if (a.has[0]) {
+          const int64_t zm = (z == 0 ? Z - 1 : z - 1) * sz + y * sy + x0, zp = (z == Z - 1 ? 0 : z + 1) * sz + y * sy + x0;
+          const T2 cm = *(const T2*)(c + (int64_t)a.slot[0] * a.size + i);
+          const T2 cp = *(const T2*)(c + (int64_t)(a.slot[0] + 1) * a.size + i);
+          ax = ax + cm * *(const T2*)(x + zm);
+          ax = ax + cp * *(const T2*)(x + zp);
+        }
+        const T2 r = bb - ax;
+        local += (double)(r.x * r.x) + (double)(r.y * r.y);
+        sum = sum + r.x;
+        sum = sum + r.y;
+      }
     coarse[I] = scale * sum;
   }
   const double total = block_sum(local);

@@ -137,8 +137,10 @@ def test_newton_step_with_multigrid_equals_direct_solve(dev, kind, ndim, N):
     # (1e-12 of the right-hand side: ~0.17 - 0.25 per cycle towards the rounding floor)
     assert stat and "variable coefficients" in stat[-1]["method"] and stat[-1]["niter"] <= 25, stat
     scale = float(ud.abs().max())
-    assert float((um - ud).abs().max()) <= 1e-9 * scale, (kind, float((um - ud).abs().max()) / scale)
-    assert errm < 1e-9 and errd < 1e-7  # the problem is linear: one step solves it (rhs = the operator on ref_u)
+    # the two iterates agree to what the DIRECT route's conditioning allows (it factorises M^T M: cond(M)^2, ~1e14 with the
+    # 1 : 1000 jump at 128^2); against the exact discrete solution (rhs = the operator on ref_u) multigrid is the closer one
+    assert float((um - ud).abs().max()) <= 1e-7 * scale, (kind, float((um - ud).abs().max()) / scale)
+    assert errm < 1e-9 and errd < 1e-7  # the problem is linear: one step solves it
 
 
 def test_poisson_through_the_general_cycle_equals_the_dedicated_one(dev):
