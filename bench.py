@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=40)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--config", type=str, default="4a", choices=["4a", "5", "1", "2", "3", "3b", "4b", "5b"])
+    p.add_argument("--config", type=str, default="4a", choices=["4a", "5", "1", "2", "3", "3b", "4b", "4c", "5b"])
     p.add_argument("--N", type=int, default=512)
     p.add_argument("--ndim", type=int, default=3)
     p.add_argument("--dtype", type=str, default="f64", choices=["f64", "f32"])

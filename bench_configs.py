@@ -20,7 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-for sub in ("poisson", "heat", "velocity_from_tracer"):
+for sub in ("poisson", "heat", "velocity_from_tracer", "diffusion"):
     sys.path.insert(0, os.path.join(ROOT, "examples", sub))
 
 import odil_amd as odil  # noqa: E402
@@ -90,6 +90,10 @@ CONFIGS = {
     "4a": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512))], "adam", 20, 2, "poisson 3D {0}^3 adam f64 mg"),
     "4b": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512)), "--multigrid", "0", "--linsolver", "multigrid",
                                   "--linsolver_tol", "1e-10"], "newton", 1, 1, "poisson 3D {0}^3 newton + gmg f64 (second step: work buffers exist)"),
+    # not a BASELINE config: the general Newton route on an operator with VARIABLE coefficients (examples/diffusion)
+    "4c": ("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver", "multigrid",
+                                   "--linsolver_tol", "1e-10"], "newton", 1, 1,
+           "diffusion div(k grad u), k jumps 1 : 1000, 3D {0}^3 newton + variable-coefficient gmg f64"),
     "5": ("veltracer", lambda sc: ["--Nt", str(sc(128)), "--Nx", str(sc(256)), "--Ny", str(sc(256))], "adam", 20, 2,
           "veltracer {0}x{1}x{1} adam f32 mg (traced operator)"),
     # (20 epochs per `optimize` call: the call's own set-up -- 17 GB of moment arrays allocated and zeroed, the packed

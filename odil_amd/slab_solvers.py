@@ -258,6 +258,192 @@ class SlabPoissonNewtonCG:
         return loss0, loss1
 
 
+class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
+    """The Newton step of the slab-decomposed Poisson problem solved by GEOMETRIC MULTIGRID -- the slab form of
+    `gmg.PoissonGMG` ("Newton: matrix-free M / M^T apply = same halo pattern"; the reference's Newton driver,
+    src/odil/util.py:152-187, solves M^T M delta = -M^T f with SuperLU, linsolver.py:17-26; for the square nonsingular
+    Laplacian M delta = -f has the same solution).  `SlabPoissonNewtonCG` above is unpreconditioned CG on the normal
+    equations: O(N) iterations; this one needs ~12 cycles at any size.
+
+    Levels: the box (world nz, N, N) is coarsened by 2 along every axis while every rank keeps >= 2 planes and the
+    cross-section extents stay even; level arrays are ghost-extended like the epochs' (`slab.SlabLevel`, G = 2 planes per
+    interior interface).  One V(2, 2) cycle per level, everything with the unmodified single-GPU kernels on the extended
+    arrays (an array end that is a ghost plane is treated as a wall by the kernel: only the ghost planes themselves see that):
+      * two planes of x to each neighbour, then TWO Chebyshev-weighted Jacobi sweeps (the first leaves owned + inner ghost
+        planes valid, the second the owned planes);
+      * one plane of x, the residual A x - b on the owned planes (its squared norm summed over the ranks by one all-gather),
+        full-weighting restriction of the owned planes (pairs of owned planes: no exchange), one plane of the coarse
+        right-hand side to each neighbour;
+      * the coarse correction; one plane of it to each neighbour, then x += P x_c by the multigrid decomposition's
+        prolongation on the ghost-extended coarse array (`SlabLevel.inner`: exact on owned + inner ghost planes);
+      * two planes of x, two sweeps.
+    Five exchanges per level and cycle, 1 - 2 planes each (512^2 f64 planes: 2 - 4 MB at the finest level, halved twice per
+    level).  Below the last slab level the problem is AGGLOMERATED: the coarse right-hand side is all-gathered
+    (a few thousand numbers), every rank runs the remaining cycle on the whole coarse box and keeps its planes -- the same
+    bits on every rank, no further exchange."""
+
+    def __init__(self, N, rank, world, dtype=torch.float64, device=None, rhs_global=None, nz=None, nu=2):
+        super().__init__(N, rank, world, dtype=dtype, device=device, rhs_global=rhs_global, nz=nz)
+        self.nu = nu
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        nz = self.lv.nz
+        self.mlv, self.mh2 = [self.lv], [list(self.h2)]
+        shape = (nz, N, N)
+        while all(s % 2 == 0 for s in shape) and shape[0] // 2 >= 2 and shape[1] // 2 >= 2:
+            shape = tuple(s // 2 for s in shape)
+            self.mlv.append(slab.SlabLevel(shape[0], shape[1], shape[2], rank, world))
+            self.mh2.append([v * npdt(4) for v in self.mh2[-1]])
+        # the agglomerated box below the last slab level (None when that level cannot be coarsened at all)
+        last = self.mlv[-1]
+        self.agg_shape = None
+        if last.nz % 2 == 0 and last.ny % 2 == 0 and last.nx % 2 == 0:
+            self.agg_shape = (world * last.nz // 2, last.ny // 2, last.nx // 2)
+            self.agg_h2 = [v * npdt(4) for v in self.mh2[-1]]
+        mk = lambda lv: torch.zeros(lv.shape, dtype=dtype, device=device)
+        self.mx = [None] + [mk(lv) for lv in self.mlv[1:]]
+        self.mb = [None] + [mk(lv) for lv in self.mlv[1:]]
+        self.spare = [mk(lv) for lv in self.mlv]
+        self.res = [mk(lv) for lv in self.mlv]
+        self._dense = dict()
+
+    # ---- pieces -------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def weights(n):
+        lo, hi = 1.0 / 3.0, 2.0  # the part of the spectrum of D^-1 A the coarse grid cannot see (gmg.PoissonGMG.weights)
+        mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+        return [1.0 / (mid - half * np.cos(np.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
+
+    def _halo_planes(self, comm, a, lv, planes):
+        """`planes` (1 or 2) boundary planes of `a` into the neighbours' ghost planes nearest the interface."""
+        lo = a[lv.g_lo: lv.g_lo + planes] if self.rank > 0 else None
+        hi = a[lv.g_lo + lv.nz - planes: lv.g_lo + lv.nz] if self.rank < self.world - 1 else None
+        recv_lo, recv_hi = comm.exchange("halo", lo, hi)
+        if recv_lo is not None:
+            a[lv.g_lo - planes: lv.g_lo].copy_(recv_lo.view(planes, lv.ny, lv.nx))
+        if recv_hi is not None:
+            a[lv.g_lo + lv.nz: lv.g_lo + lv.nz + planes].copy_(recv_hi.view(planes, lv.ny, lv.nx))
+
+    def _smooth(self, comm, l, x, b):
+        """`nu` sweeps, two per exchange of two planes; returns the tensor holding the iterate (owned planes valid)."""
+        lv, w = self.mlv[l], self.weights(self.nu)
+        k = 0
+        while k < len(w):
+            pair = w[k: k + 2]
+            self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            for wk in pair:
+                y = self.spare[l]
+                self.ops.poisson_jacobi(x, b, self.mh2[l], wk, out=y)
+                self.spare[l] = x
+                x = y
+            k += 2
+        return x
+
+    def _residual(self, comm, l, x, b, out):
+        """out = A x - b on the owned planes; -> its squared norm over all ranks."""
+        lv = self.mlv[l]
+        self._halo_planes(comm, x, lv, 1)
+        self.ops.poisson_residual(x, b, self.mh2[l], fu=out, loss=self.part, zrange=(lv.g_lo, lv.g_lo + lv.nz), denom=1.0)
+        return float(comm.exchange("gather", self.part.to(torch.float64).reshape(1), None).sum())
+
+    def _dense_solve(self, b, h2):
+        """A^-1 b on a box of at most 512 cells (the residual kernel applied to unit vectors, factorised once)."""
+        shape = tuple(b.shape)
+        inv = self._dense.get(shape)
+        if inv is None:
+            n = int(np.prod(shape))
+            eye = torch.eye(n, dtype=self.dtype, device=self.device)
+            zero = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            cols = [self.ops.poisson_residual(eye[j].view(shape).contiguous(), zero, h2)[0].reshape(-1) for j in range(n)]
+            amat = torch.stack(cols, dim=1).cpu().numpy().astype(np.float64)
+            inv = self._dense[shape] = torch.as_tensor(np.linalg.inv(amat), dtype=self.dtype).to(self.device)
+        return (inv @ b.reshape(-1)).view(shape)
+
+    def _local_cycle(self, x, b, h2):
+        """One V(nu, nu) cycle on a WHOLE box held by this rank (the agglomerated coarse problem): returns the iterate."""
+        shape = tuple(b.shape)
+        if int(np.prod(shape)) <= 512 or any(s % 2 or s // 2 < 2 for s in shape):
+            if int(np.prod(shape)) <= 512:
+                return self._dense_solve(b, h2)
+            for _ in range(20):  # (cannot coarsen further: by iteration)
+                for wk in self.weights(2):
+                    x = self.ops.poisson_jacobi(x, b, h2, wk, out=torch.empty_like(x))
+            return x
+        for wk in self.weights(self.nu):
+            x = self.ops.poisson_jacobi(x, b, h2, wk, out=torch.empty_like(x))
+        r, _ = self.ops.poisson_residual(x, b, h2)
+        bc = self.ops.restrict_to_coarser(r, "ccc").mul_(-1.0)
+        xc = self._local_cycle(torch.zeros_like(bc), bc, [v * 4 for v in h2])
+        x = self.ops.interp_add(xc.contiguous(), "ccc", add=x)
+        for wk in self.weights(self.nu):
+            x = self.ops.poisson_jacobi(x, b, h2, wk, out=torch.empty_like(x))
+        return x
+
+    def _coarse_correction(self, comm, l, r):
+        """x_c with A_c x_c ~= -R r for the residual r = A x - b of level l (owned planes valid); returned on level l + 1's
+        ghost-extended array with owned + inner ghost planes valid."""
+        lv = self.mlv[l]
+        if l + 1 < len(self.mlv):
+            lc = self.mlv[l + 1]
+            bc, xc = self.mb[l + 1], self.mx[l + 1]
+            lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")).mul_(-1.0)
+            self._halo_planes(comm, bc, lc, 1)
+            xc.zero_()
+            xc = self._vcycle(comm, l + 1, xc, bc)
+            self.mx[l + 1] = xc
+            self._halo_planes(comm, xc, lc, 1)
+            return lc.inner(xc)
+        # agglomerated: every rank gets the whole coarse right-hand side and solves the whole coarse problem alike
+        part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc").mul_(-1.0)
+        bc = comm.exchange("gather", part.contiguous(), None).reshape(self.agg_shape)
+        xc = self._local_cycle(torch.zeros_like(bc), bc.contiguous(), self.agg_h2)
+        nzc = lv.nz // 2
+        lo = self.rank * nzc - (1 if self.rank > 0 else 0)
+        hi = (self.rank + 1) * nzc + (1 if self.rank < self.world - 1 else 0)
+        return xc[lo:hi]
+
+    def _vcycle(self, comm, l, x, b, pre=True):
+        """One V(nu, nu) cycle on level l of the slab hierarchy: returns the tensor holding the iterate (owned planes)."""
+        lv = self.mlv[l]
+        if pre:
+            x = self._smooth(comm, l, x, b)
+        r = self.res[l]
+        self._last_res2 = self._residual(comm, l, x, b, r)
+        if l + 1 < len(self.mlv) or self.agg_shape is not None:
+            xc = self._coarse_correction(comm, l, r)
+            y = self.spare[l]
+            self.ops.interp_add(xc.contiguous(), "ccc", add=x, out=y)
+            self.spare[l] = x
+            x = y
+        return self._smooth(comm, l, x, b)
+
+    # ---- the Newton step ----------------------------------------------------------------------------------------------
+    def step(self, comm, maxiter=40, tol=1e-10, damp=0.0):
+        """One Newton step u <- u + delta with A delta = -f(u) by V-cycles; -> (loss before, loss after).
+        self.status: cycles, relative residual of the linear system, converged."""
+        assert not damp, "the multigrid step solves the undamped system"
+        loss0 = self.residual(comm, self.u, self.f)
+        lv = self.lv
+        b = self.z
+        b.copy_(self.f).mul_(-1.0)  # owned planes valid; the neighbours' planes of b follow
+        self._halo_planes(comm, b, lv, 1)
+        bb = float(comm.exchange("gather", (lv.owned(b).to(torch.float64) ** 2).sum().reshape(1), None).sum())
+        x = torch.zeros_like(self.u)
+        it, rel = 0, 1.0
+        while it < maxiter:
+            x = self._vcycle(comm, 0, x, b)
+            it += 1
+            # (the residual a cycle forms on its way down belongs to its pre-smoothed iterate: a cheap, slightly
+            # pessimistic convergence test that costs no pass of its own)
+            rel = float(np.sqrt(self._last_res2 / bb)) if bb > 0 else 0.0
+            if rel <= tol:
+                break
+        self.owned(self.u).add_(self.owned(x))
+        loss1 = self.residual(comm, self.u, self.f)
+        self.status = dict(niter=it, residual=rel, converged=rel <= tol, method="slab gmg-vcycle ({} slab levels{})".format(
+            len(self.mlv), " + agglomerated {}".format(self.agg_shape) if self.agg_shape else ""))
+        return loss0, loss1
+
+
 class ReplicatedTailVectors(SlabLbfgsVectors):
     """`SlabLbfgsVectors` for a local vector [owned entries | entries EVERY rank holds] (coarse levels agglomerated on
     every rank, network parameters): the tail takes part in every rank's vector algebra -- all ranks then update it alike,

@@ -89,3 +89,20 @@ class PlaneList:
 
     def unpack_add(self, arr, buf):
         arr.index_add_(0, self.index, buf[self.start: self.count])
+
+
+def poisson_jacobi(u, rhs, h2, omega, out):
+    """out = u - omega (A u - rhs) / diag(A) (odil_poisson_jacobi): diag from the oracle's coefficient arrays."""
+    dw = [np.sqrt(h) for h in h2]
+    un, bn = _np(u), _np(rhs)
+    diag = onp.poisson_jac_coeffs(un.shape, dw)[(0,) * un.ndim]
+    res = un - omega * (onp.poisson_residual(un, bn, dw)) / diag
+    out.copy_(torch.from_numpy(np.ascontiguousarray(res)))
+    return out
+
+
+def restrict_to_coarser(u, loc, depth=1):
+    res = _np(u)
+    for _ in range(depth):
+        res = onp.restrict_to_coarser(res, loc)
+    return torch.from_numpy(np.ascontiguousarray(res))

@@ -233,3 +233,70 @@ def test_slab_traced_lbfgs_thread_ranks_follow_the_undivided_run(which, world, n
                 want = ref[:, r * k:(r + 1) * k]
             assert got.shape == want.shape
             assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want))), (i, r)
+
+
+def gmg_rank(rank, world, comm, N, rhs, nz=None, tol=1e-13):
+    import slab_oracle_ops
+
+    from odil_amd import slab_solvers
+
+    slab_solvers.hip_ops = slab_oracle_ops
+    run = slab_solvers.SlabPoissonNewtonGMG(N, rank, world, dtype=torch.float64, device=torch.device("cpu"),
+                                            rhs_global=torch.from_numpy(rhs), nz=nz)
+    loss0, loss1 = run.step(comm, maxiter=40, tol=tol)
+    return loss0, loss1, dict(run.status), run.owned(run.u).clone().numpy()
+
+
+@pytest.mark.parametrize("world,N,nz", [(2, 8, 8), (4, 8, 4), (3, 8, 8), (2, 16, 16)])
+def test_slab_newton_multigrid_step_solves_the_undivided_problem(world, N, nz):
+    """The slab form of the geometric multigrid (two to three slab levels, the rest agglomerated) lands on the exact
+    discrete solution of the UNDIVIDED box -- the Newton iterate of the reference's direct solve -- in a dozen cycles,
+    with the same cycle count as one rank holding every plane."""
+    from odil_amd.slab import LocalComm
+    from odil_amd.slab_solvers import run_threads
+
+    cshape = (nz * world, N, N)
+    dw = (1.0 / N,) * 3
+    ref_u = np.random.default_rng(3).standard_normal(cshape)
+    rhs = onp.poisson_discrete_rhs(ref_u, dw)
+    results = run_threads(world, lambda rank, comm: gmg_rank(rank, world, comm, N, rhs, nz=nz))
+    scale = np.abs(ref_u).max()
+    for r, (loss0, loss1, status, u) in enumerate(results):
+        assert abs(loss0 - np.mean(rhs**2)) <= 1e-12 * np.mean(rhs**2)
+        assert status["converged"] and status["niter"] <= 20, status
+        assert loss1 < 1e-18 * loss0
+        np.testing.assert_allclose(u, ref_u[r * nz:(r + 1) * nz], rtol=0, atol=1e-9 * scale)
+    # every rank took the same decisions
+    assert len({res[2]["niter"] for res in results}) == 1
+    # one rank holding every plane (no exchange at all): the same cycle count, the same solution to round-off
+    loss0, loss1, status, u = gmg_rank(0, 1, LocalComm(), N, rhs, nz=nz * world)
+    # (its hierarchy is deeper -- a rank with few planes agglomerates earlier --, so the counts may differ by a few cycles)
+    assert abs(status["niter"] - results[0][2]["niter"]) <= 3
+    np.testing.assert_allclose(u, np.concatenate([res[3] for res in results]), rtol=0, atol=1e-9 * scale)
+
+
+def gmg_gloo_worker(rank, world, N, nz, port, out):
+    from odil_amd.slab import TorchDistComm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cshape = (nz * world, N, N)
+        ref_u = np.random.default_rng(3).standard_normal(cshape)
+        rhs = onp.poisson_discrete_rhs(ref_u, (1.0 / N,) * 3)
+        res = gmg_rank(rank, world, TorchDistComm(rank, world), N, rhs, nz=nz)
+        torch.save(res, os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_newton_multigrid_two_gloo_ranks(tmp_path):
+    world, N, nz = 2, 8, 8
+    port = 29500 + (os.getpid() + 311) % 2000
+    mp.spawn(gmg_gloo_worker, args=(world, N, nz, port, str(tmp_path)), nprocs=world, join=True)
+    ref_u = np.random.default_rng(3).standard_normal((nz * world, N, N))
+    for r in range(world):
+        loss0, loss1, status, u = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
+        assert status["converged"] and loss1 < 1e-18 * loss0
+        np.testing.assert_allclose(u, ref_u[r * nz:(r + 1) * nz], rtol=0, atol=1e-9 * np.abs(ref_u).max())

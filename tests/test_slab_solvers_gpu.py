@@ -116,6 +116,45 @@ def test_slab_newton_cg_emulated_ranks_solve_the_undivided_problem(world):
         np.testing.assert_allclose(u, ref_u[r * N:(r + 1) * N], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("world,N,nz", [(2, 16, 16), (4, 32, 8), (3, 64, 64)])
+def test_slab_newton_multigrid_emulated_ranks_solve_the_undivided_problem(world, N, nz):
+    """`SlabPoissonNewtonGMG` on the HIP kernels, ranks as threads on one GPU: the Newton step by slab-decomposed V-cycles
+    lands on the exact discrete solution of the undivided box (the iterate of the reference's direct solve,
+    linsolver.py:17-26) in a dozen cycles -- where the unpreconditioned CG of the test above needs hundreds -- and on the
+    iterate of the single-GPU `gmg.PoissonGMG` for the same box."""
+    from odil_amd import gmg
+    from odil_amd.slab_solvers import SlabPoissonNewtonGMG, run_threads
+
+    dev = torch.device("cuda:0")
+    cshape = (nz * world, N, N)
+    dw = (1.0 / N,) * 3
+    gen = torch.Generator().manual_seed(3)
+    ref_u = torch.randn(cshape, generator=gen, dtype=torch.float64)
+    from odil_amd import ops
+
+    h2 = [np.float64(1.0 / N) ** 2] * 3
+    rhs, _ = ops.poisson_residual(ref_u.to(dev), torch.zeros(cshape, dtype=torch.float64, device=dev), h2)
+    rhs_host = rhs.cpu()
+
+    def body(rank, comm):
+        torch.cuda.set_device(dev)
+        run = SlabPoissonNewtonGMG(N, rank, world, dtype=torch.float64, device=dev, rhs_global=rhs_host, nz=nz)
+        loss0, loss1 = run.step(comm, maxiter=40, tol=1e-13)
+        return loss0, loss1, dict(run.status), run.owned(run.u).cpu()
+
+    results = run_threads(world, body)
+    scale = float(ref_u.abs().max())
+    for r, (loss0, loss1, status, u) in enumerate(results):
+        assert status["converged"] and status["niter"] <= 20, status
+        assert loss1 < 1e-18 * loss0
+        assert float((u - ref_u[r * nz:(r + 1) * nz]).abs().max()) <= 1e-9 * scale
+    if all(s % 2 == 0 for s in cshape):
+        solver = gmg.PoissonGMG(cshape, h2, torch.float64, dev)
+        x = solver.solve(rhs, tol=1e-13, maxiter=40)  # A x = rhs: x = ref_u
+        whole = torch.cat([res[3] for res in results])
+        assert float((x.cpu() - whole).abs().max()) <= 1e-9 * scale
+
+
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 16), ("veltracer3d", 4, 4), ("heat2d", 2, 16)])
 def test_slab_traced_lbfgs_emulated_ranks_follow_the_single_gpu_optimizer(which, world, nx_rank):
     """L-BFGS-B of a traced operator on the slabs (generated kernels in slab mode, ranks as threads on one GPU; (4, 4):
