@@ -56,14 +56,8 @@ inline int64_t prod4(const int64_t n[4]) { return n[0] * n[1] * n[2] * n[3]; }
 // Flat streaming kernels (optimizer update, axpy, scale ...) get ONE chunk per workgroup: with the grid capped at
 // kGridCap and a grid-stride loop k_adam moved 4.4-4.9 TB/s (f64) / 4.8-5.5 (f32), uncapped 5.6-6.1 / 5.2-6.1 on the same
 // boxes (the streams of a looping workgroup are gridDim x 4 KB apart; tools/mb_tile_traffic.hip shows the same
-// for a bare copy).  ODIL_FLAT_GRID_CAP restores a cap.
-inline int flat_grid_cap() {
-  static const int cap = [] {
-    const char* e = getenv("ODIL_FLAT_GRID_CAP");
-    return e && atoi(e) > 0 ? atoi(e) : (1 << 20);
-  }();
-  return cap;
-}
+// for a bare copy).
+inline int flat_grid_cap() { return 1 << 20; }
 
 inline int grid_flat(int64_t work_items, int per_block) {
   int64_t nb = (work_items + per_block - 1) / per_block;

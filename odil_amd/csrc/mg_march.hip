@@ -468,25 +468,15 @@ static bool lead_tile_launch(const T* coarse, const T* add, T* fine, const March
   if ((nlead > 1 || NV == 2) && a.fvol % 4) return false;  // every fine volume starts on a pack boundary
   // 32 x 8 x 2 coarse cells per workgroup: measured on the tracer rank's arrays (four fields, tools/mb_transfers_cfg5.py)
   // 1.92 ms against 1.99 (64 x 4 x 2), 1.97 (32 x 4 x 4), 2.24 (128 x 2 x 2: whole fine rows) and 2.41 (marching kernel)
-  int tx = 32, ty = 8, tz = 2;
-  if (const char* e = getenv("ODIL_LEAD_TILE_SHAPE")) {  // "64,4,2", "128,2,2", "32,4,4"
-    int ex = 0, ey = 0, ez = 0;
-    if (sscanf(e, "%d,%d,%d", &ex, &ey, &ez) == 3 && ex <= m.cn[2]) tx = ex, ty = ey, tz = ez;
-  }
+  constexpr int tx = 32, ty = 8, tz = 2;
   a.ntx = (m.cn[2] + tx - 1) / tx;
   a.nty = (m.cn[1] + ty - 1) / ty;
   const int64_t tiles = (int64_t)a.ntx * a.nty * ((m.cn[0] + tz - 1) / tz);
   if (tiles >= ((int64_t)1 << 31) || nlead > 65535 || nlead < 1) return false;
   const dim3 grid((unsigned)tiles, (unsigned)nlead);
-#define ODIL_LT(X, Y, Z)                                                                                                 \
-  if (tx == X && ty == Y && tz == Z) {                                                                                   \
-    hipLaunchKernelGGL((k_interp_add_lead_tile<T, NV, X, Y, Z>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale, \
-                       ascale);                                                                                          \
-    return true;                                                                                                         \
-  }
-  ODIL_LT(32, 8, 2) ODIL_LT(64, 4, 2) ODIL_LT(128, 2, 2) ODIL_LT(32, 4, 4)
-#undef ODIL_LT
-  return false;
+  hipLaunchKernelGGL((k_interp_add_lead_tile<T, NV, tx, ty, tz>), grid, dim3(kBlock), 0, stream, coarse, add, fine, a, cscale,
+                     ascale);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1523,9 +1513,8 @@ static int add_launch(const T* coarse, const T* add, T* fine, const InterpArgs& 
   if (m.lead_fn != 1) {
     if (m.lead_loc == kNode) {
       // even fine indices read one coarse volume, odd ones two
-      // (ODIL_LEAD_PAIR=0: one launch per parity -- config 5 as one rank: P chain 3.25 ms against 2.70 with pairs)
-      static const bool pair = getenv("ODIL_LEAD_PAIR") ? atoi(getenv("ODIL_LEAD_PAIR")) != 0 : true;
-      if (pair && m.lead_fn == 2 * m.lead_cn - 1 && m.lead_cn >= 2) {
+      // (one launch per parity instead: config 5 as one rank, P chain 3.25 ms against 2.70 with pairs)
+      if (m.lead_fn == 2 * m.lead_cn - 1 && m.lead_cn >= 2) {
         // pairs (2k, 2k + 1) by one thread, then the last (even) index alone
         const dim3 pairs(unit_grid(m.usched), m.lead_cn - 1), last(unit_grid(m.usched), 1);
         if (!lead_tile_launch<T, 2>(coarse, add, fine, m, cscale, ascale, stream))
@@ -1900,11 +1889,7 @@ int poisson_adjoint_transpose(const T* fu, T* g0, T* g1, const int64_t* fshape, 
   }
   // workgroups per launch: 512^3 epoch 2.84 / 2.80 / 2.75 / 2.81 / 3.03 ms for 1024 / 2048 / 4096 / 8192 / 16384 (shorter
   // chunks re-prime their windows more often, longer ones leave the phases of resident workgroups in step)
-  static const int fused_units = [] {
-    const char* e = getenv("ODIL_FUSED_UNITS");
-    return e && atoi(e) > 0 ? atoi(e) : 2 * kGridCap;
-  }();
-  m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, fused_units);
+  m.usched = make_unit_sched(m.cn[0], ytiles, xtiles, 2 * kGridCap);
   T h[3] = {h2[0], h2[1], h2[2]};
   const H2<T> hh = make_h2<T>(h);
   // (the C ABI passes one set of hyper-parameters for both levels)

@@ -183,7 +183,7 @@ class HipSlabKernels:
         self.src_keys, self.gather_keys = list(cg.src_keys), list(cg.gathers)
         # fields whose own arrays the gathers read again (local derivatives re-evaluated there, stencil_grad.py)
         self.reread = {k for keys in cg.gather_reads_sources.values() for k in keys}
-        self.merged = list(cg.merged) if int(os.environ.get("ODIL_TRACE_MERGE", 1)) else []
+        self.merged = list(cg.merged)
         if self.merged:
             self.lib.jit_gather_all.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4 + [
                 ctypes.c_double] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
@@ -367,13 +367,13 @@ class SlabTracedAdam:
         self.hvec = mk() if scaled else None
         pos = 0
         self._rep = []  # (start, size) of the replicated level arrays in the packed vectors
-        # REDUNDANT GHOST UPDATES (ODIL_SLAB_GHOST_UPDATE=0: off): every rank applies the optimizer's update to its inner
+        # REDUNDANT GHOST UPDATES: every rank applies the optimizer's update to its inner
         # ghost planes as well as to its own planes -- the gradient message carries, besides the sender's contribution to
         # the receiver's boundary plane, the sender's own boundary plane of the partial gradient, so both ranks hold
         # the same complete gradient of the shared planes (a + b on one side, b + a on the other: the same bits) and
         # make the same update with the same library kernel; the exchange of the updated unknowns at the start of every
         # epoch disappears (one initial synchronisation of the ghost planes remains).  Same bytes, one exchange fewer.
-        self.redundant = os.environ.get("ODIL_SLAB_GHOST_UPDATE", "1") != "0"
+        self.redundant = True
         self._x_synced = False
         send_own = dict(lo=[], hi=[])  # plane descriptors (ops.PlaneList): owned boundary planes / inner ghost planes
         recv_ghost = dict(lo=[], hi=[])
@@ -518,9 +518,9 @@ class SlabTracedAdam:
         # neighbour's share or the periodic closure): the kernels that can, update those entries where they form the
         # gradient, and the launches at the end of the epoch cover the rest of the packed vector -- the two end pieces of
         # every such array (strided when the sharded axis is not the leading one) and the ranges between the arrays
-        # (coarser levels, fields without a gather, parameters).  ODIL_SLAB_FUSE_ADAM=0: one launch over everything.
+        # (coarser levels, fields without a gather, parameters).
         self._fused, self._post_flat, self._post_pieces = dict(), [], []
-        if getattr(self.kern, "fused_adam", False) and os.environ.get("ODIL_SLAB_FUSE_ADAM", "1") != "0":
+        if getattr(self.kern, "fused_adam", False):
             spans = []
             for key in self.kern.gather_keys:
                 e = self.by_key[key]
@@ -549,11 +549,11 @@ class SlabTracedAdam:
 
     # ---- pieces of the epoch -------------------------------------------------------------------------
     def _field_streams(self, keys):
-        """One side stream per field for the TRANSPOSE chains (ODIL_SLAB_STREAMS=0: one stream): the small, latency-bound
+        """One side stream per field for the TRANSPOSE chains: the small, latency-bound
         launches at the coarse end of one field's chain overlap the long launches of another's -- config 5 as one rank:
         P^T chains 1.80 -> 1.69 ms; the prolongation chains gain nothing that way (2.68 -> 2.71) and stay on one stream.
         Returns [(key, stream or None)] and a function that joins the streams back into the current one."""
-        if not int(os.environ.get("ODIL_SLAB_STREAMS", 1)) or len(keys) < 2 or self.device.type != "cuda":
+        if len(keys) < 2 or self.device.type != "cuda":
             return [(key, None) for key in keys], lambda: None
         cur = torch.cuda.current_stream()
         pool = self.__dict__.setdefault("_streams", [torch.cuda.Stream() for _ in range(4)])

@@ -22,7 +22,7 @@ _HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-
 # float kernels (tolerance 2e-5, stated in the tests): contraction to FMA allowed -- the 5 x 5 layers of a pointwise
 # network and their parameter-gradient accumulations become (packed) FMAs instead of multiply + add pairs
 _HIPCC_FLAGS_F32 = [f if f != "-ffp-contract=off" else "-ffp-contract=fast" for f in _HIPCC_FLAGS]
-_FAST_F32 = bool(int(os.environ.get("ODIL_TRACE_FAST_F32", 1)))
+_FAST_F32 = True
 
 
 # ======================================================================================
@@ -62,7 +62,7 @@ __device__ inline void wg_barrier() {  // (one per wave, wherever it stands in i
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ inline int wrap(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
-// (float kernels with ODIL_TRACE_FAST_F32: the quotient and the square root of the update through v_rcp_f32 / v_sqrt_f32,
+// (float kernels: the quotient and the square root of the update through v_rcp_f32 / v_sqrt_f32,
 // ~1 ulp each, as every other division of those kernels; the IEEE forms are ~10 instructions each, sixteen of each per
 // thread in a merged gather)
 #ifdef ODIL_FAST_F32
@@ -194,7 +194,7 @@ class _Codegen:
         if self.total >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         self.lines = []
-        self.max_blocks = int(os.environ.get("ODIL_JIT_NBLOCKS", 0))  # 0: chosen by the operator (stencil_jit)
+        self.max_blocks = 0  # 0: chosen by the operator (stencil_jit)
         # reachable nodes
         live = set()
         stack = list(outputs)
@@ -235,19 +235,19 @@ class _Codegen:
         self.partner, self.pair_first = dict(), set()
         self.share, self.shared_A, self.shared_B = [], set(), set()
         self._choose_shared_calls()
-        if self.fast and int(os.environ.get("ODIL_TRACE_PAIR_MLP", 1)):
+        if self.fast:
             self._pair_mlps()
         # per output: None (the whole grid) or the lens of its window; the mean runs over that many points
         self.out_lens = [None if o.win is None else tuple(o.win[0]) for o in outputs]
         self.out_count = [int(np.prod(l)) if l is not None else int(np.prod(self.G)) for l in self.out_lens]  # GLOBAL counts
-        # four points of the last axis per thread, 16-byte accesses (ODIL_TRACE_VEC=0: one point per thread)
+        # four points of the last axis per thread, 16-byte accesses
         last = self.ndim - 1
         can_vec = self.GL[last] % 4 == 0 and self.GL[last] >= 8 and (slab is None or slab[0] != last)
-        vec = os.environ.get("ODIL_TRACE_VEC", "auto")  # 0 / 1 / auto; ODIL_TRACE_VEC_FWD overrides for k_fwd
+        vec = "auto"  # (frozen: "0" / "1" force one / four points per thread in tests of the generator)
         # a forward kernel with a pointwise network is bound by its arithmetic, not by its loads: four points per thread
         # only cost it registers (heat with two space dimensions: 2.0 -> 2.5 ms)
         has_net = any(n.op == "mlp" for n in self.order)
-        vec_fwd = os.environ.get("ODIL_TRACE_VEC_FWD", vec)
+        vec_fwd = vec
         self.vw_gat = 4 if can_vec and vec != "0" else 1
         self.vw_fwd = 4 if can_vec and (vec_fwd == "1" or (vec_fwd == "auto" and not has_net)) else 1
         self.vw = self.vw_fwd
@@ -260,7 +260,7 @@ class _Codegen:
         self.mlp_out_seen = dict()  # network call idx -> {output index: mlp_out node}
         self.pseudo_slot = dict()  # "@..." pseudo-field of a stored adjoint array -> its slot in a.cot
         self.out_mode = self._choose_output_cuts()
-        self.cut_set = self._choose_cuts() if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
+        self.cut_set = self._choose_cuts()
 
     def _needs_grad(self):
         need = dict()
@@ -376,7 +376,7 @@ class _Codegen:
         self.all_regular = all(self._regular(n) for n in self.order if n.op == "read")
         if not int(os.environ.get("ODIL_TRACE_RECOMPUTE", 1)) or not self.all_regular:
             return mode
-        virt_max = int(os.environ.get("ODIL_TRACE_VIRT_MAX", 12))
+        virt_max = 12
         used = {a.idx for n in self.order for a in n.args}
         self.tr.state_locs = dict(getattr(self.tr, "state_locs", dict()))
         out_ids = [o.idx for o in self.outputs]
@@ -417,7 +417,7 @@ class _Codegen:
                 for e in adj.values():
                     extra.update(n.idx for n in stencil_grad.subdag(e) if not n.host)
                 jheavy = stencil_grad.cost([self.tr.nodes[i] for i in extra])[1]
-                if jheavy > int(os.environ.get("ODIL_TRACE_JAC_HEAVY_MAX", 0)):
+                if jheavy > 0:
                     continue
             mode[k] = "virt" if virt else "jac"
             self.seed_key[k] = None if virt else key
@@ -446,7 +446,7 @@ class _Codegen:
 
         def traffic(on):
             modes = [mode[k] if k in on else "legacy" for k in range(nout)]
-            cuts = self._choose_cuts(modes) if int(os.environ.get("ODIL_TRACE_CUT", 1)) else dict()
+            cuts = self._choose_cuts(modes)
             stored = self._stored_nodes(cuts, modes)
             words = len(stored) + sum(1 for k in on if mode[k] == "jac")  # written once by k_fwd
             reads = dict()
@@ -468,7 +468,7 @@ class _Codegen:
                     return best, on
                 best, on = cost, on ^ {k}
 
-        if int(os.environ.get("ODIL_TRACE_RECOMPUTE_ALL", 0)):
+        if 0:
             chosen = set(cand)
         else:
             (c0, on0), (c1, on1) = descend(frozenset()), descend(frozenset(cand))
@@ -1270,10 +1270,8 @@ class _Codegen:
         self._launder_params(base, nl)
         for j, vals in enumerate(dvals):
             self.emit("const {} {}_d{}_{} = {};".format(V, p, nl, j, vals if width == 1 else "{{{}, {}}}".format(*vals)))
-        # (marching kernel, ODIL_TRACE_MARCH_ACC=t: the two slots of a packed evaluation summed into ONE accumulator per
-        # parameter -- two multiply-adds instead of one packed one, half the 92 accumulator registers of a [1, 5, 5, 1] net)
-        acc1 = width == 2 and getattr(self, "acc_scalar", False)
-        if not frozen and width == 2 and not acc1:
+        # (one accumulator per parameter for both slots of a packed evaluation was measured in round 4 and lost: removed)
+        if not frozen and width == 2:
             self.pg2_used.add(key)
         if not frozen and key not in self.pgrads:
             names = []
@@ -1286,13 +1284,7 @@ class _Codegen:
             self.pg_decl.extend(name for group in names for name in group)
         for l in range(nl, 0, -1):
             ni, no = layers[l - 1], layers[l]
-            if not frozen and acc1:
-                for j in range(no):
-                    for i in range(ni):
-                        self.emit("pw_{0}_{1}_{2} = pw_{0}_{1}_{2} + ({3}_d{4}_{5}.x * {3}_h{6}_{7}.x + {3}_d{4}_{5}.y * {3}_h{6}_{7}.y);".format(
-                            base, l - 1, j * ni + i, p, l, j, l - 1, i))
-                    self.emit("pb_{0}_{1}_{2} = pb_{0}_{1}_{2} + ({3}_d{4}_{2}.x + {3}_d{4}_{2}.y);".format(base, l - 1, j, p, l))
-            elif not frozen:
+            if not frozen:
                 for j in range(no):
                     for i in range(ni):
                         self.emit("pw{8}_{0}_{1}_{2} = pw{8}_{0}_{1}_{2} + {3}_d{4}_{5} * {3}_h{6}_{7};".format(
@@ -1323,9 +1315,9 @@ class _Codegen:
         # multiples of a row), so every index but the last is the same in all of them.  Said so explicitly (the first
         # lane's value in a scalar register), the row base pointers, the wrap / slab-plane selects and the index
         # predicates are scalar arithmetic instead of one copy per lane: config 5 as one rank, merged gather 7.48 -> 7.30
-        # ms (ODIL_TRACE_UNIFORM=0: as before).  Smaller grids (rows shorter than a wavefront) are emitted unchanged.
+        # ms.  Smaller grids (rows shorter than a wavefront) are emitted unchanged.
         uniform = (len(shape) >= 2 and (shape[last] // vw) % 64 == 0 and shape[last] % vw == 0
-                   and int(os.environ.get("ODIL_TRACE_UNIFORM", 1)))
+                   )
         for d in reversed(range(len(shape))):
             ext = shape[d] // vw if d == last else shape[d]
             var = "ib" if (vw == 4 and d == last) else names[d]
@@ -1474,9 +1466,9 @@ class _Codegen:
         T = "double" if tdt == torch.float64 else "float"
         fn = "name" if T == "double" else "name##f"
         # the optimizer state and the gradient stream through a gather once per epoch: non-temporal accesses keep them
-        # out of the way of the rows the kernel re-reads (config 5 as one rank: gather 7.77 -> 7.47 ms; ODIL_TRACE_NT=0)
+        # out of the way of the rows the kernel re-reads (config 5 as one rank: gather 7.77 -> 7.47 ms)
         # (only where an array is beyond what the caches could hand to the next launch anyway)
-        self.nt_streams = bool(int(os.environ.get("ODIL_TRACE_NT", 1))) and self.total * (8 if T == "double" else 4) > (64 << 20)
+        self.nt_streams = self.total * (8 if T == "double" else 4) > (64 << 20)
         nt = "#define ODIL_NT_STREAMS 1\n" if self.nt_streams else ""
         HEAD = [("#define ODIL_FAST_F32 1\n" if self.fast else "") + nt + _PRELUDE.replace("@T@", T).replace("@FN@", fn)]
         if self.fast:
@@ -1497,7 +1489,8 @@ class _Codegen:
         S.append("#define AP(s, k) a.par[{} + s][k]".format(o))  # Array unknowns follow the net arrays
         # the marching kernel keeps the network's parameters in registers for the whole launch (they would be re-read
         # through the vector memory pipe -- uniform addresses, but stores to the adjoint arrays in between -- in every
-        # evaluation and every reverse pass of every step): ODIL_TRACE_MARCH_W = const (default) | vgpr | sgpr | mem
+        # evaluation and every reverse pass of every step).  (Round 4 also measured them as vector-register and as
+        # scalar-register residents: both lost to the constant-address-space form and were removed.)
         if self.wregs == "const":
             # the parameter arrays read through the CONSTANT address space: the compiler may then use scalar loads, merge
             # them across the stores of the adjoint arrays and re-load instead of spilling
@@ -1506,9 +1499,6 @@ class _Codegen:
             S.append("typedef const __attribute__((address_space(4))) T* CP;")
             S.append("#define W(s, l, k) wp_##s##_##l[k]")
             S.append("#define Bv(s, l, k) bp_##s##_##l[k]")
-        elif self.wregs != "mem":
-            S.append("#define W(s, l, k) wr_##s##_##l##_##k")
-            S.append("#define Bv(s, l, k) br_##s##_##l##_##k")
         else:
             S.append("#define W(s, l, k) a.par[WOFS_##s##_##l][k]")
             S.append("#define Bv(s, l, k) a.par[BOFS_##s##_##l][k]")
@@ -1517,7 +1507,7 @@ class _Codegen:
         for (s, l), v in bofs.items():
             S.append("#define BOFS_{}_{} {}".format(s, l, v))
         # ---- k_fwd ---------------------------------------------------------------------------------------------
-        occ = int(os.environ.get("ODIL_TRACE_WAVES_FWD", 0))  # register budget of k_fwd as waves per SIMD (0: the compiler's)
+        occ = 0  # register budget of k_fwd as waves per SIMD (0: the compiler's)
         self.fwd_threads = 256
 
         S.append('extern "C" __global__ __launch_bounds__({}) {}void k_fwd(const Args a) {{'.format(
@@ -1698,7 +1688,7 @@ class _Codegen:
                 attr = self.tr.nodes[ridx].attr
                 by_key.setdefault(attr[0], []).append((len(self.cots) + k, attr, coeff))
         symbolic = dict()
-        if self.all_regular and int(os.environ.get("ODIL_TRACE_NEWGATHER", 1)):
+        if self.all_regular:
             symbolic = self._gradient_terms()
         self.gather_blocks = dict()
         keys = list(by_key) + [k for k in symbolic if k not in by_key]
@@ -1766,7 +1756,7 @@ class _Codegen:
         sym_keys = [key for key in self.gathers if key in symbolic and symbolic[key] is not None
                     and tuple(self._field_shape(key)) == self.G
                     and all(attr[2] == self.state.fields[key].loc for _, attr, _ in by_key.get(key, []))]
-        if len(sym_keys) >= 2 and int(os.environ.get("ODIL_TRACE_MERGE", 1)):
+        if len(sym_keys) >= 2:
             self.merged = sym_keys
             nk = len(sym_keys)
             S.append("struct GatAll {{ T* g[{0}]; AdamP ad[{0}]; }};".format(nk))
@@ -1849,8 +1839,7 @@ class _Codegen:
         """Line groups of the marching forward kernel (see _march_kernel): per variant (general / interior) the forward
         lines before and after the shared network values, and the reverse pass."""
         a1, a2 = self.ndim - 2, self.ndim - 1
-        self.wregs = os.environ.get("ODIL_TRACE_MARCH_W", "const")
-        self.acc_scalar = os.environ.get("ODIL_TRACE_MARCH_ACC", "t2") == "t"
+        self.wregs = "const"
         by_axis = {axis: (A, B) for A, B, axis in self.share}
         (Ax, Bx), (Ay, By) = by_axis[a1], by_axis[a2]
         shared = {x.idx for x in (Ax, Bx, Ay, By)}
@@ -1865,14 +1854,14 @@ class _Codegen:
         parts = dict(Ax=Ax, Bx=Bx, Ay=Ay, By=By, nz=nz, nin=nin, attr=attr, variants=[])
         plan = self._fold_plan(self.order, 1, windows=True)
         # a third copy for the strips that touch a wall of the LANE axis (2 of 9 at 512 columns): predicates of the other
-        # axes folded, those of the lane axis kept (ODIL_TRACE_MARCH_VARIANTS=2: general and interior only)
-        plan_w = self._fold_plan(self.order, 4, windows=True) if plan is not None and int(os.environ.get("ODIL_TRACE_MARCH_VARIANTS", 3)) >= 3 else None
+        # axes folded, those of the lane axis kept
+        plan_w = self._fold_plan(self.order, 4, windows=True) if plan is not None and 3 >= 3 else None
         if plan_w is not None and (plan_w[0] == plan[0] or a2 not in plan[1]):
             plan_w = None  # (no predicate of the lane axis: the interior copy serves every strip)
         parts["plan"], parts["plan_w"] = plan, plan_w
         keep = ("cots", "cut_nodes", "jac_store", "pg_decl", "pg_offset", "pgrads", "pg2_used")
         first = None
-        self.march_pref = dict() if int(os.environ.get("ODIL_TRACE_MARCH_PREFETCH", 1)) else None
+        self.march_pref = dict()
         for fold in ([None] if plan is None else ([None, plan[0]] + ([plan_w[0]] if plan_w is not None else []))):
             self.fold, self.lines, self.loads = fold, [], dict()
             self.march_live, self.march_used = (None if fold is None else self._live_under(fold)), set()
@@ -1941,7 +1930,7 @@ class _Codegen:
         leading axes) instead of one per stencil read -- heat with two space dimensions: 2 instead of 10 (32 bytes per
         point less written by k_fwd and read again by the gather).  What crosses a segment of rows or a strip of columns
         goes to small EDGE arrays which the final gather adds.  None when the reads do not have that shape."""
-        if not int(os.environ.get("ODIL_TRACE_MARCH_GATHER", 1)) or self.cut_nodes or self.jac_store or not self.cots:
+        if self.cut_nodes or self.jac_store or not self.cots:
             return None
         a1, a2 = self.ndim - 2, self.ndim - 1
         groups = dict()
@@ -2088,19 +2077,6 @@ class _Codegen:
         nl = len(attr[2]) - 1
         Ax, Bx, Ay, By = parts["Ax"], parts["Bx"], parts["Ay"], parts["By"]
         acts = parts["acts"]
-        if self.wregs not in ("mem", "const"):
-            # vgpr: an empty asm with a vector-register constraint keeps the (uniform) value out of the scalar file, whose
-            # 100-odd registers already hold the kernel's ~30 array pointers: 46 more spill to lanes of vector registers
-            # and every use costs a v_readlane
-            for s_, (key, layers) in enumerate(self.nets):
-                for l in range(len(layers) - 1):
-                    names = [("wr_{}_{}_{}".format(s_, l, k), "a.par[WOFS_{}_{}][{}]".format(s_, l, k)) for k in range(layers[l] * layers[l + 1])]
-                    names += [("br_{}_{}_{}".format(s_, l, k), "a.par[BOFS_{}_{}][{}]".format(s_, l, k)) for k in range(layers[l + 1])]
-                    for name, src in names:
-                        if self.wregs == "vgpr":
-                            S.append('  T {0} = {1}; asm volatile("" : "+v"({0}));'.format(name, src))
-                        else:
-                            S.append("  const T {} = {};".format(name, src))
         S.append("  const int lane = threadIdx.x & 63;")
         S.append("  const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);")
         S.append("  for (int item = blockIdx.x * 4 + wave_; item < {}; item += a.nblocks * 4) {{".format(nitems))
@@ -2399,7 +2375,7 @@ class _Codegen:
         if threads >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         flat = "l4" if vw == 4 else "l"
-        occ = int(os.environ.get("ODIL_TRACE_WAVES_GAT", 0))
+        occ = 0
         S.append('extern "C" __global__ __launch_bounds__(NB) {}void {}(const Args a, {}) {{'.format(
             "__attribute__((amdgpu_waves_per_eu({0}, {0}))) ".format(occ) if occ else "", name, params))
         S.append(self._block_index(shape, vw))

@@ -337,10 +337,10 @@ class TracedOperator:
     def _side_streams(self, nfields):
         """Streams for per-field chains; none for a single field, for fields beyond 64 MB (their kernels
         fill the GPU on their own and concurrent streams only fight for HBM and allocator pools:
-        veltracer3d 83 -> 134 ms) or when ODIL_TRACE_STREAMS=0.  Measured gain where it applies: 5 %."""
+        veltracer3d 83 -> 134 ms).  Measured gain where it applies: 5 %."""
         esize = 8 if self.tr.torch_dtype == torch.float64 else 4
         if (nfields < 2 or self.total * esize > (64 << 20) or not torch.cuda.is_available()
-                or not int(os.environ.get("ODIL_TRACE_STREAMS", 1))):
+                or not 1):
             return []
         pool = self.__dict__.setdefault("_streams", [])
         while len(pool) < min(nfields, 4):
@@ -447,7 +447,7 @@ class TracedOperator:
         # small and medium grids are better off with ONE optimizer launch over the packed vector (heat 256 x 512: 0.19
         # ms per epoch against 0.22 fused; tracer 128 x 256^2, three fields on side streams: 0.66 against 0.71); the
         # fusion pays where the update is a long pass over HBM (heat 256 x 512^2: 3.63 -> 3.52, tracer 32 x 256^3: -12 %)
-        if self.total < (1 << 25) and not int(os.environ.get("ODIL_FUSE_ADAM_SMALL", 0)):
+        if self.total < (1 << 25) and not 0:
             return None
         # gathers that re-evaluate local derivatives read the fields' own regular arrays: for a plain `Field` that array
         # IS the unknown, which no launch may update while another gather of this epoch still reads it
@@ -478,7 +478,7 @@ class TracedOperator:
         cur = torch.cuda.current_stream()
         chains = [item for item in self.layout if item[1] in ("field", "mg") and (item[0] in cg.gathers or item[0] in cg.direct)]
         merged = set()
-        if cg.merged and int(os.environ.get("ODIL_TRACE_MERGE", 1)):
+        if cg.merged:
             # the gradients of all these fields in ONE launch (what their expressions read is read once)
             by_key = {key: (pos, n) for key, kind, pos, n in self.layout}
             nk = len(cg.merged)
