@@ -368,6 +368,12 @@ int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, 
                                            void* stream);
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream);
 int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream);
+/* Mixed-precision iterative refinement of the multigrid Newton solve (gmg.py; no reference counterpart -- the reference's
+ * direct solver is double throughout): float32 V-cycles inside a float64 residual loop.  narrow_scale: y32 = s x64 with
+ * s = a / sqrt(*msq) (msq: device scalar, the mean square the residual kernel just wrote; NULL: s = a); widen_axpy:
+ * y64 += s x32 with s = a sqrt(*msq). */
+int odil_narrow_scale(const double* x, float* y, int64_t n, double a, const double* msq, void* stream);
+int odil_widen_axpy(double* y, const float* x, int64_t n, double a, const double* msq, void* stream);
 /* out[0] = max |a - b|, out[1] = max |b| over n entries in one pass (NaN differences propagate): the comparison by which
  * a linearised operator's coefficient arrays are recognised as a known stencil (gmg.recognise_poisson) -- no reference
  * counterpart.  `partials`: odil_reduce_workspace_bytes(). */

@@ -70,7 +70,7 @@ _SIGNATURES = {
 
 EXPORTED = [
     "odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes", "odil_dots_workspace_bytes",
-    "odil_dense_block_workspace_bytes",
+    "odil_dense_block_workspace_bytes", "odil_narrow_scale", "odil_widen_axpy",
 ] + [
     "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
 ]
@@ -101,6 +101,10 @@ def load():
     lib.odil_dots_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.argtypes = [c_int]
     lib.odil_dense_block_workspace_bytes.restype = c_size_t
+    for name in ("odil_narrow_scale", "odil_widen_axpy"):  # (mixed precision: no type suffix)
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = [_P, _P, c_int64, c_double, _P, _P]
     for name, sig in _SIGNATURES.items():
         for suffix, real in (("f64", c_double), ("f32", c_float)):
             fn = getattr(lib, "odil_{}_{}".format(name, suffix))

@@ -175,6 +175,22 @@ static int axpy(T* y, const T* x, int64_t n, T a, void* stream) {
   return check_launch("k_axpy");
 }
 
+// Mixed-precision iterative refinement (gmg.py: float32 V-cycles inside a float64 residual loop): the two conversions
+// with their scalings, one pass each.  narrow: y32 = (a / sqrt(*msq)) * x64 (the residual normalised by its own RMS, read
+// from the device scalar the residual kernel just wrote: no host round trip); widen: y64 += (a * sqrt(*msq)) * x32.
+__global__ __launch_bounds__(kBlock) void k_narrow_scale(const double* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                        double a, const double* __restrict__ msq) {
+  const double s = msq ? a / sqrt(*msq > 0.0 ? *msq : 1.0) : a;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) y[i] = (float)(s * x[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_widen_axpy(double* __restrict__ y, const float* __restrict__ x, int64_t n,
+                                                      double a, const double* __restrict__ msq) {
+  const double s = msq ? a * sqrt(*msq > 0.0 ? *msq : 1.0) : a;
+  const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) y[i] = y[i] + s * (double)x[i];
+}
+
 // y = a * (adev ? *adev : 1) * x   (cotangent of mean(x^2): 2/n * gout * x, core.py:1093)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, T* __restrict__ y, int64_t n, T a,
@@ -510,6 +526,24 @@ int odil_adam_step_pieces_f32(float* x, float* m, float* v, const float* g, int6
                               float eps, const float* alpha_dev, void* stream) {
   return adam_pieces<float>(x, m, v, g, npieces, stride, offset, count, alpha, one_minus_b1, one_minus_b2, eps, alpha_dev,
                             stream);
+}
+int odil_narrow_scale(const double* x, float* y, int64_t n, double a, const double* msq, void* stream) {
+  if (!x || !y || n < 0) {
+    set_error("narrow_scale: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_narrow_scale, dim3(grid_flat(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, y, n, a, msq);
+  return check_launch("k_narrow_scale");
+}
+int odil_widen_axpy(double* y, const float* x, int64_t n, double a, const double* msq, void* stream) {
+  if (!x || !y || n < 0) {
+    set_error("widen_axpy: null pointer or n < 0");
+    return ODIL_E_INVAL;
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_widen_axpy, dim3(grid_flat(n, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, y, x, n, a, msq);
+  return check_launch("k_widen_axpy");
 }
 int odil_axpy_f64(double* y, const double* x, int64_t n, double a, void* stream) {
   return axpy<double>(y, x, n, a, stream);

@@ -279,10 +279,15 @@ __global__ __launch_bounds__(kBlock) void k_max_abs_diff(const T* __restrict__ a
 template <typename T>
 __global__ __launch_bounds__(64) void k_max_abs_final(const double* __restrict__ partials, int count, T* __restrict__ out) {
   double md = 0.0, mb = 0.0;
-  for (int i = 0; i < count; ++i) {  // (a few thousand entries at most: one lane, fixed order)
+  for (int i = threadIdx.x; i < count; i += 64) {  // one wavefront: strided maxima, then a butterfly over the lanes
     const double vd = partials[2 * i], vb = partials[2 * i + 1];
     md = vd > md || vd != vd ? vd : md;
     mb = vb > mb ? vb : mb;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double od = __shfl_xor(md, off, 64), ob = __shfl_xor(mb, off, 64);
+    md = od > md || od != od ? od : md;
+    mb = ob > mb ? ob : mb;
   }
   if (threadIdx.x == 0) {
     out[0] = (T)md;

@@ -25,7 +25,9 @@ from . import ops
 
 
 class PoissonGMG:
-    def __init__(self, shape, h2, dtype, device, omega=None, nu1=2, nu2=2, min_size=2):
+    def __init__(self, shape, h2, dtype, device, omega=None, nu1=2, nu2=2, min_size=2, lite=False):
+        """lite: the finest level's operator only, no work arrays of the cycle -- the float64 half of a mixed-precision
+        solve (`solve_mixed`), which needs this object for the residual alone."""
         self.ndim = len(shape)
         self.loc = "c" * self.ndim
         self.dtype, self.device = dtype, device
@@ -38,12 +40,16 @@ class PoissonGMG:
             self.h2s.append([v * npdt(4) for v in self.h2s[-1]])
         self.nlvl = len(self.shapes)
         mk = lambda s: torch.zeros(s, dtype=dtype, device=device)
-        self.x = [None] + [mk(s) for s in self.shapes[1:]]   # coarse corrections
-        self.b = [None] + [mk(s) for s in self.shapes[1:]]   # coarse right-hand sides
-        self._r = [None] * self.nlvl                         # residuals (only where the fused restriction cannot be used)
-        self.spare = [torch.empty(s, dtype=dtype, device=device) for s in self.shapes]  # target of a sweep / prolongation
         self.loss = mk(())
         self._coarse_inv = None
+        self._r = [None] * self.nlvl                         # residuals (only where the fused restriction cannot be used)
+        if lite:
+            return
+        self.x = [None] + [mk(s) for s in self.shapes[1:]]   # coarse corrections
+        self.b = [None] + [mk(s) for s in self.shapes[1:]]   # coarse right-hand sides
+        self.spare = [torch.empty(s, dtype=dtype, device=device) for s in self.shapes]  # target of a sweep / prolongation
+
+    residual_sign = 1.0  # `residual` returns A x - b
 
     def coarse_inverse(self):
         """Inverse of the coarsest-grid operator (at most a few dozen unknowns), built once from the
@@ -200,6 +206,45 @@ class PoissonGMG:
         return x.clone() if copy else x
 
 
+def solve_mixed(high, low, b, tol=1e-12, maxiter=60, status=None, fmg=True):
+    """A x = b in float64 by ITERATIVE REFINEMENT around float32 V-cycles: every pass forms the float64 residual
+    r = A x - b with `high` (one pass over the fine level, its norm on the way), hands -r / rms(r) in float32 to one cycle of
+    `low` (the first pass: its nested-iteration start) and adds the correction back in float64 -- the cycle is a
+    preconditioner, so its precision limits the contraction per pass (~0.17, far above float32 rounding), not the accuracy
+    of the answer, which is the float64 residual's.  The cycle's traffic -- everything but one residual per pass -- is
+    halved.  Conversions: `odil_narrow_scale` / `odil_widen_axpy`, the scale read from the device scalar the residual
+    kernel wrote.  (No reference counterpart: the reference's direct solve is double throughout, linsolver.py:17-26; the
+    Newton iterate it defines is reached to the same tolerance.)"""
+    n = b.numel()
+    tol = max(tol, 50 * float(torch.finfo(b.dtype).eps))
+    x = torch.zeros_like(b)
+    r = high.r(0)
+    rl = torch.empty(b.shape, dtype=torch.float32, device=b.device)
+    bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
+    res, it, e = bn, 0, None
+    while True:
+        high.residual(0, x, b, r)  # r = A x - b, high.loss = its mean square
+        prev, res = res, math.sqrt(max(float(high.loss), 0.0) * n)
+        if res <= tol * max(bn, 1e-300) or it >= maxiter or (it >= 3 and res >= 0.98 * prev):
+            break
+        ops.narrow_scale(r, rl, a=-high.residual_sign, msq=high.loss)  # right-hand side of the error equation A e = b - A x
+        if it == 0 and fmg and low.nlvl > 2:
+            e = low.full_multigrid(rl)
+        else:
+            e = low.vcycle(0, torch.zeros_like(rl) if e is None else e.zero_(), rl)
+        ops.widen_axpy(x, e, a=1.0, msq=high.loss)
+        it += 1
+    converged = res <= tol * max(bn, 1e-300)
+    if not converged:
+        from .util import printlog
+
+        printlog("odil_amd: mixed-precision multigrid stopped at relative residual {:.2e} after {} passes (tolerance {:.1e})".format(
+            res / max(bn, 1e-300), it, tol))
+    if status is not None:
+        status.update(residual=res, niter=it, method="gmg-vcycle (float32 cycles, float64 residual)", converged=converged)
+    return x
+
+
 class StencilGMG(PoissonGMG):
     """V-cycles for ANY (2 d + 1)-point operator with variable coefficients on a cell-centred grid (d <= 3): the Newton
     system M delta = -r of a single-field operator as `Problem.linearize` delivers it (reference core.py:1113-1217) --
@@ -218,20 +263,33 @@ class StencilGMG(PoissonGMG):
     solution of the normal equations the reference forms, linsolver.py:17-23).  `solve` reports `converged`; the caller
     (linsolver.solve) falls back to the normal-equation routes when the cycles do not contract."""
 
-    def __init__(self, coeffs, nu1=2, nu2=2, min_size=2):
+    def __init__(self, coeffs, nu1=2, nu2=2, min_size=2, lite=False, store=None):
+        """lite: the finest level only (the float64 half of `solve_mixed`); store: dtype the hierarchy is KEPT in (the
+        coarse operators are formed in the precision of `coeffs` and cast level by level: the float32 half)."""
         shape = tuple(coeffs.shape[1:])
         self.ndim = len(shape)
         assert coeffs.shape[0] == 2 * self.ndim + 1 and self.ndim <= 3 and coeffs.is_contiguous()
         self.loc = "c" * self.ndim
-        self.dtype, self.device = coeffs.dtype, coeffs.device
+        self.dtype, self.device = store or coeffs.dtype, coeffs.device
         self.omega = {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
         self.nu1, self.nu2 = nu1, nu2
         self.coeffs, self.shapes = [coeffs], [shape]
-        while all(s % 2 == 0 and s // 2 >= min_size for s in self.shapes[-1]):
-            self.coeffs.append(ops.stencil_var_coarsen(self.coeffs[-1]))
+        cur = coeffs
+        while not lite and all(s % 2 == 0 and s // 2 >= min_size for s in self.shapes[-1]):
+            cur = ops.stencil_var_coarsen(cur)
+            self.coeffs.append(cur)
             self.shapes.append(tuple(s // 2 for s in self.shapes[-1]))
+        if store is not None and store != coeffs.dtype:
+            assert coeffs.dtype == torch.float64 and store == torch.float32
+            self.coeffs = [ops.narrow_scale(c.reshape(-1), torch.empty(c.numel(), dtype=store, device=c.device)).view(c.shape)
+                           for c in self.coeffs]
         self.nlvl = len(self.shapes)
         mk = lambda s: torch.zeros(s, dtype=self.dtype, device=self.device)
+        self.loss = mk(())
+        self._coarse_inv = None
+        self._r = [None] * self.nlvl
+        if lite:
+            return
         self.x = [None] + [mk(s) for s in self.shapes[1:]]
         self.b = [None] + [mk(s) for s in self.shapes[1:]]
         self._r = [None] * self.nlvl
@@ -254,10 +312,11 @@ class StencilGMG(PoissonGMG):
             self._coarse_inv = torch.as_tensor(inv, dtype=self.dtype).to(self.device).contiguous()
         return self._coarse_inv
 
+    residual_sign = -1.0  # `residual` returns b - A x (PoissonGMG: A x - b)
+
     def residual(self, lvl, x, b, out):
-        """out = A x - b, mean square in self.loss."""
+        """out = b - A x, its mean square in self.loss."""
         ops.stencil_var_residual(self.coeffs[lvl], x, b, out=out)
-        ops.scale(out, -1.0, out=out)
         ops.mean_reduce(out.reshape(-1), square=True, out=self.loss)
         return out
 
@@ -304,6 +363,23 @@ def recognise_stencil(op):
     want = [(0,) * ndim]
     for i in range(ndim):
         want += [tuple(-1 if j == i else 0 for j in range(ndim)), tuple(1 if j == i else 0 for j in range(ndim))]
+    # the arrays already lie back to back in the wanted order (the generated Jacobian kernel writes slices of one buffer
+    # in the order the operator reads them): a view, no copies
+    by_shift = dict()
+    for row0, nrows, kind, k, payload in op.blocks:
+        if kind == "stencil" and row0 == 0 and nrows == op.ncols and payload[2] == field.loc and tuple(payload[3]) == shape:
+            norm = tuple(((s + n // 2) % n) - n // 2 for s, n in zip(payload[1], shape))
+            if norm in by_shift:
+                by_shift = None
+                break
+            by_shift[norm] = payload[0]
+    if by_shift is not None and len(by_shift) == len(op.blocks) and sorted(by_shift) == sorted(want):
+        arrs = [by_shift[sft] for sft in want]
+        first, size = arrs[0], arrs[0].numel()
+        if all(a.is_contiguous() and a.dtype == first.dtype and a.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()
+               and a.storage_offset() == first.storage_offset() + j * size for j, a in enumerate(arrs)):
+            return torch.empty(0, dtype=first.dtype, device=first.device).set_(
+                first.untyped_storage(), first.storage_offset(), (len(want),) + shape)
     coeffs = torch.zeros((len(want),) + shape, dtype=op.dtype, device=op.device)
     seen = set()
     for row0, nrows, kind, k, payload in op.blocks:

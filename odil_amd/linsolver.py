@@ -395,9 +395,16 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         # the variable-coefficient cycle (measurement, tests), `poisson` switches that cycle off
         mode = os.environ.get("ODIL_GMG", "auto")
         gtol = 1e-12 if linsolver == "direct" else tol
+        # ODIL_GMG_MIXED=1: float32 V-cycles inside a float64 residual loop (gmg.solve_mixed; float64 problems only)
+        mixed = matr.dtype == torch.float64 and bool(int(os.environ.get("ODIL_GMG_MIXED", 0)))
         rec = gmg.recognise_poisson(matr) if mode != "stencil" else None
         if rec is not None:
             shape, h2 = rec
+            if mixed:
+                x = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, matr.dtype, matr.device, lite=True),
+                                    gmg.PoissonGMG(shape, h2, torch.float32, matr.device),
+                                    rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
+                return x.reshape(-1)
             solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
             x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
             return x.reshape(-1)
@@ -408,10 +415,16 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         coeffs = gmg.recognise_stencil(matr) if mode != "poisson" else None
         if coeffs is not None:
             sub = dict()
-            solver = gmg.StencilGMG(coeffs)
-            x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
-            if sub.get("converged") and bool(torch.isfinite(x).all()):
-                sub["method"] = "gmg-vcycle (variable coefficients, {} levels)".format(solver.nlvl)
+            if mixed:
+                solver = gmg.StencilGMG(coeffs, store=torch.float32)
+                x = gmg.solve_mixed(gmg.StencilGMG(coeffs, lite=True), solver, rhs.reshape(tuple(coeffs.shape[1:])).contiguous(),
+                                    tol=gtol, maxiter=maxiter or 60, status=sub)
+            else:
+                solver = gmg.StencilGMG(coeffs)
+                x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+            if sub.get("converged"):  # (a residual below the tolerance: the iterate is finite)
+                sub["method"] = "gmg-vcycle (variable coefficients, {} levels{})".format(
+                    solver.nlvl, "; float32 cycles, float64 residual" if mixed else "")
                 status.update(sub)
                 return x.reshape(-1)
             from .util import printlog

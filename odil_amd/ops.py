@@ -177,6 +177,26 @@ def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss):
     return out
 
 
+def narrow_scale(x64, y32, a=1.0, msq=None):
+    """y32 = (a / sqrt(msq)) * x64 in one pass (msq: 0-d float64 device tensor or None)."""
+    assert x64.dtype == torch.float64 and y32.dtype == torch.float32 and x64.numel() == y32.numel()
+    lib = _lib.load()
+    status = lib.odil_narrow_scale(ptr(x64), ptr(y32), c_int64(x64.numel()), float(a), ptr(msq), stream_ptr())
+    if status != 0:
+        raise _lib.OdilHipError("odil_narrow_scale: {}".format(lib.odil_last_error().decode()))
+    return y32
+
+
+def widen_axpy(y64, x32, a=1.0, msq=None):
+    """y64 += (a * sqrt(msq)) * x32 in one pass."""
+    assert y64.dtype == torch.float64 and x32.dtype == torch.float32 and y64.numel() == x32.numel()
+    lib = _lib.load()
+    status = lib.odil_widen_axpy(ptr(y64), ptr(x32), c_int64(y64.numel()), float(a), ptr(msq), stream_ptr())
+    if status != 0:
+        raise _lib.OdilHipError("odil_widen_axpy: {}".format(lib.odil_last_error().decode()))
+    return y64
+
+
 def max_abs_diff(a, b):
     """2-element device tensor (max |a - b|, max |b|), one pass over both arrays."""
     assert a.numel() == b.numel() and a.dtype == b.dtype

@@ -364,7 +364,10 @@ class TracedOperator:
         keep = self._bind(state)
         dev, dt = self.out.device, self.tr.torch_dtype
         n = len(cg.jac_items)
-        arrays = [torch.empty(self.G, dtype=dt, device=dev) for _ in range(n)]
+        # (one buffer, the arrays its leading slices in the kernel's order: a multigrid solver that wants the coefficient
+        # arrays back to back -- gmg.recognise_stencil -- takes a view instead of seven copies)
+        buf = torch.empty((n,) + tuple(self.G), dtype=dt, device=dev)
+        arrays = [buf[j] for j in range(n)]
         ptrs = (ctypes.c_void_p * n)(*[a.data_ptr() for a in arrays])
         rc = self.lib.jit_jac(ctypes.byref(self.args), ptrs, ops.stream_ptr())
         if rc != 0:

@@ -293,11 +293,18 @@ def _poisson_newton_step(problem, state, args, status):
         return None
     u = field.array.contiguous()
     r, _ = ops.poisson_residual(u, ev.rhs, ev.h2, fu=ev.fu, loss=ev.loss)
-    solver = ev.__dict__.get("_gmg")
-    if solver is None:
+    mixed = ev.dtype == torch.float64 and bool(int(os.environ.get("ODIL_GMG_MIXED", 0)))
+    solver = ev.__dict__.get("_gmg_mixed" if mixed else "_gmg")
+    if solver is None and mixed:  # (float64 residual operator, float32 cycles: gmg.solve_mixed)
+        solver = ev.__dict__["_gmg_mixed"] = (gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device, lite=True),
+                                              gmg.PoissonGMG(ev.cshape, ev.h2, torch.float32, ev.device))
+    elif solver is None:
         solver = ev.__dict__["_gmg"] = gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device)
     tol = 1e-12 if linsolver == "direct" else getattr(args, "linsolver_tol", 1e-10)
     b = ops.scale(r, -1.0, out=r)  # the evaluator's residual buffer is scratch: negate it in place
+    if mixed:
+        delta = gmg.solve_mixed(solver[0], solver[1], b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status)
+        return delta.reshape(-1)
     delta = solver.solve(b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False)
     return delta.reshape(-1)  # a work buffer of the solver; optimize_newton adds it to the state right away
 

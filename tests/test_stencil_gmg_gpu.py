@@ -205,3 +205,32 @@ def test_generated_jacobian_kernel_equals_autograd(dev, modname, argv):
         for k in g:
             scale = max(float(rg[k].abs().max()), 1e-300)
             assert float((g[k] - rg[k]).abs().max()) <= 1e-13 * scale, k
+
+
+@pytest.mark.parametrize("name,make", [
+    ("poisson 64^3", lambda: sg.poisson_coeffs((64, 64, 64))),
+    ("k jumps 1 : 1000, 64^3", lambda: sg.diffusion_coeffs((64, 64, 64), jump)),
+])
+def test_mixed_precision_refinement_reaches_the_float64_answer(dev, name, make):
+    """`gmg.solve_mixed`: float32 V-cycles inside a float64 residual loop land on the float64 solver's answer -- the
+    tolerance is met by the float64 residual -- in about as many passes as the float64 solver needs cycles."""
+    from odil_amd import gmg, ops
+
+    coeffs = torch.as_tensor(np.stack(make())).to(dev)
+    xt = torch.as_tensor(np.random.default_rng(0).standard_normal(tuple(coeffs.shape[1:]))).to(dev)
+    b = ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)
+    s64, smx = dict(), dict()
+    x64 = gmg.StencilGMG(coeffs).solve(b, tol=1e-11, maxiter=40, status=s64)
+    xmx = gmg.solve_mixed(gmg.StencilGMG(coeffs, lite=True), gmg.StencilGMG(coeffs, store=torch.float32), b, tol=1e-11, maxiter=40,
+                          status=smx)
+    assert s64["converged"] and smx["converged"], (s64, smx)
+    assert smx["niter"] <= s64["niter"] + 3, (s64, smx)
+    scale = float(xt.abs().max())
+    assert float((xmx - xt).abs().max()) <= 1e-6 * scale and float((xmx - x64).abs().max()) <= 1e-6 * scale
+    # the dedicated Poisson cycle the same way
+    if name.startswith("poisson"):
+        shape, h2 = (64, 64, 64), [np.float64(1.0 / 64) ** 2] * 3
+        st = dict()
+        xp = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, torch.float64, dev, lite=True), gmg.PoissonGMG(shape, h2, torch.float32, dev),
+                             b, tol=1e-11, maxiter=40, status=st)
+        assert st["converged"] and st["niter"] <= 14 and float((xp - xt).abs().max()) <= 1e-6 * scale
