@@ -576,9 +576,13 @@ def other_configs(args, dev):
                 a.epoch_start, a.epochs = 0, 1
 
                 def step():
+                    # every timed step is the FIRST Newton step from the zero state (a step from the converged state
+                    # would iterate on rounding noise until it stagnates: twice the cycles, not the workload)
+                    for f in state.fields.values():
+                        f.array.zero_()
                     odil.util.optimize(a, "newton", problem, state, None)
 
-                ms = timed(step, 1, 1)
+                ms = timed(step, 1, 2)
                 cells = int(np.prod(problem.domain.cshape))
                 # bytes model of one Newton step with a geometric-multigrid solve (words per fine cell): per V-cycle four
                 # smoothing sweeps + the residual with its restriction, over all levels (x 8/7) -- 3 and 2 1/8 words for
@@ -589,6 +593,8 @@ def other_configs(args, dev):
                 # status of one more (untimed) step
                 seen = []
                 a.epochs = 1
+                for f in state.fields.values():
+                    f.array.zero_()
                 odil.util.optimize(a, "newton", problem, state, lambda s, e, p: seen.append(p.get("linsolver")))
                 st = next((st for st in seen if st and "niter" in st), None)
                 cycles = None if st is None else int(st["niter"])
@@ -644,6 +650,17 @@ def other_configs(args, dev):
                                                              "multigrid", "--linsolver_tol", "1e-10"],
                                    words_per_cycle=4 * 10 + 9.125, words_setup=7 * 3 + 8,
                                    name="diffusion div(k grad u), k jumps 1 : 1000, 3D {0}^3 newton + variable-coefficient multigrid f64"))
+    # the same solves with float32 V-cycles inside a float64 residual loop (gmg.solve_mixed; ODIL_GMG_MIXED=1: opt-in -- the
+    # entries above are float64 throughout): same tolerance on the float64 residual, the cycles' traffic halved
+    attempt("4b_mixed", newton(env={"ODIL_GMG_MIXED": "1"}, words_per_cycle=(4 * 3 + 2.125) / 2 + 3 + 2.5,
+                               name="poisson 3D {0}^3 newton + gmg, float32 cycles / float64 residual"))
+    attempt("4b_varcoef_mixed", newton(env={"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil", "ODIL_GMG_MIXED": "1"},
+                                       words_per_cycle=(4 * 10 + 9.125) / 2 + 10 + 2.5, words_setup=7 * 3 + 8 + 7 * 1.5,
+                                       name="poisson 3D {0}^3 newton, variable-coefficient multigrid, float32 cycles / float64 residual"))
+    attempt("4c_diffusion_mixed", newton("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver",
+                                                                   "multigrid", "--linsolver_tol", "1e-10"], env={"ODIL_GMG_MIXED": "1"},
+                                         words_per_cycle=(4 * 10 + 9.125) / 2 + 10 + 2.5, words_setup=7 * 3 + 8 + 7 * 1.5,
+                                         name="diffusion 3D {0}^3 newton, variable-coefficient multigrid, float32 cycles / float64 residual"))
     attempt("1", api("1", 400, 2))
     attempt("2", api("2", 30, 1))
     attempt("5b", api("5b", 10, 2))

@@ -89,7 +89,7 @@ CONFIGS = {
                                  "--imposed", "stripe"], "adam", 20, 2, "heat inverse {0}x{1}x{1} adam f32 mg (traced operator)"),
     "4a": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512))], "adam", 20, 2, "poisson 3D {0}^3 adam f64 mg"),
     "4b": ("poisson", lambda sc: ["--ndim", "3", "--N", str(sc(512)), "--multigrid", "0", "--linsolver", "multigrid",
-                                  "--linsolver_tol", "1e-10"], "newton", 1, 1, "poisson 3D {0}^3 newton + gmg f64 (second step: work buffers exist)"),
+                                  "--linsolver_tol", "1e-10"], "newton", 1, 1, "poisson 3D {0}^3 newton + gmg f64 (first step from the zero state, work buffers warm)"),
     # not a BASELINE config: the general Newton route on an operator with VARIABLE coefficients (examples/diffusion)
     "4c": ("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver", "multigrid",
                                    "--linsolver_tol", "1e-10"], "newton", 1, 1,

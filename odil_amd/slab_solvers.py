@@ -289,14 +289,15 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         nz = self.lv.nz
         self.mlv, self.mh2 = [self.lv], [list(self.h2)]
         shape = (nz, N, N)
-        while all(s % 2 == 0 for s in shape) and shape[0] // 2 >= 2 and shape[1] // 2 >= 2:
+        # (cross-sections of >= 4 cells on every slab level, so that the agglomerated box below the last one still has two)
+        while all(s % 2 == 0 for s in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4:
             shape = tuple(s // 2 for s in shape)
             self.mlv.append(slab.SlabLevel(shape[0], shape[1], shape[2], rank, world))
             self.mh2.append([v * npdt(4) for v in self.mh2[-1]])
         # the agglomerated box below the last slab level (None when that level cannot be coarsened at all)
         last = self.mlv[-1]
         self.agg_shape = None
-        if last.nz % 2 == 0 and last.ny % 2 == 0 and last.nx % 2 == 0:
+        if last.nz % 2 == 0 and last.ny % 2 == 0 and last.nx % 2 == 0 and min(last.ny, last.nx) >= 4:
             self.agg_shape = (world * last.nz // 2, last.ny // 2, last.nx // 2)
             self.agg_h2 = [v * npdt(4) for v in self.mh2[-1]]
         mk = lambda lv: torch.zeros(lv.shape, dtype=dtype, device=device)
