@@ -100,7 +100,8 @@ def hierarchy(coeffs, min_size=2):
     return levels
 
 
-def vcycle(levels, lvl, x, b, nu=2):
+def vcycle(levels, lvl, x, b, nu=2, top2=False):
+    """top2: two cycles on the first coarse level (what StencilGMG does in 3-D)."""
     coeffs = levels[lvl]
     nd = x.ndim
     if lvl == len(levels) - 1:
@@ -116,6 +117,8 @@ def vcycle(levels, lvl, x, b, nu=2):
         x = jacobi(coeffs, x, b, w[k])
     rc = restrict_mean(b - apply(coeffs, x))
     ec = vcycle(levels, lvl + 1, np.zeros_like(rc), rc, nu)
+    if top2 and lvl == 0 and len(levels) > 2:
+        ec = vcycle(levels, lvl + 1, ec, rc, nu)
     x = x + onp.interp_to_finer(ec, "c" * nd)
     for k in range(nu):
         x = jacobi(coeffs, x, b, w[k])
