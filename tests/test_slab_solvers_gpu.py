@@ -147,12 +147,12 @@ def test_slab_newton_multigrid_emulated_ranks_solve_the_undivided_problem(world,
     for r, (loss0, loss1, status, u) in enumerate(results):
         assert status["converged"] and status["niter"] <= 20, status
         assert loss1 < 1e-18 * loss0
-        assert float((u - ref_u[r * nz:(r + 1) * nz]).abs().max()) <= 1e-9 * scale
+        assert float((u - ref_u[r * nz:(r + 1) * nz]).abs().max()) <= 1e-8 * scale  # (cond(A) ~ 1e4 at N = 64: the residual floor)
     if all(s % 2 == 0 for s in cshape):
         solver = gmg.PoissonGMG(cshape, h2, torch.float64, dev)
         x = solver.solve(rhs, tol=1e-13, maxiter=40)  # A x = rhs: x = ref_u
         whole = torch.cat([res[3] for res in results])
-        assert float((x.cpu() - whole).abs().max()) <= 1e-9 * scale
+        assert float((x.cpu() - whole).abs().max()) <= 1e-8 * scale
 
 
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 16), ("veltracer3d", 4, 4), ("heat2d", 2, 16)])
