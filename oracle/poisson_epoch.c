@@ -14,7 +14,11 @@
  * (oracle/odil_np.py, itself pinned on the reference's golden vectors) by tests/test_oracle_c.py to round-off.
  *
  *   cc -O3 -shared -fPIC -o _build/libpoisson_epoch.so poisson_epoch.c -lm      (oracle/Makefile)
- *   cc -O3 -DODIL_C_MAIN -o _build/poisson_epoch poisson_epoch.c -lm;  ./poisson_epoch N seconds [start_unix_time]
+ *   cc -O3 -DODIL_C_MAIN -o _build/poisson_epoch poisson_epoch.c -lm;  ./poisson_epoch N seconds [start_unix_time [epochs]]
+ *   cc -O3 -fopenmp -DODIL_C_MAIN -o _build/poisson_epoch_omp ...: the same loops shared among OMP_NUM_THREADS threads --
+ *   ONE problem on all host cores (bench.py's `cpu_baseline.all_cores`).  Without -fopenmp every pragma is ignored and the
+ *   code is the serial restatement the tests pin; with it only the ORDER of a few sums changes (the two-colour transpose of
+ *   the prolongation, the reduction of the loss): tests/test_oracle_c.py holds the threaded binary to the serial one at 1e-12.
  */
 #include <math.h>
 #include <stdint.h>
@@ -31,6 +35,7 @@ static inline i64 reflecti(i64 j, i64 n) { return j < 0 ? -j : (j >= n ? 2 * n -
 /* upad = 2 * pad_symmetric(u) - pad_reflect(u), one ghost layer on every axis (core.py:640-643) */
 static void make_upad(const double* u, i64 n0, i64 n1, i64 n2, double* up) {
   const i64 p1 = n1 + 2, p2 = n2 + 2;
+#pragma omp parallel for schedule(static)
   for (i64 a = -1; a <= n0; ++a)
     for (i64 b = -1; b <= n1; ++b)
       for (i64 c = -1; c <= n2; ++c) {
@@ -52,6 +57,7 @@ static void make_upad(const double* u, i64 n0, i64 n1, i64 n2, double* up) {
 void odil_c_interp_add(const double* coarse, i64 n0, i64 n1, i64 n2, const double* add, double* fine, double* work) {
   make_upad(coarse, n0, n1, n2, work);
   const i64 p1 = n1 + 2, p2 = n2 + 2, f1 = 2 * n1, f2 = 2 * n2;
+#pragma omp parallel for schedule(static)
   for (i64 a = 0; a < 2 * n0; ++a) {
     const i64 ia = a >> 1, sa = a & 1;
     for (i64 b = 0; b < f1; ++b) {
@@ -76,6 +82,30 @@ void odil_c_interp_add(const double* coarse, i64 n0, i64 n1, i64 n2, const doubl
 void odil_c_interp_adj(const double* gfine, i64 n0, i64 n1, i64 n2, double* gcoarse, double* work) {
   const i64 p0 = n0 + 2, p1 = n1 + 2, p2 = n2 + 2, f1 = 2 * n1, f2 = 2 * n2;
   memset(work, 0, sizeof(double) * p0 * p1 * p2);
+#ifdef _OPENMP
+  /* fine planes 2 k - 1 and 2 k scatter onto the padded planes k and k + 1 only: the units k of one parity touch disjoint
+   * planes and run concurrently, the two parities one after the other */
+  for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for schedule(static)
+    for (i64 k = colour; k <= n0; k += 2)
+      for (i64 a = (2 * k - 1 < 0 ? 0 : 2 * k - 1); a <= 2 * k && a < 2 * n0; ++a) {
+        const i64 ia = a >> 1, sa = a & 1;
+        for (i64 b = 0; b < f1; ++b) {
+          const i64 ib = b >> 1, sb = b & 1;
+          for (i64 c = 0; c < f2; ++c) {
+            const i64 ic = c >> 1, sc = c & 1;
+            const double g = gfine[(a * f1 + b) * f2 + c] / 64;
+            for (int ra = 0; ra < 2; ++ra)
+              for (int rb = 0; rb < 2; ++rb)
+                for (int rc = 0; rc < 2; ++rc) {
+                  const int w = (ra == 1 - sa ? 3 : 1) * (rb == 1 - sb ? 3 : 1) * (rc == 1 - sc ? 3 : 1);
+                  work[((ia + sa + ra) * p1 + (ib + sb + rb)) * p2 + (ic + sc + rc)] += w * g;
+                }
+          }
+        }
+      }
+  }
+#else
   for (i64 a = 0; a < 2 * n0; ++a) {
     const i64 ia = a >> 1, sa = a & 1;
     for (i64 b = 0; b < f1; ++b) {
@@ -92,8 +122,28 @@ void odil_c_interp_adj(const double* gfine, i64 n0, i64 n1, i64 n2, double* gcoa
       }
     }
   }
+#endif
   memset(gcoarse, 0, sizeof(double) * n0 * n1 * n2);
+#ifdef _OPENMP
+  /* a padded plane 0 <= a < n0 folds onto coarse plane a only: those run concurrently; the ghost planes a = -1 and a = n0
+   * fold onto the planes 0, 1 / n0 - 1, n0 - 2 and run last, alone */
+#pragma omp parallel for schedule(static)
+  for (i64 a = 0; a < n0; ++a)
+    for (i64 b = -1; b <= n1; ++b)
+      for (i64 c = -1; c <= n2; ++c) {
+        const double g = work[((a + 1) * p1 + (b + 1)) * p2 + (c + 1)];
+        const int inside = b >= 0 && b < n1 && c >= 0 && c < n2;
+        if (inside) {
+          gcoarse[(a * n1 + b) * n2 + c] += g;
+        } else {
+          gcoarse[(a * n1 + clampi(b, n1)) * n2 + clampi(c, n2)] += 2 * g;
+          gcoarse[(a * n1 + reflecti(b, n1)) * n2 + reflecti(c, n2)] -= g;
+        }
+      }
+  for (i64 a = -1; a <= n0; a += n0 + 1)
+#else
   for (i64 a = -1; a <= n0; ++a)
+#endif
     for (i64 b = -1; b <= n1; ++b)
       for (i64 c = -1; c <= n2; ++c) {
         const double g = work[((a + 1) * p1 + (b + 1)) * p2 + (c + 1)];
@@ -118,6 +168,7 @@ static inline double axis_term(double q, double qwm, double qwp, int lo, int hi,
  * discarded by the wall masks, as here. */
 double odil_c_residual(const double* u, const double* rhs, i64 n0, i64 n1, i64 n2, const double* h2, double* fu) {
   double sum = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum)
   for (i64 a = 0; a < n0; ++a)
     for (i64 b = 0; b < n1; ++b)
       for (i64 c = 0; c < n2; ++c) {
@@ -145,6 +196,7 @@ static inline void axis_coeffs(i64 i, i64 n, double h2, double* cm, double* c0, 
 /* gu = scale * A^T fu (gather form: row j collects what the rows j - 1, j, j + 1 of A hold in column j) */
 void odil_c_adjoint(const double* fu, i64 n0, i64 n1, i64 n2, const double* h2, double scale, double* gu) {
   const i64 n[3] = {n0, n1, n2}, st[3] = {n1 * n2, n2, 1};
+#pragma omp parallel for schedule(static)
   for (i64 a = 0; a < n0; ++a)
     for (i64 b = 0; b < n1; ++b)
       for (i64 c = 0; c < n2; ++c) {
@@ -168,6 +220,7 @@ void odil_c_adjoint(const double* fu, i64 n0, i64 n1, i64 n2, const double* h2, 
 }
 
 void odil_c_adam(double* x, double* m, double* v, const double* g, i64 n, double alpha, double b1, double b2, double eps) {
+#pragma omp parallel for schedule(static)
   for (i64 i = 0; i < n; ++i) {
     m[i] = m[i] + (g[i] - m[i]) * (1 - b1);
     v[i] = v[i] + (g[i] * g[i] - v[i]) * (1 - b2);
@@ -211,7 +264,9 @@ static double* zalloc(i64 count) {
   void* p = NULL;
   if (posix_memalign(&p, huge, bytes)) exit(2);
   madvise(p, bytes, MADV_HUGEPAGE);
-  memset(p, 0, bytes);
+  /* first touch by the threads that will work on the pages (static schedule, as the loops): NUMA placement */
+#pragma omp parallel for schedule(static)
+  for (i64 pg = 0; pg < (i64)(bytes / huge); ++pg) memset((char*)p + (size_t)pg * huge, 0, huge);
   return (double*)p;
 }
 
@@ -237,6 +292,7 @@ int main(int argc, char** argv) {
   const i64 half = N / 2;
   double* work = zalloc((half + 2) * (half + 2) * (half + 2)), *la = zalloc(half * half * half), *lb = zalloc(half * half * half);
   const double h = 1.0 / (double)N, h2[3] = {h * h, h * h, h * h};
+#pragma omp parallel for schedule(static)
   for (i64 a = 0; a < N; ++a)
     for (i64 b = 0; b < N; ++b)
       for (i64 c = 0; c < N; ++c) {
@@ -253,6 +309,7 @@ int main(int argc, char** argv) {
     while (now() < start) {
     }
   }
+  const int fixed = argc > 4 ? atoi(argv[4]) : 0; /* exactly this many epochs (tests), else by the time budget */
   const double t0 = now();
   int k = 0;
   double el;
@@ -260,7 +317,7 @@ int main(int argc, char** argv) {
     loss = odil_c_epoch(N, nlvl, x, m, v, g, rhs, u, fu, work, la, lb, ++done, 0.005);
     ++k;
     el = now() - t0;
-  } while (el < budget && k < 200);
+  } while (fixed ? k < fixed : (el < budget && k < 200));
   printf("{\"cells\": %lld, \"epochs\": %d, \"seconds\": %.6f, \"loss\": %.17g, \"levels\": %d}\n", (long long)cells, k, el, loss, nlvl);
   return 0;
 }

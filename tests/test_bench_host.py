@@ -18,7 +18,8 @@ def test_cpu_baseline_legs_run_the_oracle_in_child_processes():
     assert res["kind"] == "port" and res["cores"] == 1 and res["unit"] == "grid-point-updates/s"
     assert res["value"] > 0 and "16^3" in res["sample"] and "one thread" in res["sample"]
     allc = res["all_cores"]
-    assert 1 <= allc["cores"] <= 64 and allc["value"] > 0 and "8^3" in allc["sample"]
+    # ONE problem of the single-thread leg's size on all cores (the OpenMP build of the same C source)
+    assert 1 <= allc["cores"] <= 512 and allc["value"] > 0 and "ONE Poisson 3-D 16^3" in allc["sample"]
 
 
 def test_cpu_bench_worker_prints_one_json_line():

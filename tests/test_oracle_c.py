@@ -99,3 +99,22 @@ def test_timing_binary_reports_one_json_line(lib):
     out = subprocess.check_output([os.path.join(ORACLE, "_build", "poisson_epoch"), "8", "0.05"], text=True)
     rec = json.loads(out.strip().splitlines()[-1])
     assert rec["cells"] == 512 and rec["levels"] == 3 and rec["epochs"] >= 1 and np.isfinite(rec["loss"])
+
+
+def test_threaded_binary_follows_the_serial_one(lib):
+    """oracle/_build/poisson_epoch_omp (the same source with -fopenmp: ONE problem on all host cores, bench.py's
+    `cpu_baseline.all_cores`) reorders a few sums only: its loss after a fixed number of epochs equals the serial binary's
+    to 1e-12, and with one thread to the last bit."""
+    import json
+
+    def loss(binary, threads):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        out = subprocess.check_output([os.path.join(ORACLE, "_build", binary), "16", "1", "0", "4"], text=True, env=env)
+        rec = json.loads(out.strip().splitlines()[-1])
+        assert rec["epochs"] == 4
+        return rec["loss"]
+
+    serial = loss("poisson_epoch", 1)
+    assert loss("poisson_epoch_omp", 1) == serial
+    for threads in (2, 3, 8):
+        assert abs(loss("poisson_epoch_omp", threads) - serial) <= 1e-12 * abs(serial)
