@@ -450,7 +450,8 @@ class TracedOperator:
         # small and medium grids are better off with ONE optimizer launch over the packed vector (heat 256 x 512: 0.19
         # ms per epoch against 0.22 fused; tracer 128 x 256^2, three fields on side streams: 0.66 against 0.71); the
         # fusion pays where the update is a long pass over HBM (heat 256 x 512^2: 3.63 -> 3.52, tracer 32 x 256^3: -12 %)
-        if self.total < (1 << 25) and not 0:
+        # (ODIL_FUSE_ADAM_SMALL=1: the tests force the fused update on their small grids)
+        if self.total < (1 << 25) and not int(os.environ.get("ODIL_FUSE_ADAM_SMALL", 0)):
             return None
         # gathers that re-evaluate local derivatives read the fields' own regular arrays: for a plain `Field` that array
         # IS the unknown, which no launch may update while another gather of this epoch still reads it

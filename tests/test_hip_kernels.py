@@ -873,10 +873,10 @@ def test_planes_copy_vs_index_arithmetic(dtype):
 
 @pytest.mark.parametrize("cshape,lo,n", [((5, 4, 32, 32), 0, 4), ((3, 7, 8, 64), 2, 3), ((3, 6, 6, 128), 1, 4),
                                           ((2, 4, 4, 160), 0, 2), ((4, 2, 2, 32), 0, 2), ((9, 20, 16, 64), 1, 18)])
-@pytest.mark.parametrize("with_add,tile", [(True, None), (False, None), (True, "64,4,2"), (True, "128,2,2"), (False, "32,4,4")])
-def test_tiled_float_prolongation_of_a_node_leading_axis_equals_the_marching_kernel(dev, cshape, lo, n, with_add, tile, monkeypatch):
+@pytest.mark.parametrize("with_add", [True, False])
+def test_tiled_float_prolongation_of_a_node_leading_axis_equals_the_marching_kernel(dev, cshape, lo, n, with_add, monkeypatch):
     """k_interp_add_lead_tile ('nccc' float: the fine volumes 2k, 2k + 1 of a tile of coarse cells staged through LDS)
-    against the register-window marching kernel it replaces (ODIL_LEAD_TILE=0): the same bits -- every tile shape built, tiles that hang over the array on z, y and x, walls inside every tile, a coarse operand that is
+    against the register-window marching kernel it replaces (ODIL_LEAD_TILE=0): the same bits -- the 32 x 8 x 2 tile (the other shapes measured in round 4 were removed in round 5), tiles that hang over the array on z, y and x, walls inside every tile, a coarse operand that is
     a view along axis 1 (slab paths), with and without the fine addend -- and the float64 oracle to rounding."""
     from odil_amd import ops
 
@@ -887,8 +887,6 @@ def test_tiled_float_prolongation_of_a_node_leading_axis_equals_the_marching_ker
     fshape = ops.fine_shape(tuple(view.shape), loc)
     add = to(rng.standard_normal(fshape).astype(np.float32), dev) if with_add else None
     monkeypatch.setenv("ODIL_LEAD_TILE", "1")
-    if tile is not None:  # (tiles wider than the array keep the default shape)
-        monkeypatch.setenv("ODIL_LEAD_TILE_SHAPE", tile)
     got = ops.interp_add(view, loc, add=add, coarse_scale=0.5, add_scale=2.0)
     monkeypatch.setenv("ODIL_LEAD_TILE", "0")
     want = ops.interp_add(view, loc, add=add, coarse_scale=0.5, add_scale=2.0)
