@@ -752,11 +752,62 @@ class LbfgsbOptimizer(Optimizer):
         gbuf = torch.zeros(n, dtype=torch.float64, device=device)
         gviews = [t.view(a.shape) for t, a in zip(gbuf.split([a.numel() for a in x0]), x0)]
 
+        # Launch-bound problems (<= 4 M unknowns: a 2-D 1024^2 evaluation is ~25 launches of 5 - 10 us each) replay the
+        # EVALUATION as a hipGraph: the optimizer always evaluates at the same buffer `xe` and the evaluator writes the same
+        # gradient buffer, so the first two evaluations run eagerly (lazy initialisation), the third is captured, the rest
+        # are replays.  The vector algebra between evaluations depends on the host's line-search decisions and stays eager.
+        ev = dict(count=0, graph=None, out=None, raw=None, begun=False)
+        want_graph = _graph_wanted(n, loss_grad, epochs or 0)
+        refresh, begin, end = (getattr(loss_grad, k, None) for k in ("refresh", "graph_begin", "graph_end"))
+
+        def close_graph():
+            if ev["begun"] and end is not None:
+                end()
+            ev.update(graph=None, begun=False)
+
+        def evaluate():
+            if ev["graph"] is not None:
+                try:
+                    if refresh is not None:
+                        refresh()
+                except RuntimeError:  # (more replays than rows of host scalars were provided for: eager from here on)
+                    close_graph()
+                    return loss_grad(xviews)
+                ev["graph"].replay()
+                loss, grads, raw = ev["out"]
+                return loss, grads, (type(raw[0])(**raw[1]) if raw[0] is not None else raw[1])
+            ev["count"] += 1
+            if want_graph and ev["count"] == 3:
+                from .util import printlog
+
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    if begin is not None:
+                        begin(4 * (epochs or 0) + 64)
+                        ev["begun"] = True
+                    if refresh is not None:
+                        refresh()
+                    with torch.cuda.graph(graph):
+                        loss, grads, pinfo = loss_grad(xviews)
+                    kind = type(pinfo) if isinstance(pinfo, dict) else None
+                    raw = {k: dict.__getitem__(pinfo, k) for k in dict.keys(pinfo)} if kind else pinfo
+                    ev.update(graph=graph, out=(loss, grads, (kind, raw)))
+                    global _graph_runtime_ready
+                    _graph_runtime_ready = True
+                    graph.replay()
+                    return loss, grads, (kind(**raw) if kind else raw)
+                except Exception as e:  # capture is an optimisation: never a reason to fail
+                    printlog("odil_amd: hipGraph capture of the L-BFGS evaluation failed ({}: {}); running eagerly".format(
+                        type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                    torch.cuda.synchronize()
+                    close_graph()
+            return loss_grad(xviews)
+
         def fg(xflat):
             self.evals += 1
             if xflat.data_ptr() != xe.data_ptr():
                 xe.copy_(xflat)  # cast to the evaluation dtype
-            loss, grads, pinfo = loss_grad(xviews)
+            loss, grads, pinfo = evaluate()
             self.pinfo = pinfo
             base = flat_base(grads)
             if base is not None and base.dtype == torch.float64 and base.numel() == n:
@@ -775,10 +826,13 @@ class LbfgsbOptimizer(Optimizer):
                 callback(xviews, self.epoch, self.pinfo)
 
         vec = LbfgsVectors(n, self.m, device)
-        res = lbfgsb_minimize(
-            x, fg, vec, maxiter=epochs, m=self.m, maxls=self.maxls, pgtol=self.pgtol, factr=self.factr,
-            callback=callback_wrap,
-        )
+        try:
+            res = lbfgsb_minimize(
+                x, fg, vec, maxiter=epochs, m=self.m, maxls=self.maxls, pgtol=self.pgtol, factr=self.factr,
+                callback=callback_wrap,
+            )
+        finally:
+            close_graph()
         if x.data_ptr() != xe.data_ptr():
             xe.copy_(x)
         optinfo = Namespace()

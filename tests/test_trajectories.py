@@ -347,3 +347,36 @@ def test_one_launch_adjoint_transpose_adam_vs_oracle(dtype, fine):
         vr = f64(v[lvl]) + (gr * gr - f64(v[lvl])) * omb2
         xr = f64(x[lvl]) - mr * alpha / (np.sqrt(vr) + eps)
         assert _rel(tm[lvl], mr) < tol and _rel(tv[lvl], vr) < tol and _rel(tx[lvl], xr) < 10 * tol
+
+
+@pytest.mark.gpu
+def test_lbfgsb_with_the_evaluation_replayed_as_a_graph_follows_the_eager_run(monkeypatch):
+    """Launch-bound problems replay the loss + gradient evaluation of L-BFGS-B as a hipGraph (optimizer.LbfgsbOptimizer):
+    the same kernels on the same buffers, so every iterate, every loss and the evaluation count are those of the eager run."""
+    import torch
+
+    import odil_amd as odil
+
+    sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+    import poisson
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+
+    def run(graph):
+        monkeypatch.setenv("ODIL_GRAPH", graph)
+        args = poisson.parse_args(["--ndim", "2", "--N", "64"])
+        problem, state = poisson.make_problem(args)
+        args.epoch_start, args.epochs = 0, 40
+        losses = []
+        try:
+            _, info = odil.util.optimize(args, "lbfgsb", problem, state, lambda s, e, p: losses.append(float(np.array(p["loss"]))))
+        except odil.EarlyStopError as e:
+            info = e.optinfo
+        return losses, info.evals, [a.clone() for a in problem.domain.arrays_from_state(state)]
+
+    l1, e1, x1 = run("1")
+    l0, e0, x0 = run("0")
+    assert len(l1) == len(l0) >= 30 and e1 == e0
+    assert l1 == l0
+    for a, b in zip(x1, x0):
+        assert torch.equal(a, b)
