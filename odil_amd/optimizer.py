@@ -775,7 +775,7 @@ class LbfgsbOptimizer(Optimizer):
                     return loss_grad(xviews)
                 ev["graph"].replay()
                 loss, grads, raw = ev["out"]
-                return loss, grads, (type(raw[0])(**raw[1]) if raw[0] is not None else raw[1])
+                return loss, grads, (raw[0](**raw[1]) if raw[0] is not None else raw[1])
             ev["count"] += 1
             if want_graph and ev["count"] == 3:
                 from .util import printlog

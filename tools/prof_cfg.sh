@@ -8,7 +8,9 @@ TAG=$1; CFG=$2; shift; shift
 for kv in "$@"; do export "$kv"; done
 OUT=$R/gpurun_out/prof_$TAG
 CMD="python3 $R/bench.py --config $CFG --no_cpu_baseline --no_other_configs --steps 4 --warmup 2"
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/K -- $CMD > /dev/null 2>&1 )
+# (the kernel-trace pass keeps bench.py's own line: its live HIP-event figure for the dominant launch and the profiler's
+# average come from the SAME process)
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/K -- $CMD > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /dev/null )
 ( cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $OUT/A -- $CMD > /dev/null 2>&1 )
 ( cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/B -- $CMD > /dev/null 2>&1 )
 if [ -n "$HBM" ]; then
