@@ -162,7 +162,50 @@ class PoissonGMG:
             x = self.vcycle(lvl, start, fb[lvl])
         return x
 
-    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True, fmg=True):
+    def solve_krylov(self, b, x, tol, maxiter, status=None, m=6):
+        """A x = b by GCR(m) with one V-cycle (from the zero start) as the preconditioner, continuing from the iterate `x`:
+        what the stationary cycles hand over to when they stop contracting well (cells far from cubes, convection-dominated
+        rows).  Per pass: one cycle, one operator application, the Gram-Schmidt products of the new direction with the last
+        m (one `odil_dots` + two `odil_lincomb` passes over the stored directions, coefficients on the device) and two
+        updates; one read-back (the residual norm).  A need not be symmetric.  Returns (x, residual norm, passes)."""
+        n = b.numel()
+        dev, dt = b.device, b.dtype
+        sign = self.residual_sign
+        r = torch.empty_like(b)
+        self.residual(0, x, b, r)                   # sign * (A x - b)
+        ops.scale(r, -sign, out=r)                  # r = b - A x
+        x = x.contiguous()
+        Z = torch.empty((m, n), dtype=dt, device=dev)   # directions z_j and their images q_j = A z_j, q_j orthonormal
+        Q = torch.empty((m, n), dtype=dt, device=dev)
+        zero_b = torch.zeros_like(b)
+        bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
+        res = float(ops.dots(r.view(1, -1), r.view(-1))[0]) ** 0.5
+        it, have, e = 0, 0, None
+        while it < maxiter and res > tol * max(bn, 1e-300) and res == res:
+            if have == m:  # restart: the stored directions are dropped
+                have = 0
+            e = self.vcycle(0, torch.zeros_like(b) if e is None else e.zero_(), r)   # M^-1 r
+            z, q = Z[have].view(b.shape), Q[have].view(b.shape)
+            z.copy_(e)
+            self.residual(0, z, zero_b, q)          # sign * A z
+            if sign != 1.0:
+                ops.scale(q, sign, out=q)
+            if have:  # Gram-Schmidt against the stored images: ONE product launch, two combination launches
+                nbeta = ops.scale(ops.dots(Q[:have], q.view(-1)), -1.0)
+                ops.lincomb(q.view(-1), 1.0, Q[:have], nbeta)
+                ops.lincomb(z.view(-1), 1.0, Z[:have], nbeta)
+            inv = torch.rsqrt(ops.dots(q.view(1, -1), q.view(-1)))          # 1 / |q|, a one-element device tensor
+            ops.scale(q, 1.0, adev=inv, out=q)
+            ops.scale(z, 1.0, adev=inv, out=z)
+            a = ops.dots(q.view(1, -1), r.view(-1))
+            ops.lincomb(x.view(-1), 1.0, z.view(1, -1), a)
+            ops.lincomb(r.view(-1), 1.0, q.view(1, -1), ops.scale(a, -1.0))
+            have += 1
+            it += 1
+            res = float(ops.dots(r.view(1, -1), r.view(-1))[0]) ** 0.5
+        return x, res, it
+
+    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True, fmg=True, krylov="auto"):
         """Solves A x = b to ||A x - b|| <= tol * ||b||.  The residual that is tested is the one every cycle
         forms anyway (after its pre-smoothing sweeps, on its way to the coarse grid): the iterate returned
         is that pre-smoothed one, so convergence costs no pass of its own."""
@@ -182,12 +225,24 @@ class PoissonGMG:
             x = self.vcycle(0, x, b)
             self.residual(0, x, b, self.r(0))
             res = math.sqrt(max(float(self.loss), 0.0) * n)
+        method = "gmg-vcycle"
         while self.nlvl > 1:
             x = self.smooth(0, x, b, self.nu1)
             self.coarse_rhs(0, x, b)
             prev, res = res, math.sqrt(max(float(self.loss), 0.0) * n)
-            if res <= tol * max(bn, 1e-300) or it >= maxiter or (it >= 3 and res >= 0.98 * prev):
-                break  # converged, out of cycles, or stagnating at the rounding floor
+            if res <= tol * max(bn, 1e-300) or it >= maxiter:
+                break
+            slow = it >= 2 and (res >= 0.5 * prev or res != res)
+            if slow and krylov != "never" and res > 1e3 * tol * max(bn, 1e-300) and res == res:
+                # the cycles contract by less than 0.5 (or not at all) well above the tolerance: the same cycle becomes the
+                # preconditioner of GCR (`solve_krylov`), which needs no contraction, only a useful direction per pass
+                x = x.clone()  # (a buffer of its own: the cycle's work buffers rotate underneath)
+                x, res, extra = self.solve_krylov(b, x, tol, maxiter - it, m=6)
+                it += extra
+                method = "gmg-vcycle + GCR(6)"
+                break
+            if it >= 3 and res >= 0.98 * prev:
+                break  # stagnating at the rounding floor
             x = self.finish_cycle(0, x, b)
             it += 1
         converged = res <= tol * max(bn, 1e-300)
@@ -199,7 +254,7 @@ class PoissonGMG:
         if status is not None:
             status["residual"] = res
             status["niter"] = it
-            status["method"] = "gmg-vcycle"
+            status["method"] = method
             status["converged"] = converged
         # the iterate may live in one of this object's work buffers: copy=False only for a caller that
         # consumes it before the next solve

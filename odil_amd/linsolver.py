@@ -400,14 +400,24 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         rec = gmg.recognise_poisson(matr) if mode != "stencil" else None
         if rec is not None:
             shape, h2 = rec
+            sub = dict()
             if mixed:
                 x = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, matr.dtype, matr.device, lite=True),
                                     gmg.PoissonGMG(shape, h2, torch.float32, matr.device),
-                                    rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
+                                    rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+            else:
+                solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
+                x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+            # cells far from cubes (point smoothing with full coarsening loses its rate) can leave the cycles short of the
+            # tolerance: the iterate is then handed to the normal-equation CG below as its starting point, not returned
+            if sub.get("converged", True) or sub.get("residual", 0.0) <= 1e-6 * float(_dot(rhs, rhs)) ** 0.5:
+                status.update(sub)
                 return x.reshape(-1)
-            solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
-            x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=status)
-            return x.reshape(-1)
+            from .util import printlog
+
+            printlog("odil_amd: Poisson multigrid stopped at relative residual {:.1e}; finishing with CG on the normal equations".format(
+                sub.get("residual", float("nan")) / max(float(_dot(rhs, rhs)) ** 0.5, 1e-300)))
+            return cg_normal(matr, rhs, tol=min(gtol, 1e-10), maxiter=maxiter, status=status, x0=x.reshape(-1))
         # Any other square (2 d + 1)-point operator on one cell-centred field (variable-coefficient diffusion, reaction,
         # convection, other wall closures): V-cycles on its own coefficient arrays.  M d = rhs is solved, which for a
         # nonsingular square M is the solution of the normal equations; cycles that do not contract hand over to the

@@ -154,17 +154,45 @@ def test_poisson_through_the_general_cycle_equals_the_dedicated_one(dev):
     assert sc[-1]["niter"] <= 18  # (tolerance 1e-11; the dedicated cycle: 11)
 
 
-def test_strongly_convective_operator_is_reported_not_converged_instead_of_returning_garbage(dev):
-    """cell Peclet number 6 at 128^2: the cycles stop contracting (tests/test_stencil_gmg_host.py shows the same of the
-    algorithm itself); `solve` must say so -- linsolver.solve then takes the normal-equation routes."""
+def test_cycles_that_stop_contracting_hand_over_to_gcr_and_report_honestly(dev):
+    """Where the stationary cycles lose their rate -- cells 1 : 4 (point smoothing with full coarsening), convection at
+    cell Peclet number 6 -- the same cycle becomes the preconditioner of GCR(6) (`solve_krylov`): the anisotropic Laplacian
+    and the moderately convective operator converge; without the hand-over (`krylov="never"`) they do not within the same
+    budget, and `converged` says so (linsolver.solve then takes the normal-equation routes)."""
     from odil_amd import gmg, ops
 
-    coeffs = torch.as_tensor(np.stack(sg.add_upwind_convection(sg.poisson_coeffs((128, 128)), 800.0))).to(dev)
-    xt = torch.as_tensor(np.random.default_rng(0).standard_normal((128, 128))).to(dev)
-    b = ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)
-    status = dict()
-    gmg.StencilGMG(coeffs).solve(b, tol=1e-10, maxiter=40, status=status)
-    assert status["converged"] is False
+    def problem(coeffs_np):
+        coeffs = torch.as_tensor(np.stack(coeffs_np)).to(dev)
+        shape = tuple(coeffs.shape[1:])
+        xt = torch.as_tensor(onp_ref(shape)).to(dev)
+        return coeffs, xt, ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)
+
+    from oracle import odil_np as onp
+
+    onp_ref = onp.poisson_ref_u
+    for name, coeffs_np, budget in (("cells 1 : 4", sg.poisson_coeffs((64, 64, 16)), 40),
+                                    ("upwind, cell Peclet 6", sg.add_upwind_convection(sg.poisson_coeffs((32, 32)), 200.0), 40)):
+        coeffs, xt, b = problem(coeffs_np)
+        st = dict()
+        x = gmg.StencilGMG(coeffs).solve(b, tol=1e-10, maxiter=budget, status=st)
+        assert st["converged"], (name, st)
+        assert float((x - xt).abs().max()) <= 1e-6 * float(xt.abs().max()), name
+        if name.startswith("cells"):
+            assert "GCR" in st["method"], st
+            plain = dict()
+            gmg.StencilGMG(coeffs).solve(b, tol=1e-10, maxiter=st["niter"], status=plain, krylov="never")
+            assert plain["converged"] is False, plain
+            # the dedicated constant-coefficient cycle on the same anisotropic box likewise
+            h2 = [np.float64(1.0 / n) ** 2 for n in (64, 64, 16)]
+            stp = dict()
+            xp = gmg.PoissonGMG((64, 64, 16), h2, torch.float64, dev).solve(b, tol=1e-10, maxiter=60, status=stp)
+            assert stp["converged"] and float((xp - xt).abs().max()) <= 1e-6 * float(xt.abs().max()), stp
+    # far beyond what a point-smoothed cycle can precondition (cell Peclet number 6 at 128^2 on the finest grid, growing on
+    # the coarse ones): reported, never returned as an answer
+    coeffs, xt, b = problem(sg.add_upwind_convection(sg.poisson_coeffs((128, 128)), 800.0))
+    st = dict()
+    gmg.StencilGMG(coeffs).solve(b, tol=1e-10, maxiter=30, status=st)
+    assert st["converged"] is False
 
 
 @pytest.mark.parametrize("modname,argv", [
