@@ -170,7 +170,7 @@ def test_cycles_that_stop_contracting_hand_over_to_gcr_and_report_honestly(dev):
     from oracle import odil_np as onp
 
     onp_ref = onp.poisson_ref_u
-    for name, coeffs_np, budget in (("cells 1 : 4", sg.poisson_coeffs((64, 64, 16)), 40),
+    for name, coeffs_np, budget in (("cells 1 : 4", sg.poisson_coeffs((64, 64, 16)), 60),
                                     ("upwind, cell Peclet 6", sg.add_upwind_convection(sg.poisson_coeffs((32, 32)), 200.0), 40)):
         coeffs, xt, b = problem(coeffs_np)
         st = dict()
