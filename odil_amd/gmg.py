@@ -178,55 +178,6 @@ class PoissonGMG:
             x = self.vcycle(lvl, start, fb[lvl])
         return x
 
-    # One unit of the solve loop -- the second half of a cycle and the first half of the next, from one residual check to
-    # the next -- is ~50 - 110 launches, most of them on coarse levels that take microseconds: below ~2.5e7 fine cells the
-    # HOST's enqueue time (~15 us per launch through ctypes) is what a cycle costs.  The unit is therefore replayed as a
-    # hipGraph.  Its launches depend on which buffers hold the iterate / the spares when it starts (they rotate: period 2 - 3),
-    # so graphs are kept per pointer signature together with the state the unit leaves behind; the first unit of a solver runs
-    # eagerly (lazy allocations), ODIL_GRAPH=0 switches replay off.
-    GRAPH_MAX_CELLS = 1 << 25
-
-    def _cycle_unit_eager(self, x, b):
-        x = self.finish_cycle(0, x, b)
-        x = self.smooth(0, x, b, self.nu1)
-        self.coarse_rhs(0, x, b)
-        return x
-
-    def _cycle_unit(self, x, b):
-        import os
-
-        state = self.__dict__.setdefault("_unit_graphs", dict(count=0, graphs=dict(), off=False))
-        state["count"] += 1
-        use = (not state["off"] and state["count"] > 1 and b.is_cuda and b.numel() <= self.GRAPH_MAX_CELLS
-               and os.environ.get("ODIL_GRAPH", "auto") != "0" and not torch.cuda.is_current_stream_capturing())
-        if not use:
-            return self._cycle_unit_eager(x, b)
-        sig = (x.data_ptr(), b.data_ptr()) + tuple(t.data_ptr() for t in self.spare) + tuple(t.data_ptr() for t in self.x[1:])
-        ent = state["graphs"].get(sig)
-        if ent is None:
-            if len(state["graphs"]) >= 8:
-                return self._cycle_unit_eager(x, b)
-            saved = (list(self.spare), list(self.x), list(self._r))
-            try:
-                self.coarse_inverse()  # (built with a host round trip: before the capture)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    y = self._cycle_unit_eager(x, b)
-                ent = state["graphs"][sig] = (graph, y, list(self.spare), list(self.x), list(self._r))
-            except Exception as e:  # capture is an optimisation: never a reason to fail
-                from .util import printlog
-
-                printlog("odil_amd: hipGraph capture of the multigrid cycle failed ({}: {}); running eagerly".format(
-                    type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
-                torch.cuda.synchronize()
-                state["off"] = True
-                self.spare, self.x, self._r = saved  # (nothing ran: the rotation of the work buffers is undone)
-                return self._cycle_unit_eager(x, b)
-        graph, y, spare, xs, rs = ent
-        self.spare, self.x, self._r = list(spare), list(xs), list(rs)
-        graph.replay()
-        return y
-
     def solve_krylov(self, b, x, tol, maxiter, status=None, m=6):
         """A x = b by GCR(m) with one V-cycle (from the zero start) as the preconditioner, continuing from the iterate `x`:
         what the stationary cycles hand over to when they stop contracting well (cells far from cubes, convection-dominated
@@ -292,10 +243,9 @@ class PoissonGMG:
             self.residual(0, x, b, self.r(0))
             res = math.sqrt(max(float(self.loss), 0.0) * n)
         method = "gmg-vcycle"
-        if self.nlvl > 1:
+        while self.nlvl > 1:
             x = self.smooth(0, x, b, self.nu1)
             self.coarse_rhs(0, x, b)
-        while self.nlvl > 1:
             prev, res = res, math.sqrt(max(float(self.loss), 0.0) * n)
             if res <= tol * max(bn, 1e-300) or it >= maxiter:
                 break
@@ -310,7 +260,7 @@ class PoissonGMG:
                 break
             if it >= 3 and res >= 0.98 * prev:
                 break  # stagnating at the rounding floor
-            x = self._cycle_unit(x, b)  # coarse-grid correction + post-smoothing, then the next cycle's first half
+            x = self.finish_cycle(0, x, b)
             it += 1
         converged = res <= tol * max(bn, 1e-300)
         if not converged:

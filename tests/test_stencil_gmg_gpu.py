@@ -262,32 +262,3 @@ def test_mixed_precision_refinement_reaches_the_float64_answer(dev, name, make):
         xp = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, torch.float64, dev, lite=True), gmg.PoissonGMG(shape, h2, torch.float32, dev),
                              b, tol=1e-11, maxiter=40, status=st)
         assert st["converged"] and st["niter"] <= 14 and float((xp - xt).abs().max()) <= 1e-6 * scale
-
-
-@pytest.mark.parametrize("which", ["poisson", "stencil"])
-def test_cycles_replayed_as_graphs_give_the_eager_iterates(dev, which, monkeypatch):
-    """Below 2^25 fine cells the unit of the solve loop (second half of a cycle + first half of the next) is replayed as a
-    hipGraph per pointer signature of the rotating work buffers: bit-identical iterates and cycle counts, also on a second
-    solve with the same solver object (cached graphs)."""
-    from odil_amd import gmg, ops
-
-    shape = (64, 64, 64)
-    coeffs = torch.as_tensor(np.stack(sg.diffusion_coeffs(shape, jump) if which == "stencil" else sg.poisson_coeffs(shape))).to(dev)
-    xt = torch.as_tensor(np.random.default_rng(1).standard_normal(shape)).to(dev)
-    b = ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)
-    h2 = [np.float64(1.0 / 64) ** 2] * 3
-
-    def make():
-        return gmg.StencilGMG(coeffs) if which == "stencil" else gmg.PoissonGMG(shape, h2, torch.float64, dev)
-
-    out = dict()
-    for mode in ("0", "auto"):
-        monkeypatch.setenv("ODIL_GRAPH", mode)
-        solver, st1, st2 = make(), dict(), dict()
-        x1 = solver.solve(b, tol=1e-11, maxiter=40, status=st1)
-        x2 = solver.solve(b, tol=1e-11, maxiter=40, status=st2)
-        out[mode] = (x1, st1, x2, st2, solver)
-    (e1, se1, e2, se2, _), (g1, sg1, g2, sg2, gs) = out["0"], out["auto"]
-    assert se1["converged"] and sg1["niter"] == se1["niter"] and sg2["niter"] == se2["niter"]
-    assert torch.equal(e1, g1) and torch.equal(e2, g2)
-    assert len(gs.__dict__["_unit_graphs"]["graphs"]) >= 1
