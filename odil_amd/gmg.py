@@ -66,22 +66,6 @@ class PoissonGMG:
             self._coarse_inv = torch.as_tensor(inv, dtype=self.dtype).to(self.device).contiguous()
         return self._coarse_inv
 
-    def own_buffers(self, b, x):
-        """(b, x) copied into buffers this solver owns (one pass each) when its cycles are replayed as graphs: a graph is
-        valid for the pointers it was captured with, and callers hand in fresh tensors every solve."""
-        import os
-
-        if not b.is_cuda or b.numel() > self.GRAPH_MAX_CELLS or os.environ.get("ODIL_GRAPH", "auto") == "0":
-            return b, x
-        own = self.__dict__.setdefault("_own", dict())
-        if "b" not in own:
-            own["b"], own["x"] = torch.empty_like(b), torch.empty_like(b)
-        if b.data_ptr() != own["b"].data_ptr():
-            own["b"].copy_(b)
-        if x.data_ptr() != own["x"].data_ptr():
-            own["x"].copy_(x)
-        return own["b"], own["x"]
-
     def r(self, lvl):
         if self._r[lvl] is None:
             self._r[lvl] = torch.empty(self.shapes[lvl], dtype=self.dtype, device=self.device)
@@ -235,7 +219,6 @@ class PoissonGMG:
             x = self.full_multigrid(b)
         else:
             x = torch.zeros_like(b)
-        b, x = self.own_buffers(b, x)
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
         if self.nlvl == 1:
@@ -385,25 +368,6 @@ class StencilGMG(PoissonGMG):
         return self._coarse_inv
 
     residual_sign = -1.0  # `residual` returns b - A x (PoissonGMG: A x - b)
-
-    def update(self, coeffs):
-        """New coefficient arrays of the same shape (the next Newton step of a nonlinear problem) into THIS solver's
-        buffers: the fine level copied, the coarse operators re-formed in place, the coarsest inverse rebuilt into its old
-        buffer -- every pointer a captured cycle graph holds stays valid."""
-        assert tuple(coeffs.shape) == tuple(self.coeffs[0].shape) and coeffs.dtype == self.coeffs[0].dtype
-        if not self.__dict__.get("_owns_fine"):
-            self.coeffs[0] = torch.empty_like(coeffs)  # (the first set may be a view of the Jacobian kernel's buffer)
-            self._owns_fine = True
-            self.__dict__.pop("_unit_graphs", None)
-        if coeffs.data_ptr() != self.coeffs[0].data_ptr():
-            self.coeffs[0].copy_(coeffs)
-        for lvl in range(1, self.nlvl):
-            ops.stencil_var_coarsen(self.coeffs[lvl - 1], out=self.coeffs[lvl])
-        old, self._coarse_inv = self._coarse_inv, None
-        if old is not None:
-            new = self.coarse_inverse()
-            old.copy_(new)
-            self._coarse_inv = old
 
     def residual(self, lvl, x, b, out):
         """out = b - A x, its mean square in self.loss."""

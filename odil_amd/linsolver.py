@@ -406,11 +406,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                                     gmg.PoissonGMG(shape, h2, torch.float32, matr.device),
                                     rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             else:
-                cache = matr.domain.__dict__.setdefault("_gmg_cache", dict())
-                key = ("poisson", tuple(shape), tuple(float(v) for v in h2), matr.dtype)
-                solver = cache.get(key)
-                if solver is None:
-                    solver = cache[key] = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
+                solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
                 x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             # cells far from cubes (point smoothing with full coarsening loses its rate) can leave the cycles short of the
             # tolerance: the iterate is then handed to the normal-equation CG below as its starting point, not returned
@@ -434,15 +430,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                 x = gmg.solve_mixed(gmg.StencilGMG(coeffs, lite=True), solver, rhs.reshape(tuple(coeffs.shape[1:])).contiguous(),
                                     tol=gtol, maxiter=maxiter or 60, status=sub)
             else:
-                # the solver object (its level buffers and, below 2^25 cells, the captured graphs of its cycles) is kept
-                # with the domain: the next Newton step refreshes its coefficients in place
-                cache = matr.domain.__dict__.setdefault("_gmg_cache", dict())
-                key = ("stencil", tuple(coeffs.shape), coeffs.dtype)
-                solver = cache.get(key)
-                if solver is None:
-                    solver = cache[key] = gmg.StencilGMG(coeffs)
-                else:
-                    solver.update(coeffs)
+                solver = gmg.StencilGMG(coeffs)
                 x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             if sub.get("converged"):  # (a residual below the tolerance: the iterate is finite)
                 sub["method"] = "gmg-vcycle (variable coefficients, {} levels{})".format(

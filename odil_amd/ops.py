@@ -205,12 +205,10 @@ def max_abs_diff(a, b):
     return out
 
 
-def stencil_var_coarsen(coeffs, out=None):
+def stencil_var_coarsen(coeffs):
     """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip)."""
     shape = tuple(coeffs.shape[1:])
-    if out is None:
-        out = torch.empty((coeffs.shape[0],) + tuple(s // 2 for s in shape), dtype=coeffs.dtype, device=coeffs.device)
-    assert tuple(out.shape) == (coeffs.shape[0],) + tuple(s // 2 for s in shape) and out.is_contiguous()
+    out = torch.empty((coeffs.shape[0],) + tuple(s // 2 for s in shape), dtype=coeffs.dtype, device=coeffs.device)
     call("stencil_var_coarsen", coeffs.dtype, ptr(coeffs), ptr(out), i64(shape), c_int(len(shape)), stream_ptr())
     return out
 
