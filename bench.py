@@ -607,7 +607,7 @@ def other_configs(args, dev):
                         f.array.zero_()
                     odil.util.optimize(a, "newton", problem, state, None)
 
-                ms = timed(step, 1, 2)
+                ms = timed(step, 2, 2)  # (two warm steps: the solver kept with the domain allocates its own coefficient buffer in the second)
                 cells = int(np.prod(problem.domain.cshape))
                 # bytes model of one Newton step with a geometric-multigrid solve (words per fine cell): per V-cycle four
                 # smoothing sweeps + the residual with its restriction, over all levels (x 8/7) -- 3 and 2 1/8 words for
