@@ -107,7 +107,10 @@ static int conv_valid(const T* in, const T* w, T* out, const int64_t* ishape, co
     a.s[d] = (int32_t)ss[d];
     taps *= ks[d];
   }
-  if (taps > kConvMaxTaps) return ODIL_E_INVAL;
+  if (taps > kConvMaxTaps) {
+    set_error("conv_valid: %lld taps (at most %d)", (long long)taps, kConvMaxTaps);
+    return ODIL_E_INVAL;
+  }
   const int64_t total = prod4(a.out);
   const int64_t nb = (total + kBlock - 1) / kBlock;
   if (nb >= (int64_t)1 << 31) {

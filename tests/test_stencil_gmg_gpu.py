@@ -262,3 +262,21 @@ def test_mixed_precision_refinement_reaches_the_float64_answer(dev, name, make):
         xp = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, torch.float64, dev, lite=True), gmg.PoissonGMG(shape, h2, torch.float32, dev),
                              b, tol=1e-11, maxiter=40, status=st)
         assert st["converged"] and st["niter"] <= 14 and float((xp - xt).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("name,make,dtype,tol", [
+    ("1-D smooth k, f64", lambda: sg.diffusion_coeffs((256,), smooth), np.float64, 1e-10),
+    ("k jumps 1 : 1000, 64^3, f32", lambda: sg.diffusion_coeffs((64, 64, 64), jump), np.float32, 2e-5),
+    ("poisson 128^2, f32", lambda: sg.poisson_coeffs((128, 128)), np.float32, 2e-5),
+])
+def test_vcycles_in_one_dimension_and_in_float32(dev, name, make, dtype, tol):
+    """the same cycle in 1-D (aggregates of two cells: 0.47 per cycle) and in float32 (tolerance clamped to 50 ulp)."""
+    from odil_amd import gmg, ops
+
+    coeffs = torch.as_tensor(np.stack(make()).astype(dtype)).to(dev)
+    xt = torch.as_tensor(np.random.default_rng(2).standard_normal(tuple(coeffs.shape[1:])).astype(dtype)).to(dev)
+    b = ops.scale(ops.stencil_var_residual(coeffs, xt, torch.zeros_like(xt)), -1.0)
+    st = dict()
+    x = gmg.StencilGMG(coeffs).solve(b, tol=tol, maxiter=40, status=st)
+    assert st["converged"] and st["niter"] <= 30, (name, st)
+    assert float((x - xt).abs().max()) <= (1e-6 if dtype == np.float64 else 2e-2) * float(xt.abs().max()), name
