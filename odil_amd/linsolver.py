@@ -406,7 +406,14 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                                     gmg.PoissonGMG(shape, h2, torch.float32, matr.device),
                                     rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             else:
-                solver = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
+                # (the constant-coefficient solver depends on shape, spacing and dtype only: kept with the domain, so that the
+                # next Newton step finds its level buffers and coarsest-grid inverse)
+                cache = matr.domain.__dict__.setdefault("_poisson_gmg", dict())
+                key = (tuple(shape), tuple(float(v) for v in h2), matr.dtype, str(matr.device))
+                solver = cache.get(key)
+                if solver is None:
+                    cache.clear()
+                    solver = cache[key] = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
                 x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             # cells far from cubes (point smoothing with full coarsening loses its rate) can leave the cycles short of the
             # tolerance: the iterate is then handed to the normal-equation CG below as its starting point, not returned
