@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(R, "examples", "poisson")); sys.path.insert(0, o
 import odil_amd as odil
 from odil_amd import linsolver, gmg
 odil.util.set_log_file(open(os.devnull, "w"))
-which = sys.argv[1]
+which = sys.argv[1] if len(sys.argv) > 1 else "diffusion"
 if which == "varcoef":
     os.environ["ODIL_NEWTON_SHORTCUT"] = "0"; os.environ["ODIL_GMG"] = "stencil"
     import poisson as ex
