@@ -690,7 +690,7 @@ def other_configs(args, dev):
     attempt("2", api("2", 30, 1))
     attempt("5b", api("5b", 10, 2))
     # HBM traffic of the dominant generated launches from the counter passes on record (profiles/, same commands)
-    for key, fname in (("3b", "r04_heat2d_pmc.txt"), ("5_one_rank", "r04_cfg5_pmc.txt")):
+    for key, fname in (("3b", "r05_heat2d_pmc.txt"), ("5_one_rank", "r05_cfg5_pmc.txt")):
         if key in out and "error" not in out[key]:
             out[key]["traffic"] = pmc_traffic(os.path.join(ROOT, "profiles", fname))
     return out
