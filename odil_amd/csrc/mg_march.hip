@@ -1619,12 +1619,15 @@ __device__ inline void rows_reduce(const PackN<float, 4> (&g)[NPL], bool lo_edge
     if (hi_edge) v[6] = v[7] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[2 + i] = g[p].e[i];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float* w = v + 2 * c;
-      const float s = mid4(w[1], w[2], w[3], w[4]);
-      xc[p][c] = __builtin_fmaf(xw[c].c3, w[3], __builtin_fmaf(xw[c].c2, w[2], s));
-      xr[p][c] = __builtin_fmaf(xw[c].r5, w[5], __builtin_fmaf(xw[c].r0, w[0], s));
+    // the rows are even (cnx = fnx / 2, fnx a power of two): the column next to the low wall is the lane's first
+    // (J = 0: tap c2) and the one next to the high wall its second (J = n - 1: c3); J = 1 (r0) is a second, J = n - 2
+    // (r5) a first column -- the other four taps of wall_taps() are zero on every lane
+    {
+      const float s0 = mid4(v[1], v[2], v[3], v[4]), s1 = mid4(v[3], v[4], v[5], v[6]);
+      xc[p][0] = __builtin_fmaf(xw[0].c2, v[2], s0);
+      xr[p][0] = __builtin_fmaf(xw[0].r5, v[5], s0);
+      xc[p][1] = __builtin_fmaf(xw[1].c3, v[5], s1);
+      xr[p][1] = __builtin_fmaf(xw[1].r0, v[2], s1);
     }
   }
 #pragma unroll
@@ -1668,16 +1671,33 @@ __device__ inline void rows_march(const float* __restrict__ vol, float* __restri
 #pragma unroll 1
   for (int cy = y0 - 2; cy < y1; ++cy) {
     {
-      PackN<float, 4> ga[NPL], gb[NPL];
-      rows_load<NPL>(vol, 2 * cy + 2, cz, fny, fnz, fplane, fnx, 4 * lx, ga);
-      rows_load<NPL>(vol, 2 * cy + 3, cz, fny, fnz, fplane, fnx, 4 * lx, gb);
       float pc[2], pr[2];
-      rows_reduce<NPL>(ga, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+      if constexpr (NPL == 6) {
+        // next to a z wall (few wavefronts): one row at a time, so that this path does not set the register count
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          PackN<float, 4> ga[NPL];
+          rows_load<NPL>(vol, 2 * cy + 2 + half, cz, fny, fnz, fplane, fnx, 4 * lx, ga);
+          rows_reduce<NPL>(ga, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+          if (half == 0) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) wc[c][4] = pc[c], wr[c][4] = pr[c];
-      rows_reduce<NPL>(gb, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+            for (int c = 0; c < 2; ++c) wc[c][4] = pc[c], wr[c][4] = pr[c];
+          } else {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) wc[c][5] = pc[c], wr[c][5] = pr[c];
+            for (int c = 0; c < 2; ++c) wc[c][5] = pc[c], wr[c][5] = pr[c];
+          }
+        }
+      } else {
+        PackN<float, 4> ga[NPL], gb[NPL];
+        rows_load<NPL>(vol, 2 * cy + 2, cz, fny, fnz, fplane, fnx, 4 * lx, ga);
+        rows_load<NPL>(vol, 2 * cy + 3, cz, fny, fnz, fplane, fnx, 4 * lx, gb);
+        rows_reduce<NPL>(ga, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wc[c][4] = pc[c], wr[c][4] = pr[c];
+        rows_reduce<NPL>(gb, lo_edge, hi_edge, xw, zwc, zwr, pc, pr);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wc[c][5] = pc[c], wr[c][5] = pr[c];
+      }
     }
     if (cy >= y0) {
       float out[2];
@@ -1740,6 +1760,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_adj_rows(const float* __restr
   const float* vol = gfine + lead * a.fvol;
   const int64_t cbase = lead * a.cvol + (int64_t)cz * a.cn[1] * a.cn[2];
   const bool z_wall = cz <= 1 || cz >= a.cn[0] - 2;
+  // (the six-plane path as its own launch behind this one -- 83 / 132 VGPRs, five waves per SIMD for the interior --
+  // was measured SLOWER, 0.363 against 0.297 ms at 128 x (32, 256, 256): its few workgroups are a serial tail; with
+  // that path one row at a time the single kernel holds 120 VGPRs instead of 163: 0.293 ms)
   if (__any(z_wall))
     rows_march<6>(vol, gcoarse, gscaled, a, cz, active, y0, y1, lx, lo_edge, hi_edge, cbase, scale, ad);
   else
