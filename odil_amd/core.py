@@ -731,10 +731,19 @@ class LinearizedOperator:
                 if isinstance(garray, list):
                     garray = torch.cat([a.reshape(nrows, -1) for a in garray], dim=1)
                 dense = garray.reshape(nrows, -1).contiguous()
+                if dense.shape[1] != self.key_to_size[key]:
+                    raise ValueError("linearize: the gradient of an output of shape {} with respect to '{}' has {} columns "
+                                     "for {} unknowns".format(tuple(value_shape), key, dense.shape[1], self.key_to_size[key]))
                 self.blocks.append((row0, nrows, "dense", key, dense))
             else:
                 if not isinstance(field, Field):
                     raise TypeError("Expected Field, got type {} for key='{}'".format(type(field).__name__, key))
+                if garray.numel() != nrows:
+                    # one matrix entry per row and (key, shift, loc), as reference core.py:1144-1171: an operator that shifts
+                    # or slices the arrays ITSELF (mod.roll, fu[1:]) instead of reading ctx.field(key, *shift) has no such form
+                    raise ValueError("linearize: output of shape {} is not pointwise in ctx.field('{}', shift={}, loc='{}') of "
+                                     "shape {}; Newton needs operators written with ctx.field shifts (reference "
+                                     "core.py:1144-1171)".format(tuple(value_shape), key, tuple(shift), loc, tuple(garray.shape)))
                 self.blocks.append((row0, nrows, "stencil", key, (garray.contiguous(), tuple(shift), loc,
                                                                   tuple(value_shape))))
         self.nrows += nrows

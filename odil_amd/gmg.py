@@ -271,11 +271,15 @@ class PoissonGMG:
             x = torch.zeros_like(b)
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
-        if self.nlvl == 1:
-            x = self.vcycle(0, x, b)
-            self.residual(0, x, b, self.r(0))
-            res = math.sqrt(max(float(self.loss), 0.0) * n)
         method = "gmg-vcycle"
+        if self.nlvl == 1:
+            # the finest level itself cannot be halved (an odd extent): its 'cycle' is the dense inverse (small), the padded
+            # continuation, or sweeps -- as the preconditioner of GCR, which needs no contraction from it (the continuation
+            # at the FINEST level contracts by 0.3 - 0.5 only, at 125^3 one mode even grows: the wall sits half a coarse
+            # cell off on every padded level)
+            x, res, it = self.solve_krylov(b, x, tol, maxiter, m=6)
+            method = "GCR(6), preconditioner: " + ("padded multigrid cycles" if self.continuation() is not None else
+                                                   "coarse inverse" if n <= 512 else "sweeps")
         while self.nlvl > 1:
             x = self.smooth(0, x, b, self.nu1)
             self.coarse_rhs(0, x, b)
@@ -459,7 +463,7 @@ class StencilGMG(PoissonGMG):
 
 def recognise_stencil(op):
     """The coefficient tensor [(2 d + 1), *shape] (order 0, -e_0, +e_0, -e_1, ...) when the LinearizedOperator is square,
-    acts on ONE cell-centred `Field` (d <= 3, even extents) and every stencil block's shift is 0 or a unit vector --
+    acts on ONE cell-centred `Field` (d <= 3, extents >= 4) and every stencil block's shift is 0 or a unit vector --
     the structure StencilGMG needs; None otherwise.  Shifts that do not occur are zero arrays, duplicates are summed."""
     from .core import Field
 
@@ -470,7 +474,7 @@ def recognise_stencil(op):
         return None
     shape = tuple(field.array.shape)
     ndim = len(shape)
-    if ndim > 3 or field.loc != "c" * ndim or any(s < 4 or s % 2 for s in shape):
+    if ndim > 3 or field.loc != "c" * ndim or any(s < 4 for s in shape):
         return None
     want = [(0,) * ndim]
     for i in range(ndim):

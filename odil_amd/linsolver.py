@@ -8,7 +8,7 @@ arrays + dense blocks), A is applied as M^T (M x) with the HIP stencil kernels a
 system is solved by Jacobi-preconditioned conjugate gradients with deterministic dot
 products (odil_dots) and no host synchronisation inside the iteration.  `direct` is a dense
 Cholesky of A = M^T M up to 49152 unknowns, memory permitting (one f64 GEMM + rocSOLVER, `dense_normal`), geometric
-multigrid for the recognised Poisson stencil above 2e5 unknowns (gmg.py), and otherwise "CG to
+multigrid for the recognised stencils beyond the dense factorisation's reach (gmg.py), and otherwise "CG to
 round-off" (tol 1e-14 relative, bounded by `--linsolver_maxiter` if given, else 20 n), which
 reproduces the reference's Newton iterate to solver tolerance; `cg` / `bicgstab` / `multigrid`
 use `--linsolver_tol`.
@@ -108,13 +108,22 @@ def _solve_small_spd(a, b, info=None):
     """x with a x = b for the p x p (p <= 63) Schur complement of the dense columns.  Network weights often leave it
     SINGULAR (redundant directions: the reference's SuperLU then returns some member of the solution set): when the
     plain solve is not finite or misses the equations, the minimum-norm solution through the eigen-decomposition."""
+    if not (bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())):
+        return None  # (an inner solve broke down: the caller takes another route)
     try:
         x = torch.linalg.solve(a, b)
         ok = bool(torch.isfinite(x).all()) and float((a @ x - b).norm()) <= 1e-8 * max(float(b.norm()), 1e-300)
     except RuntimeError:
         x, ok = None, False
     if not ok:
-        x = torch.linalg.pinv(a, hermitian=True) @ b
+        try:
+            x = torch.linalg.pinv(a, hermitian=True) @ b
+        except RuntimeError:
+            # the device eigensolver gives up on some ill-conditioned complements (error 42 of syevd): LAPACK's SVD on the
+            # host, in double -- p <= 63
+            ah = a.detach().cpu().numpy().astype(np.float64)
+            x = torch.as_tensor(np.linalg.pinv(0.5 * (ah + ah.T), rcond=1e-13) @ b.detach().cpu().numpy().astype(np.float64),
+                                dtype=a.dtype).to(a.device)
         if info is not None:
             info["schur_complement"] = "singular: minimum-norm solution"
     return x
@@ -166,6 +175,8 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
     info = dict(method="schur-mfma", dense_columns=p)
     if not stencil_blocks:
         y = _solve_small_spd(G, g, info)
+        if y is None:
+            return None
         niter = 0
     else:
         import copy
@@ -196,6 +207,8 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
         zt = zs.t().contiguous()      # unknowns x (p + 1)
         czz = ops.dense_xty(ct, zt)   # C^T [Z | z]
         y = _solve_small_spd(G - czz[:, :p], g - czz[:, p], info)
+        if y is None:
+            return None
         x.copy_(zs[p])
         ops.lincomb(x, 1.0, zs[:p].contiguous(), (-y).contiguous())
     x[dcols] = y
@@ -385,8 +398,9 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         raise ValueError("Unknown linsolver=" + linsolver)
     # Square Poisson stencil without damping: M d = rhs has the solution of the normal equations
     # and is solved by geometric multigrid V-cycles (gmg.py) -- the only option that scales to
-    # 512^3.  `multigrid` always takes it when it applies, `direct` above 2e5 unknowns.
-    if not damp and not dampdiag and (linsolver == "multigrid" or (linsolver == "direct" and matr.ncols > 200000)):
+    # 512^3.  `multigrid` always takes it when it applies, `direct` beyond the reach of the dense factorisation (49152
+    # unknowns; up to round 5 only above 2e5, and 256^2 or N = 100000 in 1-D went to 45000 - 50000 CG iterations).
+    if not damp and not dampdiag and (linsolver == "multigrid" or (linsolver == "direct" and matr.ncols > DENSE_MAX_UNKNOWNS)):
         import os
 
         from . import gmg
@@ -401,7 +415,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         if rec is not None:
             shape, h2 = rec
             sub = dict()
-            if mixed:
+            if mixed and all(n % 2 == 0 for n in shape):  # (an odd finest level is solved by GCR in one precision)
                 x = gmg.solve_mixed(gmg.PoissonGMG(shape, h2, matr.dtype, matr.device, lite=True),
                                     gmg.PoissonGMG(shape, h2, torch.float32, matr.device),
                                     rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
@@ -432,6 +446,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
         coeffs = gmg.recognise_stencil(matr) if mode != "poisson" else None
         if coeffs is not None:
             sub = dict()
+            mixed = mixed and all(n % 2 == 0 for n in coeffs.shape[1:])
             if mixed:
                 solver = gmg.StencilGMG(coeffs, store=torch.float32)
                 x = gmg.solve_mixed(gmg.StencilGMG(coeffs, lite=True), solver, rhs.reshape(tuple(coeffs.shape[1:])).contiguous(),
@@ -454,10 +469,15 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
     if not damp and not dampdiag and linsolver in ("direct", "directsq", "multigrid"):
         rec = recognise_marching(matr)
         if rec is not None:
-            x = march_solve(rec, rhs, status)
-            if bool(torch.isfinite(x).all()):
+            sub = dict()
+            x = march_solve(rec, rhs, sub)
+            # exact in exact arithmetic; a time-explicit scheme run beyond its stability limit (wave with dt > dx) amplifies
+            # rounding by the growth factor of every level: the iterate is then finite garbage.  Accept what meets the
+            # equations, leave the rest to the normal-equation routes (which the reference takes for everything)
+            if bool(torch.isfinite(x).all()) and sub["residual"] <= 1e-6 * max(float(_dot(rhs, rhs)) ** 0.5, 1e-300):
+                status.update(sub)
                 return x
-            # (a singular diagonal block met on the way: the general solvers below regularise or report it)
+            # (or a singular diagonal block met on the way: the general solvers below regularise or report it)
     if linsolver in ("direct", "directsq"):
         x = blocktri_normal(matr, rhs, damp, dampdiag, status)
         if x is not None and bool(torch.isfinite(x).all()):

@@ -634,7 +634,7 @@ def lincomb(y, beta, a, coef):
     if a.dim() == 1:
         a = a[None]
     nvec, n = a.shape
-    assert y.numel() == n and coef.numel() == nvec and a.stride(1) == 1
+    assert y.numel() == n and coef.numel() == nvec and (a.stride(1) == 1 or n == 1), (tuple(y.shape), tuple(a.shape), a.stride())
     call(
         "lincomb", y.dtype, ptr(y), float(beta), ptr_strided(a), c_int64(a.stride(0)), c_int(nvec), ptr(coef),
         c_int64(n), stream_ptr(),

@@ -277,9 +277,10 @@ def _poisson_newton_step(problem, state, args, status):
     geometric multigrid, without forming the seven coefficient arrays of the Jacobian and without
     re-recognising them (512^3: 75 ms of a 215 ms step).  None when the general route must be taken:
     other operators, multigrid-decomposed unknowns, damping, or a solver choice that is not multigrid
-    (`direct` switches to multigrid above 2e5 unknowns exactly as linsolver.solve does)."""
+    (`direct` switches to multigrid beyond the dense factorisation's reach exactly as linsolver.solve does)."""
     from . import gmg, ops
     from .core import Field
+    from .linsolver import DENSE_MAX_UNKNOWNS
 
     ev = getattr(problem, "_fused", None)
     linsolver = getattr(args, "linsolver", "direct")
@@ -289,11 +290,11 @@ def _poisson_newton_step(problem, state, args, status):
     if not isinstance(field, Field) or getattr(args, "linsolver_damp", 0) or getattr(args, "linsolver_dampdiag", 0):
         return None
     n = field.array.numel()
-    if not (linsolver == "multigrid" or (linsolver == "direct" and n > 200000)):
+    if not (linsolver == "multigrid" or (linsolver == "direct" and n > DENSE_MAX_UNKNOWNS)):
         return None
     u = field.array.contiguous()
     r, _ = ops.poisson_residual(u, ev.rhs, ev.h2, fu=ev.fu, loss=ev.loss)
-    mixed = ev.dtype == torch.float64 and bool(int(os.environ.get("ODIL_GMG_MIXED", 0)))
+    mixed = ev.dtype == torch.float64 and bool(int(os.environ.get("ODIL_GMG_MIXED", 0))) and all(n % 2 == 0 for n in ev.cshape)
     solver = ev.__dict__.get("_gmg_mixed" if mixed else "_gmg")
     if solver is None and mixed:  # (float64 residual operator, float32 cycles: gmg.solve_mixed)
         solver = ev.__dict__["_gmg_mixed"] = (gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device, lite=True),
