@@ -191,7 +191,17 @@ class _Codegen:
             self.GL = tuple(n if d == ax else g for d, g in enumerate(shape))
             self.halo = 0
         self.total = int(np.prod(self.GL))
-        if self.total >= 2**31 - 1024:
+        # element offsets are 32-bit in the generated kernels: the grid AND the largest array on it (a node-centred axis
+        # adds a layer) must stay below 2^31 elements; larger problems keep the autograd path
+        largest = self.total
+        if slab is not None:  # (the state carries the GLOBAL shapes there: the rank's arrays are its slab plus ghost planes)
+            largest = int(np.prod([(g + 5) if d == slab[0] else (g + 1) for d, g in enumerate(self.GL)]))
+        else:
+            for f in (state.fields.values() if state is not None else ()):
+                for t in ([getattr(f, "array", None)] + [getattr(x, "array", None) for x in getattr(f, "terms", [])]):
+                    if torch.is_tensor(t):
+                        largest = max(largest, int(t.numel()))
+        if largest >= 2**31 - 1024:
             raise TraceUnsupported("grid too large for 32-bit indexing")
         self.lines = []
         self.max_blocks = 0  # 0: chosen by the operator (stencil_jit)

@@ -48,12 +48,12 @@ def test_transposes_at_full_size(dev):
     assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), abs(rhs), 1.0)
 
 
-def run_epochs(dev, monkeypatch, env, epochs=3):
+def run_epochs(dev, monkeypatch, env, epochs=3, n=N):
     from odil_amd.poisson_path import PoissonMultigridAdam
 
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    run = PoissonMultigridAdam(3, N, dtype=torch.float64, device=dev)
+    run = PoissonMultigridAdam(3, n, dtype=torch.float64, device=dev)
     losses = []
     for _ in range(epochs):
         run.epoch()
@@ -74,6 +74,61 @@ def test_fused_epoch_equals_separate_kernels_at_full_size(dev, monkeypatch):
         assert torch.equal(a, b) and torch.equal(a, c)
     # zero initial state: the first loss is mean(rhs^2) of the discrete right-hand side; then it moves
     assert fused[0] > 0 and fused[1] != fused[0] and np.isfinite(fused).all()
+
+
+def test_fused_epoch_equals_separate_kernels_at_eight_times_the_full_size(dev, monkeypatch):
+    """1024^3 f64 (1.07e9 cells, 10 levels, 8.6 GB per level-0 array, ~75 GB in all: what the 288 GB of an MI355X are for;
+    element offsets beyond 2^30, byte offsets beyond 2^33): the fused epoch is still bit-identical to the separate kernels."""
+    if torch.cuda.mem_get_info(dev)[0] < 110e9:
+        pytest.skip("needs ~90 GB of free device memory")
+    fused, sf = run_epochs(dev, monkeypatch, {"ODIL_FUSE_TRANSPOSE": "1", "ODIL_SYNTH_RESIDUAL": "1", "ODIL_FUSE_ADAM0": "1"}, n=1024)
+    sums = [float(t.sum()) for t in sf]
+    del sf
+    torch.cuda.empty_cache()
+    plain, sp = run_epochs(dev, monkeypatch, {"ODIL_FUSE_TRANSPOSE": "0", "ODIL_SYNTH_RESIDUAL": "0", "ODIL_FUSE_ADAM0": "0"}, n=1024)
+    assert np.allclose(fused, plain, rtol=1e-15, atol=0) and np.isfinite(fused).all()  # (the loss: same terms, 1-ulp sums)
+    assert sums == [float(t.sum()) for t in sp]
+    assert abs(fused[0] - 651.1063812200) < 1e-6  # mean(rhs^2) of the discrete right-hand side of 'hat' at this size
+
+
+def test_arrays_beyond_two_to_the_31_elements(dev):
+    """1300^3 = 2.197e9 float cells (8.8 GB per array): residual, stencil adjoint, Adam, the reductions and both transfers
+    index with 64 bits where it matters -- the planes at the END of the arrays (element offsets beyond 2^31) against a
+    float64 evaluation of the same stencil, and the transposes as transposes."""
+    from odil_amd import ops
+
+    if torch.cuda.mem_get_info(dev)[0] < 80e9:
+        pytest.skip("needs ~60 GB of free device memory")
+    n = 1300
+    h2 = [np.float32(1.0 / n) ** 2] * 3
+    g = torch.Generator(device=dev).manual_seed(1)
+    u = torch.randn((n, n, n), dtype=torch.float32, device=dev, generator=g)
+    assert u.numel() > 2**31
+
+    def lap(block):  # planes 1 .. k - 2 of `block`, cells two away from the walls, in float64
+        d = block.double()
+        c = d[1:-1, 2:-2, 2:-2]
+        return ((d[2:, 2:-2, 2:-2] + d[:-2, 2:-2, 2:-2] - 2 * c) / float(h2[0]) + (d[1:-1, 3:-1, 2:-2] + d[1:-1, 1:-3, 2:-2] - 2 * c) / float(h2[1])
+                + (d[1:-1, 2:-2, 3:-1] + d[1:-1, 2:-2, 1:-3] - 2 * c) / float(h2[2]))
+
+    fu, _ = ops.poisson_residual(u, torch.zeros_like(u), h2)
+    ga = ops.poisson_adjoint(fu, h2, 1.0)
+    for z0 in (5, n - 12):
+        for src, out in ((u, fu), (fu, ga)):
+            ref = lap(src[z0 - 1:z0 + 4])
+            assert float((out[z0:z0 + 3, 2:-2, 2:-2].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    x, m, v = (torch.zeros_like(u) for _ in range(3))
+    ops.adam_step(x.view(-1), m.view(-1), v.view(-1), ga.view(-1), 0.01, 0.1, 0.001, 1e-7)
+    assert torch.equal(x[-1].abs() > 0, ga[-1] != 0) and bool(torch.isfinite(x[-1]).all())
+    assert abs(float(ops.dots(u.view(1, -1), u.view(-1))[0]) / u.numel() - 1.0) < 1e-3
+    del x, m, v, ga
+    torch.cuda.empty_cache()
+    c = torch.randn((n // 2,) * 3, dtype=torch.float32, device=dev, generator=g)
+    pc = ops.interp_add(c, "ccc")
+    lhs = float(ops.dots(pc.view(1, -1), fu.view(-1))[0])
+    del pc
+    rhs = float(ops.dots(c.view(1, -1), ops.interp_adj(fu, "ccc", tuple(c.shape)).view(-1))[0])
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs)
 
 
 def test_newton_step_and_lbfgs_at_full_size(dev):
