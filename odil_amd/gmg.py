@@ -35,9 +35,21 @@ class PoissonGMG:
         self.omega = omega if omega is not None else {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
         self.nu1, self.nu2 = nu1, nu2
         self.shapes, self.h2s = [tuple(shape)], [[npdt(v) for v in h2]]
-        while all(s % 2 == 0 and s // 2 >= min_size for s in self.shapes[-1]):
-            self.shapes.append(tuple(s // 2 for s in self.shapes[-1]))
-            self.h2s.append([v * npdt(4) for v in self.h2s[-1]])
+        # SEMI-coarsening while the cells are far from cubes: point smoothing only damps what oscillates along the strongly
+        # coupled axes (the small spacings), so only those are halved -- the axes whose h^2 is within a factor 2 of the
+        # smallest -- until the spacings meet; from there on (and from the start on a grid of cubes) every axis is halved.
+        # 1024 x 64 on the unit square: (512, 64), (256, 64), (128, 64), (64, 64), (32, 32), ...  With full coarsening the
+        # cycles lost their rate at cells 1 : 2 (24 passes with the Krylov hand-over), 1 : 4 (70 - 110) and failed at 1 : 16.
+        self.locs = []  # per transition lvl -> lvl + 1: 'c' on the halved axes, '.' on the others
+        while True:
+            cur, h = self.shapes[-1], self.h2s[-1]
+            hmin = min(float(v) for v in h)
+            halve = [float(v) <= 2.0 * hmin for v in h]
+            if not all(n % 2 == 0 and n // 2 >= min_size for n, on in zip(cur, halve) if on):
+                break
+            self.shapes.append(tuple(n // 2 if on else n for n, on in zip(cur, halve)))
+            self.h2s.append([v * npdt(4) if on else v for v, on in zip(h, halve)])
+            self.locs.append("".join("c" if on else "." for on in halve))
         self.nlvl = len(self.shapes)
         mk = lambda s: torch.zeros(s, dtype=dtype, device=device)
         self.loss = mk(())
@@ -105,12 +117,22 @@ class PoissonGMG:
         """b_{lvl+1} = R (b - A x), and mean((A x - b)^2) in self.loss.  One fused pass in 3-D (the fine
         residual is never stored); residual, restriction and sign as three launches otherwise."""
         bc = self.b[lvl + 1]
-        if ops.residual_restrict_supported(self.shapes[lvl], self.dtype):
+        if self.locs[lvl] == self.loc and ops.residual_restrict_supported(self.shapes[lvl], self.dtype):
             ops.poisson_residual_restrict(x, b, self.h2s[lvl], -1.0 / 2**self.ndim, bc, self.loss)
         else:
             r = self.residual(lvl, x, b, self.r(lvl))
-            ops.scale(ops.restrict_to_coarser(r, self.loc), -1.0, out=bc)
+            self.restrict(lvl, r, -1.0, out=bc)
         return bc
+
+    def restrict(self, lvl, r, sign=1.0, out=None):
+        """sign * R r onto level lvl + 1.  Every axis halved: the mean of the children (`odil_restrict`).  Some axes only:
+        the transposed interpolation scaled to unit row sums, P^T / 2^k (`odil_restrict` SUBSAMPLES a '.' axis, as the
+        reference's strided convolution does, core.py:745-751: not a restriction along it)."""
+        loc = self.locs[lvl]
+        if loc == self.loc:
+            rc = ops.restrict_to_coarser(r, loc)
+            return rc if sign == 1.0 and out is None else ops.scale(rc, sign, out=out)
+        return ops.scale(ops.interp_adj(r, loc, self.shapes[lvl + 1]), sign / 2 ** loc.count("c"), out=out)
 
     def finish_cycle(self, lvl, x, b):
         """Second half of a V(nu1, nu2) cycle: `x` is pre-smoothed and b_{lvl+1} holds its restricted
@@ -122,12 +144,12 @@ class PoissonGMG:
             self.x[lvl + 1] = xc_new
         out = self.spare[lvl]
         weights = self.weights(self.nu2)
-        if weights and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
+        if weights and self.locs[lvl] == self.loc and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
             # x + P x_c is formed in registers by the first post-smoothing sweep (3 1/8 words per cell instead of 5 1/8)
             ops.poisson_jacobi_synth(xc_new, x, b, self.h2s[lvl], weights[0], out=out)
             weights = weights[1:]
         else:
-            ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
+            ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)  # x + P x_c
         self.spare[lvl] = x
         return self.sweeps(lvl, out, b, weights)
 
@@ -200,13 +222,13 @@ class PoissonGMG:
         the cycles that follow only have to cover the remaining distance to the tolerance."""
         fb = [b]
         for lvl in range(self.nlvl - 1):
-            fb.append(ops.restrict_to_coarser(fb[-1], self.loc))
+            fb.append(self.restrict(lvl, fb[-1]))
         x = None
         for lvl in range(self.nlvl - 1, -1, -1):
             if x is None:
                 start = torch.zeros(self.shapes[lvl], dtype=self.dtype, device=self.device)
             else:
-                start = ops.interp_add(x, self.loc)  # (a fresh tensor: the cycle's work buffers rotate underneath)
+                start = ops.interp_add(x, self.locs[lvl])  # (a fresh tensor: the cycle's work buffers rotate underneath)
             # (the tensor returned is never this level's coarse-correction buffer self.x[lvl], which the next finer
             # cycle zeroes: a cycle rotates its argument with self.spare[lvl] only)
             x = self.vcycle(lvl, start, fb[lvl])
@@ -393,6 +415,7 @@ class StencilGMG(PoissonGMG):
             self.coeffs = [ops.narrow_scale(c.reshape(-1), torch.empty(c.numel(), dtype=store, device=c.device)).view(c.shape)
                            for c in self.coeffs]
         self.nlvl = len(self.shapes)
+        self.locs = [self.loc] * (self.nlvl - 1)  # (every axis is halved on every level)
         mk = lambda s: torch.zeros(s, dtype=self.dtype, device=self.device)
         self.loss = mk(())
         self._coarse_inv = None

@@ -332,3 +332,55 @@ def test_no_padding_across_a_periodic_end(dev):
     c = np.stack([np.full(n, -2.0 - 1e-3), np.ones(n), np.ones(n)])  # periodic second difference with a small reaction term
     solver = gmg.StencilGMG(torch.as_tensor(c).to(dev))
     assert solver.shapes[-1] == (513,) and solver.continuation() is None
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 128), (1024, 64), (128, 128, 32), (64, 256, 256), (256, 64, 256), (32, 512)])
+def test_semicoarsening_on_cells_far_from_cubes(dev, shape):
+    """Unit-box Poisson on grids whose cells are 1 : 2 ... 1 : 16: with every axis halved on every level the cycles lost their
+    rate (24 passes at 1 : 2 WITH the Krylov hand-over, 70 - 110 at 1 : 4, no convergence in 200 at 1 : 16); `PoissonGMG` now
+    halves only the strongly coupled axes until the spacings meet: 7 - 10 plain cycles."""
+    from odil_amd import gmg, ops
+
+    h2 = [1.0 / n**2 for n in shape]
+    solver = gmg.PoissonGMG(shape, h2, torch.float64, dev)
+    assert any("." in loc for loc in solver.locs) and solver.locs[-1] == "c" * len(shape), solver.shapes
+    rng = np.random.default_rng(1)
+    xt = torch.as_tensor(rng.standard_normal(shape)).to(dev)
+    b, _ = ops.poisson_residual(xt, torch.zeros_like(xt), h2)
+    status = dict()
+    x = solver.solve(b, tol=1e-10, maxiter=40, status=status, krylov="never")
+    assert status["converged"] and status["niter"] <= 12, (shape, status, solver.shapes)
+    assert float((x - xt).abs().max()) <= 1e-6 * float(xt.abs().max())
+
+
+def test_newton_step_on_an_anisotropic_grid_multigrid_equals_direct(dev):
+    """Through the public API: the Poisson operator of the example on a 96 x 24 grid of the unit square (cells 1 : 4),
+    `--linsolver multigrid` against `direct` (dense Cholesky of M^T M, the reference's solve)."""
+    import argparse
+
+    import odil_amd as odil
+
+    p = os.path.join(ROOT, "examples", "poisson")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import poisson as ex
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    sol = dict()
+    for ls in ("direct", "multigrid"):
+        args = ex.parse_args(["--ndim", "2", "--N", "24", "--multigrid", "0", "--double", "1", "--linsolver", ls])
+        domain = odil.Domain(cshape=(96, 24), dimnames=("x", "y"), multigrid=False, dtype=np.float64)
+        ref_u = ex.reference_solution("hat", domain)
+        extra = argparse.Namespace(ref_u=ref_u, rhs=ex.discrete_rhs(ref_u, domain), args=args)
+        state = odil.State()
+        state.fields["u"] = None
+        state = domain.init_state(state)
+        problem = odil.Problem(ex.operator, domain, extra)
+        args.epoch_start, args.epochs = 0, 1
+        seen = []
+        odil.util.optimize(args, "newton", problem, state, lambda s, e, q: seen.append(q.get("linsolver") if hasattr(q, "get") else None))
+        sol[ls] = (state.fields["u"].array.clone(), [s for s in seen if s][-1])
+    assert sol["direct"][1]["method"].startswith("dense") and sol["multigrid"][1]["method"] == "gmg-vcycle", sol
+    assert sol["multigrid"][1]["niter"] <= 12
+    a, b = sol["multigrid"][0], sol["direct"][0]
+    assert float((a - b).abs().max()) <= 1e-7 * float(b.abs().max())
