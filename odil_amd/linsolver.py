@@ -119,11 +119,12 @@ def _solve_small_spd(a, b, info=None):
         try:
             x = torch.linalg.pinv(a, hermitian=True) @ b
         except RuntimeError:
-            # the device eigensolver gives up on some ill-conditioned complements (error 42 of syevd): LAPACK's SVD on the
-            # host, in double -- p <= 63
-            ah = a.detach().cpu().numpy().astype(np.float64)
-            x = torch.as_tensor(np.linalg.pinv(0.5 * (ah + ah.T), rcond=1e-13) @ b.detach().cpu().numpy().astype(np.float64),
-                                dtype=a.dtype).to(a.device)
+            # the device eigensolver gives up on some ill-conditioned complements (error 42 of syevd): the SVD route of the
+            # same library; when that fails too the caller takes another solver
+            try:
+                x = torch.linalg.pinv(0.5 * (a + a.t())) @ b
+            except RuntimeError:
+                return None
         if info is not None:
             info["schur_complement"] = "singular: minimum-norm solution"
     return x
