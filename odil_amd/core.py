@@ -752,6 +752,16 @@ class LinearizedOperator:
     def shape(self):
         return (self.nrows, self.ncols)
 
+    def promoted(self):
+        """The same operator with float64 coefficient arrays (linsolver.solve: exact routes of float32 problems)."""
+        import copy
+
+        wide = copy.copy(self)
+        wide.dtype, wide.source_dtype = torch.float64, self.dtype
+        wide.blocks = [(row0, nrows, kind, key, payload.double() if kind == "dense" else (payload[0].double(),) + tuple(payload[1:]))
+                       for row0, nrows, kind, key, payload in self.blocks]
+        return wide
+
     def _field_view(self, x, key):
         off, size = self.key_to_offset[key], self.key_to_size[key]
         return x[off : off + size]

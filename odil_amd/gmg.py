@@ -294,6 +294,7 @@ class PoissonGMG:
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
         method = "gmg-vcycle"
+        stagnated = False
         if self.nlvl == 1:
             # the finest level itself cannot be halved (an odd extent): its 'cycle' is the dense inverse (small), the padded
             # continuation, or sweeps -- as the preconditioner of GCR, which needs no contraction from it (the continuation
@@ -318,7 +319,8 @@ class PoissonGMG:
                 method = "gmg-vcycle + GCR(6)"
                 break
             if it >= 3 and res >= 0.98 * prev:
-                break  # stagnating at the rounding floor
+                stagnated = res == res and res < bn  # at the rounding floor of the working precision (not: diverging)
+                break
             x = self.finish_cycle(0, x, b)
             it += 1
         converged = res <= tol * max(bn, 1e-300)
@@ -332,6 +334,9 @@ class PoissonGMG:
             status["niter"] = it
             status["method"] = method
             status["converged"] = converged
+            # cycles that stopped gaining at the floor of the working precision (float32: cond * 6e-8 relative): nothing that
+            # works in this precision gets further, least of all the normal equations
+            status["stagnated"] = stagnated
         # the iterate may live in one of this object's work buffers: copy=False only for a caller that
         # consumes it before the next solve
         return x.clone() if copy else x

@@ -104,12 +104,34 @@ def cg_normal(op, rhs, damp=0.0, dampdiag=0.0, tol=1e-14, maxiter=None, status=N
     return x
 
 
-def _solve_small_spd(a, b, info=None):
+def _solve_small_spd(a, b, info=None, rcond=None, floor=0.0):
     """x with a x = b for the p x p (p <= 63) Schur complement of the dense columns.  Network weights often leave it
     SINGULAR (redundant directions: the reference's SuperLU then returns some member of the solution set): when the
     plain solve is not finite or misses the equations, the minimum-norm solution through the eigen-decomposition."""
     if not (bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())):
         return None  # (an inner solve broke down: the caller takes another route)
+    if rcond is not None:
+        # coefficients that were rounded to float32: a direction the exact complement annihilates survives at 1e-7 of its
+        # scale, the plain solve follows it out to 1e7 (heat with the network: loss 45 -> 2e9 in one step) -- cut at the
+        # data's precision instead of the arithmetic's
+        # (`floor`: the complement is a DIFFERENCE G - C^T Z of nearly equal matrices -- what is left below the rounding of
+        # G itself is noise whatever its size relative to the complement's own largest eigenvalue)
+        sym = 0.5 * (a + a.t())
+        try:
+            w, v = torch.linalg.eigh(sym)
+        except RuntimeError:
+            try:
+                u_, w, vt = torch.linalg.svd(sym)
+                v = u_
+            except RuntimeError:
+                return None
+        cut = max(rcond * float(w.abs().max()), float(floor))
+        keep = w.abs() > cut
+        inv = torch.where(keep, 1.0 / torch.where(keep, w, torch.ones_like(w)), torch.zeros_like(w))
+        x = v @ (inv * (v.t() @ b))
+        if info is not None:
+            info["schur_complement"] = "minimum-norm solution, {} of {} directions kept (cut at {:.1e})".format(int(keep.sum()), w.numel(), cut)
+        return x
     try:
         x = torch.linalg.solve(a, b)
         ok = bool(torch.isfinite(x).all()) and float((a @ x - b).norm()) <= 1e-8 * max(float(b.norm()), 1e-300)
@@ -174,8 +196,9 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
     dcols = torch.cat([torch.arange(op.key_to_offset[k], op.key_to_offset[k] + op.key_to_size[k], device=device)
                        for k in dense_keys])
     info = dict(method="schur-mfma", dense_columns=p)
+    data_rcond = 1e-5 if getattr(op, "source_dtype", None) == torch.float32 else None
     if not stencil_blocks:
-        y = _solve_small_spd(G, g, info)
+        y = _solve_small_spd(G, g, info, rcond=data_rcond)
         if y is None:
             return None
         niter = 0
@@ -207,7 +230,8 @@ def schur_normal(op, rhs, damp=0.0, dampdiag=0.0, maxiter=None, status=None, inn
         ct = cz[:p].t().contiguous()  # unknowns x p
         zt = zs.t().contiguous()      # unknowns x (p + 1)
         czz = ops.dense_xty(ct, zt)   # C^T [Z | z]
-        y = _solve_small_spd(G - czz[:, :p], g - czz[:, p], info)
+        y = _solve_small_spd(G - czz[:, :p], g - czz[:, p], info, rcond=data_rcond,
+                             floor=0.0 if data_rcond is None else 1e-6 * float(G.diagonal().abs().max()))
         if y is None:
             return None
         x.copy_(zs[p])
@@ -432,7 +456,9 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                 x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
             # cells far from cubes (point smoothing with full coarsening loses its rate) can leave the cycles short of the
             # tolerance: the iterate is then handed to the normal-equation CG below as its starting point, not returned
-            if sub.get("converged", True) or sub.get("residual", 0.0) <= 1e-6 * float(_dot(rhs, rhs)) ** 0.5:
+            bnorm = float(_dot(rhs, rhs)) ** 0.5
+            if sub.get("converged", True) or sub.get("residual", 0.0) <= 1e-6 * bnorm or (
+                    sub.get("stagnated") and sub.get("residual", 0.0) <= 1e-3 * bnorm):
                 status.update(sub)
                 return x.reshape(-1)
             from .util import printlog
@@ -455,7 +481,9 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             else:
                 solver = gmg.StencilGMG(coeffs)
                 x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
-            if sub.get("converged"):  # (a residual below the tolerance: the iterate is finite)
+            # (a residual below the tolerance, or cycles that stopped at the rounding floor of the working precision
+            # well below the right-hand side: the iterate is finite)
+            if sub.get("converged") or (sub.get("stagnated") and sub.get("residual", 0.0) <= 1e-3 * float(_dot(rhs, rhs)) ** 0.5):
                 sub["method"] = "gmg-vcycle (variable coefficients, {} levels{})".format(
                     solver.nlvl, "; float32 cycles, float64 residual" if mixed else "")
                 status.update(sub)
@@ -465,6 +493,28 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             printlog("odil_amd: variable-coefficient multigrid did not converge (relative residual {:.1e} after {} cycles); "
                      "using the normal-equation routes".format(sub.get("residual", float("nan")), sub.get("niter", 0)))
             del solver, coeffs, x
+    # float32 problems: the EXACT routes below work on a float64 copy of the operator -- the normal matrix squares the
+    # condition number, which at 1e3 - 1e4 for M already exceeds what float32 resolves (heat with the network, 64 x 64:
+    # loss 45 -> 8e3 in one float32 step, 45 -> 0.5 with the copy; the reference's float32 SuperLU solve sits in between).
+    # The iterate is rounded back to the problem's precision; the matrix-free routes (multigrid above, CG below) stay
+    # in float32.
+    if matr.dtype == torch.float32 and linsolver in ("direct", "directsq", "multigrid"):
+        wide = matr.promoted()
+        x = _exact_routes(wide, rhs.double(), damp, dampdiag, maxiter, status, linsolver)
+        if x is not None:
+            return x.to(torch.float32)
+    else:
+        x = _exact_routes(matr, rhs, damp, dampdiag, maxiter, status, linsolver)
+        if x is not None:
+            return x
+    if linsolver in ("direct", "directsq"):
+        return cg_normal(matr, rhs, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=status)
+    return cg_normal(matr, rhs, damp, dampdiag, tol=tol, maxiter=maxiter or 1000, status=status)
+
+
+def _exact_routes(matr, rhs, damp, dampdiag, maxiter, status, linsolver):
+    """Substitution, block cyclic reduction, Schur complement, dense factorisation -- in this order, whichever applies;
+    None when none does (the caller iterates on the normal equations)."""
     # Square and triangular along one axis (time-explicit operators): M d = rhs by substitution is exact and has the
     # solution of the normal equations
     if not damp and not dampdiag and linsolver in ("direct", "directsq", "multigrid"):
@@ -497,9 +547,7 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
             x = dense_normal(matr, rhs, damp, dampdiag, status=status)
             if x is not None and bool(torch.isfinite(x).all()):
                 return x
-        return cg_normal(matr, rhs, damp, dampdiag, tol=1e-14, maxiter=maxiter, status=status)
-    else:
-        return cg_normal(matr, rhs, damp, dampdiag, tol=tol, maxiter=maxiter or 1000, status=status)
+    return None
 
 
 def add_arguments(parser):
