@@ -368,6 +368,13 @@ int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, 
                                            void* stream);
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream);
 int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream);
+/* ... merging two cells along the axes with halve[i] != 0 only (semi-coarsening: the strongly coupled axes of an anisotropic
+ * operator; coarse shape = shape / 2 on those axes, shape on the others).  The factor 1/2 of the second-order part goes with
+ * the merged axes; with every axis merged this is odil_stencil_var_coarsen. */
+int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, const int* halve,
+                                      void* stream);
+int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
+                                      void* stream);
 /* Mixed-precision iterative refinement of the multigrid Newton solve (gmg.py; no reference counterpart -- the reference's
  * direct solver is double throughout): float32 V-cycles inside a float64 residual loop.  narrow_scale: y32 = s x64 with
  * s = a / sqrt(*msq) (msq: device scalar, the mean square the residual kernel just wrote; NULL: s = a); widen_axpy:

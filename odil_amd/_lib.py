@@ -62,6 +62,7 @@ _SIGNATURES = {
     "stencil_var_smooth": [_P, _P, _P, _P, _I64P, c_int, _R, c_int, _P],
     "stencil_var_residual_restrict": [_P, _P, _P, _P, _I64P, c_int, _R, _P, _P, _P],
     "stencil_var_coarsen": [_P, _P, _I64P, c_int, _P],
+    "stencil_var_coarsen_axes": [_P, _P, _I64P, c_int, _P, _P],
     "max_abs_diff": [_P, _P, c_int64, _P, _P, _P],
     "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],
     "dense_block_xty": [_P, _P, c_int64, c_int, c_int, c_int64, c_int64, _P, _P, _P],

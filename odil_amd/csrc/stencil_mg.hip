@@ -33,6 +33,7 @@ struct SvarArgs {
   int64_t size;   // Z Y X
   int has[3];     // axis present (its two coefficient arrays exist)
   int slot[3];    // index of cm_a among the coefficient arrays (cp_a = slot + 1)
+  int halve[3];   // (coarsening) two cells of this axis are merged; 0: the axis keeps its cells (semi-coarsening)
 };
 
 template <typename T>
@@ -245,6 +246,117 @@ __global__ __launch_bounds__(kBlock) void k_svar_coarsen(const T* __restrict__ c
   cc[I] = diag2 + diag10;
 }
 
+// SEMI-coarsening: only the axes with a.halve are merged (the strongly coupled axes of an anisotropic operator; the
+// others keep their cells until the couplings are of one size).  Same split of A; the factor 1/2 of the second-order part
+// belongs to the axes whose spacing doubles, so A2 is taken apart axis by axis: the couplings of axis d with their share
+// -(s_m + s_p) of the diagonal get f_d = 1/2 (merged) or 1 (kept); what is left of the diagonal on an incomplete row (a
+// wall closure) goes with the incomplete axis -- 1/2 when one of those is merged.  With every axis merged this is
+// k_svar_coarsen (which stays the kernel of that case: bit-identical hierarchies for grids of cubes).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_svar_coarsen_axes(const T* __restrict__ c, T* __restrict__ cc, SvarArgs a,
+                                                             SvarArgs ca) {
+  const int64_t I = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (I >= ca.size) return;
+  int64_t cid[3];
+  svar_decode(I, ca, cid);
+  const int64_t stride[3] = {a.n[1] * a.n[2], a.n[2], 1};
+  int kk[3];
+  T f[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    kk[d] = (a.has[d] && a.halve[d]) ? 2 : 1;
+    f[d] = a.halve[d] ? T(0.5) : T(1);
+  }
+  T dd2 = T(0), d1 = T(0), d0 = T(0);
+  T s2m[3] = {T(0), T(0), T(0)}, s2p[3] = {T(0), T(0), T(0)}, n1m[3] = {T(0), T(0), T(0)}, n1p[3] = {T(0), T(0), T(0)};
+  for (int p = 0; p < kk[0]; ++p)
+    for (int q = 0; q < kk[1]; ++q)
+      for (int s = 0; s < kk[2]; ++s) {
+        const int bit[3] = {p, q, s};
+        int64_t id[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) id[d] = !a.has[d] ? 0 : (a.halve[d] ? 2 * cid[d] + bit[d] : cid[d]);
+        const int64_t i = (id[0] * a.n[1] + id[1]) * a.n[2] + id[2];
+        const T c0 = c[i];
+        T sym_sum = c0;
+        bool complete = true, half_row = false;
+        T row_sm[3], row_sp[3], row_nm[3], row_np[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          row_sm[d] = row_sp[d] = row_nm[d] = row_np[d] = T(0);
+          if (!a.has[d]) continue;
+          const int64_t n = a.n[d];
+          const int64_t im = id[d] == 0 ? i + (n - 1) * stride[d] : i - stride[d];
+          const int64_t ip = id[d] == n - 1 ? i - (n - 1) * stride[d] : i + stride[d];
+          const T* cmA = c + (int64_t)a.slot[d] * a.size;
+          const T* cpA = cmA + a.size;
+          const T cm = cmA[i], cp = cpA[i];
+          const T cmn = cmA[ip], cpp = cpA[im];  // the reverse couplings
+          const bool pair_p = cp != T(0) && cmn != T(0), pair_m = cm != T(0) && cpp != T(0);
+          row_sp[d] = pair_p ? T(0.5) * (cp + cmn) : cp;
+          row_np[d] = pair_p ? T(0.5) * (cp - cmn) : T(0);
+          row_sm[d] = pair_m ? T(0.5) * (cm + cpp) : cm;
+          row_nm[d] = pair_m ? T(0.5) * (cm - cpp) : T(0);
+          const bool both = cm != T(0) && cp != T(0);
+          complete = complete && both;
+          half_row = half_row || (!both && a.halve[d]);
+          sym_sum = sym_sum + row_sm[d] + row_sp[d];
+        }
+        const T z = complete ? sym_sum : T(0);
+        d0 = d0 + z;
+        T rem = c0 - z;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (!a.has[d]) continue;
+          const T share = -(row_sm[d] + row_sp[d]);
+          rem = rem - share;
+          dd2 = dd2 + f[d] * share;
+          if (!a.halve[d]) {  // both couplings cross the aggregate's faces
+            s2m[d] = s2m[d] + row_sm[d];
+            s2p[d] = s2p[d] + row_sp[d];
+            n1m[d] = n1m[d] + row_nm[d];
+            n1p[d] = n1p[d] + row_np[d];
+          } else if (bit[d] == 0) {
+            s2m[d] = s2m[d] + row_sm[d];
+            n1m[d] = n1m[d] + row_nm[d];
+            dd2 = dd2 + f[d] * row_sp[d];
+            d1 = d1 + row_np[d];
+          } else {
+            s2p[d] = s2p[d] + row_sp[d];
+            n1p[d] = n1p[d] + row_np[d];
+            dd2 = dd2 + f[d] * row_sm[d];
+            d1 = d1 + row_nm[d];
+          }
+        }
+        dd2 = dd2 + (half_row ? T(0.5) : T(1)) * rem;
+      }
+  const T w = T(1) / T(kk[0] * kk[1] * kk[2]);
+  T diag2 = w * dd2;
+  const T diag10 = w * (d1 + d0);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (!a.has[d]) continue;
+    T sm = f[d] * w * s2m[d], sp = f[d] * w * s2p[d];
+    const T nm = w * n1m[d], np = w * n1p[d];
+    const T sgn_d = diag2 > T(0) ? T(-1) : T(1);
+    if (fabs((double)nm) > fabs((double)sm)) {
+      const T sgn = sm != T(0) ? (sm > T(0) ? T(1) : T(-1)) : sgn_d;
+      const T snew = sgn * (T)fabs((double)nm);
+      diag2 = diag2 - (snew - sm);
+      sm = snew;
+    }
+    if (fabs((double)np) > fabs((double)sp)) {
+      const T sgn = sp != T(0) ? (sp > T(0) ? T(1) : T(-1)) : sgn_d;
+      const T snew = sgn * (T)fabs((double)np);
+      diag2 = diag2 - (snew - sp);
+      sp = snew;
+    }
+    cc[(int64_t)ca.slot[d] * ca.size + I] = sm + nm;
+    cc[(int64_t)(ca.slot[d] + 1) * ca.size + I] = sp + np;
+  }
+  cc[I] = diag2 + diag10;
+}
+
 // max |a - b| and max |b| over n entries (recognition of a known operator from its coefficient arrays: one pass over
 // both instead of several elementwise launches); one partial pair per workgroup, combined by a second tiny launch
 template <typename T>
@@ -319,6 +431,7 @@ static int svar_fill(SvarArgs& a, const int64_t* shape, int ndim, const char* wh
     a.n[d] = i >= 0 ? shape[i] : 1;
     a.has[d] = i >= 0 ? 1 : 0;
     a.slot[d] = i >= 0 ? 1 + 2 * i : 0;
+    a.halve[d] = a.has[d];
     if (a.n[d] < 1) {
       set_error("%s: empty extent", what);
       return ODIL_E_INVAL;
@@ -335,7 +448,7 @@ static int svar_fill(SvarArgs& a, const int64_t* shape, int ndim, const char* wh
 static int svar_coarse(const SvarArgs& a, SvarArgs& ca, const char* what) {
   ca = a;
   for (int d = 0; d < 3; ++d) {
-    if (!a.has[d]) continue;
+    if (!a.has[d] || !a.halve[d]) continue;
     if (a.n[d] % 2 || a.n[d] < 2) {
       set_error("%s: extent %lld of axis %d is not even", what, (long long)a.n[d], d);
       return ODIL_E_INVAL;
@@ -384,16 +497,31 @@ static int svar_residual_restrict(const T* coeffs, const T* x, const T* b, T* co
 }
 
 template <typename T>
-static int svar_coarsen(const T* coeffs, T* coarse, const int64_t* shape, int ndim, void* stream) {
+static int svar_coarsen(const T* coeffs, T* coarse, const int64_t* shape, int ndim, const int* halve, void* stream) {
   SvarArgs a, ca;
   if (int e = svar_fill(a, shape, ndim, "stencil_var_coarsen")) return e;
+  bool all = true, any = false;
+  if (halve)
+    for (int i = 0; i < ndim; ++i) {
+      a.halve[i + 3 - ndim] = halve[i] != 0;
+      all = all && halve[i] != 0;
+      any = any || halve[i] != 0;
+    }
+  if (halve && !any) {
+    set_error("stencil_var_coarsen: no axis to merge");
+    return ODIL_E_INVAL;
+  }
   if (int e = svar_coarse(a, ca, "stencil_var_coarsen")) return e;
   if (!coeffs || !coarse) {
     set_error("stencil_var_coarsen: null pointer");
     return ODIL_E_INVAL;
   }
   const int64_t nb = (ca.size + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL((k_svar_coarsen<T>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, coarse, a, ca);
+  if (all)
+    hipLaunchKernelGGL((k_svar_coarsen<T>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, coarse, a, ca);
+  else
+    hipLaunchKernelGGL((k_svar_coarsen_axes<T>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, coarse, a,
+                       ca);
   return check_launch("k_svar_coarsen");
 }
 
@@ -427,9 +555,17 @@ int odil_max_abs_diff_f32(const float* a, const float* b, int64_t n, double* par
   return max_abs_diff<float>(a, b, n, partials, out, stream);
 }
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream) {
-  return svar_coarsen<double>(coeffs, coarse, shape, ndim, stream);
+  return svar_coarsen<double>(coeffs, coarse, shape, ndim, nullptr, stream);
 }
 int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream) {
-  return svar_coarsen<float>(coeffs, coarse, shape, ndim, stream);
+  return svar_coarsen<float>(coeffs, coarse, shape, ndim, nullptr, stream);
+}
+int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, const int* halve,
+                                      void* stream) {
+  return svar_coarsen<double>(coeffs, coarse, shape, ndim, halve, stream);
+}
+int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
+                                      void* stream) {
+  return svar_coarsen<float>(coeffs, coarse, shape, ndim, halve, stream);
 }
 }

@@ -410,17 +410,32 @@ class StencilGMG(PoissonGMG):
         self.omega = {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
         self.nu1, self.nu2 = nu1, nu2
         self.coeffs, self.shapes = [coeffs], [shape]
+        self.locs = []  # per transition: 'c' on the merged axes, '.' on the others
         cur = coeffs
-        while not lite and all(s % 2 == 0 and s // 2 >= min_size for s in self.shapes[-1]):
-            cur = ops.stencil_var_coarsen(cur)
+        while not lite:
+            # SEMI-coarsening while the couplings are of different sizes (cells far from cubes, anisotropic conductivities):
+            # only the axes whose largest coupling is within a factor 2 of the largest of all are merged -- point smoothing
+            # damps nothing else -- until they meet (one read-back per level, at set-up)
+            if self.ndim == 1:
+                halve = [True]
+            else:
+                size = torch.stack([ops.max_abs_diff(cur[1 + k].reshape(-1), cur[1 + k].reshape(-1))[1]
+                                    for k in range(2 * self.ndim)]).cpu().numpy()
+                # (the smaller of the two directions: an upwind convection term inflates ONE of them, and it grows
+                # relative to the diffusion on every coarser level -- that is not an anisotropy of the smoothing problem)
+                strength = [min(float(size[2 * a]), float(size[2 * a + 1])) for a in range(self.ndim)]
+                halve = [v >= 0.5 * max(strength) for v in strength]
+            if not all(n % 2 == 0 and n // 2 >= min_size for n, on in zip(self.shapes[-1], halve) if on):
+                break
+            cur = ops.stencil_var_coarsen(cur, halve)
             self.coeffs.append(cur)
-            self.shapes.append(tuple(s // 2 for s in self.shapes[-1]))
+            self.shapes.append(tuple(n // 2 if on else n for n, on in zip(self.shapes[-1], halve)))
+            self.locs.append("".join("c" if on else "." for on in halve))
         if store is not None and store != coeffs.dtype:
             assert coeffs.dtype == torch.float64 and store == torch.float32
             self.coeffs = [ops.narrow_scale(c.reshape(-1), torch.empty(c.numel(), dtype=store, device=c.device)).view(c.shape)
                            for c in self.coeffs]
         self.nlvl = len(self.shapes)
-        self.locs = [self.loc] * (self.nlvl - 1)  # (every axis is halved on every level)
         mk = lambda s: torch.zeros(s, dtype=self.dtype, device=self.device)
         self.loss = mk(())
         self._coarse_inv = None
@@ -468,8 +483,29 @@ class StencilGMG(PoissonGMG):
 
     def coarse_rhs(self, lvl, x, b):
         bc = self.b[lvl + 1]
-        ops.stencil_var_residual_restrict(self.coeffs[lvl], x, b, 1.0 / 2**self.ndim, bc, self.loss)
+        if self.locs[lvl] == self.loc:
+            ops.stencil_var_residual_restrict(self.coeffs[lvl], x, b, 1.0 / 2**self.ndim, bc, self.loss)
+        else:  # some axes only: the residual (its norm on the way), then the mean of the children
+            self.restrict(lvl, self.residual(lvl, x, b, self.r(lvl)), 1.0, out=bc)
         return bc
+
+    def restrict(self, lvl, r, sign=1.0, out=None):
+        """sign * (mean of the children): the R of the aggregation-built coarse operators.  (P^T / 2^k, which the
+        rediscretised Poisson hierarchy uses on its semi-coarsened transitions, is NOT consistent with them: across a
+        1 : 1000 jump of the conductivity the cycle diverged.)  Merged axes only: a strided mean (torch), no kernel of
+        this library averages along a subset of the axes."""
+        loc = self.locs[lvl]
+        if loc == self.loc:
+            return PoissonGMG.restrict(self, lvl, r, sign, out)
+        pairs, dims = [], []
+        for n, l in zip(r.shape, loc):
+            if l == "c":
+                dims.append(len(pairs) + 1)
+                pairs += [n // 2, 2]
+            else:
+                pairs.append(n)
+        rc = r.reshape(pairs).mean(dim=dims)
+        return ops.scale(rc, sign, out=out) if (sign != 1.0 or out is not None) else rc
 
     def finish_cycle(self, lvl, x, b):
         xc = self.x[lvl + 1]
@@ -484,7 +520,7 @@ class StencilGMG(PoissonGMG):
         if xc_new is not xc:
             self.x[lvl + 1] = xc_new
         out = self.spare[lvl]
-        ops.interp_add(xc_new, self.loc, add=x, out=out)  # x + P x_c
+        ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)  # x + P x_c
         self.spare[lvl] = x
         return self.sweeps(lvl, out, b, self.weights(self.nu2))
 

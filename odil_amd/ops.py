@@ -205,11 +205,21 @@ def max_abs_diff(a, b):
     return out
 
 
-def stencil_var_coarsen(coeffs):
-    """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip)."""
+def stencil_var_coarsen(coeffs, halve=None):
+    """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip).  halve: per axis,
+    whether two cells are merged along it (default: every axis); the others keep their extent (semi-coarsening)."""
+    import ctypes
+
     shape = tuple(coeffs.shape[1:])
-    out = torch.empty((coeffs.shape[0],) + tuple(s // 2 for s in shape), dtype=coeffs.dtype, device=coeffs.device)
-    call("stencil_var_coarsen", coeffs.dtype, ptr(coeffs), ptr(out), i64(shape), c_int(len(shape)), stream_ptr())
+    halve = [True] * len(shape) if halve is None else [bool(h) for h in halve]
+    out = torch.empty((coeffs.shape[0],) + tuple(s // 2 if h else s for s, h in zip(shape, halve)), dtype=coeffs.dtype,
+                      device=coeffs.device)
+    if all(halve):
+        call("stencil_var_coarsen", coeffs.dtype, ptr(coeffs), ptr(out), i64(shape), c_int(len(shape)), stream_ptr())
+    else:
+        mask = (ctypes.c_int * len(shape))(*[int(h) for h in halve])
+        call("stencil_var_coarsen_axes", coeffs.dtype, ptr(coeffs), ptr(out), i64(shape), c_int(len(shape)),
+             ctypes.cast(mask, ctypes.c_void_p), stream_ptr())
     return out
 
 

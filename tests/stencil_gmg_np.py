@@ -35,11 +35,13 @@ def restrict_mean(r):
     return blocks.mean(axis=tuple(range(1, 2 * nd, 2)))
 
 
-def _galerkin_p0(coeffs):
-    """R A P0 with R = mean of the 2^d children, P0 = piecewise constant: again 2 d + 1 arrays."""
+def _galerkin_p0(coeffs, halve=None):
+    """R A P0 with R = mean of the children, P0 = piecewise constant: again 2 d + 1 arrays.  halve: the axes along which
+    two cells are merged (default: all -- 2^d children); the other axes keep their cells."""
     nd = coeffs[0].ndim
     sh = coeffs[0].shape
-    blocks = lambda a: a.reshape([v for n in sh for v in (n // 2, 2)])  # noqa: E731
+    halve = [True] * nd if halve is None else list(halve)
+    blocks = lambda a: a.reshape([v for n, on in zip(sh, halve) for v in ((n // 2, 2) if on else (n, 1))])  # noqa: E731
     pair_axes = tuple(range(1, 2 * nd, 2))
     c0 = blocks(coeffs[0]).sum(axis=pair_axes)
     out = []
@@ -53,10 +55,71 @@ def _galerkin_p0(coeffs):
             sub = arr[tuple(idx)]
             return sub.sum(axis=tuple(ax if ax < 2 * a + 1 else ax - 1 for ax in other))
 
-        c0 = c0 + red(cm, 1) + red(cp, 0)  # couplings between the two children along a are internal
-        out += [red(cm, 0), red(cp, 1)]
-    w = 1.0 / 2**nd
+        if halve[a]:
+            c0 = c0 + red(cm, 1) + red(cp, 0)  # couplings between the two children along a are internal
+            out += [red(cm, 0), red(cp, 1)]
+        else:
+            out += [red(cm, 0), red(cp, 0)]    # every cell keeps both neighbours along a
+    w = 1.0 / 2 ** sum(halve)
     return [c0 * w] + [c * w for c in out]
+
+
+def coarsen_axes(coeffs, halve):
+    """The coarse operator when only the axes `halve` are merged (semi-coarsening: the strongly coupled axes of an
+    anisotropic operator).  Same split as `coarsen`; the factor 1/2 of the second-order part belongs to the axes whose
+    spacing doubles, so that part is taken apart axis by axis: A2 = sum_a A2_a (the couplings of axis a with their share of
+    the diagonal, zero row sums) + a diagonal remainder on incomplete rows (wall closures), which goes with the incomplete
+    axis -- 1/2 when that one is merged, 1 otherwise."""
+    nd = coeffs[0].ndim
+    halve = list(halve)
+    complete, sym, anti = [], [None] * (1 + 2 * nd), [None] * (1 + 2 * nd)
+    for a in range(nd):
+        cm, cp = coeffs[1 + 2 * a], coeffs[2 + 2 * a]
+        complete.append((cm != 0) & (cp != 0))
+        cm_next, cp_prev = np.roll(cm, -1, axis=a), np.roll(cp, 1, axis=a)
+        pair_p, pair_m = (cp != 0) & (cm_next != 0), (cm != 0) & (cp_prev != 0)
+        sym[2 + 2 * a] = np.where(pair_p, 0.5 * (cp + cm_next), cp)
+        anti[2 + 2 * a] = np.where(pair_p, 0.5 * (cp - cm_next), 0.0)
+        sym[1 + 2 * a] = np.where(pair_m, 0.5 * (cm + cp_prev), cm)
+        anti[1 + 2 * a] = np.where(pair_m, 0.5 * (cm - cp_prev), 0.0)
+    sym[0], anti[0] = coeffs[0].copy(), np.zeros_like(coeffs[0])
+    all_complete = np.logical_and.reduce(complete)
+    z = np.where(all_complete, sum(sym), 0.0)
+    zeros = lambda: [np.zeros_like(z) for _ in range(1 + 2 * nd)]  # noqa: E731
+    a0 = zeros()
+    a0[0] = z
+    g = _galerkin_p0(a0, halve)
+    for k, c in enumerate(_galerkin_p0(anti, halve)):
+        g[k] = g[k] + c
+    g1 = [c.copy() for c in _galerkin_p0(anti, halve)]
+    g2 = zeros()
+    g2 = [np.zeros_like(g[0]) for _ in range(1 + 2 * nd)]
+    rem = sym[0] - z
+    for a in range(nd):
+        part = zeros()
+        part[1 + 2 * a], part[2 + 2 * a] = sym[1 + 2 * a], sym[2 + 2 * a]
+        part[0] = -(sym[1 + 2 * a] + sym[2 + 2 * a])
+        rem = rem - part[0]
+        f = 0.5 if halve[a] else 1.0
+        for k, c in enumerate(_galerkin_p0(part, halve)):
+            g2[k] = g2[k] + f * c
+    # the remainder: zero on complete rows; on a row next to a wall the closure of the incomplete axis
+    half_rows = np.zeros(z.shape, dtype=bool)
+    for a in range(nd):
+        if halve[a]:
+            half_rows |= ~complete[a]
+    for rows, f in ((half_rows, 0.5), (~half_rows, 1.0)):
+        part = zeros()
+        part[0] = np.where(rows, rem, 0.0)
+        g2[0] = g2[0] + f * _galerkin_p0(part, halve)[0]
+    for k in range(1, 1 + 2 * nd):
+        s2, n1 = g2[k], g1[k]
+        need = np.abs(n1) > np.abs(s2)
+        sgn = np.where(s2 != 0, np.sign(s2), np.where(g2[0] > 0, -1.0, 1.0))
+        s_new = np.where(need, sgn * np.abs(n1), s2)
+        g2[0] = g2[0] - (s_new - s2)
+        g2[k] = s_new
+    return [a + b for a, b in zip(g2, g)]
 
 
 def coarsen(coeffs):
