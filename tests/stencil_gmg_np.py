@@ -223,3 +223,47 @@ def add_upwind_convection(coeffs, v, axis=0):
     out[0] = out[0] - np.where(interior, v * n, 0)
     out[1 + 2 * axis] = out[1 + 2 * axis] + np.where(interior, v * n, 0)
     return out
+
+
+def pick_axes(coeffs, min_size=2):
+    """The axes StencilGMG merges on this level: largest coupling (the smaller of the two directions) within a factor 2 of
+    the largest of all axes; None when one of them cannot be halved."""
+    nd = coeffs[0].ndim
+    strength = [min(np.abs(coeffs[1 + 2 * a]).max(), np.abs(coeffs[2 + 2 * a]).max()) for a in range(nd)]
+    halve = [s >= 0.5 * max(strength) for s in strength]
+    ok = all(n % 2 == 0 and n // 2 >= min_size for n, on in zip(coeffs[0].shape, halve) if on)
+    return halve if ok else None
+
+
+def hierarchy_axes(coeffs):
+    levels, halves = [coeffs], []
+    while True:
+        h = pick_axes(levels[-1])
+        if h is None:
+            return levels, halves
+        levels.append(coarsen_axes(levels[-1], h))
+        halves.append(h)
+
+
+def vcycle_axes(levels, halves, lvl, x, b, nu=2):
+    """V(nu, nu) with semi-coarsened transitions: mean over the merged children, linear interpolation along merged axes."""
+    coeffs, nd = levels[lvl], x.ndim
+    if lvl == len(levels) - 1:
+        n = x.size
+        amat = np.zeros((n, n))
+        for j in range(n):
+            e = np.zeros(n)
+            e[j] = 1
+            amat[:, j] = apply(coeffs, e.reshape(x.shape)).ravel()
+        return (np.linalg.pinv(amat, rcond=1e-12) @ b.ravel()).reshape(x.shape)
+    w = chebyshev_weights(nu, nd)
+    for k in range(nu):
+        x = jacobi(coeffs, x, b, w[k])
+    r = b - apply(coeffs, x)
+    h = halves[lvl]
+    rc = r.reshape([v for n, on in zip(r.shape, h) for v in ((n // 2, 2) if on else (n, 1))]).mean(axis=tuple(range(1, 2 * nd, 2)))
+    ec = vcycle_axes(levels, halves, lvl + 1, np.zeros_like(rc), rc, nu)
+    x = x + onp.interp_to_finer(ec, "".join("c" if on else "." for on in h))
+    for k in range(nu):
+        x = jacobi(coeffs, x, b, w[k])
+    return x

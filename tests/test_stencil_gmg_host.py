@@ -72,3 +72,31 @@ def test_two_cycles_on_the_first_coarse_level_pay_in_three_dimensions():
                 n += 1
             counts.append(n)
         assert counts[1] <= 13 and counts[0] >= counts[1] + 3, counts
+
+
+def test_semicoarsening_restatement():
+    """`coarsen_axes` with every axis merged is `coarsen`; with the strongly coupled axes only, the cycle contracts on
+    cells 1 : 4 and 1 : 8 (Poisson, a 1 : 1000 jump, a reaction term) where merging every axis DIVERGES."""
+    jump = lambda *x: np.where(np.abs(x[0] - 0.5) < 0.25, 1000.0, 1.0) * np.ones_like(x[0])  # noqa: E731
+    smooth = lambda *x: 1 + 10 * np.prod([np.sin(np.pi * v) ** 2 for v in x], axis=0)  # noqa: E731
+    for c in (sg.poisson_coeffs((16, 16)), sg.diffusion_coeffs((16, 8, 8), jump, sigma=3.0), sg.add_upwind_convection(sg.poisson_coeffs((16, 16)), 20.0)):
+        for a, b in zip(sg.coarsen(c), sg.coarsen_axes(c, [True] * c[0].ndim)):
+            assert np.abs(a - b).max() <= 1e-14 * np.abs(a).max()
+    rng = np.random.default_rng(0)
+    for name, c, bound in (("poisson 64 x 16", sg.poisson_coeffs((64, 16)), 0.2), ("jump 64 x 16", sg.diffusion_coeffs((64, 16), jump), 0.3),
+                           ("reaction 16 x 64", sg.diffusion_coeffs((16, 64), smooth, sigma=50.0), 0.2), ("poisson 16 x 16 x 4", sg.poisson_coeffs((16, 16, 4)), 0.2)):
+        levels, halves = sg.hierarchy_axes(c)
+        assert not all(halves[0]) and all(halves[-1]), (name, halves)
+        xt = rng.standard_normal(c[0].shape)
+        b = sg.apply(c, xt)
+        x, hist = np.zeros_like(xt), []
+        for _ in range(8):
+            x = sg.vcycle_axes(levels, halves, 0, x, b)
+            hist.append(np.linalg.norm(b - sg.apply(c, x)))
+        assert (hist[-1] / hist[3]) ** 0.25 < bound, (name, hist)
+        full = sg.hierarchy(c)
+        y, grow = np.zeros_like(xt), []
+        for _ in range(6):
+            y = sg.vcycle(full, 0, y, b)
+            grow.append(np.linalg.norm(b - sg.apply(c, y)))
+        assert grow[-1] > 0.5 * grow[-2], (name, grow)  # (full coarsening: no useful contraction)
