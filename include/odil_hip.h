@@ -218,6 +218,16 @@ int odil_poisson_jacobi_f64(const double* u, const double* rhs, double* uout, co
 int odil_poisson_jacobi_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
                             const float* h2, float omega, void* stream);
 
+/* TWO sweeps of odil_poisson_jacobi (weights omega1, then omega2) in ONE pass over memory: the intermediate iterate
+ * stays on the CU (registers along z, lane shifts along x, LDS along y), so a pair of sweeps moves the 3 words per cell
+ * of one.  uout != u; bit-identical to two calls of odil_poisson_jacobi.  The last extent must be a multiple of the
+ * 16-byte pack (2 doubles / 4 floats).  zc_hint: planes per workgroup chunk, <= 0: automatic.  (Multigrid smoother of
+ * the Newton solve; the reference hands that system to SuperLU / pyamg, linsolver.py:17-26, 61-72.) */
+int odil_poisson_jacobi2_f64(const double* u, const double* rhs, double* uout, const int64_t* shape, int ndim,
+                             const double* h2, double omega1, double omega2, int zc_hint, void* stream);
+int odil_poisson_jacobi2_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
+                             const float* h2, float omega1, float omega2, int zc_hint, void* stream);
+
 /* The same residual with the LAST prolongation of the multigrid synthesis fused in: u = w0 + P coarse
  * (reference core.py:245-263, last step) is formed in registers and never stored.  `coarse`: the
  * synthesised level-1 array of shape cshape (3-D, all axes cell-centred), w0 / rhs / fu: the fine

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mean_reduce": [_P, c_int64, c_int, _P, _P, _P],
     "poisson_residual": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
     "poisson_jacobi": [_P, _P, _P, _I64P, c_int, _P, _R, _P],
+    "poisson_jacobi2": [_P, _P, _P, _I64P, c_int, _P, _R, _R, c_int, _P],
     "poisson_residual_restrict": [_P, _P, _P, _I64P, c_int, _P, _R, _P, _P, _P],
     "poisson_residual_synth": [_P, _P, _P, _P, _I64P, _P, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_jacobi_synth": [_P, _P, _P, _P, _I64P, _P, _R, _P],

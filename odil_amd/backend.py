@@ -324,7 +324,8 @@ class ModRocm:
         """Transposed VALID convolution in the layout the reference calls it with (backend.py:165-172 ->
         jax.lax.conv_transpose; core.py:656-662): input (1, *spatial, 1), filters (*kernel, 1, 1); the stride-dilated
         input is correlated with the kernel AS GIVEN (transpose_kernel=False), i.e. out[s i + K - 1 - j] += in[i] w[j].
-        Result (1, *((n - 1) s + K), 1); differentiable in `input`."""
+        Result (1, *(n s + max(K - s, 0)), 1) -- (n - 1) s + K when K >= s --; differentiable in `input`.  Kernel extents and
+        strides 1 .. 4, up to 4 axes (odil_conv_valid)."""
         input = self._t(input)
         filters = self._t(filters, input.dtype)
         dim = input.dim() - 2
@@ -343,7 +344,10 @@ class ModRocm:
             raise NotImplementedError("mod.conv_transpose: gradients with respect to the filters")
         x = input.reshape(tuple(input.shape[1:-1])).contiguous()
         w = torch.flip(filters.reshape(tuple(filters.shape[:-2])), dims=tuple(range(dim))).contiguous()
-        res = _ConvValidFn.apply(x, w, strides, True, None)
+        # jax.lax.conv_transpose(VALID) returns n s + max(K - s, 0) entries per axis: (n - 1) s + K for K >= s (every call
+        # of the reference), zero-extended when the kernel is shorter than the stride
+        oshape = [n * s + max(k - s, 0) for n, s, k in zip(x.shape, strides, w.shape)]
+        res = _ConvValidFn.apply(x, w, strides, True, oshape)
         res = res.reshape((1,) + tuple(res.shape) + (1,))
         if output_shape is not None and tuple(int(v) for v in output_shape) != tuple(res.shape):
             raise ValueError("mod.conv_transpose: output_shape {} but the VALID result is {}".format(tuple(output_shape), tuple(res.shape)))

@@ -121,8 +121,11 @@ def _solve_small_spd(a, b, info=None, rcond=None, floor=0.0):
             w, v = torch.linalg.eigh(sym)
         except RuntimeError:
             try:
-                u_, w, vt = torch.linalg.svd(sym)
-                v = u_
+                # (singular values are |eigenvalues|; a negative eigenvalue shows as u = -v: the sign comes back from
+                # diag(u^T v), so the direction is applied with the eigenvalue's own sign)
+                u_, sv, vt = torch.linalg.svd(sym)
+                v = vt.t()
+                w = sv * torch.sign((u_ * v).sum(dim=0))
             except RuntimeError:
                 return None
         cut = max(rcond * float(w.abs().max()), float(floor))

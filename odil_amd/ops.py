@@ -421,6 +421,23 @@ def poisson_jacobi(u, rhs, h2, omega, out):
     return out
 
 
+def jacobi2_supported(shape, dtype):
+    """Arrays whose rows are whole 16-byte packs (odil_poisson_jacobi2, odil_stencil_var_smooth2)."""
+    pack = 2 if dtype == torch.float64 else 4
+    return 1 <= len(shape) <= 3 and shape[-1] % pack == 0 and min(shape) >= 2
+
+
+def poisson_jacobi2(u, rhs, h2, omega1, omega2, out, zc_hint=0):
+    """Two damped-Jacobi sweeps (weights omega1, then omega2) in ONE pass: bit-identical to two calls of
+    `poisson_jacobi`, 3 words per cell instead of 6 (out is not u)."""
+    assert u.shape == rhs.shape == out.shape and out.data_ptr() != u.data_ptr() and jacobi2_supported(tuple(u.shape), u.dtype)
+    assert u.is_contiguous() and rhs.is_contiguous() and out.is_contiguous()
+    h2a, h2p = host_reals(h2, u.dtype)
+    call("poisson_jacobi2", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p, float(omega1),
+         float(omega2), c_int(zc_hint), stream_ptr())
+    return out
+
+
 def jacobi_synth_supported(shape, dtype):
     """3-D arrays with even extents >= 4 (the coarse array they are prolongated from has extents >= 2)."""
     return len(shape) == 3 and all(s % 2 == 0 and s >= 4 for s in shape)

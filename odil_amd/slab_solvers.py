@@ -408,7 +408,9 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         if pre:
             x = self._smooth(comm, l, x, b)
         r = self.res[l]
-        self._last_res2 = self._residual(comm, l, x, b, r)
+        res2 = self._residual(comm, l, x, b, r)
+        if l == 0:  # (the coarser levels' residuals belong to THEIR systems: only the finest one is the solve's measure)
+            self._last_res2 = res2
         if l + 1 < len(self.mlv) or self.agg_shape is not None:
             xc = self._coarse_correction(comm, l, r)
             y = self.spare[l]

@@ -1865,7 +1865,7 @@ class _Codegen:
         plan = self._fold_plan(self.order, 1, windows=True)
         # a third copy for the strips that touch a wall of the LANE axis (2 of 9 at 512 columns): predicates of the other
         # axes folded, those of the lane axis kept
-        plan_w = self._fold_plan(self.order, 4, windows=True) if plan is not None and 3 >= 3 else None
+        plan_w = self._fold_plan(self.order, 4, windows=True) if plan is not None else None
         if plan_w is not None and (plan_w[0] == plan[0] or a2 not in plan[1]):
             plan_w = None  # (no predicate of the lane axis: the interior copy serves every strip)
         parts["plan"], parts["plan_w"] = plan, plan_w

@@ -551,6 +551,28 @@ def test_poisson_jacobi_sweep(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(16,), (1024,), (6, 12), (40, 1000), (8, 6, 12), (5, 7, 8), (2, 2, 4), (33, 31, 136),
+                                   (20, 45, 520), (70, 16, 256), (3, 100, 4)])
+def test_two_jacobi_sweeps_in_one_pass_are_bit_identical(dev, dtype, shape):
+    """odil_poisson_jacobi2 (the intermediate iterate kept on the CU) == two calls of odil_poisson_jacobi, bit for
+    bit: whole-row and tiled x-windows (halo packs), ragged y-tiles, 1-D / 2-D, chunks of 1 .. all planes, walls on
+    every side, steps that multiply (powers of two) and steps that divide."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(41)
+    x = to(rng.standard_normal(shape).astype(dtype), dev)
+    b = to(rng.standard_normal(shape).astype(dtype), dev)
+    assert ops.jacobi2_supported(shape, x.dtype)
+    for h2 in ([0.25**2, 0.125**2, 0.5**2], [0.1**2, 0.3**2, 0.07**2]):
+        h2 = [dtype(v) for v in h2[: len(shape)]]
+        y1 = ops.poisson_jacobi(x, b, h2, 0.9, torch.empty_like(x))
+        want = ops.poisson_jacobi(y1, b, h2, 0.6, torch.empty_like(x))
+        for zc in (0, 1, 3, 64):
+            got = ops.poisson_jacobi2(x, b, h2, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
+            assert torch.equal(got, want), (shape, zc)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(4, 6, 8), (8, 12, 16), (64, 32, 520), (2, 2, 4)])
 def test_poisson_residual_restrict(dev, dtype, shape):
     """odil_poisson_residual_restrict == scale * 2^d * restrict(residual) and the same loss, from the

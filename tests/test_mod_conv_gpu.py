@@ -131,6 +131,29 @@ def test_random_kernels_against_torch_cpu_convolutions(dev, mod, shape, kshape, 
     assert rel(ggot, gwant.numpy()) < tol
 
 
+def test_conv_transpose_with_a_kernel_shorter_than_the_stride_has_the_jax_extent(dev, mod):
+    """jax.lax.conv_transpose(VALID), which the reference's `mod.conv_transpose` is (backend.py:165-172), returns
+    n s + max(K - s, 0) entries per axis: n s when the kernel is shorter than the stride (zeros behind the last tap),
+    (n - 1) s + K otherwise."""
+    x = torch.arange(1.0, 6.0, dtype=torch.float64, device=dev).requires_grad_(True)
+    w = torch.tensor([2.0], dtype=torch.float64, device=dev)
+    got = mod.conv_transpose(x.reshape(1, 5, 1), w.reshape(1, 1, 1), strides=2, padding="VALID")
+    assert tuple(got.shape) == (1, 10, 1)
+    want = torch.zeros(10, dtype=torch.float64)
+    want[0::2] = 2.0 * torch.arange(1.0, 6.0, dtype=torch.float64)
+    assert torch.equal(got[0, :, 0].detach().cpu(), want)
+    (gx,) = torch.autograd.grad(got, x, torch.ones_like(got))
+    assert torch.equal(gx.cpu(), torch.full((5,), 2.0, dtype=torch.float64))
+    # a 2-D case mixing both regimes: K = 1 < s = 3 on the first axis, K = 4 >= s = 2 on the second
+    x2 = torch.randn((3, 4), dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    w2 = torch.randn((1, 4), dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    got2 = mod.conv_transpose(x2.to(dev).reshape(1, 3, 4, 1), w2.to(dev).reshape(1, 4, 1, 1), strides=(3, 2), padding="VALID")
+    assert tuple(got2.shape) == (1, 9, 10, 1)
+    ref = torch.nn.functional.conv_transpose2d(x2.reshape(1, 1, 3, 4), torch.flip(w2, dims=(0, 1)).reshape(1, 1, 1, 4),
+                                               stride=(3, 2))[0, 0]   # (7, 10): torch stops at the last tap
+    assert rel(got2[0, :7, :, 0], ref.numpy()) < 1e-15 and float(got2[0, 7:, :, 0].abs().max()) == 0.0
+
+
 def test_unsupported_forms_are_refused_not_approximated(dev, mod):
     x = torch.zeros((8, 8), dtype=torch.float64, device=dev)
     with pytest.raises(NotImplementedError):

@@ -275,6 +275,26 @@ def test_slab_newton_multigrid_step_solves_the_undivided_problem(world, N, nz):
     np.testing.assert_allclose(u, np.concatenate([res[3] for res in results]), rtol=0, atol=1e-9 * scale)
 
 
+@pytest.mark.parametrize("tol", [1e-4, 1e-6])
+def test_slab_newton_multigrid_reports_the_finest_level_residual(tol):
+    """With a LOOSE tolerance the step must stop on the FINEST level's residual (the cycle's recursion once overwrote it
+    with the deepest slab level's: `converged` after one cycle at a true relative residual of 0.08): the loss after the
+    step, sqrt(loss1 / loss0) = |A delta + f| / |f|, is then of the order of the tolerance, and the reported residual
+    bounds it (it belongs to the pre-smoothed iterate: slightly pessimistic)."""
+    from odil_amd.slab_solvers import run_threads
+
+    world, N, nz = 2, 32, 32
+    ref_u = np.random.default_rng(5).standard_normal((nz * world, N, N))
+    rhs = onp.poisson_discrete_rhs(ref_u, (1.0 / N,) * 3)
+    results = run_threads(world, lambda rank, comm: gmg_rank(rank, world, comm, N, rhs, nz=nz, tol=tol))
+    for loss0, loss1, status, u in results:
+        true_rel = float(np.sqrt(loss1 / loss0))
+        assert status["converged"] and status["residual"] <= tol
+        assert true_rel <= 1.5 * tol, (true_rel, status)
+        assert true_rel <= 1.5 * status["residual"], (true_rel, status)
+        assert status["niter"] >= 3  # (one cycle contracts by ~0.1: 1e-4 cannot be reached in one)
+
+
 def gmg_gloo_worker(rank, world, N, nz, port, out):
     from odil_amd.slab import TorchDistComm
 
