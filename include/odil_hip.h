@@ -228,6 +228,17 @@ int odil_poisson_jacobi2_f64(const double* u, const double* rhs, double* uout, c
 int odil_poisson_jacobi2_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
                              const float* h2, float omega1, float omega2, int zc_hint, void* stream);
 
+/* The coarse-grid correction of a V-cycle and BOTH post-smoothing sweeps in one pass: two sweeps of odil_poisson_jacobi
+ * (weights omega1, omega2) of u = x + P coarse, the prolongation formed on the fly (never stored), the first sweep kept
+ * on the CU.  Bit-identical to odil_interp_add followed by odil_poisson_jacobi2.  3-D; coarse: shape cshape, x / rhs /
+ * xout: 2 * cshape, xout != x; h2: squared FINE steps.  3 1/8 words per fine cell (separately: 2 1/8 + 6). */
+int odil_poisson_jacobi2_synth_f64(const double* coarse, const double* x, const double* rhs, double* xout,
+                                   const int64_t* cshape, const double* h2, double omega1, double omega2, int zc_hint,
+                                   void* stream);
+int odil_poisson_jacobi2_synth_f32(const float* coarse, const float* x, const float* rhs, float* xout,
+                                   const int64_t* cshape, const float* h2, float omega1, float omega2, int zc_hint,
+                                   void* stream);
+
 /* The same residual with the LAST prolongation of the multigrid synthesis fused in: u = w0 + P coarse
  * (reference core.py:245-263, last step) is formed in registers and never stored.  `coarse`: the
  * synthesised level-1 array of shape cshape (3-D, all axes cell-centred), w0 / rhs / fu: the fine
@@ -385,6 +396,28 @@ int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, cons
                                       void* stream);
 int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
                                       void* stream);
+
+/* The COARSE TAIL of a multigrid V-cycle in one launch: one workgroup walks `nlev` <= 8 small levels (pre-smoothing,
+ * residual + restriction, dense solve on the coarsest, prolongation + post-smoothing) with a workgroup barrier where a
+ * launch boundary used to be (levels of a few thousand cells cost ~7 dependent launches per level and cycle otherwise).
+ *   coeffs   the (2 ndim + 1) coefficient arrays of every level, finest first, back to back (layout of
+ *            odil_stencil_var_smooth; the Poisson hierarchy passes odil_poisson_jac_coeffs of its levels)
+ *   shapes   nlev x ndim extents; halve: (nlev - 1) x ndim, 1 where the transition to the next level merges cell pairs
+ *   xin      start iterate on the finest of these levels (NULL: zero), b its right-hand side, xout the result (!= xin, b)
+ *   work     >= 3 * (cells of all levels) values of scratch;  inv: ninv x ninv (pseudo-)inverse of the coarsest operator
+ *   wpre / wpost   HOST arrays of npre / npost (<= 4) Jacobi weights;  sweep: x' = x - w (A x - b) / c0
+ *   fmg      0: one V-cycle from xin;  1: the nested-iteration start (b restricted to every level, every level one cycle
+ *            from the interpolated solution of the level below), xin ignored
+ * Transfers: mean of the merged children down, the multigrid decomposition's prolongation (reference core.py:606-700,
+ * joint ghost rule core.py:640-643) up.  (Newton solve; the reference: SuperLU / pyamg, linsolver.py:17-26, 61-72.) */
+int odil_stencil_vcycle_tail_f64(const double* coeffs, const int64_t* shapes, const int* halve, int nlev, int ndim,
+                                 const double* xin, const double* b, double* xout, double* work, int64_t work_len,
+                                 const double* inv, int ninv, const double* wpre, int npre, const double* wpost,
+                                 int npost, int fmg, void* stream);
+int odil_stencil_vcycle_tail_f32(const float* coeffs, const int64_t* shapes, const int* halve, int nlev, int ndim,
+                                 const float* xin, const float* b, float* xout, float* work, int64_t work_len,
+                                 const float* inv, int ninv, const float* wpre, int npre, const float* wpost, int npost,
+                                 int fmg, void* stream);
 /* Mixed-precision iterative refinement of the multigrid Newton solve (gmg.py; no reference counterpart -- the reference's
  * direct solver is double throughout): float32 V-cycles inside a float64 residual loop.  narrow_scale: y32 = s x64 with
  * s = a / sqrt(*msq) (msq: device scalar, the mean square the residual kernel just wrote; NULL: s = a); widen_axpy:

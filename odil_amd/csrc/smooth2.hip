@@ -7,21 +7,25 @@
 // operation order) -- asserted by the tests.
 //
 // Mapping.  A WAVE owns one row segment of 64 packs (16 bytes per lane) and marches along z; a workgroup is 16 waves =
-// 16 consecutive rows of one x-window, of which the inner 14 are owned (their second sweep is stored).
+// 16 consecutive rows of one x-window: all of them load their row of x, rows 1 .. 14 form the first sweep, rows 2 .. 13
+// (the 12 owned rows) the second, which is stored.
 //   x neighbours  adjacent lanes' registers (wave-wide DPP shifts, common.h); an x-window that is not the whole row
 //                 carries one halo pack per side, whose first sweep is recomputed here (62 owned packs of 64)
-//   y neighbours  first sweep: rows y +- 1 of x from memory (L2 hits of the neighbouring waves' own rows, as in
-//                 k_poisson_jacobi); second sweep: rows y +- 1 of y1 through LDS (one plane, double-buffered: one
-//                 barrier per plane)
-//   z neighbours  registers: x planes p - 1 .. p + 2 and y1 planes p - 2 .. p of the lane's own pack
-// Step t forms y1 on plane p = z0 - 1 + t and emits the second sweep of plane p - 1; loads run one plane ahead of
-// their use and are issued first in every step.
+//   y neighbours  LDS: every wave publishes its row of x (plane p + 1) and of y1 (plane p), two buffers each, ONE
+//                 barrier per plane
+//   z neighbours  registers: x planes p - 1 .. p + 1 and y1 planes p - 2 .. p of the lane's own pack
+// Step t forms y1 on plane p = z0 - 1 + t and emits the second sweep of plane p - 1.  Loads (one of x, one of b per
+// wave and step) are issued first and consumed kS2Ahead steps later: register rings with compile-time indices -- the
+// march is unrolled by the ring length, so nothing is copied and no load is waited for before its use.
 #include "poisson.h"
 
 namespace odil {
 
 constexpr int kS2Waves = 16;            // rows per workgroup
-constexpr int kS2Own = kS2Waves - 2;    // rows whose second sweep is stored
+constexpr int kS2Own = kS2Waves - 4;    // rows whose second sweep is stored
+constexpr int kS2Ring = 6;              // register ring (planes) = unroll factor of the march
+constexpr int kS2Ahead = 2;             // steps between a load and its use (<= kS2Ring - 4)
+constexpr int kS2CRows = kS2Waves / 2 + 2;  // coarse rows behind a workgroup's fine rows (fused prolongation)
 
 struct Smooth2Args {
   int64_t n[3];    // canonical (Z, Y, X) cells
@@ -29,61 +33,140 @@ struct Smooth2Args {
   int packs;       // X / V
   int own_x;       // packs owned per x-window (the whole row: packs)
   int halo_x;      // 1: windows of 64 packs with a halo pack per side; 0: one window = the whole row
+  int nxt;         // x-windows per row
   int stream;      // non-temporal stores of the result
   UnitSched usched;  // units (z-chunk, y-tile, x-window)
 };
 
-// q - (A q - r) w of k_poisson_jacobi for the V cells of a pack, term by term
-template <typename T, int V>
+__device__ __forceinline__ double s2_uniform(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ float s2_uniform(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+
+// q - (A q - r) w of k_poisson_jacobi for the V cells of a pack, term by term.  WALLS false: no cell of the wave touches
+// a wall on this plane (a wave-uniform fact) -- the same expressions without their index tests.
+template <typename T, bool MUL>
+__device__ __forceinline__ T s2_div_h2(T v, const H2<T>& h, int ax) {
+  if constexpr (MUL) return v * h.inv[ax];
+  return div_h2<T>(v, h, ax);
+}
+
+// MUL: all 1 / h^2 are exact (powers of two), known at launch -- the instantiation that runs carries no divide
+template <typename T, int V, bool WALLS, bool MUL>
 __device__ __forceinline__ void jacobi_pack(const T (&qc)[V], const T (&zm)[V], const T (&zp)[V], const T (&ym)[V],
-                                            const T (&yp)[V], T left, T right, const T (&r)[V], int64_t z, int64_t y,
-                                            int64_t x0, const Smooth2Args& a, const H2<T>& h, T w_in, T w_wall,
-                                            T (&out)[V]) {
-  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+                                            const T (&yp)[V], T left, T right, const T (&r)[V], int z, int y, int x0,
+                                            const Smooth2Args& a, const H2<T>& h, T w_in, T w_wall, T (&out)[V]) {
+  const int Z = (int)a.n[0], Y = (int)a.n[1], X = (int)a.n[2];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
-    const int64_t x = x0 + i;
+    const int x = x0 + i;
     const T q = qc[i];
+    const T xm = i == 0 ? left : qc[i - 1 >= 0 ? i - 1 : 0];
+    const T xp = i == V - 1 ? right : qc[i + 1 < V ? i + 1 : i];
     T acc = T(0);
-    if (a.active[0]) acc = axis_term<T>(q, zm[i], zp[i], z == 0, z == Z - 1, h, 0);
-    if (a.active[1]) acc = acc + axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h, 1);
-    {
-      const T xm = i == 0 ? left : qc[i - 1 >= 0 ? i - 1 : 0];
-      const T xp = i == V - 1 ? right : qc[i + 1 < V ? i + 1 : i];
+    if constexpr (WALLS) {
+      if (a.active[0]) acc = axis_term<T>(q, zm[i], zp[i], z == 0, z == Z - 1, h, 0);
+      if (a.active[1]) acc = acc + axis_term<T>(q, ym[i], yp[i], y == 0, y == Y - 1, h, 1);
       acc = acc + axis_term<T>(q, xm, xp, x == 0, x == X - 1, h, 2);
+      out[i] = q - (acc - r[i]) * ((x == 0 || x == X - 1) ? w_wall : w_in);
+    } else {
+      if (a.active[0]) acc = s2_div_h2<T, MUL>(zp[i] - T(2) * q + zm[i], h, 0);
+      if (a.active[1]) acc = acc + s2_div_h2<T, MUL>(yp[i] - T(2) * q + ym[i], h, 1);
+      acc = acc + s2_div_h2<T, MUL>(xp - T(2) * q + xm, h, 2);
+      out[i] = q - (acc - r[i]) * w_in;
     }
-    out[i] = q - (acc - r[i]) * ((x == 0 || x == X - 1) ? w_wall : w_in);
   }
 }
 
-template <typename T, bool HASY>
+// ---- the prolongation of the coarse-grid correction as stage 0 (SYNTH) ------------------------------------------------
+// u = x + P x_c for the lane's pack of TWO fine cells (x = 2 j, 2 j + 1 <-> coarse column j) of fine row y, plane s:
+// exactly the arithmetic of k_interp_add_march (mg_march.hip: acc_plane / store_plane; reference core.py:606-700 with the
+// joint ghost rule core.py:640-643) -- t = sum over (rz, ry, rx) of T(wz wy wx) v, then x + t / 64.
+//   c[a][b], r[a][b]   coarse value at (plane a, row b) of the two planes / rows the cell reads, at the CLAMPED resp.
+//                      REFLECTED plane / row index, own column (r == c unless that plane or row lies beyond a wall)
+//   o[a][b]            that plane or row lies beyond a wall
+//   wz0, wy0           weight of the first tap (1: even fine index, 3: odd), the second gets 4 - it
+// Columns j -+ 1 are the adjacent lanes' values (lane shifts); beyond an x wall: clamp = own column, reflect = the
+// neighbour on the other side.
+template <typename T, bool ZY>
+__device__ __forceinline__ void synth_pack(const T (&c)[2][2], const T (&r)[2][2], const bool (&o)[2][2], int wz0, int wy0,
+                                           bool jlo, bool jhi, T (&x)[2]) {
+  T t0 = T(0), t1 = T(0);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const T cc = c[a][b];
+      const T clm = from_prev_lane(cc), clp = from_next_lane(cc);
+      T rr = cc, rfm = clm, rfp = clp;
+      if constexpr (ZY) {
+        rr = r[a][b];
+        rfm = from_prev_lane(rr);
+        rfp = from_next_lane(rr);
+      }
+      const bool oo = ZY ? o[a][b] : false;
+      const T v0 = oo ? T(2) * cc - rr : cc;
+      T vm, vp;
+      {
+        const T cl = jlo ? cc : clm, rf = jlo ? rfp : rfm;
+        vm = (oo || jlo) ? T(2) * cl - rf : cl;
+      }
+      {
+        const T cl = jhi ? cc : clp, rf = jhi ? rfm : rfp;
+        vp = (oo || jhi) ? T(2) * cl - rf : cl;
+      }
+      const int wzy = (a == 0 ? wz0 : 4 - wz0) * (b == 0 ? wy0 : 4 - wy0);
+      // even fine column: columns (j - 1, j) with weights (1, 3); odd: (j, j + 1) with (3, 1)
+      t0 = t0 + T(wzy) * vm;
+      t0 = t0 + T(3 * wzy) * v0;
+      t1 = t1 + T(3 * wzy) * v0;
+      t1 = t1 + T(wzy) * vp;
+    }
+  const T r64 = T(1) / T(64);
+  x[0] = T(1) * x[0] + t0 * r64;
+  x[1] = T(1) * x[1] + t1 * r64;
+}
+
+// V: cells per lane (16 bytes; 8 bytes for float with SYNTH, where a lane is one coarse column).
+template <typename T, int V, bool HASY, bool MUL, bool SYNTH, int D = kS2Ahead>
 __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(const T* __restrict__ u,
                                                                                const T* __restrict__ rhs,
-                                                                               T* __restrict__ uout, Smooth2Args a,
-                                                                               H2<T> h, T omega1, T omega2) {
-  constexpr int V = VecOf<T>::N;
+                                                                               T* __restrict__ uout,
+                                                                               const T* __restrict__ coarse,
+                                                                               Smooth2Args a, H2<T> h, T omega1,
+                                                                               T omega2) {
+  static_assert(!SYNTH || (V == 2 && HASY), "the fused prolongation is 3-D with one coarse column per lane");
   constexpr int NW = HASY ? kS2Waves : 1;
+  constexpr int HY = HASY ? 2 : 0;  // halo rows per side
+  __shared__ T ubuf[HASY ? 2 * NW * 64 * V : 1];
   __shared__ T ybuf[HASY ? 2 * NW * 64 * V : 1];
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
   int zc, yt, xt;
   if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
+  if constexpr (MUL) h.mul_ok[0] = h.mul_ok[1] = h.mul_ok[2] = 1;  // (the wall rows lose their divide as well)
   const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
   // the lane's pack: window position -> pack index (wrapped into the row: every address is valid, what lies beyond a
   // wall or outside the owned range is computed and discarded)
   int64_t xp = (int64_t)xt * a.own_x - a.halo_x + lane;
   const int own_here = (int64_t)(xt + 1) * a.own_x <= a.packs ? a.own_x : a.packs - xt * a.own_x;
-  const bool lane_own = a.halo_x ? (lane >= 1 && lane <= own_here) : lane < a.packs;
+  const bool lane_own = a.halo_x ? (lane >= a.halo_x && lane < a.halo_x + own_here) : lane < a.packs;
+  // (lanes beyond the window load too -- wrapped, valid addresses: masking them off measured SLOWER, 0.78 -> 0.88 ms)
   xp = ((xp % a.packs) + a.packs) % a.packs;
-  const int64_t x0 = xp * V;
-  int64_t y = HASY ? (int64_t)yt * kS2Own - 1 + row : 0;
-  const bool row_own = HASY ? (row >= 1 && row <= kS2Own && y < Y) : true;
+  const int x0 = (int)xp * V;
+  int64_t y = HASY ? (int64_t)yt * kS2Own - HY + row : 0;
+  const bool row_own = HASY ? (row >= HY && row < HY + kS2Own && y < Y) : true;
+  const bool row_s1 = HASY ? (row >= 1 && row <= NW - 2) : true;  // rows that form the first sweep
   y = ((y % Y) + Y) % Y;
   const int64_t z0 = (int64_t)zc * a.usched.ZC;
   const int64_t z1 = z0 + a.usched.ZC < Z ? z0 + a.usched.ZC : Z;
-  const int64_t c_off = y * sy + x0;
-  const int64_t ym_off = (y == 0 ? Y - 1 : y - 1) * sy + x0, yp_off = (y == Y - 1 ? 0 : y + 1) * sy + x0;
-  // omega / diag by (z at a wall, x at a wall) for both sweeps -- the expressions of k_poisson_jacobi
+  const uint32_t c_off = (uint32_t)(y * sy + x0);  // (a plane has < 2^31 cells: smooth2_args)
+  // no cell of this wave at a wall of y or x (wave-uniform)
+  const bool yx_inner = (!a.active[1] || (y != 0 && y != Y - 1)) && (a.halo_x ? (xt != 0 && xt != a.nxt - 1) : false);
+  // omega / diag by (z at a wall, x at a wall) for both sweeps -- the expressions of k_poisson_jacobi; the same in every
+  // lane of a wave (y is): scalar registers
   T dterm[3];
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) dterm[ax] = a.active[ax] ? div_h2<T>(T(-2), h, ax) : T(0);
@@ -95,89 +178,198 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
     for (int xw = 0; xw < 2; ++xw) {
       const T dzv = a.active[0] ? dterm[0] * T(1 + zw) : T(0);
       const T diag = (dzv + dy) + dterm[2] * T(1 + xw);
-      wd1[zw][xw] = omega1 / diag;
-      wd2[zw][xw] = omega2 / diag;
+      wd1[zw][xw] = s2_uniform(omega1 / diag);
+      wd2[zw][xw] = s2_uniform(omega2 / diag);
     }
-  auto wrapz = [Z](int64_t q) { return ((q % Z) + Z) % Z; };
-  const int64_t p0 = z0 - 1;
-  T u_m[V], u_c[V], u_p[V], u_n[V];      // own row: planes p - 1, p, p + 1, p + 2
-  T nm_c[V], np_c[V], nm_n[V], np_n[V];  // rows y -+ 1 of planes p, p + 1
-  T b_m[V], b_c[V], b_n[V];              // rhs of planes p - 1, p, p + 1
-  T y_m[V], y_c[V];                      // first sweep of planes p - 2, p - 1
-  T ym_c[V], yp_c[V];                    // rows y -+ 1 of the first sweep of plane p - 1
-  load_vec<T, V, true>(u + wrapz(p0 - 1) * sz + c_off, V, u_m);
-  load_vec<T, V, true>(u + wrapz(p0) * sz + c_off, V, u_c);
-  load_vec<T, V, true>(u + wrapz(p0 + 1) * sz + c_off, V, u_p);
-  load_vec<T, V, true>(rhs + wrapz(p0) * sz + c_off, V, b_c);
-  if (HASY) {
-    load_vec<T, V, true>(u + wrapz(p0) * sz + ym_off, V, nm_c);
-    load_vec<T, V, true>(u + wrapz(p0) * sz + yp_off, V, np_c);
+  // plane indices wrap periodically (what lies beyond a wall is discarded by the wall rows); a chunk starts two planes
+  // early and the ring runs D + 1 planes ahead
+  const int Zi = (int)Z;
+  auto wrapz = [Zi](int q) {
+    q %= Zi;
+    return q < 0 ? q + Zi : q;
+  };
+  const int p0 = (int)z0 - 1;
+  // Rings indexed by the step number modulo R: entry (k mod R) of `uo` holds plane p0 + k of x (SYNTH: of x + P x_c once
+  // its step has formed it), of `bb` the rhs of plane p0 + k, of `y1` the first sweep of plane p0 + k.  Every index below
+  // is a constant after unrolling.
+  constexpr int R = kS2Ring;
+  T uo[R][V], bb[R][V], y1[R][V];
+  // ---- SYNTH: the coarse planes in an LDS ring of three, the kS2CRows coarse rows the workgroup's fine rows read ------
+  // (fine rows 12 yt - 2 .. 12 yt + 13 read the coarse rows 6 yt - 2 .. 6 yt + 7; wave w < kS2CRows fetches row w of a new
+  // coarse plane every second step, clamped into the array: the `cl` values of the joint ghost rule)
+  const int cnz = Zi / 2, cny = (int)(Y / 2), cnx = a.packs;
+  const int64_t cplane = (int64_t)cny * cnx;
+  __shared__ T cbuf[SYNTH ? 3 * kS2CRows * 64 : 1];
+  const bool jlo = xp == 0, jhi = xp == cnx - 1;
+  int crow[2] = {0, 0};  // LDS rows of the two coarse rows this fine row reads
+  int cq[2] = {0, 0};    // their coarse row numbers (may lie beyond a wall)
+  int srw0 = 1;          // weight of the first row tap
+  int cfetch = 0;        // offset of the coarse row this wave fetches + own column
+  if constexpr (SYNTH) {
+    const int yu = yt * kS2Own - HY + row;  // not wrapped
+    const int jy = yu >> 1, ey = yu & 1;
+    srw0 = ey ? 3 : 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      cq[b] = jy - 1 + ey + b;
+      crow[b] = (cq[b] - (yt * (kS2Own / 2) - 2)) * 64 + lane;
+    }
+    const int qf = yt * (kS2Own / 2) - 2 + row;
+    cfetch = (qf < 0 ? 0 : (qf >= cny ? cny - 1 : qf)) * cnx + (int)xp;
+  }
+  auto zcl = [cnz](int q) { return q < 0 ? 0 : (q >= cnz ? cnz - 1 : q); };
+  auto zrf = [cnz](int q) { return q < 0 ? 1 : (q >= cnz ? (cnz >= 2 ? cnz - 2 : 0) : q); };
+  auto yrf = [cny](int q) { return q < 0 ? 1 : (q >= cny ? (cny >= 2 ? cny - 2 : 0) : q); };
+  // u = x + P x_c in place on the raw pack `xv` of fine plane s; the coarse planes (qa, qa + 1) it reads lie in the ring
+  // entries ea, eb
+  auto synth = [&](int s, int ea, int eb, T (&xv)[V]) {
+    if constexpr (SYNTH) {
+      const int qa = (s >> 1) - 1 + (s & 1);
+      const bool oza = qa < 0 || qa >= cnz, ozb = qa + 1 < 0 || qa + 1 >= cnz;
+      const bool oya = cq[0] < 0 || cq[0] >= cny, oyb = cq[1] < 0 || cq[1] >= cny;
+      const int wz0 = (s & 1) ? 3 : 1;
+      T c[2][2];
+      c[0][0] = cbuf[ea * (kS2CRows * 64) + crow[0]];
+      c[0][1] = cbuf[ea * (kS2CRows * 64) + crow[1]];
+      c[1][0] = cbuf[eb * (kS2CRows * 64) + crow[0]];
+      c[1][1] = cbuf[eb * (kS2CRows * 64) + crow[1]];
+      if (oza || ozb || oya || oyb) {  // (wave-uniform: planes / rows next to a wall)
+        T r[2][2];
+        bool o[2][2];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            r[pa][b] = coarse[(int64_t)zrf(qa + pa) * cplane + (int64_t)yrf(cq[b]) * cnx + xp];
+            o[pa][b] = (pa ? ozb : oza) || (b ? oyb : oya);
+          }
+        synth_pack<T, true>(c, r, o, wz0, srw0, jlo, jhi, xv);
+      } else {
+        const bool o[2][2] = {{false, false}, {false, false}};
+        synth_pack<T, false>(c, c, o, wz0, srw0, jlo, jhi, xv);
+      }
+    }
+  };
+  load_vec<T, V, true>(u + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+#pragma unroll
+  for (int k = 0; k <= D; ++k) load_vec<T, V, true>(u + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+#pragma unroll
+  for (int k = 0; k < D; ++k) load_vec<T, V, true>(rhs + wrapz(p0 + k) * sz + c_off, V, bb[k]);
+  T cnew = T(0);  // the coarse value this wave fetched, on its way to the LDS ring
+  if constexpr (SYNTH) {
+    // planes z0 - 2 (even) and z0 - 1 (odd) of u for the first step read the coarse planes js0 - 2 .. js0: entries 1, 2, 0
+    // of the ring (plane js0 - 2 sits where js0 + 1 belongs and is replaced below)
+    const int js0 = (int)(z0 >> 1);
+    if (row < kS2CRows) {
+      cbuf[(1 * kS2CRows + row) * 64 + lane] = coarse[(int64_t)zcl(js0 - 2) * cplane + cfetch];
+      cbuf[(2 * kS2CRows + row) * 64 + lane] = coarse[(int64_t)zcl(js0 - 1) * cplane + cfetch];
+      cbuf[(0 * kS2CRows + row) * 64 + lane] = coarse[(int64_t)zcl(js0) * cplane + cfetch];
+      cnew = coarse[(int64_t)zcl(js0 + 1) * cplane + cfetch];
+    }
+    __syncthreads();
+    synth((int)z0 - 2, 1, 2, uo[R - 1]);
+    synth((int)z0 - 1, 2, 0, uo[0]);
+    __syncthreads();
+    if (row < kS2CRows) cbuf[(1 * kS2CRows + row) * 64 + lane] = cnew;
   }
 #pragma unroll
-  for (int i = 0; i < V; ++i) y_m[i] = y_c[i] = ym_c[i] = yp_c[i] = b_m[i] = T(0);
+  for (int i = 0; i < V; ++i) y1[R - 2][i] = y1[R - 1][i] = bb[R - 1][i] = T(0);
+  const int slot = (row * 64 + lane) * V;
+  const int slot_m = ((row == 0 ? 0 : row - 1) * 64 + lane) * V, slot_p = ((row == NW - 1 ? NW - 1 : row + 1) * 64 + lane) * V;
+  if (HASY) {  // plane p0 of x for the first step's neighbours
+    store_vec<T, V, true>(ubuf + slot, V, uo[0]);
+    __syncthreads();
+  }
+  // whole groups of R steps (no exit inside the unrolled body: straight-line code); the steps beyond the chunk's last
+  // plane load valid (wrapped) planes and store nothing
   const int nt = (int)(z1 - z0) + 2;
-  for (int t = 0; t < nt; ++t) {
-    const int64_t p = p0 + t;
-    // (1) the loads of this step: they are consumed by the NEXT step
-    {
-      const int64_t pa = wrapz(p + 2) * sz, pb = wrapz(p + 1) * sz;
-      load_vec<T, V, true>(u + pa + c_off, V, u_n);
-      load_vec<T, V, true>(rhs + pb + c_off, V, b_n);
-      if (HASY) {
-        load_vec<T, V, true>(u + pb + ym_off, V, nm_n);
-        load_vec<T, V, true>(u + pb + yp_off, V, np_n);
-      }
-    }
-    // (2) first sweep on plane p
-    const int64_t pw = wrapz(p);
-    T y_p[V];
-    {
-      T left = from_prev_lane(u_c[V - 1]), right = from_next_lane(u_c[0]);
-      const bool zw = a.active[0] && (pw == 0 || pw == Z - 1);
-      jacobi_pack<T, V>(u_c, u_m, u_p, nm_c, np_c, left, right, b_c, pw, y, x0, a, h, zw ? wd1[1][0] : wd1[0][0],
-                        zw ? wd1[1][1] : wd1[0][1], y_p);
-    }
-    T ym_p[V], yp_p[V];
-    if (HASY) {
-      T* buf = ybuf + (t & 1) * (NW * 64 * V);
-      store_vec<T, V, true>(buf + (row * 64 + lane) * V, V, y_p);
-      __syncthreads();
-      const int rm = row == 0 ? 0 : row - 1, rp = row == NW - 1 ? NW - 1 : row + 1;
-      load_vec<T, V, true>(buf + (rm * 64 + lane) * V, V, ym_p);
-      load_vec<T, V, true>(buf + (rp * 64 + lane) * V, V, yp_p);
-    }
-    // (3) second sweep on plane p - 1
-    if (t >= 2) {
-      const int64_t z = p - 1;  // in [z0, z1)
-      T out[V];
-      T left = from_prev_lane(y_c[V - 1]), right = from_next_lane(y_c[0]);
-      const bool zw = a.active[0] && (z == 0 || z == Z - 1);
-      jacobi_pack<T, V>(y_c, y_m, y_p, ym_c, yp_c, left, right, b_m, z, y, x0, a, h, zw ? wd2[1][0] : wd2[0][0],
-                        zw ? wd2[1][1] : wd2[0][1], out);
-      if (row_own && lane_own) {
-        if (a.stream)
-          store_vec<T, V, true, true>(uout + z * sz + c_off, V, out);
-        else
-          store_vec<T, V, true, false>(uout + z * sz + c_off, V, out);
-      }
-    }
+  int pw = wrapz(p0);                 // plane p, wrapped
+  int pa = wrapz(p0 + 1 + D);         // plane p + 1 + D, wrapped
+  int pb = wrapz(p0 + D);             // plane p + D, wrapped
+  for (int t0 = 0; t0 < nt; t0 += R) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      u_m[i] = u_c[i], u_c[i] = u_p[i], u_p[i] = u_n[i];
-      b_m[i] = b_c[i], b_c[i] = b_n[i];
-      y_m[i] = y_c[i], y_c[i] = y_p[i];
-      if (HASY) {
-        nm_c[i] = nm_n[i], np_c[i] = np_n[i];
-        ym_c[i] = ym_p[i], yp_c[i] = yp_p[i];
+    for (int k = 0; k < R; ++k) {
+      const int t = t0 + k;
+      // (1) the loads of this step, consumed D steps later
+      // (uniform plane pointer + 32-bit lane offset: the scalar-base form of the load, no 64-bit lane arithmetic)
+      load_vec<T, V, true>(u + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
+      if (row_s1) load_vec<T, V, true>(rhs + pb * sz + c_off, V, bb[(k + D) % R]);
+      if constexpr (SYNTH) {
+        // fine plane s = z0 + t (parity of k: z0 and t0 are even) reads the coarse planes js - 1, js (even) or js, js + 1
+        // (odd), js = s / 2 in ring entry (k / 2) % 3.  An odd step fetches plane js + 2, the next (even) step puts it
+        // into the entry of plane js - 1 -- last read by the even step before -- and the odd step after that reads it.
+        if ((k & 1) && row < kS2CRows) cnew = coarse[(int64_t)zcl((int)(z0 >> 1) + (t >> 1) + 2) * cplane + cfetch];
+        if (!(k & 1) && t > 0 && row < kS2CRows) cbuf[((((k >> 1) + 1) % 3) * kS2CRows + row) * 64 + lane] = cnew;
+        const int s = (int)z0 + t;
+        if (k & 1)
+          synth(s, (k >> 1) % 3, ((k >> 1) + 1) % 3, uo[(k + 1) % R]);
+        else
+          synth(s, ((k >> 1) + 2) % 3, (k >> 1) % 3, uo[(k + 1) % R]);
       }
+      // (2) plane p + 1 of x for the next step's y neighbours
+      if (HASY) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
+      if (row_s1) {
+        // (3) first sweep on plane p
+        {
+          const T (&qc)[V] = uo[k];
+          T nm[V], np[V];
+          if (HASY) {
+            const T* buf = ubuf + (k & 1) * (NW * 64 * V);
+            load_vec<T, V, true>(buf + slot_m, V, nm);
+            load_vec<T, V, true>(buf + slot_p, V, np);
+          }
+          T left = from_prev_lane(qc[V - 1]), right = from_next_lane(qc[0]);
+          const bool zw = a.active[0] && (pw == 0 || pw == Zi - 1);
+          if (yx_inner && !zw)
+            jacobi_pack<T, V, false, MUL>(qc, uo[(k + R - 1) % R], uo[(k + 1) % R], nm, np, left, right, bb[k], pw, (int)y, x0, a,
+                                          h, wd1[0][0], wd1[0][0], y1[k]);
+          else
+            jacobi_pack<T, V, true, MUL>(qc, uo[(k + R - 1) % R], uo[(k + 1) % R], nm, np, left, right, bb[k], pw, (int)y, x0, a,
+                                         h, zw ? wd1[1][0] : wd1[0][0], zw ? wd1[1][1] : wd1[0][1], y1[k]);
+        }
+        if (HASY) store_vec<T, V, true>(ybuf + (k & 1) * (NW * 64 * V) + slot, V, y1[k]);
+        // (4) second sweep on plane p - 1 (its y neighbours were published by the previous step)
+        {
+          const int z = p0 + t - 1;  // not wrapped: a plane of this chunk when t >= 2 and z < z1
+          const T (&qc)[V] = y1[(k + R - 1) % R];
+          T nm[V], np[V], out[V];
+          if (HASY) {
+            const T* buf = ybuf + ((k + 1) & 1) * (NW * 64 * V);
+            load_vec<T, V, true>(buf + slot_m, V, nm);
+            load_vec<T, V, true>(buf + slot_p, V, np);
+          }
+          T left = from_prev_lane(qc[V - 1]), right = from_next_lane(qc[0]);
+          const bool zw = a.active[0] && (z == 0 || z == Zi - 1);
+          if (yx_inner && !zw)
+            jacobi_pack<T, V, false, MUL>(qc, y1[(k + R - 2) % R], y1[k], nm, np, left, right, bb[(k + R - 1) % R], z, (int)y, x0,
+                                          a, h, wd2[0][0], wd2[0][0], out);
+          else
+            jacobi_pack<T, V, true, MUL>(qc, y1[(k + R - 2) % R], y1[k], nm, np, left, right, bb[(k + R - 1) % R], z, (int)y, x0,
+                                         a, h, zw ? wd2[1][0] : wd2[0][0], zw ? wd2[1][1] : wd2[0][1], out);
+          if (t >= 2 && z < (int)z1 && row_own && lane_own) {
+            if (a.stream)
+              store_vec<T, V, true, true>(uout + (int64_t)z * sz + c_off, V, out);
+            else
+              store_vec<T, V, true, false>(uout + (int64_t)z * sz + c_off, V, out);
+          }
+        }
+      }
+      if (HASY) __syncthreads();
+      // (the steps stay apart: hoisting the loads of all R unrolled steps to the top costs the registers of R planes)
+#ifndef S2_NO_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      pw = pw + 1 == Zi ? 0 : pw + 1;
+      pa = pa + 1 == Zi ? 0 : pa + 1;
+      pb = pb + 1 == Zi ? 0 : pb + 1;
     }
   }
 }
 
+// V: cells per lane; halo: packs of x-halo per side of a window that is not the whole row
 template <typename T>
-static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T* h2, T h[3], int zc_hint,
-                        const char* what) {
-  constexpr int V = VecOf<T>::N;
+static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T* h2, T h[3], int zc_hint, int V,
+                        int halo, const char* what) {
   if (ndim < 1 || ndim > 3 || !shape || !h2) {
     set_error("%s: ndim=%d out of range [1,3] or null shape/h2", what, ndim);
     return ODIL_E_INVAL;
@@ -199,7 +391,7 @@ static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T*
     }
   }
   if (a.n[2] % V) {
-    set_error("%s: the last extent must be a multiple of %d (use two single sweeps)", what, V);
+    set_error("%s: the last extent must be a multiple of %d (use single sweeps)", what, V);
     return ODIL_E_INVAL;
   }
   a.packs = (int)(a.n[2] / V);
@@ -207,12 +399,13 @@ static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T*
   if (a.packs <= 64) {
     a.halo_x = 0, a.own_x = a.packs, nxt = 1;
   } else {
-    a.halo_x = 1;
-    nxt = (a.packs + 61) / 62;
+    a.halo_x = halo;
+    nxt = (a.packs + 63 - 2 * halo) / (64 - 2 * halo);
     a.own_x = (int)((a.packs + nxt - 1) / nxt);
   }
+  a.nxt = (int)nxt;
   const int64_t nyt = a.active[1] ? (a.n[1] + kS2Own - 1) / kS2Own : 1;
-  if (a.n[0] * nyt * nxt >= ((int64_t)1 << 31)) {
+  if (a.n[0] * nyt * nxt >= ((int64_t)1 << 31) || a.n[1] * a.n[2] >= ((int64_t)1 << 31) || a.n[0] >= ((int64_t)1 << 30)) {
     set_error("%s: grid too large for one launch", what);
     return ODIL_E_INVAL;
   }
@@ -244,21 +437,69 @@ static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T*
 template <typename T>
 static int poisson_jacobi2(const T* u, const T* rhs, T* uout, const int64_t* shape, int ndim, const T* h2, T omega1,
                            T omega2, int zc_hint, void* stream) {
+  constexpr int V = VecOf<T>::N;
   Smooth2Args a;
   T h[3];
-  if (int e = smooth2_args<T>(a, shape, ndim, h2, h, zc_hint, "poisson_jacobi2")) return e;
+  if (int e = smooth2_args<T>(a, shape, ndim, h2, h, zc_hint, V, 1, "poisson_jacobi2")) return e;
   if (!u || !rhs || !uout || u == uout) {
     set_error("poisson_jacobi2: null pointer, or the sweeps in place (x_out must differ from x)");
     return ODIL_E_INVAL;
   }
   const int grid = unit_grid(a.usched);
-  if (a.active[1])
-    hipLaunchKernelGGL((k_poisson_jacobi2<T, true>), dim3(grid), dim3(64 * kS2Waves), 0, (hipStream_t)stream, u, rhs,
-                       uout, a, make_h2<T>(h), omega1, omega2);
-  else
-    hipLaunchKernelGGL((k_poisson_jacobi2<T, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, u, rhs, uout, a,
-                       make_h2<T>(h), omega1, omega2);
+  const H2<T> hh = make_h2<T>(h);
+  const bool mul = hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2];
+  const T* none = nullptr;
+#define ODIL_LAUNCH_J2(HASY, MUL, THREADS)                                                                          \
+  hipLaunchKernelGGL((k_poisson_jacobi2<T, V, HASY, MUL, false>), dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, u, \
+                     rhs, uout, none, a, hh, omega1, omega2)
+  if (a.active[1]) {
+    if (mul)
+      ODIL_LAUNCH_J2(true, true, 64 * kS2Waves);
+    else
+      ODIL_LAUNCH_J2(true, false, 64 * kS2Waves);
+  } else {
+    if (mul)
+      ODIL_LAUNCH_J2(false, true, 64);
+    else
+      ODIL_LAUNCH_J2(false, false, 64);
+  }
+#undef ODIL_LAUNCH_J2
   return check_launch("k_poisson_jacobi2");
+}
+
+// x + P coarse, then two sweeps: the coarse-grid correction of a V-cycle and its post-smoothing in one pass
+template <typename T>
+static int poisson_jacobi2_synth(const T* coarse, const T* x, const T* rhs, T* xout, const int64_t* cshape, const T* h2,
+                                 T omega1, T omega2, int zc_hint, void* stream) {
+  if (!coarse || !x || !rhs || !xout || x == xout || !cshape) {
+    set_error("poisson_jacobi2_synth: null pointer, or the sweeps in place");
+    return ODIL_E_INVAL;
+  }
+  int64_t shape[3];
+  for (int i = 0; i < 3; ++i) {
+    if (cshape[i] < 2 || cshape[i] >= (1 << 29)) {
+      set_error("poisson_jacobi2_synth: coarse extent %lld on axis %d", (long long)cshape[i], i);
+      return ODIL_E_INVAL;
+    }
+    shape[i] = 2 * cshape[i];
+  }
+  Smooth2Args a;
+  T h[3];
+  if (zc_hint > 0) zc_hint += zc_hint & 1;  // (chunks of an even number of planes: the parity of a step is its plane's)
+  if (int e = smooth2_args<T>(a, shape, 3, h2, h, zc_hint, 2, 2, "poisson_jacobi2_synth")) return e;
+  if (a.usched.ZC & 1) {  // (only when the whole array is one odd chunk -- impossible: fine extents are even)
+    set_error("poisson_jacobi2_synth: odd chunk length");
+    return ODIL_E_INVAL;
+  }
+  const int grid = unit_grid(a.usched);
+  const H2<T> hh = make_h2<T>(h);
+  if (hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2])
+    hipLaunchKernelGGL((k_poisson_jacobi2<T, 2, true, true, true, 1>), dim3(grid), dim3(64 * kS2Waves), 0,
+                       (hipStream_t)stream, x, rhs, xout, coarse, a, hh, omega1, omega2);
+  else
+    hipLaunchKernelGGL((k_poisson_jacobi2<T, 2, true, false, true, 1>), dim3(grid), dim3(64 * kS2Waves), 0,
+                       (hipStream_t)stream, x, rhs, xout, coarse, a, hh, omega1, omega2);
+  return check_launch("k_poisson_jacobi2<synth>");
 }
 
 }  // namespace odil
@@ -273,5 +514,15 @@ int odil_poisson_jacobi2_f64(const double* u, const double* rhs, double* uout, c
 int odil_poisson_jacobi2_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
                              const float* h2, float omega1, float omega2, int zc_hint, void* stream) {
   return poisson_jacobi2<float>(u, rhs, uout, shape, ndim, h2, omega1, omega2, zc_hint, stream);
+}
+int odil_poisson_jacobi2_synth_f64(const double* coarse, const double* x, const double* rhs, double* xout,
+                                   const int64_t* cshape, const double* h2, double omega1, double omega2, int zc_hint,
+                                   void* stream) {
+  return poisson_jacobi2_synth<double>(coarse, x, rhs, xout, cshape, h2, omega1, omega2, zc_hint, stream);
+}
+int odil_poisson_jacobi2_synth_f32(const float* coarse, const float* x, const float* rhs, float* xout,
+                                   const int64_t* cshape, const float* h2, float omega1, float omega2, int zc_hint,
+                                   void* stream) {
+  return poisson_jacobi2_synth<float>(coarse, x, rhs, xout, cshape, h2, omega1, omega2, zc_hint, stream);
 }
 }  // extern "C"

@@ -106,12 +106,67 @@ class PoissonGMG:
         return [1.0 / (mid - half * math.cos(math.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
 
     def sweeps(self, lvl, x, b, weights):
-        for w in weights:
+        """Sweeps with the given weights, in PAIRS through the one-pass kernel (odil_poisson_jacobi2: the intermediate
+        iterate stays on the CU, 3 words per cell and pair instead of 6; bit-identical to two single sweeps) on levels
+        large enough to be bandwidth-bound."""
+        weights = list(weights)
+        pair = ops.jacobi2_supported(self.shapes[lvl], self.dtype) and math.prod(self.shapes[lvl]) >= self.pair_min_cells
+        while weights:
             y = self.spare[lvl]
-            ops.poisson_jacobi(x, b, self.h2s[lvl], w, out=y)
+            if pair and len(weights) >= 2:
+                ops.poisson_jacobi2(x, b, self.h2s[lvl], weights[0], weights[1], out=y)
+                weights = weights[2:]
+            else:
+                ops.poisson_jacobi(x, b, self.h2s[lvl], weights[0], out=y)
+                weights = weights[1:]
             self.spare[lvl] = x
             x = y
         return x
+
+    pair_min_cells = 64**3  # below: the levels are launch-bound and the single-sweep kernel's smaller workgroups fill the chip better
+
+    # ---- the coarse tail in one launch --------------------------------------------------------------------------------
+    tail_max_cells = 8192  # levels of at most this many cells form the tail (odil_stencil_vcycle_tail); 0: off
+
+    def tail_coeffs(self, lvl):
+        """Coefficient arrays [(2 d + 1), *shape] of level `lvl` (what the one-launch tail works on)."""
+        return ops.poisson_jac_coeffs(self.shapes[lvl], self.h2s[lvl], self.dtype, self.device)
+
+    def tail(self):
+        """(first tail level, flat coefficient tensor, work tensor) when the hierarchy ends in levels small enough to be
+        walked by ONE workgroup -- every level from the first with <= tail_max_cells cells (never the finest) down to a
+        coarsest grid of <= 512 unknowns with its dense inverse --, else None."""
+        key = (self.tail_max_cells, self.nu1, self.nu2)
+        cached = self.__dict__.get("_tail")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        res = None
+        first = next((l for l in range(1, self.nlvl) if math.prod(self.shapes[l]) <= self.tail_max_cells), None)
+        if first is not None:
+            first = max(first, self.nlvl - 8)  # (at most eight levels per launch: long 1-D hierarchies enter it lower down)
+        if (self.tail_max_cells and first is not None and math.prod(self.shapes[-1]) <= 512
+                and self.nu1 <= 4 and self.nu2 <= 4 and self.tail_transfers_ok(first)):
+            flat = torch.cat([self.tail_coeffs(l).reshape(-1) for l in range(first, self.nlvl)])
+            work = torch.empty(3 * sum(math.prod(s) for s in self.shapes[first:]), dtype=self.dtype, device=self.device)
+            outs = [torch.empty(self.shapes[first], dtype=self.dtype, device=self.device) for _ in range(2)]
+            res = (first, flat, work, outs)
+        self.__dict__["_tail"] = (key, res)
+        return res
+
+    def tail_transfers_ok(self, first):
+        """(the rediscretised hierarchy restricts with P^T / 2^k on semi-coarsened transitions, the tail with the mean of the
+        children: the same only where every axis is halved)"""
+        return all(loc == self.loc for loc in self.locs[first:])
+
+    def tail_cycle(self, lvl, x, b, fmg=False):
+        """One V-cycle (fmg: the nested-iteration start) on level `lvl` = the first tail level, in one launch."""
+        first, flat, work, outs = self.tail()
+        # (two result buffers in turn: a result may be the start iterate of the next call -- the second cycle on the first
+        # coarse level of the variable-coefficient hierarchy -- and is otherwise consumed before the call after the next)
+        out = outs[0] if x is None or x.data_ptr() != outs[0].data_ptr() else outs[1]
+        ops.stencil_vcycle_tail(flat, self.shapes[first:], [[c == "c" for c in loc] for loc in self.locs[first:]], x, b, out, work,
+                                self.coarse_inverse(), self.weights(self.nu1), self.weights(self.nu2), fmg=fmg)
+        return out
 
     def coarse_rhs(self, lvl, x, b):
         """b_{lvl+1} = R (b - A x), and mean((A x - b)^2) in self.loss.  One fused pass in 3-D (the fine
@@ -137,11 +192,7 @@ class PoissonGMG:
     def finish_cycle(self, lvl, x, b):
         """Second half of a V(nu1, nu2) cycle: `x` is pre-smoothed and b_{lvl+1} holds its restricted
         residual.  Coarse-grid correction and post-smoothing; returns the tensor holding the new iterate."""
-        xc = self.x[lvl + 1]
-        xc.zero_()
-        xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1])
-        if xc_new is not xc:  # keep the zeroed-per-cycle buffer distinct from the level's spare
-            self.x[lvl + 1] = xc_new
+        xc_new = self.coarse_correction(lvl)
         out = self.spare[lvl]
         weights = self.weights(self.nu2)
         if weights and self.locs[lvl] == self.loc and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
@@ -152,6 +203,18 @@ class PoissonGMG:
             ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)  # x + P x_c
         self.spare[lvl] = x
         return self.sweeps(lvl, out, b, weights)
+
+    def coarse_correction(self, lvl):
+        """x_c with A_c x_c ~= b_{lvl+1}: one cycle on level lvl + 1 from the zero iterate."""
+        xc = self.x[lvl + 1]
+        t = self.tail()
+        if t is not None and lvl + 1 == t[0]:
+            return self.tail_cycle(lvl + 1, None, self.b[lvl + 1])  # (the zero start is not even stored)
+        xc.zero_()
+        xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1], zero=True)
+        if xc_new is not xc:  # keep the zeroed-per-cycle buffer distinct from the level's spare
+            self.x[lvl + 1] = xc_new
+        return xc_new
 
     def last_level_coeffs(self):
         """The last level's operator as coefficient arrays [(2 d + 1), *shape] (what `continuation` pads)."""
@@ -200,8 +263,11 @@ class PoissonGMG:
         self.spare[lvl] = x
         return out
 
-    def vcycle(self, lvl, x, b):
-        """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate."""
+    def vcycle(self, lvl, x, b, zero=False):
+        """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate.  zero: `x` is the zero vector."""
+        t = self.tail()
+        if t is not None and lvl == t[0]:
+            return self.tail_cycle(lvl, None if zero else x, b)
         if lvl == self.nlvl - 1:
             if math.prod(self.shapes[lvl]) <= 512:  # coarsest grid: x = A^-1 b
                 out = self.spare[lvl]
@@ -220,11 +286,16 @@ class PoissonGMG:
         solved, and each finer level starts one V-cycle from the prolongated solution of the level below.  Costs about
         one V-cycle of the finest level plus 1/7 and leaves the error near the discretisation level instead of O(1):
         the cycles that follow only have to cover the remaining distance to the tolerance."""
+        t = self.tail()
+        bottom = self.nlvl - 1 if t is None else t[0]  # (the tail restricts and nests on its own levels in one launch)
         fb = [b]
-        for lvl in range(self.nlvl - 1):
+        for lvl in range(bottom):
             fb.append(self.restrict(lvl, fb[-1]))
         x = None
-        for lvl in range(self.nlvl - 1, -1, -1):
+        for lvl in range(bottom, -1, -1):
+            if x is None and t is not None:
+                x = self.tail_cycle(lvl, None, fb[lvl], fmg=True)
+                continue
             if x is None:
                 start = torch.zeros(self.shapes[lvl], dtype=self.dtype, device=self.device)
             else:
@@ -464,6 +535,12 @@ class StencilGMG(PoissonGMG):
 
     residual_sign = -1.0  # `residual` returns b - A x (PoissonGMG: A x - b)
 
+    def tail_coeffs(self, lvl):
+        return self.coeffs[lvl]
+
+    def tail_transfers_ok(self, first):
+        return True  # (mean of the merged children on every transition: what the tail does)
+
     def last_level_coeffs(self):
         return self.coeffs[-1]
 
@@ -508,16 +585,13 @@ class StencilGMG(PoissonGMG):
         return ops.scale(rc, sign, out=out) if (sign != 1.0 or out is not None) else rc
 
     def finish_cycle(self, lvl, x, b):
-        xc = self.x[lvl + 1]
-        xc.zero_()
-        xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1])
+        xc_new = self.coarse_correction(lvl)
         # TWO cycles on the first coarse level in 3-D (a W-cycle's top, V below): the aggregation-built coarse operators
         # are slightly less accurate than a rediscretisation at the walls, and a more exact level-1 solve takes the
         # contraction from 0.24 to 0.14 per cycle (17 -> 13 cycles to 1e-10, tests/test_stencil_gmg_host.py) for 1/7 more
         # work; a full W-cycle gains one more cycle and pays it back in ~700 launch-bound coarse launches
         if lvl == 0 and self.ndim == 3 and self.nlvl > 2:
             xc_new = self.vcycle(lvl + 1, xc_new, self.b[lvl + 1])
-        if xc_new is not xc:
             self.x[lvl + 1] = xc_new
         out = self.spare[lvl]
         ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)  # x + P x_c

@@ -223,6 +223,23 @@ def stencil_var_coarsen(coeffs, halve=None):
     return out
 
 
+def stencil_vcycle_tail(coeffs, shapes, halve, xin, b, xout, work, inv, wpre, wpost, fmg=False):
+    """The coarse tail of a multigrid cycle in one launch (include/odil_hip.h: odil_stencil_vcycle_tail).  coeffs: one
+    flat tensor holding the coefficient arrays of every tail level; shapes: their extents, finest first; halve: per
+    transition and axis, whether cell pairs are merged; xin None: zero start."""
+    import ctypes
+
+    nlev, ndim = len(shapes), len(shapes[0])
+    flat = [int(n) for shape in shapes for n in shape]
+    mask = (ctypes.c_int * max(1, (nlev - 1) * ndim))(*[int(bool(h)) for tr in halve for h in tr])
+    wa, wap = host_reals(list(wpre) or [0.0], b.dtype)
+    wb, wbp = host_reals(list(wpost) or [0.0], b.dtype)
+    call("stencil_vcycle_tail", b.dtype, ptr(coeffs), i64(flat), ctypes.cast(mask, ctypes.c_void_p), c_int(nlev), c_int(ndim),
+         ptr(xin), ptr(b), ptr(xout), ptr(work), ctypes.c_int64(work.numel()), ptr(inv), c_int(inv.shape[0]), wap,
+         c_int(len(wpre)), wbp, c_int(len(wpost)), c_int(1 if fmg else 0), stream_ptr())
+    return xout
+
+
 def restrict_adj(gcoarse, loc, fshape):
     """R^T gcoarse (cotangent of restrict_to_coarser) for a fine array of shape `fshape`."""
     fshape = tuple(int(s) for s in fshape)
@@ -434,6 +451,17 @@ def poisson_jacobi2(u, rhs, h2, omega1, omega2, out, zc_hint=0):
     assert u.is_contiguous() and rhs.is_contiguous() and out.is_contiguous()
     h2a, h2p = host_reals(h2, u.dtype)
     call("poisson_jacobi2", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p, float(omega1),
+         float(omega2), c_int(zc_hint), stream_ptr())
+    return out
+
+
+def poisson_jacobi2_synth(coarse, x, rhs, h2, omega1, omega2, out, zc_hint=0):
+    """Two sweeps (weights omega1, omega2) of u = x + P coarse in ONE pass: the coarse-grid correction of a V-cycle and
+    its post-smoothing; bit-identical to `interp_add` + `poisson_jacobi2` (out is not x; see jacobi_synth_supported)."""
+    assert coarse.dim() == 3 and tuple(x.shape) == tuple(2 * s for s in coarse.shape) and x.shape == rhs.shape == out.shape
+    assert coarse.is_contiguous() and x.is_contiguous() and rhs.is_contiguous() and out.data_ptr() != x.data_ptr()
+    h2a, h2p = host_reals(h2, x.dtype)
+    call("poisson_jacobi2_synth", x.dtype, ptr(coarse), ptr(x), ptr(rhs), ptr(out), i64(coarse.shape), h2p, float(omega1),
          float(omega2), c_int(zc_hint), stream_ptr())
     return out
 

@@ -573,6 +573,29 @@ def test_two_jacobi_sweeps_in_one_pass_are_bit_identical(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cshape", [(4, 6, 10), (2, 2, 2), (9, 5, 7), (16, 20, 64), (6, 33, 70), (35, 7, 130), (3, 50, 2)])
+def test_correction_and_two_sweeps_in_one_pass_are_bit_identical(dev, dtype, cshape):
+    """odil_poisson_jacobi2_synth (x + P coarse formed on the fly, the first sweep kept on the CU) == odil_interp_add
+    followed by two calls of odil_poisson_jacobi, bit for bit: walls of the joint ghost rule on every side, whole-row and
+    tiled x-windows (two halo packs), ragged y-tiles, chunks of 2 .. all planes."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(43)
+    fshape = tuple(2 * s for s in cshape)
+    coarse = to(rng.standard_normal(cshape).astype(dtype), dev)
+    x = to(rng.standard_normal(fshape).astype(dtype), dev)
+    b = to(rng.standard_normal(fshape).astype(dtype), dev)
+    for h2 in ([0.25**2, 0.125**2, 0.5**2], [0.1**2, 0.3**2, 0.07**2]):
+        h2 = [dtype(v) for v in h2]
+        u = ops.interp_add(coarse, "ccc", add=x)
+        y1 = ops.poisson_jacobi(u, b, h2, 0.9, torch.empty_like(x))
+        want = ops.poisson_jacobi(y1, b, h2, 0.6, torch.empty_like(x))
+        for zc in (0, 2, 6, 64):
+            got = ops.poisson_jacobi2_synth(coarse, x, b, h2, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
+            assert torch.equal(got, want), (cshape, zc, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(4, 6, 8), (8, 12, 16), (64, 32, 520), (2, 2, 4)])
 def test_poisson_residual_restrict(dev, dtype, shape):
     """odil_poisson_residual_restrict == scale * 2^d * restrict(residual) and the same loss, from the

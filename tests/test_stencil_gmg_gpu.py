@@ -442,3 +442,68 @@ def test_variable_coefficient_cycle_semicoarsens_too(dev, name, make, limit):
     x = solver.solve(b, tol=1e-10, maxiter=40, status=status, krylov="never")
     assert status["converged"] and status["niter"] <= limit, (name, status, solver.shapes)
     assert float((x - xt).abs().max()) <= 1e-6 * float(xt.abs().max()), name
+
+
+def diffusion_coeffs(shape, rng, periodic=None):
+    """-div(k grad u) + r u with a smooth positive conductivity (1 : 20), face conductivities by averaging, zero-Dirichlet
+    walls at half a cell (the face coefficient doubled into the diagonal) or one periodic axis, in the layout of the
+    Jacobian's coefficient arrays (0, -e_0, +e_0, ...)."""
+    nd = len(shape)
+    grids = np.meshgrid(*[(np.arange(n) + 0.5) / n for n in shape], indexing="ij")
+    k = 1.0 + 19.0 * np.prod([np.sin(np.pi * g * rng.integers(1, 3)) ** 2 for g in grids], axis=0)
+    off, diag = [], rng.uniform(0.0, 1.0, shape)
+    for a in range(nd):
+        h2 = (1.0 / shape[a]) ** 2
+        km = 0.5 * (k + np.roll(k, 1, axis=a)) / h2
+        kp = 0.5 * (k + np.roll(k, -1, axis=a)) / h2
+        idx = np.arange(shape[a]).reshape([-1 if j == a else 1 for j in range(nd)])
+        if periodic != a:
+            diag = diag + np.where(idx == 0, 2.0 * k / h2, km) + np.where(idx == shape[a] - 1, 2.0 * k / h2, kp)
+            km, kp = np.where(idx == 0, 0.0, km), np.where(idx == shape[a] - 1, 0.0, kp)
+        else:
+            diag = diag + km + kp
+        off += [-km, -kp]
+    return [diag] + off
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("kind,shape", [("poisson", (32, 32, 32)), ("poisson", (64, 64)), ("poisson", (4096,)),
+                                        ("poisson", (16, 32, 64)), ("stencil", (32, 32, 32)), ("stencil", (64, 32)),
+                                        ("stencil-periodic", (16, 16, 16)), ("stencil", (8, 64, 64))])
+def test_coarse_tail_in_one_launch_equals_the_level_by_level_cycle(dev, kind, shape, dtype, tol):
+    """odil_stencil_vcycle_tail (one workgroup walks every level of <= 8192 cells: sweeps, restricted residuals, the dense
+    coarsest solve, prolongations) against the same cycles launched kernel by kernel: one V-cycle from a random start, one
+    from the zero start, the nested-iteration start, and a whole solve -- the same algorithm in another operation order, so
+    equal to rounding (and the solve to its tolerance).  Constant-coefficient hierarchy (rediscretised levels), the
+    variable-coefficient one (aggregation-built levels, semi-coarsened where the couplings differ), a periodic axis."""
+    from odil_amd import gmg
+
+    rng = np.random.default_rng(17)
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    if kind == "poisson":
+        h2 = [npdt(1.0 / n) ** 2 for n in shape]
+        make = lambda: gmg.PoissonGMG(shape, h2, dtype, dev)
+    else:
+        coeffs = diffusion_coeffs(shape, rng, periodic=1 if kind == "stencil-periodic" else None)
+        ct = torch.as_tensor(np.stack(coeffs).astype(npdt)).to(dev)
+        make = lambda: gmg.StencilGMG(ct)
+    b = torch.as_tensor(rng.standard_normal(shape).astype(npdt)).to(dev)
+    x0 = torch.as_tensor(rng.standard_normal(shape).astype(npdt)).to(dev)
+    results = []
+    for cells in (0, 8192):
+        solver = make()
+        solver.tail_max_cells = cells
+        assert (solver.tail() is not None) == (cells > 0), (kind, shape, solver.shapes)
+        one = solver.vcycle(0, x0.clone(), b).clone()
+        zero = solver.vcycle(0, torch.zeros_like(b), b).clone()
+        start = solver.full_multigrid(b).clone() if solver.nlvl > 2 else zero
+        st = dict()
+        sol = solver.solve(b, tol=1e-9 if dtype == torch.float64 else 1e-3, status=st)
+        results.append((one, zero, start, sol, st))
+    ref, got = results
+    scale = float(ref[3].abs().max())
+    for a, c, what in zip(ref[:3], got[:3], ("cycle", "cycle from zero", "nested iteration")):
+        assert float((a - c).abs().max()) <= tol * max(float(a.abs().max()), scale), (what, kind, shape)
+    done = lambda st: st["converged"] or st.get("stagnated")  # (float32 stops at its rounding floor on long 1-D grids)
+    assert done(ref[4]) and done(got[4]) and abs(ref[4]["niter"] - got[4]["niter"]) <= 1, (ref[4], got[4])
+    assert float((ref[3] - got[3]).abs().max()) <= (1e-7 if dtype == torch.float64 else 5e-3) * scale

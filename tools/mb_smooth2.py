@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from odil_amd import ops  # noqa: E402
 
 
@@ -47,6 +47,13 @@ def main():
                 for zc in (0, 16, 32, 64, 128):
                     t2 = timeit(lambda: ops.poisson_jacobi2(x, b, h2, 0.9, 0.6, z, zc_hint=zc))
                     line += " | zc {} {:.3f} ms ({:.2f} TB/s on 3)".format(zc, t2, 3 * w * x.numel() / t2 / 1e9)
+                print(line, flush=True)
+                xc = torch.randn(tuple(v // 2 for v in shape), dtype=dtype, device=dev, generator=g)
+                t1 = timeit(lambda: (ops.poisson_jacobi_synth(xc, x, b, h2, 0.9, y), ops.poisson_jacobi(y, b, h2, 0.6, z)))
+                line = "   with the correction: synth + sweep, sweep {:.3f} ms".format(t1)
+                for zc in (0, 16, 32, 64, 128):
+                    t2 = timeit(lambda: ops.poisson_jacobi2_synth(xc, x, b, h2, 0.9, 0.6, z, zc_hint=zc))
+                    line += " | zc {} {:.3f} ms ({:.2f} TB/s on 3 1/8)".format(zc, t2, 3.125 * w * x.numel() / t2 / 1e9)
                 print(line, flush=True)
             else:
                 c = ops.poisson_jac_coeffs(shape, [np.float64(v) for v in h2], dtype, dev)
