@@ -579,7 +579,8 @@ def other_configs(args, dev):
                 "frac_model": res["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": res["kernel_ms"],
                 "traced": True}  # (SlabTracedAdam runs generated kernels only: it has no autograd path)
 
-    def newton(modname="poisson", argv=None, env=None, name=None, words_per_cycle=(4 * 3 + 2.125), words_setup=0.0):
+    def newton(modname="poisson", argv=None, env=None, name=None, words_per_cycle=(4 * 3 + 2.125), words_setup=0.0,
+               words_moved=None):
         """One Newton step (the SECOND of two: work buffers exist) of a 3-D problem through `odil.util.optimize`.
         env: switches for the step (ODIL_NEWTON_SHORTCUT=0: the general route eval_operator_grad -> linearize ->
         linsolver.solve instead of the recognised-Poisson shortcut; ODIL_GMG=stencil: the variable-coefficient cycle)."""
@@ -628,6 +629,8 @@ def other_configs(args, dev):
                 return {"workload": (name or bench_configs.CONFIGS["4b"][5]).format(problem.domain.cshape[0], problem.domain.cshape[-1]),
                         "ms_per_step": ms, "value": cells / (ms * 1e-3), "vcycles": cycles,
                         "solver": None if st is None else st.get("method"), "model_bytes_per_update": model,
+                        # (what the cycle's launches really stream per fine cell: sweeps in pairs, one pass per pair)
+                        "words_moved_per_cycle": words_moved,
                         "frac_model": None if model is None else cells * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "loss_after": float(problem.eval_loss_grad(state)[0]), "env": env or {},
                         "vram_peak_gb": torch.cuda.max_memory_allocated() / 1e9}
@@ -663,12 +666,12 @@ def other_configs(args, dev):
     attempt("3b", heat)
     attempt("5_one_rank", tracer)
     attempt("4a_api", api("4a", 20, 3))  # the headline workload through odil.util.optimize(args, "adam", problem, state, cb)
-    attempt("4b", newton())
+    attempt("4b", newton(words_moved=3 + 2.125 + 2.125 + 3))  # pre pair, restricted residual, x + P x_c, post pair
     # the same Newton step WITHOUT the recognised-Poisson shortcut: eval_operator_grad (seven coefficient arrays) ->
     # linearize_device -> linsolver.solve -> recognise -> V-cycles; then with the constant-coefficient cycle switched off
     # as well (the cycle any (2 d + 1)-point operator gets), and that cycle on a genuinely variable operator at 256^3
     attempt("4b_general", newton(env={"ODIL_NEWTON_SHORTCUT": "0"}, name="poisson 3D {0}^3 newton, general route (linearize + solve) f64",
-                                 words_setup=7 * 3))
+                                 words_setup=7 * 3, words_moved=3 + 2.125 + 2.125 + 3))
     attempt("4b_varcoef", newton(env={"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil"}, words_per_cycle=4 * 10 + 9.125,
                                  words_setup=7 * 3 + 8, name="poisson 3D {0}^3 newton, variable-coefficient multigrid f64"))
     attempt("4c_diffusion", newton("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver",

@@ -25,7 +25,9 @@ from . import ops
 
 
 class PoissonGMG:
-    def __init__(self, shape, h2, dtype, device, omega=None, nu1=2, nu2=2, min_size=2, lite=False):
+    nu_default = (2, 2)  # pre- / post-smoothing sweeps of a cycle
+
+    def __init__(self, shape, h2, dtype, device, omega=None, nu1=None, nu2=None, min_size=2, lite=False):
         """lite: the finest level's operator only, no work arrays of the cycle -- the float64 half of a mixed-precision
         solve (`solve_mixed`), which needs this object for the residual alone."""
         self.ndim = len(shape)
@@ -33,7 +35,8 @@ class PoissonGMG:
         self.dtype, self.device = dtype, device
         npdt = np.float64 if dtype == torch.float64 else np.float32
         self.omega = omega if omega is not None else {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
-        self.nu1, self.nu2 = nu1, nu2
+        self.nu1 = self.nu_default[0] if nu1 is None else nu1
+        self.nu2 = self.nu_default[1] if nu2 is None else nu2
         self.shapes, self.h2s = [tuple(shape)], [[npdt(v) for v in h2]]
         # SEMI-coarsening while the cells are far from cubes: point smoothing only damps what oscillates along the strongly
         # coupled axes (the small spacings), so only those are halved -- the axes whose h^2 is within a factor 2 of the
@@ -123,6 +126,7 @@ class PoissonGMG:
             x = y
         return x
 
+    post_pair = True
     pair_min_cells = 64**3  # below: the levels are launch-bound and the single-sweep kernel's smaller workgroups fill the chip better
 
     # ---- the coarse tail in one launch --------------------------------------------------------------------------------
@@ -195,7 +199,13 @@ class PoissonGMG:
         xc_new = self.coarse_correction(lvl)
         out = self.spare[lvl]
         weights = self.weights(self.nu2)
-        if weights and self.locs[lvl] == self.loc and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
+        pair = (self.post_pair and len(weights) >= 2 and ops.jacobi2_supported(self.shapes[lvl], self.dtype)
+                and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
+        if pair:
+            # x + P x_c as a pass of its own (2 1/8 words), then the post-smoothing PAIR in one pass (3 words): 5 1/8
+            # against 3 1/8 + 3 for the prolongation fused into the first of two single sweeps
+            ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)
+        elif weights and self.locs[lvl] == self.loc and ops.jacobi_synth_supported(self.shapes[lvl], self.dtype):
             # x + P x_c is formed in registers by the first post-smoothing sweep (3 1/8 words per cell instead of 5 1/8)
             ops.poisson_jacobi_synth(xc_new, x, b, self.h2s[lvl], weights[0], out=out)
             weights = weights[1:]
@@ -470,7 +480,7 @@ class StencilGMG(PoissonGMG):
     solution of the normal equations the reference forms, linsolver.py:17-23).  `solve` reports `converged`; the caller
     (linsolver.solve) falls back to the normal-equation routes when the cycles do not contract."""
 
-    def __init__(self, coeffs, nu1=2, nu2=2, min_size=2, lite=False, store=None):
+    def __init__(self, coeffs, nu1=None, nu2=None, min_size=2, lite=False, store=None):
         """lite: the finest level only (the float64 half of `solve_mixed`); store: dtype the hierarchy is KEPT in (the
         coarse operators are formed in the precision of `coeffs` and cast level by level: the float32 half)."""
         shape = tuple(coeffs.shape[1:])
@@ -479,7 +489,8 @@ class StencilGMG(PoissonGMG):
         self.loc = "c" * self.ndim
         self.dtype, self.device = store or coeffs.dtype, coeffs.device
         self.omega = {1: 2.0 / 3.0, 2: 4.0 / 5.0, 3: 6.0 / 7.0}[self.ndim]
-        self.nu1, self.nu2 = nu1, nu2
+        self.nu1 = self.nu_default[0] if nu1 is None else nu1
+        self.nu2 = self.nu_default[1] if nu2 is None else nu2
         self.coeffs, self.shapes = [coeffs], [shape]
         self.locs = []  # per transition: 'c' on the merged axes, '.' on the others
         cur = coeffs

@@ -47,10 +47,9 @@ def step():
 
 
 VARIANTS = {
-    "pairs off, tail off": dict(pair_min_cells=10**18, tail_max_cells=0),
-    "pairs on,  tail off": dict(pair_min_cells=64**3, tail_max_cells=0),
-    "pairs off, tail on ": dict(pair_min_cells=10**18, tail_max_cells=8192),
-    "pairs on,  tail on ": dict(pair_min_cells=64**3, tail_max_cells=8192),
+    "pairs off, tail off": dict(pair_min_cells=10**18, tail_max_cells=0, post_pair=False),
+    "pre pairs, tail": dict(pair_min_cells=64**3, tail_max_cells=8192, post_pair=False),
+    "pre + post pairs, tail": dict(pair_min_cells=64**3, tail_max_cells=8192, post_pair=True),
 }
 best = {k: (1e9, None) for k in VARIANTS}
 for rnd in range(4):
@@ -58,6 +57,7 @@ for rnd in range(4):
         for k, v in attrs.items():
             setattr(gmg.PoissonGMG, k, v)
         problem.domain.__dict__.pop("_poisson_gmg", None)  # (solvers are kept with the domain: rebuild under the new switches)
+        getattr(problem, "_fused", None) is not None and problem._fused.__dict__.pop("_gmg", None)
         step()
         dt, it = min(step() for _ in range(2))
         if dt < best[name][0]:
