@@ -673,10 +673,11 @@ def other_configs(args, dev):
     attempt("4b_general", newton(env={"ODIL_NEWTON_SHORTCUT": "0"}, name="poisson 3D {0}^3 newton, general route (linearize + solve) f64",
                                  words_setup=7 * 3, words_moved=3 + 2.125 + 2.125 + 3))
     attempt("4b_varcoef", newton(env={"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil"}, words_per_cycle=4 * 10 + 9.125,
-                                 words_setup=7 * 3 + 8, name="poisson 3D {0}^3 newton, variable-coefficient multigrid f64"))
+                                 words_setup=7 * 3 + 8, words_moved=2 * 10 + 9.125 + 2.125,
+                                 name="poisson 3D {0}^3 newton, variable-coefficient multigrid f64"))
     attempt("4c_diffusion", newton("diffusion", lambda sc: ["--ndim", "3", "--N", str(sc(256)), "--kind", "jump", "--linsolver",
                                                              "multigrid", "--linsolver_tol", "1e-10"],
-                                   words_per_cycle=4 * 10 + 9.125, words_setup=7 * 3 + 8,
+                                   words_per_cycle=4 * 10 + 9.125, words_setup=7 * 3 + 8, words_moved=2 * 10 + 9.125 + 2.125,
                                    name="diffusion div(k grad u), k jumps 1 : 1000, 3D {0}^3 newton + variable-coefficient multigrid f64"))
     # the same solves with float32 V-cycles inside a float64 residual loop (gmg.solve_mixed; ODIL_GMG_MIXED=1: opt-in -- the
     # entries above are float64 throughout): same tolerance on the float64 residual, the cycles' traffic halved

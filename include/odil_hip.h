@@ -397,6 +397,15 @@ int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, cons
 int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
                                       void* stream);
 
+/* TWO sweeps of odil_stencil_var_smooth (mode 0; weights omega1, then omega2) in ONE pass: the coefficient arrays -- 7 of
+ * the 10 words a sweep moves in 3-D -- are read once for both, the intermediate iterate stays on the CU.  out != x;
+ * bit-identical to two calls of odil_stencil_var_smooth.  The last extent must be even.  zc_hint: planes per workgroup
+ * chunk, <= 0: automatic. */
+int odil_stencil_var_smooth2_f64(const double* coeffs, const double* x, const double* b, double* out, const int64_t* shape,
+                                 int ndim, double omega1, double omega2, int zc_hint, void* stream);
+int odil_stencil_var_smooth2_f32(const float* coeffs, const float* x, const float* b, float* out, const int64_t* shape,
+                                 int ndim, float omega1, float omega2, int zc_hint, void* stream);
+
 /* The COARSE TAIL of a multigrid V-cycle in one launch: one workgroup walks `nlev` <= 8 small levels (pre-smoothing,
  * residual + restriction, dense solve on the coarsest, prolongation + post-smoothing) with a workgroup barrier where a
  * launch boundary used to be (levels of a few thousand cells cost ~7 dependent launches per level and cycle otherwise).

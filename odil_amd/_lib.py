@@ -62,6 +62,7 @@ _SIGNATURES = {
     "stencil_apply": [_P, _I64P, c_int, _P, _P, _I64P, c_int, c_int, _P],
     "stencil_march": [_P, _I64P, c_int, c_int, _P, _P, _I64P, c_int, c_int, c_int, _P],
     "stencil_var_smooth": [_P, _P, _P, _P, _I64P, c_int, _R, c_int, _P],
+    "stencil_var_smooth2": [_P, _P, _P, _P, _I64P, c_int, _R, _R, c_int, _P],
     "stencil_var_residual_restrict": [_P, _P, _P, _P, _I64P, c_int, _R, _P, _P, _P],
     "stencil_var_coarsen": [_P, _P, _I64P, c_int, _P],
     "stencil_var_coarsen_axes": [_P, _P, _I64P, c_int, _P, _P],

@@ -25,6 +25,9 @@ constexpr int kS2Waves = 16;            // rows per workgroup
 constexpr int kS2Own = kS2Waves - 4;    // rows whose second sweep is stored
 constexpr int kS2Ring = 6;              // register ring (planes) = unroll factor of the march
 constexpr int kS2Ahead = 2;             // steps between a load and its use (<= kS2Ring - 4)
+#ifndef S2_SVAR_DC
+#define S2_SVAR_DC 0  // steps the coefficient loads of the variable-coefficient pair run ahead
+#endif
 constexpr int kS2CRows = kS2Waves / 2 + 2;  // coarse rows behind a workgroup's fine rows (fused prolongation)
 
 struct Smooth2Args {
@@ -35,6 +38,8 @@ struct Smooth2Args {
   int halo_x;      // 1: windows of 64 packs with a halo pack per side; 0: one window = the whole row
   int nxt;         // x-windows per row
   int stream;      // non-temporal stores of the result
+  int slot[3];     // (variable coefficients) index of the -e_a array among the coefficient arrays, +e_a = slot + 1
+  int64_t size;    // cells of the array
   UnitSched usched;  // units (z-chunk, y-tile, x-window)
 };
 
@@ -366,6 +371,177 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
   }
 }
 
+// ---- two sweeps of the VARIABLE-coefficient smoother (stencil_mg.hip: k_svar_smooth) in one pass ------------------------
+// x' = x - w (A x - b) / c0 with A x = c0 x + c_-z x[-z] + c_-y x[-y] + c_+y x[+y] + c_-x x[-x] + c_+x x[+x] + c_+z x[+z]
+// (this order: the +z term LAST, in the single-sweep kernel too).  The coefficient arrays are 7 of the 10 words a sweep
+// moves, so they must be read ONCE for both sweeps: step t loads the coefficients of plane p, forms the first sweep
+// y1[p] with them, and -- after the barrier that publishes y1[p] to the neighbouring rows -- everything of the SECOND
+// sweep of plane p that does not need y1[p + 1]: the partial sum of A y1 without its +z term.  What the next step needs
+// to finish that cell (partial sum, c_+z, c0, b) is four values; the coefficients themselves are dead when the step ends.
+// Same mapping as k_poisson_jacobi2 (a wave per row of 64 packs, 16 rows per workgroup of which 12 are owned, lane shifts
+// along x, LDS along y, registers along z); every window carries a halo pack per side, whose addresses wrap
+// periodically like every index of this operator (wall rows carry zero coefficients instead).
+template <typename T, int V, bool HASY, int DC>
+__global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_svar_smooth2(const T* __restrict__ c,
+                                                                            const T* __restrict__ x,
+                                                                            const T* __restrict__ rhs,
+                                                                            T* __restrict__ xout, Smooth2Args a,
+                                                                            T omega1, T omega2) {
+  constexpr int NW = HASY ? kS2Waves : 1;
+  constexpr int HY = HASY ? 2 : 0;
+  constexpr int R = kS2Ring, D = 1;  // x runs one step ahead of its use, the coefficient set DC steps
+  __shared__ T ubuf[HASY ? 2 * NW * 64 * V : 1];
+  __shared__ T ybuf[HASY ? 2 * NW * 64 * V : 1];
+  const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
+  const int64_t sy = X, sz = Y * X;
+  int zc, yt, xt;
+  if (!unit_decode(a.usched, zc, yt, xt)) return;  // whole workgroup
+  const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+  int64_t xp = (int64_t)xt * a.own_x - 1 + lane;
+  const int own_here = (int64_t)(xt + 1) * a.own_x <= a.packs ? a.own_x : a.packs - xt * a.own_x;
+  const bool lane_own = lane >= 1 && lane <= own_here;
+  xp = ((xp % a.packs) + a.packs) % a.packs;
+  int64_t y = HASY ? (int64_t)yt * kS2Own - HY + row : 0;
+  const bool row_own = HASY ? (row >= HY && row < HY + kS2Own && y < Y) : true;
+  const bool row_s1 = HASY ? (row >= 1 && row <= NW - 2) : true;
+  y = ((y % Y) + Y) % Y;
+  const int64_t z0 = (int64_t)zc * a.usched.ZC;
+  const int64_t z1 = z0 + a.usched.ZC < Z ? z0 + a.usched.ZC : Z;
+  const uint32_t c_off = (uint32_t)(y * sy + xp * V);
+  const int Zi = (int)Z;
+  auto wrapz = [Zi](int q) {
+    q %= Zi;
+    return q < 0 ? q + Zi : q;
+  };
+  const int p0 = (int)z0 - 1;
+  const bool hz = a.active[0], hy = a.active[1];
+  // the coefficient arrays (0, -z, +z, -y, +y, -x, +x as far as the axes exist) and the right-hand side
+  const T* cz = c + (int64_t)a.slot[0] * a.size;
+  const T* cy = c + (int64_t)a.slot[1] * a.size;
+  const T* cx = c + (int64_t)a.slot[2] * a.size;
+  T uo[R][V], y1[R][V];
+  // coefficient sets in a ring of DC + 1: entry (k % (DC + 1)) for plane p0 + k -- [0] c0, [1] -z, [2] +z, [3] -y, [4] +y,
+  // [5] -x, [6] +x, [7] b
+  T cs[DC + 1][8][V];
+  T hp[V], hzp[V], hc0[V], hb[V];  // second sweep of plane p - 1, waiting for y1[p]: partial sum, c_+z, c0, b
+  auto load_set = [&](int pl, T (&s)[8][V]) {
+    const int64_t off = (int64_t)pl * sz + c_off;
+    load_vec<T, V, true>(c + off, V, s[0]);
+    if (hz) {
+      load_vec<T, V, true>(cz + off, V, s[1]);
+      load_vec<T, V, true>(cz + a.size + off, V, s[2]);
+    }
+    if (hy) {
+      load_vec<T, V, true>(cy + off, V, s[3]);
+      load_vec<T, V, true>(cy + a.size + off, V, s[4]);
+    }
+    load_vec<T, V, true>(cx + off, V, s[5]);
+    load_vec<T, V, true>(cx + a.size + off, V, s[6]);
+    load_vec<T, V, true>(rhs + off, V, s[7]);
+  };
+  load_vec<T, V, true>(x + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+#pragma unroll
+  for (int k = 0; k <= D; ++k) load_vec<T, V, true>(x + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+#pragma unroll
+  for (int k = 0; k < DC; ++k) load_set(wrapz(p0 + k), cs[k % (DC + 1)]);
+#pragma unroll
+  for (int i = 0; i < V; ++i) y1[R - 1][i] = hp[i] = hzp[i] = hb[i] = T(0), hc0[i] = T(1);
+  const int slot = (row * 64 + lane) * V;
+  const int slot_m = ((row == 0 ? 0 : row - 1) * 64 + lane) * V, slot_p = ((row == NW - 1 ? NW - 1 : row + 1) * 64 + lane) * V;
+  if (HASY) {
+    store_vec<T, V, true>(ubuf + slot, V, uo[0]);
+    __syncthreads();
+  }
+  const int nt = (int)(z1 - z0) + 2;
+  int pw = wrapz(p0 + DC), pa = wrapz(p0 + 1 + D);  // the planes whose coefficients / x this step loads
+  for (int t0 = 0; t0 < nt; t0 += R) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int t = t0 + k;
+      T (&cc)[8][V] = cs[k % (DC + 1)];  // the coefficients of plane p
+      // (1) loads: x of plane p + 2, the coefficient set of plane p + DC
+      load_vec<T, V, true>(x + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
+      if (row_s1) load_set(pw, cs[(k + DC) % (DC + 1)]);
+      // (2) plane p + 1 of x for the next step's y neighbours
+      if (HASY) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
+      if (row_s1) {
+        // (3) first sweep on plane p
+        {
+          const T (&qc)[V] = uo[k];
+          T nm[V], np[V];
+          if (HASY) {
+            const T* buf = ubuf + (k & 1) * (NW * 64 * V);
+            load_vec<T, V, true>(buf + slot_m, V, nm);
+            load_vec<T, V, true>(buf + slot_p, V, np);
+          }
+          const T left = from_prev_lane(qc[V - 1]), right = from_next_lane(qc[0]);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            T acc = cc[0][i] * qc[i];
+            if (hz) acc = acc + cc[1][i] * uo[(k + R - 1) % R][i];
+            if (hy) {
+              acc = acc + cc[3][i] * nm[i];
+              acc = acc + cc[4][i] * np[i];
+            }
+            acc = acc + cc[5][i] * (i == 0 ? left : qc[i - 1 >= 0 ? i - 1 : 0]);
+            acc = acc + cc[6][i] * (i == V - 1 ? right : qc[i + 1 < V ? i + 1 : i]);
+            if (hz) acc = acc + cc[2][i] * uo[(k + 1) % R][i];
+            y1[k][i] = qc[i] - omega1 * (acc - cc[7][i]) / cc[0][i];
+          }
+        }
+        if (HASY) store_vec<T, V, true>(ybuf + (k & 1) * (NW * 64 * V) + slot, V, y1[k]);
+        // (4) the second sweep of plane p - 1 gets its +z term
+        {
+          const int z = p0 + t - 1;
+          const T (&qc)[V] = y1[(k + R - 1) % R];
+          T out[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            T acc = hp[i];
+            if (hz) acc = acc + hzp[i] * y1[k][i];
+            out[i] = qc[i] - omega2 * (acc - hb[i]) / hc0[i];
+          }
+          if (t >= 2 && z < (int)z1 && row_own && lane_own) {
+            if (a.stream)
+              store_vec<T, V, true, true>(xout + (int64_t)z * sz + c_off, V, out);
+            else
+              store_vec<T, V, true, false>(xout + (int64_t)z * sz + c_off, V, out);
+          }
+        }
+      }
+      if (HASY) __syncthreads();
+      if (row_s1) {
+        // (5) the second sweep of plane p without its +z term
+        const T (&qc)[V] = y1[k];
+        T nm[V], np[V];
+        if (HASY) {
+          const T* buf = ybuf + (k & 1) * (NW * 64 * V);
+          load_vec<T, V, true>(buf + slot_m, V, nm);
+          load_vec<T, V, true>(buf + slot_p, V, np);
+        }
+        const T left = from_prev_lane(qc[V - 1]), right = from_next_lane(qc[0]);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          T acc = cc[0][i] * qc[i];
+          if (hz) acc = acc + cc[1][i] * y1[(k + R - 1) % R][i];
+          if (hy) {
+            acc = acc + cc[3][i] * nm[i];
+            acc = acc + cc[4][i] * np[i];
+          }
+          acc = acc + cc[5][i] * (i == 0 ? left : qc[i - 1 >= 0 ? i - 1 : 0]);
+          acc = acc + cc[6][i] * (i == V - 1 ? right : qc[i + 1 < V ? i + 1 : i]);
+          hp[i] = acc, hzp[i] = cc[2][i], hc0[i] = cc[0][i], hb[i] = cc[7][i];
+        }
+      }
+#ifndef S2_NO_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      pw = pw + 1 == Zi ? 0 : pw + 1;
+      pa = pa + 1 == Zi ? 0 : pa + 1;
+    }
+  }
+}
+
 // V: cells per lane; halo: packs of x-halo per side of a window that is not the whole row
 template <typename T>
 static int smooth2_args(Smooth2Args& a, const int64_t* shape, int ndim, const T* h2, T h[3], int zc_hint, int V,
@@ -502,6 +678,56 @@ static int poisson_jacobi2_synth(const T* coarse, const T* x, const T* rhs, T* x
   return check_launch("k_poisson_jacobi2<synth>");
 }
 
+template <typename T>
+static int svar_smooth2(const T* coeffs, const T* x, const T* b, T* out, const int64_t* shape, int ndim, T omega1, T omega2,
+                        int zc_hint, void* stream) {
+  constexpr int V = 2;  // (two cells per lane in either precision: with four floats the coefficient set spills)
+  Smooth2Args a;
+  T h[3];
+  const T ones[3] = {T(1), T(1), T(1)};
+  if (int e = smooth2_args<T>(a, shape, ndim, ones, h, zc_hint, V, 1, "stencil_var_smooth2")) return e;
+  if (!coeffs || !x || !b || !out || x == out) {
+    set_error("stencil_var_smooth2: null pointer or in-place sweeps");
+    return ODIL_E_INVAL;
+  }
+  // every window carries its halo pack (the indices of this operator wrap periodically: also a window that is the whole row)
+  a.halo_x = 1;
+  a.nxt = (a.packs + 61) / 62;
+  a.own_x = (a.packs + a.nxt - 1) / a.nxt;
+  {
+    const int64_t nyt = a.active[1] ? (a.n[1] + kS2Own - 1) / kS2Own : 1;
+    const int zc = a.usched.ZC;
+    a.usched = make_unit_sched(a.n[0], nyt, a.nxt, 1);
+    a.usched.ZC = zc;
+    a.usched.ZCH = (int)((a.n[0] + zc - 1) / zc);
+    if (a.usched.axis == 1) {
+      a.usched.per_xcd = a.usched.ZCH * a.usched.chunk * a.usched.XS;
+    } else if (a.usched.ZCH >= kNumXcd) {
+      a.usched.axis = 0, a.usched.chunk = 0;
+      a.usched.per_xcd = (int)(((int64_t)a.usched.ZCH * a.usched.Y * a.usched.XS + kNumXcd - 1) / kNumXcd);
+    } else {
+      a.usched.axis = -1, a.usched.chunk = 0;
+      a.usched.per_xcd = a.usched.ZCH * a.usched.Y * a.usched.XS;
+    }
+  }
+  a.size = a.n[0] * a.n[1] * a.n[2];
+  // array axis i is canonical axis map3[ndim - 1][i] (smooth2_args: the slowest real axis is the marched one); its two
+  // coefficient arrays follow the diagonal in array-axis order
+  {
+    static const int map3[3][3] = {{2, 0, 0}, {0, 2, 0}, {0, 1, 2}};
+    for (int d = 0; d < 3; ++d) a.slot[d] = 0;
+    for (int i = 0; i < ndim; ++i) a.slot[map3[ndim - 1][i]] = 1 + 2 * i;
+  }
+  const int grid = unit_grid(a.usched);
+  if (a.active[1])
+    hipLaunchKernelGGL((k_svar_smooth2<T, V, true, S2_SVAR_DC>), dim3(grid), dim3(64 * kS2Waves), 0, (hipStream_t)stream,
+                       coeffs, x, b, out, a, omega1, omega2);
+  else
+    hipLaunchKernelGGL((k_svar_smooth2<T, V, false, S2_SVAR_DC>), dim3(grid), dim3(64), 0, (hipStream_t)stream, coeffs, x, b,
+                       out, a, omega1, omega2);
+  return check_launch("k_svar_smooth2");
+}
+
 }  // namespace odil
 
 using namespace odil;
@@ -524,5 +750,13 @@ int odil_poisson_jacobi2_synth_f32(const float* coarse, const float* x, const fl
                                    const int64_t* cshape, const float* h2, float omega1, float omega2, int zc_hint,
                                    void* stream) {
   return poisson_jacobi2_synth<float>(coarse, x, rhs, xout, cshape, h2, omega1, omega2, zc_hint, stream);
+}
+int odil_stencil_var_smooth2_f64(const double* coeffs, const double* x, const double* b, double* out, const int64_t* shape,
+                                 int ndim, double omega1, double omega2, int zc_hint, void* stream) {
+  return svar_smooth2<double>(coeffs, x, b, out, shape, ndim, omega1, omega2, zc_hint, stream);
+}
+int odil_stencil_var_smooth2_f32(const float* coeffs, const float* x, const float* b, float* out, const int64_t* shape,
+                                 int ndim, float omega1, float omega2, int zc_hint, void* stream) {
+  return svar_smooth2<float>(coeffs, x, b, out, shape, ndim, omega1, omega2, zc_hint, stream);
 }
 }  // extern "C"

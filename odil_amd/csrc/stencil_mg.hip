@@ -61,8 +61,12 @@ __device__ inline void svar_decode(int64_t i, const SvarArgs& a, int64_t (&id)[3
 template <typename T>
 __device__ inline T svar_apply(const T* __restrict__ c, const T* __restrict__ x, const SvarArgs& a, int64_t i,
                                const int64_t (&id)[3]) {
+  // order of the terms: the diagonal, then per axis -e, +e -- except that the +e term of the SLOWEST existing axis comes
+  // LAST, so that the one-pass pair of sweeps (smooth2.hip: k_svar_smooth2), which marches along that axis and must
+  // finish a cell one plane late, forms bit for bit the same sum
   T acc = c[i] * x[i];
   const int64_t stride[3] = {a.n[1] * a.n[2], a.n[2], 1};
+  const int first = a.has[0] ? 0 : (a.has[1] ? 1 : 2);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     if (!a.has[d]) continue;
@@ -70,6 +74,12 @@ __device__ inline T svar_apply(const T* __restrict__ c, const T* __restrict__ x,
     const int64_t im = id[d] == 0 ? i + (n - 1) * stride[d] : i - stride[d];
     const int64_t ip = id[d] == n - 1 ? i - (n - 1) * stride[d] : i + stride[d];
     acc = acc + c[(int64_t)a.slot[d] * a.size + i] * x[im];
+    if (d != first) acc = acc + c[(int64_t)(a.slot[d] + 1) * a.size + i] * x[ip];
+  }
+  {
+    const int d = first;
+    const int64_t n = a.n[d];
+    const int64_t ip = id[d] == n - 1 ? i - (n - 1) * stride[d] : i + stride[d];
     acc = acc + c[(int64_t)(a.slot[d] + 1) * a.size + i] * x[ip];
   }
   return acc;

@@ -127,7 +127,7 @@ class PoissonGMG:
         return x
 
     post_pair = True
-    pair_min_cells = 64**3  # below: the levels are launch-bound and the single-sweep kernel's smaller workgroups fill the chip better
+    pair_min_cells = 128**3  # below: the levels are launch-bound and the single-sweep kernels' smaller workgroups fill the chip better (measured: 128^3 / 64^3 / 32^3 as the threshold -> 25.0 / 25.7 / 26.6 ms for the 256^3 diffusion step)
 
     # ---- the coarse tail in one launch --------------------------------------------------------------------------------
     tail_max_cells = 8192  # levels of at most this many cells form the tail (odil_stencil_vcycle_tail); 0: off
@@ -562,9 +562,18 @@ class StencilGMG(PoissonGMG):
         return out
 
     def sweeps(self, lvl, x, b, weights):
-        for w in weights:
+        """Sweeps in PAIRS through the one-pass kernel (odil_stencil_var_smooth2: the coefficient arrays -- 7 of a sweep's
+        10 words in 3-D -- read once for both sweeps; bit-identical to two single sweeps) on the bandwidth-bound levels."""
+        weights = list(weights)
+        pair = ops.smooth2_supported(self.shapes[lvl]) and math.prod(self.shapes[lvl]) >= self.pair_min_cells
+        while weights:
             y = self.spare[lvl]
-            ops.stencil_var_smooth(self.coeffs[lvl], x, b, w, out=y)
+            if pair and len(weights) >= 2:
+                ops.stencil_var_smooth2(self.coeffs[lvl], x, b, weights[0], weights[1], out=y)
+                weights = weights[2:]
+            else:
+                ops.stencil_var_smooth(self.coeffs[lvl], x, b, weights[0], out=y)
+                weights = weights[1:]
             self.spare[lvl] = x
             x = y
         return x

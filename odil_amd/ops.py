@@ -160,6 +160,20 @@ def stencil_var_smooth(coeffs, x, b, omega, out):
     return out
 
 
+def smooth2_supported(shape):
+    return 1 <= len(shape) <= 3 and shape[-1] % 2 == 0 and min(shape) >= 2
+
+
+def stencil_var_smooth2(coeffs, x, b, omega1, omega2, out, zc_hint=0):
+    """Two sweeps of `stencil_var_smooth` (weights omega1, then omega2) in ONE pass over the coefficient arrays;
+    bit-identical to two calls (out is not x)."""
+    assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape) and out.data_ptr() != x.data_ptr()
+    assert smooth2_supported(tuple(x.shape)) and coeffs.is_contiguous() and x.is_contiguous() and b.is_contiguous()
+    call("stencil_var_smooth2", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()), float(omega1),
+         float(omega2), c_int(zc_hint), stream_ptr())
+    return out
+
+
 def stencil_var_residual(coeffs, x, b, out=None):
     """b - A x (mode 1 of odil_stencil_var_smooth)."""
     assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape)

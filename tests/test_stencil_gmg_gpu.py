@@ -507,3 +507,24 @@ def test_coarse_tail_in_one_launch_equals_the_level_by_level_cycle(dev, kind, sh
     done = lambda st: st["converged"] or st.get("stagnated")  # (float32 stops at its rounding floor on long 1-D grids)
     assert done(ref[4]) and done(got[4]) and abs(ref[4]["niter"] - got[4]["niter"]) <= 1, (ref[4], got[4])
     assert float((ref[3] - got[3]).abs().max()) <= (1e-7 if dtype == torch.float64 else 5e-3) * scale
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,periodic", [((64,), None), ((130,), 0), ((12, 20), None), ((40, 1000), 1), ((8, 6, 10), None),
+                                            ((4, 4, 4), 0), ((33, 31, 136), None), ((20, 45, 260), 2), ((5, 100, 2), 1)])
+def test_two_variable_coefficient_sweeps_in_one_pass_are_bit_identical(dev, shape, periodic, dtype):
+    """odil_stencil_var_smooth2 (coefficients read once for both sweeps, the second sweep of a plane finished one step late
+    from its partial sum) == two calls of odil_stencil_var_smooth, bit for bit: walls and periodic axes (wrapped halo
+    packs, rows and planes), tiled x-windows, ragged y-tiles, 1-D / 2-D, chunks of 1 .. all planes."""
+    from odil_amd import ops
+
+    rng = np.random.default_rng(23)
+    coeffs = diffusion_coeffs(shape, rng, periodic=periodic)
+    ct = torch.as_tensor(np.stack(coeffs).astype(dtype)).to(dev)
+    x = torch.as_tensor(rng.standard_normal(shape).astype(dtype)).to(dev)
+    b = torch.as_tensor(rng.standard_normal(shape).astype(dtype)).to(dev)
+    y1 = ops.stencil_var_smooth(ct, x, b, 0.9, out=torch.empty_like(x))
+    want = ops.stencil_var_smooth(ct, y1, b, 0.6, out=torch.empty_like(x))
+    for zc in (0, 1, 3, 64):
+        got = ops.stencil_var_smooth2(ct, x, b, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
+        assert torch.equal(got, want), (shape, zc, int((got != want).sum()))

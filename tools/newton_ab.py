@@ -47,9 +47,11 @@ def step():
 
 
 VARIANTS = {
-    "pairs off, tail off": dict(pair_min_cells=10**18, tail_max_cells=0, post_pair=False),
-    "pre pairs, tail": dict(pair_min_cells=64**3, tail_max_cells=8192, post_pair=False),
-    "pre + post pairs, tail": dict(pair_min_cells=64**3, tail_max_cells=8192, post_pair=True),
+    "pairs off, tail off": dict(pair_min_cells=10**18, tail_max_cells=0),
+    "pairs off, tail on ": dict(pair_min_cells=10**18, tail_max_cells=8192),
+    "pairs >= 128^3, tail": dict(pair_min_cells=128**3, tail_max_cells=8192),
+    "pairs >= 64^3, tail": dict(pair_min_cells=64**3, tail_max_cells=8192),
+    "pairs >= 32^3, tail": dict(pair_min_cells=32**3, tail_max_cells=8192),
 }
 best = {k: (1e9, None) for k in VARIANTS}
 for rnd in range(4):
