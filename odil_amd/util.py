@@ -322,9 +322,8 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
 
     opt = Optimizer(name="newton", displayname="Newton")
     printlog("Running {} optimizer".format(opt.displayname))
-    pinfo = eval_pinfo(state)
-    if callback:
-        callback(state, args.epoch_start, pinfo)
+    if callback:  # (the evaluations around the steps exist for the report only, reference util.py:156-158, 180)
+        callback(state, args.epoch_start, eval_pinfo(state))
     for epoch in range(args.epoch_start, args.epochs):
         opt.evals += 1
         linstatus = dict()

@@ -155,3 +155,138 @@ def test_public_api_reproduces_the_c_oracle(dev, N):
     summarize(report, "public API N={}".format(N))
     del problem, state, arrays, moments
     torch.cuda.empty_cache()
+
+
+# ---- BASELINE config 2 at its own size: 2-D Poisson 1024^2, 10 levels, L-BFGS-B --------------------------------------------
+_spec2 = importlib.util.spec_from_file_location("make_golden_fullsize_lbfgsb",
+                                                os.path.join(ROOT, "tests", "golden", "make_golden_fullsize_lbfgsb.py"))
+mk2 = importlib.util.module_from_spec(_spec2)
+_spec2.loader.exec_module(mk2)
+
+
+def test_lbfgsb_at_1024_squared_follows_the_reference_optimizer(dev):
+    """`odil.util.optimize(args, "lbfgsb", ...)` on the example's operator against the first ten iterates of the REFERENCE's
+    own LbfgsbOptimizer (optimizer.py:54-117 -> SciPy's L-BFGS-B) driving the reference's own loss and gradient at 1024^2
+    (tests/golden/make_golden_fullsize_lbfgsb.py): every accepted loss to 1e-10, sums / sums of squares / 64 samples per
+    level of every iterate to 1e-6 of the level's scale (two reference runs one ulp apart agree to 1e-6 over 18 iterations
+    of this problem class, tests/test_trajectories.py).  Inputs bit-identical by construction (rhs by the HIP residual
+    kernel from the NumPy reference solution; the fixture's samples are required exactly)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+    import odil_amd as odil
+    import poisson
+    from odil_amd import ops
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    fx = dict(np.load(os.path.join(ROOT, "tests", "golden", "fullsize_lbfgsb_2d_N1024.npz")))
+    N, iters = int(fx["N"]), int(fx["iters"])
+    ref_u = torch.as_tensor(mk2.reference_u2d(N)).to(dev)
+    h2 = [np.float64(1.0 / N) ** 2] * 2
+    rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), h2)
+    ri = torch.as_tensor(fx["rhs_index"], device=dev)
+    assert np.array_equal(ref_u.reshape(-1)[ri].cpu().numpy(), fx["ref_u_samples"]), "ref_u drifted (another libm?)"
+    assert np.array_equal(rhs.reshape(-1)[ri].cpu().numpy(), fx["rhs_samples"]), "rhs is not the fixture's bit for bit"
+    args = poisson.parse_args(["--ndim", "2", "--N", str(N), "--optimizer", "lbfgsb", "--bfgs_m", "50", "--bfgs_maxls", "50"])
+    problem, state = poisson.make_problem(args)
+    assert not problem._fused_checked
+    problem.extra.rhs = rhs
+    idx = np.split(fx["sample_index"], np.cumsum(fx["sample_count"])[:-1])
+    seen = []
+
+    def cb(st, epoch, pinfo):
+        arrays = problem.domain.arrays_from_state(st)
+        flat = [a.reshape(-1) for a in arrays]
+        seen.append((float(np.array(pinfo["loss"])),
+                     np.array([float(f.sum()) for f in flat]), np.array([float((f * f).sum()) for f in flat]),
+                     np.concatenate([f[torch.as_tensor(i, device=f.device)].cpu().numpy() for f, i in zip(flat, idx)])))
+
+    args.epoch_start, args.epochs = 0, iters
+    try:
+        odil.util.optimize(args, "lbfgsb", problem, state, cb)
+    except odil.EarlyStopError:
+        pass
+    assert abs(seen[0][0] - float(fx["loss0"])) <= 1e-12 * float(fx["loss0"])  # (the evaluation of the zero state)
+    got = seen[1:]
+    assert len(got) >= iters, len(got)
+    worst = dict(loss=0.0, sum=0.0, sq=0.0, samples=0.0)
+    counts = fx["sample_count"]
+    for k in range(iters):
+        loss, sums, sqs, samples = got[k]
+        worst["loss"] = max(worst["loss"], abs(loss - fx["losses"][k]) / abs(fx["losses"][k]))
+        scale = np.sqrt(np.maximum(fx["sqs"][k], 1e-300))  # a level's 2-norm
+        nl = np.array([float(np.prod(s)) for s in fx["shapes"]])
+        worst["sum"] = max(worst["sum"], float(np.max(np.abs(sums - fx["sums"][k]) / (scale * np.sqrt(nl)))))
+        worst["sq"] = max(worst["sq"], float(np.max(np.abs(sqs - fx["sqs"][k]) / np.maximum(fx["sqs"][k], 1e-300))))
+        ref_s = np.split(fx["samples"][k], np.cumsum(counts)[:-1])
+        got_s = np.split(samples, np.cumsum(counts)[:-1])
+        for r, g in zip(ref_s, got_s):
+            worst["samples"] = max(worst["samples"], float(np.max(np.abs(g - r)) / max(np.max(np.abs(r)), 1e-300)))
+    print("\n[config 2, 1024^2 L-BFGS-B, {} iterates] worst relative deviations: {}".format(iters, worst))
+    assert worst["loss"] <= 1e-10 and worst["sum"] <= 1e-6 and worst["sq"] <= 1e-6 and worst["samples"] <= 1e-6, worst
+    assert getattr(problem, "_fused", None) is not None
+    del problem, state
+    torch.cuda.empty_cache()
+
+
+# ---- BASELINE config 4, Newton half, at its own size: three routes to the same iterate, checked by the C oracle -----------
+def test_newton_routes_at_512_cubed_agree_and_solve_the_system(dev, monkeypatch):
+    """One Newton step of the 512^3 Poisson problem (reference util.py:152-187: M delta = -r through linearize + solve)
+    by the three routes of this package -- the recognised-Poisson shortcut, the GENERAL route (eval_operator_grad ->
+    linearize -> linsolver.solve -> recognition -> constant-coefficient cycles), and the general route with the
+    VARIABLE-coefficient cycles any (2 d + 1)-point operator gets: the three iterates agree to 1e-9 of the solution's
+    scale, and the residual of the shortcut's iterate, evaluated on the HOST by the C oracle (oracle/poisson_epoch.c:
+    odil_c_residual, pinned to the NumPy oracle, which is pinned on the reference's golden vectors), is below 1e-9 of the
+    right-hand side's -- the step solves the system, by an evaluation that shares no code with the kernels."""
+    import ctypes
+    import subprocess
+
+    sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+    import odil_amd as odil
+    import poisson
+
+    odil.util.set_log_file(open(os.devnull, "w"))
+    N = 512
+    results = {}
+    for name, env in (("shortcut", {}), ("general", {"ODIL_NEWTON_SHORTCUT": "0"}),
+                      ("varcoef", {"ODIL_NEWTON_SHORTCUT": "0", "ODIL_GMG": "stencil"})):
+        for k in ("ODIL_NEWTON_SHORTCUT", "ODIL_GMG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        args = poisson.parse_args(["--ndim", "3", "--N", str(N), "--multigrid", "0", "--linsolver", "multigrid",
+                                   "--linsolver_tol", "1e-11"])
+        problem, state = poisson.make_problem(args)
+        args.epoch_start, args.epochs = 0, 1
+        status = []
+        odil.util.optimize(args, "newton", problem, state, lambda s, e, p: status.append(p.get("linsolver")))
+        st = [s for s in status if s][-1]
+        assert st.get("converged", True), (name, st)
+        (field,) = state.fields.values()
+        results[name] = (field.array.detach().clone(), st)
+        if name == "shortcut":
+            rhs_host = problem.extra.rhs.detach().cpu().numpy().astype(np.float64)
+        del problem, state, field
+        torch.cuda.empty_cache()
+    u = results["shortcut"][0]
+    scale = float(u.abs().max())
+    for name in ("general", "varcoef"):
+        err = float((results[name][0] - u).abs().max()) / scale
+        print("\n[512^3 Newton] {} vs shortcut: {:.2e} ({} cycles)".format(name, err, results[name][1].get("niter")))
+        assert err <= 1e-9, (name, err)
+    # the C oracle's residual of the iterate, on the host
+    oracle = os.path.join(ROOT, "oracle")
+    so = os.path.join(oracle, "_build", "libpoisson_epoch.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", oracle, "-s"])
+    lib = ctypes.CDLL(so)
+    P = ctypes.POINTER(ctypes.c_double)
+    i64 = ctypes.c_int64
+    lib.odil_c_residual.argtypes = [P, P, i64, i64, i64, P, P]
+    lib.odil_c_residual.restype = ctypes.c_double
+    uh = u.cpu().numpy()
+    del results
+    h2 = np.array([(1.0 / N) ** 2] * 3)
+    fu = np.empty_like(uh)
+    ssum = lib.odil_c_residual(uh.ctypes.data_as(P), rhs_host.ctypes.data_as(P), N, N, N, h2.ctypes.data_as(P), fu.ctypes.data_as(P))
+    rel = np.sqrt(ssum / float((rhs_host * rhs_host).sum()))
+    print("[512^3 Newton] C oracle: |A u - rhs| / |rhs| = {:.2e}".format(rel))
+    assert rel <= 1e-9, rel
