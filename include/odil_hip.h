@@ -218,7 +218,7 @@ int odil_poisson_jacobi_f64(const double* u, const double* rhs, double* uout, co
 int odil_poisson_jacobi_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,
                             const float* h2, float omega, void* stream);
 
-/* TWO sweeps of odil_poisson_jacobi (weights omega1, then omega2) in ONE pass over memory: the intermediate iterate
+/* TWO sweeps of odil_poisson_jacobi, with the weights omega1 and then omega2, in ONE pass over memory: the intermediate iterate
  * stays on the CU (registers along z, lane shifts along x, LDS along y), so a pair of sweeps moves the 3 words per cell
  * of one.  uout != u; bit-identical to two calls of odil_poisson_jacobi.  The last extent must be a multiple of the
  * 16-byte pack (2 doubles / 4 floats).  zc_hint: planes per workgroup chunk, <= 0: automatic.  (Multigrid smoother of
@@ -397,7 +397,7 @@ int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, cons
 int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
                                       void* stream);
 
-/* TWO sweeps of odil_stencil_var_smooth (mode 0; weights omega1, then omega2) in ONE pass: the coefficient arrays -- 7 of
+/* TWO sweeps of odil_stencil_var_smooth in mode 0, with the weights omega1 and then omega2, in ONE pass: the coefficient arrays -- 7 of
  * the 10 words a sweep moves in 3-D -- are read once for both, the intermediate iterate stays on the CU.  out != x;
  * bit-identical to two calls of odil_stencil_var_smooth.  The last extent must be even.  zc_hint: planes per workgroup
  * chunk, <= 0: automatic. */
