@@ -397,6 +397,30 @@ int odil_stencil_var_coarsen_axes_f64(const double* coeffs, double* coarse, cons
 int odil_stencil_var_coarsen_axes_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, const int* halve,
                                       void* stream);
 
+/* WHOLE EPOCHS of the multigrid Poisson problem (1-D or 2-D, all axes cell-centred) in ONE launch: one workgroup walks
+ * synthesis, residual + loss, adjoint, transposed prolongations and the Adam update of every level -- the 17 dependent
+ * launches of a 1-D N = 256 epoch -- `nepochs` times, the state resident in LDS when it fits.  Every phase repeats the
+ * arithmetic of the kernel it replaces and the loss is summed in the order of the two-stage reduction: the trajectory is
+ * bit-identical to the multi-launch path.
+ *   x, m, v, g   packed vectors of all levels, finest first (unknowns, Adam moments, gradient: all updated)
+ *   u            scratch of the same length (the synthesised field of every level; level 0 = the field u)
+ *   fu, rhs      residual (out) and right-hand side on the finest level
+ *   shapes       nlvl x ndim extents, each level half the one before; h2: squared steps of the finest level
+ *   alphas       DEVICE array of nepochs step sizes lr sqrt(1 - b2^t) / (1 - b1^t); losses: DEVICE array, the loss each
+ *                epoch evaluated (before its update), norms: their square roots; partials: the reduction workspace
+ * Reference: core.py:245-263, 606-700; examples/poisson/poisson.py:57-113; core.py:1093-1100; optimizer.py:311-336. */
+/* 1 when odil_poisson_small_epochs keeps the state of these levels in LDS for the whole launch (elem_size 4 / 8 bytes):
+ * x, m, v, the gradient (= the synthesis scratch) of all levels, residual and right-hand side of the finest -- 156 KB. */
+int odil_poisson_small_epochs_resident(const int64_t* shapes, int nlvl, int ndim, int elem_size);
+int odil_poisson_small_epochs_f64(double* x, double* m, double* v, double* g, double* u, double* fu, const double* rhs,
+                                  const int64_t* shapes, int nlvl, int ndim, const double* h2, const double* alphas,
+                                  int nepochs, double one_minus_b1, double one_minus_b2, double eps, double* losses,
+                                  double* norms, double* partials, void* stream);
+int odil_poisson_small_epochs_f32(float* x, float* m, float* v, float* g, float* u, float* fu, const float* rhs,
+                                  const int64_t* shapes, int nlvl, int ndim, const float* h2, const float* alphas,
+                                  int nepochs, float one_minus_b1, float one_minus_b2, float eps, float* losses,
+                                  float* norms, double* partials, void* stream);
+
 /* TWO sweeps of odil_stencil_var_smooth in mode 0, with the weights omega1 and then omega2, in ONE pass: the coefficient arrays -- 7 of
  * the 10 words a sweep moves in 3-D -- are read once for both, the intermediate iterate stays on the CU.  out != x;
  * bit-identical to two calls of odil_stencil_var_smooth.  The last extent must be even.  zc_hint: planes per workgroup

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "field_scatter": [_P, _P, _I64P, c_int, c_char_p, c_char_p, _I64P, c_int, _P],
     "mean_reduce": [_P, c_int64, c_int, _P, _P, _P],
     "poisson_residual": [_P, _P, _P, _I64P, c_int, _P, _P, _P, _P],
+    "poisson_small_epochs": [_P, _P, _P, _P, _P, _P, _P, _I64P, c_int, c_int, _P, _P, c_int, _R, _R, _R, _P, _P, _P, _P],
     "poisson_jacobi": [_P, _P, _P, _I64P, c_int, _P, _R, _P],
     "poisson_jacobi2": [_P, _P, _P, _I64P, c_int, _P, _R, _R, c_int, _P],
     "poisson_jacobi2_synth": [_P, _P, _P, _P, _I64P, _P, _R, _R, c_int, _P],
@@ -75,7 +76,7 @@ _SIGNATURES = {
 
 EXPORTED = [
     "odil_last_error", "odil_version", "odil_device_count", "odil_reduce_workspace_bytes", "odil_dots_workspace_bytes",
-    "odil_dense_block_workspace_bytes", "odil_narrow_scale", "odil_widen_axpy",
+    "odil_dense_block_workspace_bytes", "odil_narrow_scale", "odil_widen_axpy", "odil_poisson_small_epochs_resident",
 ] + [
     "odil_{}_{}".format(name, suffix) for name in _SIGNATURES for suffix in ("f64", "f32")
 ]
@@ -106,6 +107,8 @@ def load():
     lib.odil_dots_workspace_bytes.restype = c_size_t
     lib.odil_dots_workspace_bytes.argtypes = [c_int]
     lib.odil_dense_block_workspace_bytes.restype = c_size_t
+    lib.odil_poisson_small_epochs_resident.restype = c_int
+    lib.odil_poisson_small_epochs_resident.argtypes = [_I64P, c_int, c_int, c_int]
     for name in ("odil_narrow_scale", "odil_widen_axpy"):  # (mixed precision: no type suffix)
         fn = getattr(lib, name)
         fn.restype = c_int

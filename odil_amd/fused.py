@@ -164,6 +164,48 @@ class PoissonEvaluator:
         return loss, list(grads), [loss], self.names, [torch.sqrt(loss)], self.nlvl
 
 
+    # ---- whole epochs in one launch (small 1-D / 2-D problems) --------------------------------------------------------------
+    # ONE workgroup walks the epoch (odil_poisson_small_epochs) when the state fits its LDS (1-D N <= 1024 in float64, 2-D
+    # 32^2; twice that in float32) -- 15 us per epoch at 1-D N = 256 against 58 replayed as a hipGraph -- and, from
+    # global memory, for 1-D grids up to this many cells (N = 4096: 40 us against 82).  Beyond, the separate kernels win:
+    # one workgroup is one CU's worth of bandwidth and a memory round trip per phase.
+    small_max_cells = 4096
+    small_force = False  # (tests: the global-memory form on any 1-D / 2-D problem)
+
+    def small_plan(self, arrays, m, v):
+        """The packed vectors (x, m, v, g) when `arrays` / m / v are the level slices of packed vectors in level order and
+        the problem is small enough for one workgroup; None otherwise."""
+        from ._lib import i64, load
+
+        if self.ndim > 2 or self.nlvl > 12 or len(arrays) != self.nlvl or not self.small_max_cells:
+            return None
+        flat = [int(n) for shape in self.shapes for n in shape]
+        resident = bool(load().odil_poisson_small_epochs_resident(i64(flat), self.nlvl, self.ndim, 8 if self.dtype == torch.float64 else 4))
+        if not resident and not self.small_force and not (self.ndim == 1 and self.sizes[0] <= self.small_max_cells):
+            return None
+        if any(tuple(b) != tuple(n // 2 for n in a) for a, b in zip(self.shapes, self.shapes[1:])):
+            return None
+
+        def packed(levels):
+            base, item, off = levels[0].data_ptr(), levels[0].element_size(), 0
+            for t, size in zip(levels, self.sizes):
+                if not t.is_contiguous() or t.numel() != size or t.dtype != self.dtype or t.data_ptr() != base + off * item:
+                    return None
+                off += size
+            return levels[0]
+
+        heads = [packed(list(levels)) for levels in (arrays, m, v, self.gw)]
+        return None if any(hd is None for hd in heads) else heads
+
+    def small_epochs(self, heads, alphas, losses, norms, omb1, omb2, eps):
+        """alphas.numel() Adam epochs in ONE launch on the packed vectors of `small_plan`; the loss every epoch evaluated
+        (and its square root) land in `losses` / `norms` (device tensors like `alphas`)."""
+        if self.__dict__.get("_small_u") is None:
+            self._small_u = torch.empty(sum(self.sizes), dtype=self.dtype, device=self.device)
+        ops.poisson_small_epochs(heads[0], heads[1], heads[2], heads[3], self._small_u, self.fu, self.rhs, self.shapes,
+                                 self.h2, alphas, omb1, omb2, eps, losses, norms)
+
+
 def _close(a, b, rtol):
     scale = max(float(b.abs().max()), 1e-300)
     return float((a - b).abs().max()) <= rtol * scale

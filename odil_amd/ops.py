@@ -452,6 +452,17 @@ def poisson_jacobi(u, rhs, h2, omega, out):
     return out
 
 
+def poisson_small_epochs(x, m, v, g, u, fu, rhs, shapes, h2, alphas, omb1, omb2, eps, losses, norms):
+    """alphas.numel() whole epochs of the 1-D / 2-D multigrid Poisson problem in one launch (include/odil_hip.h:
+    odil_poisson_small_epochs).  x, m, v, g, u: packed flat vectors of all levels; alphas, losses, norms: device tensors."""
+    flat = [int(n) for shape in shapes for n in shape]
+    h2a, h2p = host_reals(h2, x.dtype)
+    call("poisson_small_epochs", x.dtype, ptr(x), ptr(m), ptr(v), ptr(g), ptr(u), ptr(fu), ptr(rhs), i64(flat),
+         c_int(len(shapes)), c_int(len(shapes[0])), h2p, ptr(alphas), c_int(alphas.numel()), float(omb1), float(omb2),
+         float(eps), ptr(losses), ptr(norms), ptr(reduce_workspace(x.device)), stream_ptr())
+    return losses
+
+
 def jacobi2_supported(shape, dtype):
     """Arrays whose rows are whole 16-byte packs (odil_poisson_jacobi2, odil_stencil_var_smooth2)."""
     pack = 2 if dtype == torch.float64 else 4

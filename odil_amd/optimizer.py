@@ -213,6 +213,26 @@ class AdamNativeOptimizer(Optimizer):
 
         first, last = epoch_start + 1, epoch_start + epochs
         epoch = first
+        # Problems small enough for ONE workgroup (1-D / 2-D Poisson: fused.PoissonEvaluator.small_epochs) run whole epochs
+        # in one launch -- as many as lie before the callback's next active epoch (a callback that cannot tell is called
+        # after every epoch, as the reference does, optimizer.py:331-336).
+        small = getattr(loss_grad, "small_epochs", None)
+        runner = None
+        if small is not None and epochs > 0:
+            table = torch.tensor(np.array([step_size(e) for e in range(first, last + 1)], dtype=np.float64), dtype=tdtype,
+                                 device=xf.device)
+            runner = small(x, mviews, vviews, table, 1 - beta_1, 1 - beta_2, epsilon)
+        while runner is not None and epoch <= last:
+            nxt = getattr(callback, "next_active", None) if callback is not None else (lambda e: last)
+            stop = min(last, max(epoch, nxt(epoch - 1)) if nxt is not None else epoch, epoch + 4095)
+            pinfo = runner(epoch - first, stop - epoch + 1)
+            self.evals += stop - epoch + 1
+            epoch = stop + 1
+            if callback is not None and stop > 0:
+                captured = [a.data_ptr() for a in x]
+                callback(x, stop, pinfo)
+                if [a.data_ptr() for a in x] != captured:
+                    runner = None  # (the callback swapped arrays: the packed vectors are no longer the state)
         # Launch-bound problems (a few million unknowns or fewer: dozens of launches of a few
         # microseconds each) replay the epoch as ONE hipGraph: the first two epochs run eagerly (lazy
         # initialisation, allocator warm-up), the third is captured with the step size read from

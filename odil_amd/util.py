@@ -260,7 +260,23 @@ def make_callback(problem, args=None, epoch_func=None, report_func=None, history
                 checkpoint_save(domain, state, path)
         cbinfo.time_callback += time.time() - t_in
 
+    def next_active(epoch):
+        """The first epoch after `epoch` at which this callback does anything (report, history, plot, checkpoint, a user
+        hook): on the epochs before it a call is a no-op, so an optimizer may run them without calling."""
+        args = cbinfo.args
+        if epoch_func is not None:
+            return epoch + 1
+        e = epoch + 1
+        while True:
+            if ((bool(args.report_every) and e % args.report_every == 0)
+                    or (cbinfo.history is not None and (e % args.history_every == 0 or e < (args.history_full or 0)))
+                    or (e % args.plot_every == 0 and bool(e or args.frames))
+                    or (bool(args.checkpoint_every) and e % args.checkpoint_every == 0)):
+                return e
+            e += 1
+
     callback.cbinfo = cbinfo
+    callback.next_active = next_active
     return callback
 
 
@@ -377,7 +393,30 @@ def make_loss_grad(problem, state):
         loss, grads, terms, names, norms, done = res
         return loss, grads, _pinfo(loss, terms, names, norms), done
 
+    def small_epochs(arrays, m, v, table, omb1, omb2, eps):
+        """A runner of whole Adam epochs in ONE launch each call (small 1-D / 2-D Poisson problems,
+        fused.PoissonEvaluator.small_epochs), or None when the problem is not of that kind.  `table`: device tensor of
+        the run's step sizes; runner(first, count) runs the epochs that use table[first : first + count] and returns the
+        report of the last of them (device scalars, read lazily)."""
+        ev = getattr(problem, "_fused", None)
+        if ev is None or not hasattr(ev, "small_plan"):
+            return None
+        heads = ev.small_plan(arrays, m, v)
+        if heads is None:
+            return None
+        domain.arrays_to_state(arrays, state)
+        losses, norms = torch.empty_like(table), torch.empty_like(table)
+
+        def runner(first, count):
+            ev.small_epochs(heads, table[first:first + count], losses[first:first + count], norms[first:first + count],
+                            omb1, omb2, eps)
+            k = first + count - 1
+            return _pinfo(losses[k], [losses[k]], ev.names, [norms[k]])
+
+        return runner
+
     loss_grad.fused_adam = fused_adam
+    loss_grad.small_epochs = small_epochs
     # hipGraph replay of whole Adam epochs (optimizer._EpochGraph): possible when the evaluation is
     # made of this package's kernels only -- the generic path has its own graph (Problem(jit=True))
     # (outputs in parameter space: replayable when they run as the generated kernel of param_expr.py; the torch replay
@@ -413,6 +452,10 @@ def optimize_grad(args, optname, problem, state, callback=None, **kwargs):
             new = domain.arrays_from_state(state)
             for i in range(len(new)):
                 arrays[i] = new[i]
+
+    # (a callback that tells when it next DOES something lets the optimizer run the epochs in between in one launch)
+    if not getattr(args, "callback_update_state", 0):
+        callback_wrap.next_active = getattr(callback, "next_active", None)
 
     for src, dst in [("bfgs_m", "m"), ("bfgs_pgtol", "pgtol"), ("bfgs_maxls", "maxls"), ("adam_epsilon", "epsilon"),
                      ("adam_beta_1", "beta_1"), ("adam_beta_2", "beta_2")]:

@@ -380,3 +380,36 @@ def test_lbfgsb_with_the_evaluation_replayed_as_a_graph_follows_the_eager_run(mo
     assert l1 == l0
     for a, b in zip(x1, x0):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("double", [1, 0])
+@pytest.mark.parametrize("ndim,N,epochs", [(1, 256, 60), (1, 4096, 12), (1, 8, 8), (2, 32, 40), (2, 256, 6), (2, 4, 8)])
+def test_whole_epochs_in_one_launch_are_bit_identical(ndim, N, epochs, double, monkeypatch):
+    """odil_poisson_small_epochs (ONE workgroup walks synthesis, residual + loss, adjoint, transposes and every level's Adam
+    update; state in LDS when it fits) against the same epochs as separate kernels: every loss and the final x, m, v BIT
+    for bit -- one launch per epoch (a callback that must see every epoch) and all epochs in ONE launch (no callback) --
+    1-D and 2-D, one and several virtual workgroups of the loss reduction (4096 cells; 256 rows), LDS-resident and
+    global-memory states, both precisions."""
+    from odil_amd import fused
+
+    monkeypatch.setenv("ODIL_GRAPH", "0")
+    runs = {}
+    for mode in ("separate", "per-epoch", "one-launch"):
+        odil, poisson, args = _api(ndim, N, epochs=epochs, lr=0.005, double=double)
+        monkeypatch.setattr(fused.PoissonEvaluator, "small_max_cells", 0 if mode == "separate" else 4096)
+        monkeypatch.setattr(fused.PoissonEvaluator, "small_force", mode != "separate")
+        problem, state = poisson.make_problem(args)
+        losses = []
+        cb = None if mode == "one-launch" else (lambda st, ep, pinfo: losses.append(float(np.array(pinfo["loss"]))))
+        arrays, info = odil.util.optimize_grad(args, "adam", problem, state, cb)
+        assert getattr(problem, "_fused", None) is not None
+        used = problem._fused.__dict__.get("_small_u") is not None
+        assert used == (mode != "separate"), (mode, used)
+        runs[mode] = (losses, [a.clone() for a in arrays], [a.clone() for a in info.m], [a.clone() for a in info.v])
+    ref = runs["separate"]
+    assert len(ref[0]) == epochs + 1 and runs["per-epoch"][0] == ref[0], "losses differ"
+    for mode in ("per-epoch", "one-launch"):
+        for part, name in zip(runs[mode][1:], "xmv"):
+            for lvl, (a, b) in enumerate(zip(part, ref[1:]["xmv".index(name)])):
+                assert torch.equal(a, b), (mode, name, lvl, float((a - b).abs().max()))
