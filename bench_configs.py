@@ -71,7 +71,21 @@ def run(problem, state, args, optname, epochs, warmup=2):
     loss = float(problem.eval_loss_grad(state)[0])
     cells = int(np.prod(problem.domain.cshape))
     med = float(np.median(times)) if times else 1e3 * wall / max(epochs, 1)
-    return dict(cells=cells, epochs=done, wall_s=wall, ms_per_epoch=med, ms_mean=float(np.mean(times)) if times else med,
+    extra = dict()
+    ev = getattr(problem, "_fused", None)
+    if optname == "adam" and ev is not None and ev.__dict__.get("_small_u") is not None:
+        # a problem small enough for whole epochs in one launch (odil_poisson_small_epochs): the per-epoch callback above
+        # forces one launch PER epoch; without a callback (or with one that tells its cadence: util.make_callback) the
+        # optimizer runs them in one launch -- 4000 epochs, the call's set-up included in the time
+        n = 4000
+        args.epoch_start, args.epochs = 0, n
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        odil.util.optimize(args, optname, problem, state, None)
+        torch.cuda.synchronize()
+        extra["us_per_epoch_whole_epochs_in_one_launch"] = 1e6 * (time.perf_counter() - t1) / n
+        extra["whole_epochs_kernel"] = True
+    return dict(**extra, cells=cells, epochs=done, wall_s=wall, ms_per_epoch=med, ms_mean=float(np.mean(times)) if times else med,
                 ms_max=float(np.max(times)) if times else med, ms_min=float(np.min(times)) if times else med,
                 setup_s=wall - 1e-3 * float(np.sum(times)) if times else 0.0,
                 updates_per_s=cells / (med * 1e-3), loss=loss, fused=problem._fused is not None,
