@@ -252,8 +252,84 @@ def spin_up(dev, ms):
     del buf
 
 
+class ApiPoissonRun:
+    """The headline workload THROUGH THE PUBLIC API: `examples/poisson/poisson.py` (the reference example's operator
+    callback, `Domain` / `Problem`) driven by `odil.util.optimize_grad(args, "adam", problem, state, callback)` --
+    reference src/odil/util.py:190-240 -> optimizer.py:286-341.  Same attributes as the bespoke driver
+    (`poisson_path.PoissonMultigridAdam`, timed here up to round 5; tools/headline_ab.py holds the two side by side)."""
+
+    def __init__(self, ndim, N, dtype, dev, ref_u=None):
+        sys.path.insert(0, os.path.join(ROOT, "examples", "poisson"))
+        import odil_amd as odil
+        import poisson
+        from odil_amd import ops
+
+        self.odil = odil
+        odil.util.set_log_file(open(os.devnull, "w"))
+        self.args = poisson.parse_args(["--ndim", str(ndim), "--N", str(N), "--double", "1" if dtype == torch.float64 else "0"])
+        self.problem, self.state = poisson.make_problem(self.args)
+        if ref_u is not None:
+            # the fixture's inputs bit for bit: the example forms its reference solution on the device (torch pow: last-bit
+            # differences from NumPy's, which this problem amplifies to O(1) within three epochs)
+            h2 = [np.float64(1.0 / N) ** 2] * ndim
+            rhs, _ = ops.poisson_residual(ref_u, torch.zeros_like(ref_u), h2)
+            assert not self.problem._fused_checked
+            self.problem.extra.rhs = rhs
+        self.ref_u = ref_u if ref_u is not None else self.problem.extra.ref_u
+        self.problem.eval_loss_grad_device(self.state)  # (the operator is recognised here: fused HIP route)
+        self.ev = self.problem._fused
+        assert self.ev is not None, "the Poisson operator must take the fused HIP route"
+        self.nlvl = self.ev.nlvl
+        self.local_cells = self.global_cells = int(np.prod(self.problem.domain.cshape))
+        self.n_unknowns_local = sum(self.ev.sizes)
+        self.w = self.problem.domain.arrays_from_state(self.state)
+        self.mw = self.vw = None
+        self.done = 0
+        self._loss = None
+
+    def _call(self, epochs, callback):
+        a = self.args
+        a.epoch_start, a.epochs = 0, epochs
+        moments = None if self.mw is None else (self.mw, self.vw)
+        arrays, info = self.odil.util.optimize_grad(a, "adam", self.problem, self.state, callback, moments=moments,
+                                                    steps_done=self.done)
+        self.w, self.mw, self.vw = arrays, [t.clone() for t in info.m], [t.clone() for t in info.v]
+        self.done += epochs
+
+    def epoch(self, timers=None):
+        """One epoch as a call of its own (warm-up: every call also makes the driver's initial evaluation)."""
+        self.ev.timers = timers
+        seen = []
+        self._call(1, lambda st, ep, pinfo: seen.append(pinfo))
+        self.ev.timers = None
+        self._loss = seen[-1]["loss"]
+
+    def timed(self, steps, timers, barrier):
+        """EXACTLY `steps` optimizer steps of ONE `optimize_grad` call between two barriers (the driver's per-epoch callback
+        brackets them: the call's own set-up -- packed copy, moments, the initial evaluation for the callback -- lies
+        before the first barrier); -> seconds."""
+        marks, seen = [], []
+
+        def cb(st, ep, pinfo):
+            seen.append(pinfo)
+            if ep == 0:
+                self.ev.timers = timers
+                barrier()
+                marks.append(time.perf_counter())
+            elif ep == steps:
+                barrier()
+                marks.append(time.perf_counter())
+                self.ev.timers = None
+
+        self._call(steps, cb)
+        self._loss = seen[-1]["loss"]
+        return marks[1] - marks[0]
+
+    def last_loss(self):
+        return float(np.array(self._loss))
+
+
 def run_poisson(args, rank, world, dev, comm, barrier):
-    from odil_amd.poisson_path import PoissonMultigridAdam
     from odil_amd.slab import SlabPoissonAdam
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
@@ -271,7 +347,7 @@ def run_poisson(args, rank, world, dev, comm, barrier):
             # with the C oracle's (oracle_values_check) -- a last-bit change of the inputs is amplified to O(1) within
             # three epochs of this problem
             ref_u = torch.as_tensor(hat_reference_host(N)).to(dev)
-        run = PoissonMultigridAdam(ndim, N, dtype=dtype, device=dev, ref_u=ref_u)
+        run = ApiPoissonRun(ndim, N, dtype, dev, ref_u=ref_u)
         del ref_u
         step = lambda timers=None: run.epoch(timers)
     # (created and primed before the warm-up: growing the runtime's event pool stalls the queue, see Timers)
@@ -286,17 +362,23 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         step()
         if world == 1:  # the run starts from the zero state: its first epochs ARE the epochs of the value-level fixture
             oracle = oracle_values_check(run, k + 1, oracle, (ndim, N, args.dtype))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timers)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if world == 1:
+        elapsed = run.timed(args.steps, timers, barrier)
+    else:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timers)
+        barrier()
+        elapsed = time.perf_counter() - t0
     gc.enable()
     loss = run.last_loss(comm) if world > 1 else run.last_loss()
     every = Timers(prealloc=8 * 5)  # the other sections: a few epochs outside the timed region (events primed: see Timers)
-    for _ in range(5):
-        step(every)
+    if world == 1:
+        run.timed(5, every, barrier)
+    else:
+        for _ in range(5):
+            step(every)
     barrier()
     wordsize = 8 if dtype == torch.float64 else 4
     kt = every.summary()
@@ -332,7 +414,8 @@ def run_poisson(args, rank, world, dev, comm, barrier):
         elapsed=elapsed, cells=run.global_cells, loss=loss, kernel_ms=kt,
         metric="grid-point-updates/s, Poisson {}^{} multigrid".format(N, ndim),
         workload=("3D Poisson 512^3 multigrid (9 levels) Adam epoch, {}".format(
-            "1xMI355X" if world == 1 else "512^3 slab per GPU x {} MI355X".format(world))
+            "1xMI355X, public operator API (odil.util.optimize_grad on examples/poisson/poisson.py)" if world == 1
+            else "512^3 slab per GPU x {} MI355X".format(world))
             if (ndim, N) == (3, 512) else "{}D Poisson {}^{} multigrid Adam epoch".format(ndim, N, ndim)),
         config=dict(cells_per_gpu=run.local_cells, levels=run.nlvl, optimizer="adam lr=0.005"),
         roofline=roofline(kernel, model, moved, ms, traffic, source), abytes=abytes, dtype=args.dtype,

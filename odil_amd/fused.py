@@ -47,6 +47,7 @@ class PoissonEvaluator:
             : self.nlvl
         ]
         self.scale = self.npdt(2) / self.npdt(self.fu.numel())
+        self.timers = None  # (measurement: event pairs around the launches of every evaluation, see loss_grad_arrays)
         import os
 
         # last prolongation fused into the residual (u never stored): 3-D, even extents, >= 2 levels
@@ -106,6 +107,8 @@ class PoissonEvaluator:
         adam = (m_levels, v_levels, alpha, 1-b1, 1-b2, eps): also apply the Adam update of EVERY
         level array inside the launch that forms its gradient (adjoint for level 0, the P^T
         chain for the others); no separate optimizer launch is needed then."""
+
+        timers = timers if timers is not None else self.timers
 
         def tic(name):
             if timers is None:
