@@ -210,16 +210,18 @@ def restrict_to_coarser(u, loc=None, method=None, mod=None, depth=1):
 
 
 def check_multigrid_cshapes(cshapes, axes=None):
-    """Level n must halve level n-1 on every decomposed axis (reference core.py:758-776)."""
-    if not len(cshapes):
+    """Every level halves the one before on every decomposed axis; a ValueError naming the offending pair otherwise
+    (the check of reference core.py:758-776)."""
+    cshapes = [tuple(s) for s in cshapes]
+    if not cshapes:
         return
-    dim = len(cshapes[0])
-    axes = axes or [True] * dim
-    assert_equal(len(axes), dim)
-    for i in range(1, len(cshapes)):
-        for j in range(dim):
-            if axes[j]:
-                assert_equal(cshapes[i - 1][j], cshapes[i][j] * 2, " with cshapes={:}".format(cshapes))
+    axes = [True] * len(cshapes[0]) if not axes else list(axes)
+    assert_equal(len(axes), len(cshapes[0]))
+    where = " with cshapes={:}".format(cshapes)
+    for fine, coarse in zip(cshapes, cshapes[1:]):
+        for halved, nf, nc in zip(axes, fine, coarse):
+            if halved:
+                assert_equal(nf, 2 * nc, where)
 
 
 # ======================================================================================
@@ -927,11 +929,9 @@ class Problem:
         self.domain.arrays_to_state(arrays, shadow)
         return shadow
 
-    # ---- loss + gradient (reference core.py:1038-1111, 1219-1241) --------------------------
-    def eval_loss_grad_device(self, state):
-        """Like eval_loss_grad but loss / terms / norms stay 0-d DEVICE tensors (no host sync)."""
-        if not state.initialized:
-            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+    def recognise(self, state):
+        """Once per problem (like the reference's jit cache, core.py:1023-1025): the operator is probed for the fused
+        Poisson route (fused.detect) and, failing that, traced into generated kernels (stencil_jit.trace)."""
         if not self._fused_checked:
             self._fused_checked = True
             from . import fused, runtime
@@ -942,6 +942,13 @@ class Problem:
                 from . import stencil_jit
 
                 self._traced = stencil_jit.trace(self, state)
+
+    # ---- loss + gradient (reference core.py:1038-1111, 1219-1241) --------------------------
+    def eval_loss_grad_device(self, state):
+        """Like eval_loss_grad but loss / terms / norms stay 0-d DEVICE tensors (no host sync)."""
+        if not state.initialized:
+            raise RuntimeError("Uninitialized state, use `state = domain.init_state(state)`")
+        self.recognise(state)
         if self._fused is not None:
             return self._fused.eval_loss_grad(state)
         if self._traced is not None:
@@ -1180,19 +1187,19 @@ def checkpoint_save(domain, state, path):
 
 
 def checkpoint_load(domain, state, path, skip_missing=True, keys=None):
+    """Fills the fields of `state` from a checkpoint (the pickle layout of reference core.py:1389-1436: {"fields": {key:
+    array or list of arrays}}); a missing key is an error only with skip_missing=False."""
     with open(path, "rb") as f:
-        data = pickle.load(f).get("fields", dict())
-    keys = keys or state.fields.keys()
-    for key in keys:
-        if key not in data:
-            if not skip_missing:
-                raise RuntimeError(f"Field {key} not found in {path}")
-            continue
-        arrays = data[key]
-        if not isinstance(arrays, list):
-            arrays = [arrays]
-        arrays = [domain.mod.variable(a, dtype=domain.dtype) for a in arrays]
-        domain.arrays_to_field(arrays, state.fields[key])
+        stored = pickle.load(f).get("fields", dict())
+    wanted = list(state.fields) if not keys else list(keys)
+    missing = [key for key in wanted if key not in stored]
+    if missing and not skip_missing:
+        raise RuntimeError(f"Field {missing[0]} not found in {path}")
+    for key in wanted:
+        if key in stored:
+            entry = stored[key]
+            levels = entry if isinstance(entry, list) else [entry]
+            domain.arrays_to_field([domain.mod.variable(a, dtype=domain.dtype) for a in levels], state.fields[key])
 
 
 def extrap_quadh(u0, u1, u1p):
@@ -1211,14 +1218,13 @@ def extrap_linear(u0, u1):
 
 
 def struct_to_numpy(mod, d):
+    """`d` with every tensor inside its dicts / lists / tuples replaced by a NumPy array (dicts are rewritten in place, as
+    the reference's helper does, core.py:1460-1476)."""
     if mod.is_tensor(d):
         return _to_numpy(d)
     if isinstance(d, dict):
-        for key in d:
-            d[key] = struct_to_numpy(mod, d[key])
+        d.update({key: struct_to_numpy(mod, val) for key, val in d.items()})
         return d
-    if isinstance(d, list):
-        return [struct_to_numpy(mod, a) for a in d]
-    if isinstance(d, tuple):
-        return tuple(struct_to_numpy(mod, a) for a in d)
+    if isinstance(d, (list, tuple)):
+        return type(d)(struct_to_numpy(mod, item) for item in d)
     return d

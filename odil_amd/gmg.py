@@ -24,6 +24,17 @@ import torch
 from . import ops
 
 
+def skewed(shape, dtype, device, k, zero=False):
+    """A work array whose base address is moved k x 4 KB off its allocation.  The arrays of a 512^3 float64 level are
+    exactly 2^30 bytes each; allocated back to back they start 2^30 bytes apart, and the streams of a sweep (x, b, x') then
+    walk the same memory channels in step: 0.66 against 0.61 ms for a sweep, 0.81 against 0.77 for a pair
+    (tools/mb_alias.py: any offset from 256 B up removes it)."""
+    n = math.prod(shape)
+    pad = (k % 16) * 4096 // torch.empty((), dtype=dtype).element_size()
+    flat = (torch.zeros if zero else torch.empty)(n + pad, dtype=dtype, device=device)
+    return flat[pad:pad + n].view(shape)
+
+
 class PoissonGMG:
     nu_default = (2, 2)  # pre- / post-smoothing sweeps of a cycle
 
@@ -61,9 +72,9 @@ class PoissonGMG:
         self._r = [None] * self.nlvl                         # residuals (only where the fused restriction cannot be used)
         if lite:
             return
-        self.x = [None] + [mk(s) for s in self.shapes[1:]]   # coarse corrections
-        self.b = [None] + [mk(s) for s in self.shapes[1:]]   # coarse right-hand sides
-        self.spare = [torch.empty(s, dtype=dtype, device=device) for s in self.shapes]  # target of a sweep / prolongation
+        self.x = [None] + [skewed(s, dtype, device, 2, zero=True) for s in self.shapes[1:]]   # coarse corrections
+        self.b = [None] + [skewed(s, dtype, device, 3, zero=True) for s in self.shapes[1:]]   # coarse right-hand sides
+        self.spare = [skewed(s, dtype, device, 1) for s in self.shapes]  # target of a sweep / prolongation
 
     residual_sign = 1.0  # `residual` returns A x - b
 
@@ -113,7 +124,9 @@ class PoissonGMG:
         iterate stays on the CU, 3 words per cell and pair instead of 6; bit-identical to two single sweeps) on levels
         large enough to be bandwidth-bound."""
         weights = list(weights)
-        pair = ops.jacobi2_supported(self.shapes[lvl], self.dtype) and math.prod(self.shapes[lvl]) >= self.pair_min_cells
+        # (float64 only: with four floats per lane the pair is bound by the vector ALU, 0.85 against 0.70 ms at 512^3)
+        pair = (self.dtype == torch.float64 and ops.jacobi2_supported(self.shapes[lvl], self.dtype)
+                and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
         while weights:
             y = self.spare[lvl]
             if pair and len(weights) >= 2:
@@ -199,8 +212,8 @@ class PoissonGMG:
         xc_new = self.coarse_correction(lvl)
         out = self.spare[lvl]
         weights = self.weights(self.nu2)
-        pair = (self.post_pair and len(weights) >= 2 and ops.jacobi2_supported(self.shapes[lvl], self.dtype)
-                and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
+        pair = (self.post_pair and len(weights) >= 2 and self.dtype == torch.float64
+                and ops.jacobi2_supported(self.shapes[lvl], self.dtype) and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
         if pair:
             # x + P x_c as a pass of its own (2 1/8 words), then the post-smoothing PAIR in one pass (3 words): 5 1/8
             # against 3 1/8 + 3 for the prolongation fused into the first of two single sweeps
@@ -307,9 +320,10 @@ class PoissonGMG:
                 x = self.tail_cycle(lvl, None, fb[lvl], fmg=True)
                 continue
             if x is None:
-                start = torch.zeros(self.shapes[lvl], dtype=self.dtype, device=self.device)
+                start = skewed(self.shapes[lvl], self.dtype, self.device, 5, zero=True)
             else:
-                start = ops.interp_add(x, self.locs[lvl])  # (a fresh tensor: the cycle's work buffers rotate underneath)
+                # (a fresh tensor: the cycle's work buffers rotate underneath)
+                start = ops.interp_add(x, self.locs[lvl], out=skewed(self.shapes[lvl], self.dtype, self.device, 5))
             # (the tensor returned is never this level's coarse-correction buffer self.x[lvl], which the next finer
             # cycle zeroes: a cycle rotates its argument with self.spare[lvl] only)
             x = self.vcycle(lvl, start, fb[lvl])
@@ -525,9 +539,9 @@ class StencilGMG(PoissonGMG):
         self._r = [None] * self.nlvl
         if lite:
             return
-        self.x = [None] + [mk(s) for s in self.shapes[1:]]
-        self.b = [None] + [mk(s) for s in self.shapes[1:]]
-        self.spare = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.shapes]
+        self.x = [None] + [skewed(s, self.dtype, self.device, 2, zero=True) for s in self.shapes[1:]]
+        self.b = [None] + [skewed(s, self.dtype, self.device, 3, zero=True) for s in self.shapes[1:]]
+        self.spare = [skewed(s, self.dtype, self.device, 1) for s in self.shapes]
 
     def coarse_inverse(self):
         """(Pseudo-)inverse of the coarsest operator, from the residual kernel applied to unit vectors; a singular

@@ -25,18 +25,15 @@ from . import ops
 
 
 class Optimizer:
+    """Base of the optimizers: a name pair, the dtype and an evaluation counter (interface of reference
+    optimizer.py:8-19); `run` of the base makes no step."""
+
     def __init__(self, name=None, displayname=None, dtype=None):
-        self.name = name
-        self.displayname = displayname if displayname is not None else name
-        self.dtype = dtype
-        self.pinfo = None
-        self.evals = 0
+        self.name, self.displayname = name, displayname or name
+        self.dtype, self.pinfo, self.evals = dtype, None, 0
 
     def run(self, x0, loss_grad, epochs, callback=None, epoch_start=0, **kwargs):
-        optinfo = Namespace()
-        optinfo.evals = 0
-        optinfo.epochs = 0
-        return x0, optinfo
+        return x0, Namespace(evals=0, epochs=0)
 
 
 class EarlyStopError(Exception):

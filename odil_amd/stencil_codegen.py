@@ -548,8 +548,6 @@ class _Codegen:
     def _fold_plan(self, nodes, vw, windows=False):
         """(fold, exc, inbox) or None: fold = {predicate node idx: its value away from the exceptional indices},
         exc = {axis: sorted exceptional index values}, inbox = {(output, axis)} window tests that hold in the interior."""
-        if not int(os.environ.get("ODIL_TRACE_FOLD", 1)):
-            return None
         last, memo = self.ndim - 1, dict()
         fold, exc, inbox = dict(), dict(), set()
         for n in nodes:

@@ -139,7 +139,7 @@ class TracedOperator:
         # ... as ONE generated kernel when the taped operations have an elementwise form (param_expr.py); else the torch
         # replay of _eval_offgrid
         self.par_outputs = None
-        if self.offgrid and int(os.environ.get("ODIL_TRACE_PAR_KERNEL", 1)):
+        if self.offgrid:
             from . import param_expr
             from .core import Array, NeuralNet
 

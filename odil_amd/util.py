@@ -298,6 +298,8 @@ def _poisson_newton_step(problem, state, args, status):
     from .core import Field
     from .linsolver import DENSE_MAX_UNKNOWNS
 
+    if state.initialized:
+        problem.recognise(state)  # (without a callback no evaluation precedes the first step)
     ev = getattr(problem, "_fused", None)
     linsolver = getattr(args, "linsolver", "direct")
     if ev is None or ev.nlvl != 1 or len(state.fields) != 1 or not int(os.environ.get("ODIL_NEWTON_SHORTCUT", 1)):
@@ -318,12 +320,16 @@ def _poisson_newton_step(problem, state, args, status):
     elif solver is None:
         solver = ev.__dict__["_gmg"] = gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device)
     tol = 1e-12 if linsolver == "direct" else getattr(args, "linsolver_tol", 1e-10)
-    b = ops.scale(r, -1.0, out=r)  # the evaluator's residual buffer is scratch: negate it in place
     if mixed:
+        b = ops.scale(r, -1.0, out=r)  # the evaluator's residual buffer is scratch: negate it in place
         delta = gmg.solve_mixed(solver[0], solver[1], b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status)
         return delta.reshape(-1)
-    delta = solver.solve(b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False)
-    return delta.reshape(-1)  # a work buffer of the solver; optimize_newton adds it to the state right away
+    # A d = r is solved and u - d formed (the solver is linear: d = -delta) -- the residual need not be negated first
+    d = solver.solve(r, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False)
+    ops.axpy(u, d, -1.0)  # (d: a work buffer of the solver, consumed here)
+    if u.data_ptr() != field.array.data_ptr():
+        field.array.copy_(u)
+    return True
 
 
 def optimize_newton(args, problem, state, callback=None, **kwargs):
@@ -344,6 +350,7 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         opt.evals += 1
         linstatus = dict()
         delta = _poisson_newton_step(problem, state, args, linstatus)
+        applied = delta is True  # (the recognised-Poisson step updates the state itself)
         if delta is None:
             vector, matrix = problem.linearize_device(state)
             from . import ops as _ops
@@ -355,7 +362,9 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         from .core import Field
 
         fields = list(state.fields.values())
-        if len(fields) == 1 and type(fields[0]) is Field and torch.is_tensor(fields[0].array) \
+        if applied:
+            pass
+        elif len(fields) == 1 and type(fields[0]) is Field and torch.is_tensor(fields[0].array) \
                 and fields[0].array.is_contiguous() and fields[0].array.numel() == delta.numel():
 
             ops.axpy(fields[0].array, delta.to(fields[0].array.dtype), 1.0)  # x += delta in place (util.py:176-178)

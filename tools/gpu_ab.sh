@@ -2,7 +2,7 @@
 # GPU-side A/B harness (run through gpurun): traced-operator parity tests, then the traced configs with a switch of the
 # code generator on / off.  Usage: tools/gpu_ab.sh <ENV_VAR> [configs...]   (the variable is run with 1 and 0)
 cd $GRAFT_REPO_ROOT
-VAR=${1:-ODIL_TRACE_FOLD}; shift
+VAR=${1:-ODIL_TRACE_SHARE}; shift
 CFGS=${@:-3b 5 5b}
 touch /tmp/odil_run_start
 if [ -z "$SKIP_TESTS" ]; then
