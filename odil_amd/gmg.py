@@ -206,12 +206,13 @@ class PoissonGMG:
             return rc if sign == 1.0 and out is None else ops.scale(rc, sign, out=out)
         return ops.scale(ops.interp_adj(r, loc, self.shapes[lvl + 1]), sign / 2 ** loc.count("c"), out=out)
 
-    def finish_cycle(self, lvl, x, b):
+    def finish_cycle(self, lvl, x, b, post=True):
         """Second half of a V(nu1, nu2) cycle: `x` is pre-smoothed and b_{lvl+1} holds its restricted
-        residual.  Coarse-grid correction and post-smoothing; returns the tensor holding the new iterate."""
+        residual.  Coarse-grid correction and post-smoothing (post=False: none -- the caller smooths next anyway);
+        returns the tensor holding the new iterate."""
         xc_new = self.coarse_correction(lvl)
         out = self.spare[lvl]
-        weights = self.weights(self.nu2)
+        weights = self.weights(self.nu2) if post else []
         pair = (self.post_pair and len(weights) >= 2 and self.dtype == torch.float64
                 and ops.jacobi2_supported(self.shapes[lvl], self.dtype) and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
         if pair:
@@ -286,7 +287,7 @@ class PoissonGMG:
         self.spare[lvl] = x
         return out
 
-    def vcycle(self, lvl, x, b, zero=False):
+    def vcycle(self, lvl, x, b, zero=False, post=True):
         """One V(nu1, nu2) cycle on A x = b; returns the tensor holding the new iterate.  zero: `x` is the zero vector."""
         t = self.tail()
         if t is not None and lvl == t[0]:
@@ -302,9 +303,9 @@ class PoissonGMG:
             return self.smooth(lvl, x, b, 40, chebyshev=False)  # cannot coarsen further: by iteration
         x = self.smooth(lvl, x, b, self.nu1)
         self.coarse_rhs(lvl, x, b)
-        return self.finish_cycle(lvl, x, b)
+        return self.finish_cycle(lvl, x, b, post=post)
 
-    def full_multigrid(self, b):
+    def full_multigrid(self, b, post=True):
         """First iterate by nested iteration: the right-hand side is restricted to every level, the coarsest problem is
         solved, and each finer level starts one V-cycle from the prolongated solution of the level below.  Costs about
         one V-cycle of the finest level plus 1/7 and leaves the error near the discretisation level instead of O(1):
@@ -326,7 +327,9 @@ class PoissonGMG:
                 start = ops.interp_add(x, self.locs[lvl], out=skewed(self.shapes[lvl], self.dtype, self.device, 5))
             # (the tensor returned is never this level's coarse-correction buffer self.x[lvl], which the next finer
             # cycle zeroes: a cycle rotates its argument with self.spare[lvl] only)
-            x = self.vcycle(lvl, start, fb[lvl])
+            # (post=False: the finest level's cycle ends at its coarse-grid correction -- `solve` pre-smooths right after,
+            # and four sweeps in a row buy less than the pass they cost)
+            x = self.vcycle(lvl, start, fb[lvl], post=post or lvl > 0)
         return x
 
     def solve_krylov(self, b, x, tol, maxiter, status=None, m=6):
@@ -383,7 +386,7 @@ class PoissonGMG:
         if x0 is not None:
             x = x0.clone()
         elif fmg and self.nlvl > 2:
-            x = self.full_multigrid(b)
+            x = self.full_multigrid(b, post=False)
         else:
             x = torch.zeros_like(b)
         bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
@@ -618,7 +621,7 @@ class StencilGMG(PoissonGMG):
         rc = r.reshape(pairs).mean(dim=dims)
         return ops.scale(rc, sign, out=out) if (sign != 1.0 or out is not None) else rc
 
-    def finish_cycle(self, lvl, x, b):
+    def finish_cycle(self, lvl, x, b, post=True):
         xc_new = self.coarse_correction(lvl)
         # TWO cycles on the first coarse level in 3-D (a W-cycle's top, V below): the aggregation-built coarse operators
         # are slightly less accurate than a rediscretisation at the walls, and a more exact level-1 solve takes the
@@ -630,7 +633,7 @@ class StencilGMG(PoissonGMG):
         out = self.spare[lvl]
         ops.interp_add(xc_new, self.locs[lvl], add=x, out=out)  # x + P x_c
         self.spare[lvl] = x
-        return self.sweeps(lvl, out, b, self.weights(self.nu2))
+        return self.sweeps(lvl, out, b, self.weights(self.nu2) if post else [])
 
 
 def recognise_stencil(op):
