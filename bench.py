@@ -154,7 +154,7 @@ def measured_traffic(kernel, ndim, N, dtype):
     (collected in passes of their own with rocprofv3 --pmc -- FETCH_SIZE / WRITE_SIZE or the TCC_EA0 request counters they
     are derived from -- gfx950 correction applied; the newest round's file first), and the
     file they come from; (None, None) when no profile of this kernel / workload is on record."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:

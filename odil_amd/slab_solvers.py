@@ -447,6 +447,219 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         return loss0, loss1
 
 
+class SlabStencilGMG:
+    """Geometric multigrid for ANY (2 d + 1)-point operator with variable coefficients on a slab-decomposed 3-D grid -- the
+    slab form of `gmg.StencilGMG` (the Newton system M delta = -r of a single-field operator from its Jacobian's coefficient
+    arrays, reference src/odil/core.py:1113-1217, linsolver.py:17-26; SURVEY 8 E: "Newton: matrix-free M / M^T apply = same
+    halo pattern").  The global grid (world nz, ny, nx) is cut along axis 0, whose two ENDS are walls (zero coefficients
+    towards them; a periodic cut axis would need the ring closure).
+
+    Every rank holds its planes of the 7 coefficient arrays.  Levels are coarsened by 2 along every axis while a rank keeps
+    >= 2 planes and the cross-section >= 4 cells; level arrays and coefficient arrays are ghost-extended (`slab.SlabLevel`,
+    G = 2 planes per interior interface).  Set-up, once per solve (the coefficients change with the state): two boundary
+    planes of the seven arrays to each neighbour (ONE packed message per level); the coarse operators by
+    `odil_stencil_var_coarsen` on the extended arrays -- aggregates of 2^3 cells never straddle an interface, the
+    matrix-symmetric split reads the neighbour's coefficient one plane into the valid ghosts.  Below the last slab level the
+    problem is AGGLOMERATED: coefficient arrays and right-hand side are all-gathered and every rank runs the rest of the
+    cycle on the whole coarse box (the same bits on every rank).  One V(nu, nu) cycle per level, with the unmodified
+    single-GPU kernels on the extended arrays (their periodic wrap at an array end only reaches the outer ghost plane):
+    two planes of x, two sweeps (as ONE pass, `odil_stencil_var_smooth2`, on large levels); one plane of x, the residual on
+    the owned planes (its norm by one all-gather), the mean of the children as the coarse right-hand side, one plane of
+    it; the coarse correction, one plane of it, x += P x_c; two planes, two sweeps."""
+
+    def __init__(self, coeffs, rank, world, ops=None, nu=2, pair_min_cells=128**3):
+        assert coeffs.dim() == 4 and coeffs.shape[0] == 7 and coeffs.is_contiguous()
+        self.ops = ops or hip_ops
+        self.rank, self.world, self.nu, self.pair_min_cells = rank, world, nu, pair_min_cells
+        self.dtype, self.device = coeffs.dtype, coeffs.device
+        nz, ny, nx = (int(v) for v in coeffs.shape[1:])
+        shape = (nz, ny, nx)
+        self.mlv = [slab.SlabLevel(nz, ny, nx, rank, world)]
+        while all(v % 2 == 0 for v in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4:
+            shape = tuple(v // 2 for v in shape)
+            self.mlv.append(slab.SlabLevel(shape[0], shape[1], shape[2], rank, world))
+        self.c_owned = coeffs
+        self.mc = None  # ghost-extended coefficient arrays per slab level, built by setup(comm)
+        self.status = dict()
+
+    @staticmethod
+    def weights(n):
+        lo, hi = 1.0 / 3.0, 2.0  # (gmg.PoissonGMG.weights, d = 3)
+        mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+        return [1.0 / (mid - half * np.cos(np.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
+
+    # ---- exchanges ----------------------------------------------------------------------------------------------------
+    def _halo_planes(self, comm, a, lv, planes):
+        """`planes` boundary planes of `a` ([..., z, y, x]: one array or a stack of arrays) into the neighbours' ghosts."""
+        lo = a[..., lv.g_lo: lv.g_lo + planes, :, :].contiguous() if self.rank > 0 else None
+        hi = a[..., lv.g_lo + lv.nz - planes: lv.g_lo + lv.nz, :, :].contiguous() if self.rank < self.world - 1 else None
+        recv_lo, recv_hi = comm.exchange("halo", lo, hi)
+        if recv_lo is not None:
+            a[..., lv.g_lo - planes: lv.g_lo, :, :].copy_(recv_lo.view(lo.shape))
+        if recv_hi is not None:
+            a[..., lv.g_lo + lv.nz: lv.g_lo + lv.nz + planes, :, :].copy_(recv_hi.view(hi.shape))
+
+    def setup(self, comm):
+        """The operators of every level (see the class text); the agglomerated hierarchy below the last slab level."""
+        mk = lambda lv, lead=(): torch.zeros(tuple(lead) + lv.shape, dtype=self.dtype, device=self.device)
+        self.mc = []
+        c = mk(self.mlv[0], (7,))
+        c[:, self.mlv[0].g_lo: self.mlv[0].g_lo + self.mlv[0].nz].copy_(self.c_owned)
+        self._unit_ghost_diagonal(c, self.mlv[0])
+        self._halo_planes(comm, c, self.mlv[0], min(slab.G, self.mlv[0].nz))
+        self.mc.append(c)
+        for l in range(1, len(self.mlv)):
+            fine, lf, lc = self.mc[-1], self.mlv[l - 1], self.mlv[l]
+            cc_all = self.ops.stencil_var_coarsen(fine.contiguous())
+            c = mk(lc, (7,))
+            c[:, lc.g_lo: lc.g_lo + lc.nz].copy_(cc_all[:, lf.g_lo // 2: lf.g_lo // 2 + lc.nz])
+            self._unit_ghost_diagonal(c, lc)
+            self._halo_planes(comm, c, lc, min(slab.G, lc.nz))
+            self.mc.append(c)
+        self.mx = [None] + [mk(lv) for lv in self.mlv[1:]]
+        self.mb = [None] + [mk(lv) for lv in self.mlv[1:]]
+        self.spare = [mk(lv) for lv in self.mlv]
+        self.res = [mk(lv) for lv in self.mlv]
+        # the agglomerated box: every rank gets the whole coarse operator of the level below the last slab level
+        last, ll = self.mc[-1], self.mlv[-1]
+        self.agg = None
+        if ll.nz % 2 == 0 and ll.ny % 2 == 0 and ll.nx % 2 == 0 and min(ll.ny, ll.nx) >= 4:
+            cc_all = self.ops.stencil_var_coarsen(last.contiguous())
+            part = cc_all[:, ll.g_lo // 2: ll.g_lo // 2 + ll.nz // 2].contiguous()
+            rows = comm.exchange("gather", part, None)  # (world, 7, nz / 2, ny / 2, nx / 2)
+            whole = torch.cat([rows[r] for r in range(self.world)], dim=1).contiguous()
+            self.agg = [whole]
+            while all(v % 2 == 0 and v // 2 >= 2 for v in self.agg[-1].shape[1:]) and self.agg[-1][0].numel() > 512:
+                self.agg.append(self.ops.stencil_var_coarsen(self.agg[-1]))
+            self._agg_inv = None
+        self.part = torch.zeros((), dtype=self.dtype, device=self.device)
+
+    @staticmethod
+    def _unit_ghost_diagonal(c, lv):
+        """Ghost rows that no neighbour fills (the outer planes of a thin level) keep a unit diagonal: the sweeps divide by it."""
+        if lv.g_lo:
+            c[0, : lv.g_lo].fill_(1.0)
+        if lv.g_hi:
+            c[0, lv.g_lo + lv.nz:].fill_(1.0)
+
+    # ---- pieces -------------------------------------------------------------------------------------------------------
+    def _sweeps(self, l, x, b, weights):
+        c, size = self.mc[l], self.mlv[l].size
+        weights = list(weights)
+        pair = hasattr(self.ops, "stencil_var_smooth2") and size >= self.pair_min_cells and x.shape[-1] % 2 == 0
+        while weights:
+            y = self.spare[l]
+            if pair and len(weights) >= 2:
+                self.ops.stencil_var_smooth2(c, x, b, weights[0], weights[1], out=y)
+                weights = weights[2:]
+            else:
+                self.ops.stencil_var_smooth(c, x, b, weights[0], out=y)
+                weights = weights[1:]
+            self.spare[l] = x
+            x = y
+        return x
+
+    def _smooth(self, comm, l, x, b):
+        lv, w = self.mlv[l], self.weights(self.nu)
+        k = 0
+        while k < len(w):
+            pair = w[k: k + 2]
+            self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            x = self._sweeps(l, x, b, pair)
+            k += 2
+        return x
+
+    def _residual(self, comm, l, x, b, out):
+        """out = b - A x on the owned planes; -> its squared norm over all ranks."""
+        lv = self.mlv[l]
+        self._halo_planes(comm, x, lv, 1)
+        self.ops.stencil_var_residual(self.mc[l], x, b, out=out)
+        mine = (lv.owned(out).to(torch.float64) ** 2).sum().reshape(1)
+        return float(comm.exchange("gather", mine, None).sum())
+
+    def _agg_cycle(self, k, x, b):
+        """One V(nu, nu) cycle on level k of the agglomerated hierarchy (the whole coarse box on this rank)."""
+        c = self.agg[k]
+        if k == len(self.agg) - 1:
+            if self._agg_inv is None:
+                shape = tuple(c.shape[1:])
+                n = int(np.prod(shape))
+                eye = torch.eye(n, dtype=self.dtype, device=self.device)
+                zero = torch.zeros(shape, dtype=self.dtype, device=self.device)
+                cols = [-self.ops.stencil_var_residual(c, eye[j].view(shape).contiguous(), zero).reshape(-1) for j in range(n)]
+                amat = torch.stack(cols, dim=1).cpu().numpy().astype(np.float64)
+                self._agg_inv = torch.as_tensor(np.linalg.pinv(amat, rcond=1e-12), dtype=self.dtype).to(self.device)
+            return (self._agg_inv @ b.reshape(-1)).view(b.shape)
+        for wk in self.weights(self.nu):
+            x = self.ops.stencil_var_smooth(c, x, b, wk, out=torch.empty_like(x))
+        r = self.ops.stencil_var_residual(c, x, b)
+        bc = self.ops.restrict_to_coarser(r, "ccc")
+        xc = self._agg_cycle(k + 1, torch.zeros_like(bc), bc.contiguous())
+        x = self.ops.interp_add(xc.contiguous(), "ccc", add=x)
+        for wk in self.weights(self.nu):
+            x = self.ops.stencil_var_smooth(c, x, b, wk, out=torch.empty_like(x))
+        return x
+
+    def _coarse_correction(self, comm, l, r):
+        lv = self.mlv[l]
+        if l + 1 < len(self.mlv):
+            lc = self.mlv[l + 1]
+            bc, xc = self.mb[l + 1], self.mx[l + 1]
+            lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc"))
+            self._halo_planes(comm, bc, lc, 1)
+            xc.zero_()
+            xc = self._vcycle(comm, l + 1, xc, bc)
+            if l == 0 and len(self.mlv) > 2:
+                # TWO cycles on the first coarse level, as gmg.StencilGMG.finish_cycle: the aggregation-built coarse
+                # operators are less accurate at the walls than a rediscretisation (0.24 -> 0.14 per cycle there)
+                xc = self._vcycle(comm, l + 1, xc, bc)
+            self.mx[l + 1] = xc
+            self._halo_planes(comm, xc, lc, 1)
+            return lc.inner(xc)
+        part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")
+        bc = comm.exchange("gather", part.contiguous(), None).reshape(tuple(self.agg[0].shape[1:]))
+        xc = self._agg_cycle(0, torch.zeros_like(bc), bc.contiguous())
+        nzc = lv.nz // 2
+        lo = self.rank * nzc - (1 if self.rank > 0 else 0)
+        hi = (self.rank + 1) * nzc + (1 if self.rank < self.world - 1 else 0)
+        return xc[lo:hi]
+
+    def _vcycle(self, comm, l, x, b):
+        x = self._smooth(comm, l, x, b)
+        r = self.res[l]
+        res2 = self._residual(comm, l, x, b, r)
+        if l == 0:
+            self._last_res2 = res2
+        if l + 1 < len(self.mlv) or self.agg is not None:
+            xc = self._coarse_correction(comm, l, r)
+            y = self.spare[l]
+            self.ops.interp_add(xc.contiguous(), "ccc", add=x, out=y)
+            self.spare[l] = x
+            x = y
+        return self._smooth(comm, l, x, b)
+
+    def solve(self, comm, b_owned, tol=1e-10, maxiter=40):
+        """x (owned planes) with A x = b to |b - A x| <= tol |b| over all ranks; self.status: niter, residual, converged."""
+        if self.mc is None:
+            self.setup(comm)
+        lv = self.mlv[0]
+        b = torch.zeros(lv.shape, dtype=self.dtype, device=self.device)
+        lv.owned(b).copy_(b_owned)
+        self._halo_planes(comm, b, lv, 1)
+        bb = float(comm.exchange("gather", (b_owned.to(torch.float64) ** 2).sum().reshape(1), None).sum())
+        x = torch.zeros_like(b)
+        it, rel = 0, 1.0
+        while it < maxiter:
+            x = self._vcycle(comm, 0, x, b)
+            it += 1
+            rel = float(np.sqrt(self._last_res2 / bb)) if bb > 0 else 0.0  # (of the cycle's pre-smoothed iterate)
+            if rel <= tol:
+                break
+        self.status = dict(niter=it, residual=rel, converged=rel <= tol, method="slab variable-coefficient gmg ({} slab levels{})".format(
+            len(self.mlv), " + agglomerated {}".format(tuple(self.agg[0].shape[1:])) if self.agg else ""))
+        return lv.owned(x).clone()
+
+
 class ReplicatedTailVectors(SlabLbfgsVectors):
     """`SlabLbfgsVectors` for a local vector [owned entries | entries EVERY rank holds] (coarse levels agglomerated on
     every rank, network parameters): the tail takes part in every rank's vector algebra -- all ranks then update it alike,

@@ -106,3 +106,32 @@ def restrict_to_coarser(u, loc, depth=1):
     for _ in range(depth):
         res = onp.restrict_to_coarser(res, loc)
     return torch.from_numpy(np.ascontiguousarray(res))
+
+
+# ---- the variable-coefficient multigrid kernels (csrc/stencil_mg.hip), by their NumPy restatement tests/stencil_gmg_np.py ------
+def _coeff_list(coeffs):
+    return [np.asarray(c, dtype=np.float64) for c in _np(coeffs)]
+
+
+def stencil_var_smooth(coeffs, x, b, omega, out):
+    import stencil_gmg_np as sg
+
+    out.copy_(torch.from_numpy(np.ascontiguousarray(sg.jacobi(_coeff_list(coeffs), _np(x), _np(b), omega))))
+    return out
+
+
+def stencil_var_residual(coeffs, x, b, out=None):
+    import stencil_gmg_np as sg
+
+    res = torch.from_numpy(np.ascontiguousarray(_np(b) - sg.apply(_coeff_list(coeffs), _np(x))))
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def stencil_var_coarsen(coeffs, halve=None):
+    import stencil_gmg_np as sg
+
+    assert halve is None or all(halve)
+    return torch.from_numpy(np.ascontiguousarray(np.stack(sg.coarsen(_coeff_list(coeffs)))))

@@ -320,3 +320,101 @@ def test_slab_newton_multigrid_two_gloo_ranks(tmp_path):
         loss0, loss1, status, u = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
         assert status["converged"] and loss1 < 1e-18 * loss0
         np.testing.assert_allclose(u, ref_u[r * nz:(r + 1) * nz], rtol=0, atol=1e-9 * np.abs(ref_u).max())
+
+
+# ---- the variable-coefficient multigrid on the slabs (slab_solvers.SlabStencilGMG) ------------------------------------------
+def _diffusion_global(shape, seed=3, reaction=1.0):
+    """-div(k grad u) + r u on the global box: smooth k (1 : 20), zero-Dirichlet walls half a cell off on every side."""
+    rng = np.random.default_rng(seed)
+    grids = np.meshgrid(*[(np.arange(n) + 0.5) / n for n in shape], indexing="ij")
+    k = 1.0 + 19.0 * np.prod([np.sin(np.pi * g * rng.integers(1, 3)) ** 2 for g in grids], axis=0)
+    off, diag = [], reaction * rng.uniform(0.5, 1.0, shape)
+    for a in range(3):
+        h2 = (1.0 / shape[a]) ** 2
+        km, kp = 0.5 * (k + np.roll(k, 1, axis=a)) / h2, 0.5 * (k + np.roll(k, -1, axis=a)) / h2
+        idx = np.arange(shape[a]).reshape([-1 if j == a else 1 for j in range(3)])
+        diag = diag + np.where(idx == 0, 2.0 * k / h2, km) + np.where(idx == shape[a] - 1, 2.0 * k / h2, kp)
+        off += [-np.where(idx == 0, 0.0, km), -np.where(idx == shape[a] - 1, 0.0, kp)]
+    return [diag] + off
+
+
+def stencil_gmg_rank(rank, world, comm, coeffs, b, nz, tol=1e-10):
+    import slab_oracle_ops
+
+    from odil_amd import slab_solvers
+
+    own = slice(rank * nz, (rank + 1) * nz)
+    c = torch.from_numpy(np.ascontiguousarray(np.stack([a[own] for a in coeffs])))
+    run = slab_solvers.SlabStencilGMG(c, rank, world, ops=slab_oracle_ops)
+    x = run.solve(comm, torch.from_numpy(np.ascontiguousarray(b[own])), tol=tol, maxiter=60)
+    return x.numpy(), dict(run.status), len(run.mlv)
+
+
+@pytest.mark.parametrize("world,shape", [(2, (16, 8, 8)), (4, (16, 8, 8)), (2, (32, 16, 16)), (3, (24, 8, 16))])
+def test_slab_variable_coefficient_multigrid_solves_the_undivided_system(world, shape):
+    """The slab form of the variable-coefficient cycle (ghost-extended coefficient arrays, coarse operators formed on the
+    extended arrays, the rest agglomerated) lands on the solution of the UNDIVIDED system -- dense solve of the assembled
+    operator -- and needs the cycles of the undivided NumPy hierarchy (+- 3: a rank with few planes agglomerates earlier)."""
+    import stencil_gmg_np as sg
+
+    from odil_amd.slab_solvers import run_threads
+
+    coeffs = _diffusion_global(shape)
+    rng = np.random.default_rng(9)
+    b = rng.standard_normal(shape)
+    n = int(np.prod(shape))
+    if n <= 4096:
+        amat = np.stack([sg.apply(coeffs, e.reshape(shape)).ravel() for e in np.eye(n)], axis=1)
+        want = np.linalg.solve(amat, b.ravel()).reshape(shape)
+    else:  # (the undivided NumPy cycles, converged)
+        levels = sg.hierarchy(coeffs)
+        want = np.zeros(shape)
+        for _ in range(80):
+            want = sg.vcycle(levels, 0, want, b, top2=True)
+    nz = shape[0] // world
+    results = run_threads(world, lambda rank, comm: stencil_gmg_rank(rank, world, comm, coeffs, b, nz))
+    scale = np.abs(want).max()
+    for r, (x, status, nlev) in enumerate(results):
+        assert status["converged"] and status["niter"] <= 45, status
+        np.testing.assert_allclose(x, want[r * nz:(r + 1) * nz], rtol=0, atol=1e-7 * scale)
+    assert len({res[1]["niter"] for res in results}) == 1
+    # the undivided hierarchy's cycle count (two cycles on its first coarse level where the slab hierarchy has them)
+    levels = sg.hierarchy(coeffs)
+    x, it = np.zeros(shape), 0
+    while np.linalg.norm(b - sg.apply(coeffs, x)) > 1e-10 * np.linalg.norm(b) and it < 60:
+        x = sg.vcycle(levels, 0, x, b, top2=results[0][2] > 2)
+        it += 1
+    assert abs(it - results[0][1]["niter"]) <= 4, (it, results[0][1])
+
+
+def stencil_gmg_gloo_worker(rank, world, shape, port, out):
+    from odil_amd.slab import TorchDistComm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        coeffs = _diffusion_global(shape)
+        b = np.random.default_rng(9).standard_normal(shape)
+        res = stencil_gmg_rank(rank, world, TorchDistComm(rank, world), coeffs, b, shape[0] // world)
+        torch.save(res, os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_variable_coefficient_multigrid_two_gloo_ranks(tmp_path):
+    import stencil_gmg_np as sg
+
+    world, shape = 2, (16, 8, 8)
+    port = 29500 + (os.getpid() + 577) % 2000
+    mp.spawn(stencil_gmg_gloo_worker, args=(world, shape, port, str(tmp_path)), nprocs=world, join=True)
+    coeffs = _diffusion_global(shape)
+    b = np.random.default_rng(9).standard_normal(shape)
+    n = int(np.prod(shape))
+    amat = np.stack([sg.apply(coeffs, e.reshape(shape)).ravel() for e in np.eye(n)], axis=1)
+    want = np.linalg.solve(amat, b.ravel()).reshape(shape)
+    nz = shape[0] // world
+    for r in range(world):
+        x, status, _ = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
+        assert status["converged"]
+        np.testing.assert_allclose(x, want[r * nz:(r + 1) * nz], rtol=0, atol=1e-8 * np.abs(want).max())

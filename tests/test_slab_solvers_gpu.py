@@ -155,6 +155,44 @@ def test_slab_newton_multigrid_emulated_ranks_solve_the_undivided_problem(world,
         assert float((x.cpu() - whole).abs().max()) <= 1e-8 * scale
 
 
+@pytest.mark.parametrize("world,shape", [(2, (32, 16, 16)), (4, (64, 32, 32)), (3, (48, 64, 32)), (2, (256, 128, 128))])
+def test_slab_variable_coefficient_multigrid_emulated_ranks(world, shape):
+    """`SlabStencilGMG` on the HIP kernels, ranks as threads on one GPU: variable-coefficient diffusion with a reaction
+    term on the box cut along axis 0 -- the slab-decomposed cycles (coefficient ghosts exchanged at set-up, coarse operators
+    on the extended arrays, sweeps in pairs on the large levels, the bottom agglomerated) reach the iterate of the single-GPU
+    `gmg.StencilGMG` on the undivided box, in about as many cycles."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_slab_solvers_cpu import _diffusion_global
+
+    from odil_amd import gmg
+    from odil_amd.slab_solvers import SlabStencilGMG, run_threads
+
+    dev = torch.device("cuda:0")
+    coeffs = torch.as_tensor(np.stack(_diffusion_global(shape))).to(dev)
+    b = torch.as_tensor(np.random.default_rng(9).standard_normal(shape)).to(dev)
+    nz = shape[0] // world
+
+    def body(rank, comm):
+        torch.cuda.set_device(dev)
+        run = SlabStencilGMG(coeffs[:, rank * nz:(rank + 1) * nz].contiguous(), rank, world, pair_min_cells=32**3)
+        x = run.solve(comm, b[rank * nz:(rank + 1) * nz].contiguous(), tol=1e-10, maxiter=60)
+        return x.cpu(), dict(run.status)
+
+    results = run_threads(world, body)
+    solver = gmg.StencilGMG(coeffs)
+    st = dict()
+    want = solver.solve(b, tol=1e-11, maxiter=60, status=st).cpu()
+    assert st["converged"]
+    scale = float(want.abs().max())
+    for r, (x, status) in enumerate(results):
+        assert status["converged"], status
+        assert abs(status["niter"] - st["niter"]) <= 6, (status, st)
+        assert float((x - want[r * nz:(r + 1) * nz]).abs().max()) <= 1e-7 * scale, (r, status)
+    assert len({res[1]["niter"] for res in results}) == 1
+
+
 @pytest.mark.parametrize("which,world,nx_rank", [("veltracer", 2, 16), ("veltracer3d", 4, 4), ("heat2d", 2, 16)])
 def test_slab_traced_lbfgs_emulated_ranks_follow_the_single_gpu_optimizer(which, world, nx_rank):
     """L-BFGS-B of a traced operator on the slabs (generated kernels in slab mode, ranks as threads on one GPU; (4, 4):

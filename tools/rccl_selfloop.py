@@ -72,6 +72,42 @@ def main():
         outs.append((res["f"], res["funcalls"], run.x.clone()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
     torch.cuda.synchronize()
+    if "--sweep" in sys.argv:
+        # per-exchange cost of the communication layer as the slab epochs use it (`batch_isend_irecv` of a pair of planes +
+        # wait, enqueued back to back: the device-side time per exchange, the host's enqueue time beside it) by message
+        # size -- the latency term of DESIGN section 6's weak-scaling prediction.  (One device: RCCL's send / receive
+        # kernels copy through its own buffers; no xGMI link is crossed.)
+        import time
+
+        for nbytes in (8, 4096, 65536, 1 << 20, 4 << 20, 32 << 20, 128 << 20):
+            k = max(2, nbytes // 4)
+            a, b = torch.zeros(k, device=dev), torch.zeros(k, device=dev)
+            reps = 200 if nbytes <= (4 << 20) else 30
+            for _ in range(5):
+                comm.exchange("halo", a, b)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                comm.exchange("halo", a, b)
+            e1.record()
+            host = (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize()
+            dev_s = e0.elapsed_time(e1) * 1e-3 / reps
+            print("exchange of 2 x {:>9d} B: {:8.1f} us on the device ({:6.1f} GB/s per direction), host enqueue {:6.1f} us".format(
+                4 * k, dev_s * 1e6, 4 * k / dev_s / 1e9, host * 1e6), flush=True)
+        for nbytes in (8, 64):
+            t = torch.zeros(nbytes // 8, dtype=torch.float64, device=dev)
+            for _ in range(5):
+                comm.exchange("sum", t, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                comm.exchange("sum", t, None)
+            torch.cuda.synchronize()
+            print("all-reduce of {} B: {:.1f} us per call (enqueue + completion, back to back)".format(
+                nbytes, (time.perf_counter() - t0) / 200 * 1e6), flush=True)
     dist.destroy_process_group()
     print("rccl self-loop ok: 200 exchanges of 2 x {} MB (halo / post + wait), all-reduce, all-gather, wrap, "
           "6 L-BFGS iterations".format(4 * n >> 20))
