@@ -194,6 +194,15 @@ int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, doubl
                                        void* stream);
 int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape, int ndim,
                                        const float* h2, float scale, double* partials, float* loss, void* stream);
+/* Slab variant (multi-GPU V-cycles, odil_amd/slab_solvers.py): the same pass over a ghost-extended local array, the
+ * convergence measure restricted to the rank's own planes: *loss = sum over planes z0 <= z < z1 of (A u - rhs)^2 / denom
+ * (z1 < 0: all planes; denom <= 0: the array size). */
+int odil_poisson_residual_restrict_slab_f64(const double* u, const double* rhs, double* coarse, const int64_t* shape,
+                                            int ndim, const double* h2, double scale, int64_t z0, int64_t z1,
+                                            double denom, double* partials, double* loss, void* stream);
+int odil_poisson_residual_restrict_slab_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape,
+                                            int ndim, const float* h2, float scale, int64_t z0, int64_t z1, double denom,
+                                            double* partials, float* loss, void* stream);
 /* Stencil adjoint and the first transposed prolongation in one pass (3-D, even extents >= 4):
  * g0 = scale * A^T fu (stored only when g0 != NULL), g1 = P^T g0 on the grid of half the extents, and the Adam
  * update of the finest level (x0, m0, v0; all NULL: no update, g0 required) and of the next level (x1, m1, v1;
@@ -387,6 +396,13 @@ int odil_stencil_var_residual_restrict_f64(const double* coeffs, const double* x
 int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, const float* b, float* coarse,
                                            const int64_t* shape, int ndim, float scale, double* partials, float* loss,
                                            void* stream);
+/* slab variant: the norm over the planes z0 <= z < z1 only, divided by denom (conventions of the Poisson one above) */
+int odil_stencil_var_residual_restrict_slab_f64(const double* coeffs, const double* x, const double* b, double* coarse,
+                                                const int64_t* shape, int ndim, double scale, int64_t z0, int64_t z1,
+                                                double denom, double* partials, double* loss, void* stream);
+int odil_stencil_var_residual_restrict_slab_f32(const float* coeffs, const float* x, const float* b, float* coarse,
+                                                const int64_t* shape, int ndim, float scale, int64_t z0, int64_t z1,
+                                                double denom, double* partials, float* loss, void* stream);
 int odil_stencil_var_coarsen_f64(const double* coeffs, double* coarse, const int64_t* shape, int ndim, void* stream);
 int odil_stencil_var_coarsen_f32(const float* coeffs, float* coarse, const int64_t* shape, int ndim, void* stream);
 /* ... merging two cells along the axes with halve[i] != 0 only (semi-coarsening: the strongly coupled axes of an anisotropic

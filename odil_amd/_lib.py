@@ -42,6 +42,7 @@ _SIGNATURES = {
     "poisson_jacobi2": [_P, _P, _P, _I64P, c_int, _P, _R, _R, c_int, _P],
     "poisson_jacobi2_synth": [_P, _P, _P, _P, _I64P, _P, _R, _R, c_int, _P],
     "poisson_residual_restrict": [_P, _P, _P, _I64P, c_int, _P, _R, _P, _P, _P],
+    "poisson_residual_restrict_slab": [_P, _P, _P, _I64P, c_int, _P, _R, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_residual_synth": [_P, _P, _P, _P, _I64P, _P, c_int64, c_int64, c_double, _P, _P, _P],
     "poisson_jacobi_synth": [_P, _P, _P, _P, _I64P, _P, _R, _P],
     "poisson_residual_slab": [_P, _P, _P, _I64P, c_int, _P, c_int64, c_int64, c_double, _P, _P, _P],
@@ -65,6 +66,7 @@ _SIGNATURES = {
     "stencil_var_smooth": [_P, _P, _P, _P, _I64P, c_int, _R, c_int, _P],
     "stencil_var_smooth2": [_P, _P, _P, _P, _I64P, c_int, _R, _R, c_int, _P],
     "stencil_var_residual_restrict": [_P, _P, _P, _P, _I64P, c_int, _R, _P, _P, _P],
+    "stencil_var_residual_restrict_slab": [_P, _P, _P, _P, _I64P, c_int, _R, c_int64, c_int64, c_double, _P, _P, _P],
     "stencil_var_coarsen": [_P, _P, _I64P, c_int, _P],
     "stencil_var_coarsen_axes": [_P, _P, _I64P, c_int, _P, _P],
     "stencil_vcycle_tail": [_P, _I64P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int, _P, c_int, _P, c_int, c_int, _P],

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_restrict(const T* _
         eb = u[pz + yb * sy + xr];
       }
       const bool zlo = z == 0, zhi = z == Z - 1;
+      const bool counted = z >= a.loss_z0 && z < a.loss_z1;  // (slab form: the norm of the rank's own planes)
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const int64_t x = x0 + i;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual_restrict(const T* _
         fb = fb + axis_term<T>(bc[i], i == 0 ? wb : bc[i - 1], i == V - 1 ? eb : bc[i + 1 < V ? i + 1 : i], xlo, xhi,
                                h, 2);
         fb = fb - rb[i];
-        local += (double)(fa * fa) + (double)(fb * fb);
+        if (counted) local += (double)(fa * fa) + (double)(fb * fb);
         const T pair = fa + fb;
         if ((i & 1) == 0)
           acc[i / 2] = ((z & 1) ? acc[i / 2] : T(0)) + pair;
@@ -500,7 +501,8 @@ static int poisson_jacobi(const T* u, const T* rhs, T* uout, const int64_t* shap
 
 template <typename T>
 static int poisson_residual_restrict(const T* u, const T* rhs, T* coarse, const int64_t* shape, int ndim, const T* h2,
-                                     T scale, double* partials, T* loss, void* stream) {
+                                     T scale, double* partials, T* loss, void* stream, int64_t z0 = 0, int64_t z1 = -1,
+                                     double denom = 0.0) {
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
@@ -512,15 +514,16 @@ static int poisson_residual_restrict(const T* u, const T* rhs, T* coarse, const 
     set_error("poisson_residual_restrict: needs ndim = 3, even extents and n[2] %% %d == 0", VecOf<T>::N);
     return ODIL_E_INVAL;
   }
-  a.loss_z0 = 0;
-  a.loss_z1 = a.n[0];
+  a.loss_z0 = z1 < 0 ? 0 : z0;
+  a.loss_z1 = z1 < 0 ? a.n[0] : z1;
+  if (denom <= 0.0) denom = (double)(a.n[0] * a.n[1] * a.n[2]);
   const int per = kBlock * VecOf<T>::N;
   a.usched = make_unit_sched(a.n[0] / 2, a.n[1] / 2, (a.n[2] + per - 1) / per);
   const int grid = unit_grid(a.usched);
   hipLaunchKernelGGL((k_poisson_residual_restrict<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, coarse,
                      a, make_h2<T>(h), scale, partials);
   if (int e = check_launch("k_poisson_residual_restrict")) return e;
-  return launch_final_reduce<T>(partials, grid, 0, 1, (double)(a.n[0] * a.n[1] * a.n[2]), loss, (hipStream_t)stream);
+  return launch_final_reduce<T>(partials, grid, 0, 1, denom, loss, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -569,6 +572,16 @@ int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, doubl
 int odil_poisson_residual_restrict_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape, int ndim,
                                        const float* h2, float scale, double* partials, float* loss, void* stream) {
   return poisson_residual_restrict<float>(u, rhs, coarse, shape, ndim, h2, scale, partials, loss, stream);
+}
+int odil_poisson_residual_restrict_slab_f64(const double* u, const double* rhs, double* coarse, const int64_t* shape,
+                                            int ndim, const double* h2, double scale, int64_t z0, int64_t z1,
+                                            double denom, double* partials, double* loss, void* stream) {
+  return poisson_residual_restrict<double>(u, rhs, coarse, shape, ndim, h2, scale, partials, loss, stream, z0, z1, denom);
+}
+int odil_poisson_residual_restrict_slab_f32(const float* u, const float* rhs, float* coarse, const int64_t* shape,
+                                            int ndim, const float* h2, float scale, int64_t z0, int64_t z1, double denom,
+                                            double* partials, float* loss, void* stream) {
+  return poisson_residual_restrict<float>(u, rhs, coarse, shape, ndim, h2, scale, partials, loss, stream, z0, z1, denom);
 }
 int odil_poisson_adjoint_f64(const double* fu, double* gu, const int64_t* shape, int ndim, const double* h2,
                              double scale, void* stream) {

@@ -108,7 +108,8 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_svar_residual_restrict(const T* __restrict__ c, const T* __restrict__ x,
                                                                   const T* __restrict__ b, T* __restrict__ coarse,
                                                                   SvarArgs a, SvarArgs ca, T scale,
-                                                                  double* __restrict__ partials) {
+                                                                  double* __restrict__ partials, int64_t lz0,
+                                                                  int64_t lz1) {
   typedef typename Vec2<T>::type T2;
   // a contiguous chunk of coarse cells per workgroup: the order of the partial sums does not depend on the grid
   const int64_t per = (ca.size + gridDim.x - 1) / gridDim.x;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_svar_residual_restrict(const T* __re
           ax = ax + cp * *(const T2*)(x + zp);
         }
         const T2 r = bb - ax;
-        local += (double)(r.x * r.x) + (double)(r.y * r.y);
+        if (z >= lz0 && z < lz1) local += (double)(r.x * r.x) + (double)(r.y * r.y);  // (slab form: own planes only)
         sum = sum + r.x;
         sum = sum + r.y;
       }
@@ -490,7 +491,8 @@ static int svar_smooth(const T* coeffs, const T* x, const T* b, T* out, const in
 
 template <typename T>
 static int svar_residual_restrict(const T* coeffs, const T* x, const T* b, T* coarse, const int64_t* shape, int ndim,
-                                  T scale, double* partials, T* loss, void* stream) {
+                                  T scale, double* partials, T* loss, void* stream, int64_t z0 = 0, int64_t z1 = -1,
+                                  double denom = 0.0) {
   SvarArgs a, ca;
   if (int e = svar_fill(a, shape, ndim, "stencil_var_residual_restrict")) return e;
   if (int e = svar_coarse(a, ca, "stencil_var_residual_restrict")) return e;
@@ -500,10 +502,12 @@ static int svar_residual_restrict(const T* coeffs, const T* x, const T* b, T* co
   }
   int64_t nb = (ca.size + kBlock - 1) / kBlock;
   if (nb > kMaxPartials) nb = kMaxPartials;  // (one partial sum per workgroup in the reduction workspace)
+  if (z1 < 0) z0 = 0, z1 = a.n[0];
+  if (denom <= 0.0) denom = (double)a.size;
   hipLaunchKernelGGL((k_svar_residual_restrict<T>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, x,
-                     b, coarse, a, ca, scale, partials);
+                     b, coarse, a, ca, scale, partials, z0, z1);
   if (int e = check_launch("k_svar_residual_restrict")) return e;
-  return launch_final_reduce<T>(partials, (int)nb, 0, 1, (double)a.size, loss, (hipStream_t)stream);
+  return launch_final_reduce<T>(partials, (int)nb, 0, 1, denom, loss, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -557,6 +561,16 @@ int odil_stencil_var_residual_restrict_f32(const float* coeffs, const float* x, 
                                            const int64_t* shape, int ndim, float scale, double* partials, float* loss,
                                            void* stream) {
   return svar_residual_restrict<float>(coeffs, x, b, coarse, shape, ndim, scale, partials, loss, stream);
+}
+int odil_stencil_var_residual_restrict_slab_f64(const double* coeffs, const double* x, const double* b, double* coarse,
+                                                const int64_t* shape, int ndim, double scale, int64_t z0, int64_t z1,
+                                                double denom, double* partials, double* loss, void* stream) {
+  return svar_residual_restrict<double>(coeffs, x, b, coarse, shape, ndim, scale, partials, loss, stream, z0, z1, denom);
+}
+int odil_stencil_var_residual_restrict_slab_f32(const float* coeffs, const float* x, const float* b, float* coarse,
+                                                const int64_t* shape, int ndim, float scale, int64_t z0, int64_t z1,
+                                                double denom, double* partials, float* loss, void* stream) {
+  return svar_residual_restrict<float>(coeffs, x, b, coarse, shape, ndim, scale, partials, loss, stream, z0, z1, denom);
 }
 int odil_max_abs_diff_f64(const double* a, const double* b, int64_t n, double* partials, double* out, void* stream) {
   return max_abs_diff<double>(a, b, n, partials, out, stream);

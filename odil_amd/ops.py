@@ -6,7 +6,7 @@ semantics follow the reference functions cited in include/odil_hip.h.
 """
 
 import math
-from ctypes import c_int, c_int64, c_void_p
+from ctypes import c_double, c_int, c_int64, c_void_p
 
 import torch
 
@@ -183,11 +183,17 @@ def stencil_var_residual(coeffs, x, b, out=None):
     return out
 
 
-def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss):
-    """out = scale * (sum over the 2^d children of b - A x), loss <- mean((A x - b)^2), one pass."""
+def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss, zrange=None, denom=0.0):
+    """out = scale * (sum over the 2^d children of b - A x), loss <- mean((A x - b)^2), one pass.  zrange = (z0, z1): the
+    slab form -- loss = sum over those planes of (A x - b)^2 / denom."""
     assert tuple(out.shape) == tuple(s // 2 for s in x.shape) and out.is_contiguous()
-    call("stencil_var_residual_restrict", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()),
-         float(scale), ptr(reduce_workspace(x.device)), ptr(loss), stream_ptr())
+    if zrange is None:
+        call("stencil_var_residual_restrict", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()),
+             float(scale), ptr(reduce_workspace(x.device)), ptr(loss), stream_ptr())
+    else:
+        call("stencil_var_residual_restrict_slab", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape),
+             c_int(x.dim()), float(scale), c_int64(int(zrange[0])), c_int64(int(zrange[1])), c_double(float(denom)),
+             ptr(reduce_workspace(x.device)), ptr(loss), stream_ptr())
     return out
 
 
@@ -417,8 +423,6 @@ def poisson_residual(u, rhs, h2, fu=None, loss=None, want_fu=True, zrange=None, 
             ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr(),
         )
     else:
-        from ctypes import c_double
-
         call(
             "poisson_residual_slab", u.dtype, ptr(u), ptr(rhs), ptr(fu), i64(u.shape), c_int(u.dim()), h2p,
             c_int64(zrange[0]), c_int64(zrange[1]), c_double(float(denom)), ptr(reduce_workspace(u.device)), ptr(loss),
@@ -432,14 +436,20 @@ def residual_restrict_supported(shape, dtype):
     return len(shape) == 3 and shape[0] % 2 == 0 and shape[1] % 2 == 0 and shape[2] % pack == 0 and min(shape) >= 2
 
 
-def poisson_residual_restrict(u, rhs, h2, scale, out, loss):
+def poisson_residual_restrict(u, rhs, h2, scale, out, loss, zrange=None, denom=0.0):
     """out = scale * (sum over 2x2x2 fine cells of (A u - rhs)) on the next coarser grid, loss = mean((A u -
-    rhs)**2), in one pass over u and rhs (3-D; see residual_restrict_supported)."""
+    rhs)**2), in one pass over u and rhs (3-D; see residual_restrict_supported).  zrange = (z0, z1): the slab form --
+    loss = sum over those planes of (A u - rhs)**2 / denom."""
     assert u.shape == rhs.shape and tuple(out.shape) == tuple(n // 2 for n in u.shape)
     assert residual_restrict_supported(tuple(u.shape), u.dtype) and out.is_contiguous()
     h2a, h2p = host_reals(h2, u.dtype)
-    call("poisson_residual_restrict", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p, float(scale),
-         ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr())
+    if zrange is None:
+        call("poisson_residual_restrict", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p, float(scale),
+             ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr())
+    else:
+        call("poisson_residual_restrict_slab", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p,
+             float(scale), c_int64(int(zrange[0])), c_int64(int(zrange[1])), c_double(float(denom)),
+             ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr())
     return out, loss
 
 

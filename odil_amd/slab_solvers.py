@@ -282,7 +282,11 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
     (a few thousand numbers), every rank runs the remaining cycle on the whole coarse box and keeps its planes -- the same
     bits on every rank, no further exchange."""
 
-    def __init__(self, N, rank, world, dtype=torch.float64, device=None, rhs_global=None, nz=None, nu=2):
+    def __init__(self, N, rank, world, dtype=torch.float64, device=None, rhs_global=None, nz=None, nu=2, agg_cells=32**3,
+                 pair_min_cells=128**3):
+        """agg_cells: a level is a SLAB level only while a rank holds more cells of it than this -- an exchange costs ~65 us of
+        host time whatever its size (`profiles/r06_rccl_selfloop_sweep.txt`), four of them per level and cycle, and a level of
+        32^3 cells per rank is sooner solved redundantly on the whole agglomerated box (0: down to two planes per rank)."""
         super().__init__(N, rank, world, dtype=dtype, device=device, rhs_global=rhs_global, nz=nz)
         self.nu = nu
         npdt = np.float64 if dtype == torch.float64 else np.float32
@@ -290,7 +294,8 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         self.mlv, self.mh2 = [self.lv], [list(self.h2)]
         shape = (nz, N, N)
         # (cross-sections of >= 4 cells on every slab level, so that the agglomerated box below the last one still has two)
-        while all(s % 2 == 0 for s in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4:
+        while (all(s % 2 == 0 for s in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4
+               and int(np.prod(shape)) // 8 > agg_cells):
             shape = tuple(s // 2 for s in shape)
             self.mlv.append(slab.SlabLevel(shape[0], shape[1], shape[2], rank, world))
             self.mh2.append([v * npdt(4) for v in self.mh2[-1]])
@@ -306,6 +311,16 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         self.spare = [mk(lv) for lv in self.mlv]
         self.res = [mk(lv) for lv in self.mlv]
         self._dense = dict()
+        self.pair_min_cells = pair_min_cells
+        # with the library's own kernels underneath the cycle is the single-GPU one's: sweeps in pairs
+        # (`odil_poisson_jacobi2`), the residual restricted in the pass that forms it (`odil_poisson_residual_restrict`),
+        # the agglomerated box cycled by `gmg.PoissonGMG`; a stand-in `ops` (the host tests) keeps the plain launches
+        self.native = getattr(self.ops, "__name__", "") == "odil_amd.ops"
+        self.agg_gmg = None
+        if self.native and self.agg_shape is not None and min(self.agg_shape) >= 4:
+            from . import gmg
+
+            self.agg_gmg = gmg.PoissonGMG(self.agg_shape, self.agg_h2, dtype, device)
 
     # ---- pieces -------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -324,13 +339,22 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         if recv_hi is not None:
             a[lv.g_lo + lv.nz: lv.g_lo + lv.nz + planes].copy_(recv_hi.view(planes, lv.ny, lv.nx))
 
-    def _smooth(self, comm, l, x, b):
-        """`nu` sweeps, two per exchange of two planes; returns the tensor holding the iterate (owned planes valid)."""
+    def _smooth(self, comm, l, x, b, zero=False):
+        """`nu` sweeps, two per exchange of two planes; returns the tensor holding the iterate (owned planes valid).
+        zero: x is zero on every rank -- its ghost planes are right as they are, the first exchange is skipped."""
         lv, w = self.mlv[l], self.weights(self.nu)
         k = 0
         while k < len(w):
             pair = w[k: k + 2]
-            self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            if not (zero and k == 0):
+                self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            if (self.native and len(pair) == 2 and self.dtype == torch.float64 and lv.size >= self.pair_min_cells
+                    and self.ops.jacobi2_supported(tuple(x.shape), self.dtype)):
+                y = self.spare[l]
+                self.ops.poisson_jacobi2(x, b, self.mh2[l], pair[0], pair[1], out=y)  # (== the two sweeps below, bit for bit)
+                self.spare[l] = x
+                x = y
+                pair = []
             for wk in pair:
                 y = self.spare[l]
                 self.ops.poisson_jacobi(x, b, self.mh2[l], wk, out=y)
@@ -340,11 +364,32 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         return x
 
     def _residual(self, comm, l, x, b, out):
-        """out = A x - b on the owned planes; -> its squared norm over all ranks."""
+        """out = A x - b on the owned planes; -> its squared norm over all ranks (finest level only)."""
         lv = self.mlv[l]
         self._halo_planes(comm, x, lv, 1)
         self.ops.poisson_residual(x, b, self.mh2[l], fu=out, loss=self.part, zrange=(lv.g_lo, lv.g_lo + lv.nz), denom=1.0)
+        if l:  # (a coarser level's norm is nobody's measure: no collective, no read-back)
+            return None
         return float(comm.exchange("gather", self.part.to(torch.float64).reshape(1), None).sum())
+
+    def _restricted_residual(self, comm, l, x, b, out):
+        """out = -R (A x - b) of level l's owned planes in ONE pass over the ghost-extended arrays (the fine residual is never
+        stored): `out` has half the extended planes -- the owned coarse planes and one plane per interface formed from the
+        fine ghost planes, which nobody reads.  -> the squared norm of A x - b over all ranks' owned planes (finest level
+        only; `odil_poisson_residual_restrict_slab` counts the rank's own planes)."""
+        lv = self.mlv[l]
+        self._halo_planes(comm, x, lv, 1)
+        self.ops.poisson_residual_restrict(x, b, self.mh2[l], -0.125, out, self.part, zrange=(lv.g_lo, lv.g_lo + lv.nz),
+                                           denom=1.0)
+        if l:
+            return None
+        return float(comm.exchange("gather", self.part.to(torch.float64).reshape(1), None).sum())
+
+    def _fused_restriction(self, l, x):
+        lv = self.mlv[l]
+        shape = tuple(x.shape)
+        return (self.native and shape[0] % 2 == 0 and lv.g_lo % 2 == 0
+                and self.ops.residual_restrict_supported(shape, self.dtype))
 
     def _dense_solve(self, b, h2):
         """A^-1 b on a box of at most 512 cells (the residual kernel applied to unit vectors, factorised once)."""
@@ -386,32 +431,51 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
         if l + 1 < len(self.mlv):
             lc = self.mlv[l + 1]
             bc, xc = self.mb[l + 1], self.mx[l + 1]
-            lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")).mul_(-1.0)
+            if r is not None:  # (else: `_restricted_residual` has written the owned planes of bc)
+                lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")).mul_(-1.0)
             self._halo_planes(comm, bc, lc, 1)
             xc.zero_()
-            xc = self._vcycle(comm, l + 1, xc, bc)
+            xc = self._vcycle(comm, l + 1, xc, bc, zero=True)
             self.mx[l + 1] = xc
             self._halo_planes(comm, xc, lc, 1)
             return lc.inner(xc)
         # agglomerated: every rank gets the whole coarse right-hand side and solves the whole coarse problem alike
-        part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc").mul_(-1.0)
-        bc = comm.exchange("gather", part.contiguous(), None).reshape(self.agg_shape)
-        xc = self._local_cycle(torch.zeros_like(bc), bc.contiguous(), self.agg_h2)
+        if r is not None:
+            part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc").mul_(-1.0)
+        else:
+            part = self._agg_part[lv.g_lo // 2: lv.g_lo // 2 + lv.nz // 2]
+        bc = comm.exchange("gather", part.contiguous(), None).reshape(self.agg_shape).contiguous()
+        if self.agg_gmg is not None:
+            xc = self.agg_gmg.vcycle(0, torch.zeros_like(bc), bc, zero=True)
+        else:
+            xc = self._local_cycle(torch.zeros_like(bc), bc, self.agg_h2)
         nzc = lv.nz // 2
         lo = self.rank * nzc - (1 if self.rank > 0 else 0)
         hi = (self.rank + 1) * nzc + (1 if self.rank < self.world - 1 else 0)
         return xc[lo:hi]
 
-    def _vcycle(self, comm, l, x, b, pre=True):
+    def _vcycle(self, comm, l, x, b, pre=True, zero=False):
         """One V(nu, nu) cycle on level l of the slab hierarchy: returns the tensor holding the iterate (owned planes)."""
         lv = self.mlv[l]
         if pre:
-            x = self._smooth(comm, l, x, b)
+            x = self._smooth(comm, l, x, b, zero=zero)
         r = self.res[l]
-        res2 = self._residual(comm, l, x, b, r)
+        coarser = l + 1 < len(self.mlv) or self.agg_shape is not None
+        if coarser and self._fused_restriction(l, x):
+            if l + 1 < len(self.mlv):  # straight into the coarse right-hand side: its owned planes + one per interface
+                lc = self.mlv[l + 1]
+                target = self.mb[l + 1][lc.g_lo - lv.g_lo // 2: lc.g_lo + lc.nz + lv.g_hi // 2]
+            else:
+                if getattr(self, "_agg_part", None) is None:
+                    self._agg_part = torch.empty(tuple(n // 2 for n in x.shape), dtype=self.dtype, device=self.device)
+                target = self._agg_part
+            res2 = self._restricted_residual(comm, l, x, b, target)
+            r = None
+        else:
+            res2 = self._residual(comm, l, x, b, r)
         if l == 0:  # (the coarser levels' residuals belong to THEIR systems: only the finest one is the solve's measure)
             self._last_res2 = res2
-        if l + 1 < len(self.mlv) or self.agg_shape is not None:
+        if coarser:
             xc = self._coarse_correction(comm, l, r)
             y = self.spare[l]
             self.ops.interp_add(xc.contiguous(), "ccc", add=x, out=y)
@@ -467,7 +531,9 @@ class SlabStencilGMG:
     the owned planes (its norm by one all-gather), the mean of the children as the coarse right-hand side, one plane of
     it; the coarse correction, one plane of it, x += P x_c; two planes, two sweeps."""
 
-    def __init__(self, coeffs, rank, world, ops=None, nu=2, pair_min_cells=128**3):
+    def __init__(self, coeffs, rank, world, ops=None, nu=2, pair_min_cells=128**3, agg_cells=32**3):
+        """agg_cells: as SlabPoissonNewtonGMG -- levels of at most this many cells per rank are not slab levels but part of
+        the agglomerated box (0: slab levels down to two planes per rank)."""
         assert coeffs.dim() == 4 and coeffs.shape[0] == 7 and coeffs.is_contiguous()
         self.ops = ops or hip_ops
         self.rank, self.world, self.nu, self.pair_min_cells = rank, world, nu, pair_min_cells
@@ -475,7 +541,8 @@ class SlabStencilGMG:
         nz, ny, nx = (int(v) for v in coeffs.shape[1:])
         shape = (nz, ny, nx)
         self.mlv = [slab.SlabLevel(nz, ny, nx, rank, world)]
-        while all(v % 2 == 0 for v in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4:
+        while (all(v % 2 == 0 for v in shape) and shape[0] // 2 >= 2 and min(shape[1], shape[2]) // 2 >= 4
+               and int(np.prod(shape)) // 8 > agg_cells):
             shape = tuple(v // 2 for v in shape)
             self.mlv.append(slab.SlabLevel(shape[0], shape[1], shape[2], rank, world))
         self.c_owned = coeffs
@@ -532,6 +599,13 @@ class SlabStencilGMG:
             while all(v % 2 == 0 and v // 2 >= 2 for v in self.agg[-1].shape[1:]) and self.agg[-1][0].numel() > 512:
                 self.agg.append(self.ops.stencil_var_coarsen(self.agg[-1]))
             self._agg_inv = None
+            # with the library's own kernels underneath, the box is cycled by the single-GPU solver (its paired sweeps and
+            # one-launch coarse tail); a stand-in `ops` (the host tests) keeps the plain recursion of `_agg_cycle`
+            self.agg_gmg = None
+            if getattr(self.ops, "__name__", "") == "odil_amd.ops" and min(whole.shape[1:]) >= 4:
+                from . import gmg
+
+                self.agg_gmg = gmg.StencilGMG(whole)
         self.part = torch.zeros((), dtype=self.dtype, device=self.device)
 
     @staticmethod
@@ -559,21 +633,24 @@ class SlabStencilGMG:
             x = y
         return x
 
-    def _smooth(self, comm, l, x, b):
+    def _smooth(self, comm, l, x, b, zero=False):
         lv, w = self.mlv[l], self.weights(self.nu)
         k = 0
         while k < len(w):
             pair = w[k: k + 2]
-            self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            if not (zero and k == 0):  # (a zero iterate has the right ghost planes on every rank)
+                self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
             x = self._sweeps(l, x, b, pair)
             k += 2
         return x
 
     def _residual(self, comm, l, x, b, out):
-        """out = b - A x on the owned planes; -> its squared norm over all ranks."""
+        """out = b - A x on the owned planes; -> its squared norm over all ranks (finest level only)."""
         lv = self.mlv[l]
         self._halo_planes(comm, x, lv, 1)
         self.ops.stencil_var_residual(self.mc[l], x, b, out=out)
+        if l:  # (a coarser level's norm is nobody's measure: no collective, no read-back)
+            return None
         mine = (lv.owned(out).to(torch.float64) ** 2).sum().reshape(1)
         return float(comm.exchange("gather", mine, None).sum())
 
@@ -605,32 +682,64 @@ class SlabStencilGMG:
         if l + 1 < len(self.mlv):
             lc = self.mlv[l + 1]
             bc, xc = self.mb[l + 1], self.mx[l + 1]
-            lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc"))
+            if r is not None:  # (else: the fused pass has written the owned planes of bc)
+                lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc"))
             self._halo_planes(comm, bc, lc, 1)
             xc.zero_()
-            xc = self._vcycle(comm, l + 1, xc, bc)
-            if l == 0 and len(self.mlv) > 2:
+            xc = self._vcycle(comm, l + 1, xc, bc, zero=True)
+            if l == 0 and len(self.mlv) + (len(self.agg) if self.agg else 0) > 2:
                 # TWO cycles on the first coarse level, as gmg.StencilGMG.finish_cycle: the aggregation-built coarse
                 # operators are less accurate at the walls than a rediscretisation (0.24 -> 0.14 per cycle there)
                 xc = self._vcycle(comm, l + 1, xc, bc)
             self.mx[l + 1] = xc
             self._halo_planes(comm, xc, lc, 1)
             return lc.inner(xc)
-        part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")
+        if r is not None:
+            part = self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")
+        else:
+            part = self._agg_part[lv.g_lo // 2: lv.g_lo // 2 + lv.nz // 2]
         bc = comm.exchange("gather", part.contiguous(), None).reshape(tuple(self.agg[0].shape[1:]))
-        xc = self._agg_cycle(0, torch.zeros_like(bc), bc.contiguous())
+        bc = bc.contiguous()
+        # (the box is the FIRST coarse level when there is one slab level: two cycles there, as above)
+        twice = l == 0 and len(self.agg) > 1
+        if self.agg_gmg is not None:
+            xc = self.agg_gmg.vcycle(0, torch.zeros_like(bc), bc, zero=True)
+            if twice:
+                xc = self.agg_gmg.vcycle(0, xc, bc)
+        else:
+            xc = self._agg_cycle(0, torch.zeros_like(bc), bc)
+            if twice:
+                xc = self._agg_cycle(0, xc, bc)
         nzc = lv.nz // 2
         lo = self.rank * nzc - (1 if self.rank > 0 else 0)
         hi = (self.rank + 1) * nzc + (1 if self.rank < self.world - 1 else 0)
         return xc[lo:hi]
 
-    def _vcycle(self, comm, l, x, b):
-        x = self._smooth(comm, l, x, b)
-        r = self.res[l]
-        res2 = self._residual(comm, l, x, b, r)
+    def _vcycle(self, comm, l, x, b, zero=False):
+        x = self._smooth(comm, l, x, b, zero=zero)
+        r, lv = self.res[l], self.mlv[l]
+        coarser = l + 1 < len(self.mlv) or self.agg is not None
+        if (coarser and getattr(self.ops, "__name__", "") == "odil_amd.ops" and x.shape[0] % 2 == 0 and lv.g_lo % 2 == 0
+                and x.shape[2] % 2 == 0):
+            # residual and restriction in ONE pass over the ghost-extended arrays (the fine residual is never stored),
+            # straight into the coarse right-hand side: its owned planes + one plane per interface that nobody reads
+            if l + 1 < len(self.mlv):
+                lc = self.mlv[l + 1]
+                target = self.mb[l + 1][lc.g_lo - lv.g_lo // 2: lc.g_lo + lc.nz + lv.g_hi // 2]
+            else:
+                if getattr(self, "_agg_part", None) is None:
+                    self._agg_part = torch.empty(tuple(n // 2 for n in x.shape), dtype=self.dtype, device=self.device)
+                target = self._agg_part
+            self._halo_planes(comm, x, lv, 1)
+            self.ops.stencil_var_residual_restrict(self.mc[l], x, b, 0.125, target, self.part,
+                                                   zrange=(lv.g_lo, lv.g_lo + lv.nz), denom=1.0)
+            res2 = None if l else float(comm.exchange("gather", self.part.to(torch.float64).reshape(1), None).sum())
+            r = None
+        else:
+            res2 = self._residual(comm, l, x, b, r)
         if l == 0:
             self._last_res2 = res2
-        if l + 1 < len(self.mlv) or self.agg is not None:
+        if coarser:
             xc = self._coarse_correction(comm, l, r)
             y = self.spare[l]
             self.ops.interp_add(xc.contiguous(), "ccc", add=x, out=y)

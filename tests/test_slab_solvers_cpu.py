@@ -235,14 +235,14 @@ def test_slab_traced_lbfgs_thread_ranks_follow_the_undivided_run(which, world, n
             assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want))), (i, r)
 
 
-def gmg_rank(rank, world, comm, N, rhs, nz=None, tol=1e-13):
+def gmg_rank(rank, world, comm, N, rhs, nz=None, tol=1e-13, agg_cells=0):
     import slab_oracle_ops
 
     from odil_amd import slab_solvers
 
     slab_solvers.hip_ops = slab_oracle_ops
     run = slab_solvers.SlabPoissonNewtonGMG(N, rank, world, dtype=torch.float64, device=torch.device("cpu"),
-                                            rhs_global=torch.from_numpy(rhs), nz=nz)
+                                            rhs_global=torch.from_numpy(rhs), nz=nz, agg_cells=agg_cells)
     loss0, loss1 = run.step(comm, maxiter=40, tol=tol)
     return loss0, loss1, dict(run.status), run.owned(run.u).clone().numpy()
 
@@ -338,14 +338,14 @@ def _diffusion_global(shape, seed=3, reaction=1.0):
     return [diag] + off
 
 
-def stencil_gmg_rank(rank, world, comm, coeffs, b, nz, tol=1e-10):
+def stencil_gmg_rank(rank, world, comm, coeffs, b, nz, tol=1e-10, agg_cells=0):
     import slab_oracle_ops
 
     from odil_amd import slab_solvers
 
     own = slice(rank * nz, (rank + 1) * nz)
     c = torch.from_numpy(np.ascontiguousarray(np.stack([a[own] for a in coeffs])))
-    run = slab_solvers.SlabStencilGMG(c, rank, world, ops=slab_oracle_ops)
+    run = slab_solvers.SlabStencilGMG(c, rank, world, ops=slab_oracle_ops, agg_cells=agg_cells)
     x = run.solve(comm, torch.from_numpy(np.ascontiguousarray(b[own])), tol=tol, maxiter=60)
     return x.numpy(), dict(run.status), len(run.mlv)
 
@@ -418,3 +418,32 @@ def test_slab_variable_coefficient_multigrid_two_gloo_ranks(tmp_path):
         x, status, _ = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False)
         assert status["converged"]
         np.testing.assert_allclose(x, want[r * nz:(r + 1) * nz], rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+def test_slab_multigrids_agglomerate_small_levels_by_default():
+    """With the default `agg_cells` a level of <= 32^3 cells per rank is not a slab level (four exchanges of ~65 us per level
+    and cycle) but part of the agglomerated box: (64, 32, 32) on two ranks keeps ONE slab level, and both cycles still land
+    on the undivided solution."""
+    import stencil_gmg_np as sg
+
+    from odil_amd.slab_solvers import run_threads
+
+    world, shape = 2, (64, 32, 32)
+    nz = shape[0] // world
+    coeffs = _diffusion_global(shape)
+    b = np.random.default_rng(9).standard_normal(shape)
+    results = run_threads(world, lambda rank, comm: stencil_gmg_rank(rank, world, comm, coeffs, b, nz, agg_cells=32**3))
+    levels = sg.hierarchy(coeffs)
+    want = np.zeros(shape)
+    for _ in range(80):
+        want = sg.vcycle(levels, 0, want, b, top2=True)
+    for r, (x, status, nlev) in enumerate(results):
+        assert nlev == 1 and status["converged"], (nlev, status)
+        np.testing.assert_allclose(x, want[r * nz:(r + 1) * nz], rtol=0, atol=1e-7 * np.abs(want).max())
+    N = 32
+    ref_u = np.random.default_rng(3).standard_normal(shape)
+    rhs = onp.poisson_discrete_rhs(ref_u, (1.0 / N,) * 3)
+    results = run_threads(world, lambda rank, comm: gmg_rank(rank, world, comm, N, rhs, nz=nz, agg_cells=32**3))
+    for r, (loss0, loss1, status, u) in enumerate(results):
+        assert status["converged"] and "1 slab levels" in status["method"], status
+        np.testing.assert_allclose(u, ref_u[r * nz:(r + 1) * nz], rtol=0, atol=1e-8 * np.abs(ref_u).max())
