@@ -733,8 +733,9 @@ def other_configs(args, dev):
             out = bench_configs.run_config(key, args.scale, epochs=epochs, warmup=warmup)
             model = out.get("model_bytes_per_update")
             ms = out["ms_per_epoch"]
+            whole = {k: out[k] for k in ("us_per_epoch_whole_epochs_in_one_launch", "whole_epochs_kernel") if k in out}
             return {"workload": out["name"], "ms_per_step": ms, "value": out["cells"] / (ms * 1e-3), "optimizer": out["optimizer"],
-                    "model_bytes_per_update": model,
+                    **whole, "model_bytes_per_update": model,
                     "frac_model": None if not model else out["cells"] * model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "loss_after": out["loss"], "timing": "median of {} epochs, HIP events in the driver's per-epoch callback".format(out["epochs"]),
                     "ms_mean": out["ms_mean"], "ms_max": out["ms_max"], "ms_min": out["ms_min"], "setup_s": out["setup_s"],
