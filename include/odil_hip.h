@@ -188,7 +188,8 @@ int odil_poisson_residual_slab_f32(const float* u, const float* rhs, float* fu, 
 /* Residual restricted to the next coarser grid in one pass (3-D, even extents, shape[2] a multiple of the
  * 16-byte pack): coarse[K,J,I] = scale * sum over the 2x2x2 fine cells of (A u - rhs), *loss = mean((A u -
  * rhs)^2).  Replaces odil_poisson_residual + odil_restrict in the V-cycle that solves the Newton system
- * (reference linsolver.py:61-72 uses pyamg there); `partials`: odil_reduce_workspace_bytes() scratch. */
+ * (reference linsolver.py:61-72 uses pyamg there); `partials`: odil_reduce_workspace_bytes() scratch.  loss == NULL
+ * (coarse levels of a cycle, whose norm nobody reads): the reduction launch is skipped. */
 int odil_poisson_residual_restrict_f64(const double* u, const double* rhs, double* coarse, const int64_t* shape,
                                        int ndim, const double* h2, double scale, double* partials, double* loss,
                                        void* stream);
@@ -221,7 +222,9 @@ int odil_poisson_adjoint_transpose_adam_f32(const float* fu, float* g0, float* g
                                             float eps, const float* alpha_dev, int cut_lo, int cut_hi, void* stream);
 /* One damped-Jacobi sweep of that operator: uout = u - omega (A u - rhs) / diag(A), uout != u.  The
  * smoother of the geometric multigrid that solves the Newton system of the Poisson stencil
- * (reference linsolver.py:61-72 hands that system to pyamg). */
+ * (reference linsolver.py:61-72 hands that system to pyamg).  u == NULL here and in the two-sweep form below: the sweeps
+ * start from the ZERO vector (every coarse level of a V-cycle) -- u is neither read nor need it be zeroed by the caller;
+ * the results are those of the same call on an array of zeros, bit for bit. */
 int odil_poisson_jacobi_f64(const double* u, const double* rhs, double* uout, const int64_t* shape, int ndim,
                             const double* h2, double omega, void* stream);
 int odil_poisson_jacobi_f32(const float* u, const float* rhs, float* uout, const int64_t* shape, int ndim,

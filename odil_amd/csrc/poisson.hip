@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kBlock) void k_poisson_residual(const T* __restrict
 // of k_poisson_residual, with the diagonal -- sum over the active axes of (-2 - 2 [low wall] -
 // 2 [high wall]) / h^2, see adj_axis -- formed from the indices instead of read from memory.
 // Reads x and b, writes x_out (3 words per cell; residual + update as two kernels move 7).
-template <typename T, bool FULL>
+// ZERO: the sweep starts from the zero vector (u is not read; the same arithmetic on zeros: the same bits).
+template <typename T, bool FULL, bool ZERO = false>
 __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__ u, const T* __restrict__ rhs,
                                                           T* __restrict__ uout, StencilArgs a, H2<T> h, T omega) {
   constexpr int V = VecOf<T>::N;
@@ -146,19 +147,30 @@ __global__ __launch_bounds__(kBlock) void k_poisson_jacobi(const T* __restrict__
       wdiag[zw][xw] = omega / ((dzv + dy) + dterm[2] * T(1 + xw));
     }
   T um[V], uc[V], up[V];
-  if (a.active[0]) load_vec<T, V, FULL>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
-  load_vec<T, V, FULL>(u + z0 * sz + c_off, valid, uc);
+  if constexpr (ZERO) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) um[i] = uc[i] = up[i] = T(0);
+  } else {
+    if (a.active[0]) load_vec<T, V, FULL>(u + (z0 == 0 ? Z - 1 : z0 - 1) * sz + c_off, valid, um);
+    load_vec<T, V, FULL>(u + z0 * sz + c_off, valid, uc);
+  }
   for (int64_t z = z0; z < z1; ++z) {
     const int64_t pz = z * sz;
-    if (a.active[0]) load_vec<T, V, FULL>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
+    if constexpr (!ZERO)
+      if (a.active[0]) load_vec<T, V, FULL>(u + (z == Z - 1 ? 0 : z + 1) * sz + c_off, valid, up);
     T r[V], ym[V], yp[V], out[V];
     load_vec<T, V, FULL, true>(rhs + pz + c_off, valid, r);
-    if (a.active[1]) {
+    if constexpr (ZERO) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) ym[i] = yp[i] = T(0);
+    } else if (a.active[1]) {
       load_vec<T, V, FULL>(u + pz + ym_off, valid, ym);
       load_vec<T, V, FULL>(u + pz + yp_off, valid, yp);
     }
     T left, right;
-    if (FULL) {
+    if constexpr (ZERO) {
+      left = right = T(0);
+    } else if (FULL) {
       const int lane = threadIdx.x & 63;
       left = from_prev_lane(uc[V - 1]);
       right = from_next_lane(uc[0]);
@@ -484,13 +496,19 @@ static int poisson_jacobi(const T* u, const T* rhs, T* uout, const int64_t* shap
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
-  if (!u || !rhs || !uout || u == uout) {
+  if (!rhs || !uout || u == uout) {  // (u == NULL: the sweep starts from the zero vector)
     set_error("poisson_jacobi: null pointer, or the sweep in place (x_out must differ from x)");
     return ODIL_E_INVAL;
   }
   a.loss_z0 = 0;
   a.loss_z1 = 0;
-  if (a.n[2] % VecOf<T>::N == 0)
+  if (!u && a.n[2] % VecOf<T>::N == 0)
+    hipLaunchKernelGGL((k_poisson_jacobi<T, true, true>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream,
+                       u, rhs, uout, a, make_h2<T>(h), omega);
+  else if (!u)
+    hipLaunchKernelGGL((k_poisson_jacobi<T, false, true>), dim3(unit_grid(a.usched)), dim3(kBlock), 0,
+                       (hipStream_t)stream, u, rhs, uout, a, make_h2<T>(h), omega);
+  else if (a.n[2] % VecOf<T>::N == 0)
     hipLaunchKernelGGL((k_poisson_jacobi<T, true>), dim3(unit_grid(a.usched)), dim3(kBlock), 0, (hipStream_t)stream, u,
                        rhs, uout, a, make_h2<T>(h), omega);
   else
@@ -506,7 +524,7 @@ static int poisson_residual_restrict(const T* u, const T* rhs, T* coarse, const 
   StencilArgs a;
   T h[3];
   if (int e = fill_args<T>(a, shape, ndim, h2, h)) return e;
-  if (!u || !rhs || !coarse || !partials || !loss) {
+  if (!u || !rhs || !coarse || !partials) {  // (loss == NULL: the norm is nobody's measure -- no reduction launch)
     set_error("poisson_residual_restrict: null pointer");
     return ODIL_E_INVAL;
   }
@@ -523,6 +541,7 @@ static int poisson_residual_restrict(const T* u, const T* rhs, T* coarse, const 
   hipLaunchKernelGGL((k_poisson_residual_restrict<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, u, rhs, coarse,
                      a, make_h2<T>(h), scale, partials);
   if (int e = check_launch("k_poisson_residual_restrict")) return e;
+  if (!loss) return 0;
   return launch_final_reduce<T>(partials, grid, 0, 1, denom, loss, (hipStream_t)stream);
 }
 

@@ -135,7 +135,10 @@ __device__ __forceinline__ void synth_pack(const T (&c)[2][2], const T (&r)[2][2
 }
 
 // V: cells per lane (16 bytes; 8 bytes for float with SYNTH, where a lane is one coarse column).
-template <typename T, int V, bool HASY, bool MUL, bool SYNTH, int D = kS2Ahead>
+// ZERO: the iterate the sweeps start from is the zero vector (every coarse level of a V-cycle): x is not read -- the ring
+// holds zeros, the same arithmetic on them gives the same bits (0 - w (A 0 - b) = w b exactly) --, nothing of x goes through
+// LDS, and the caller need not zero an array first: 2 words per cell instead of 3 + 1.
+template <typename T, int V, bool HASY, bool MUL, bool SYNTH, int D = kS2Ahead, bool ZERO = false>
 __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(const T* __restrict__ u,
                                                                                const T* __restrict__ rhs,
                                                                                T* __restrict__ uout,
@@ -143,9 +146,10 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
                                                                                Smooth2Args a, H2<T> h, T omega1,
                                                                                T omega2) {
   static_assert(!SYNTH || (V == 2 && HASY), "the fused prolongation is 3-D with one coarse column per lane");
+  static_assert(!(SYNTH && ZERO), "x + P x_c is not a zero start");
   constexpr int NW = HASY ? kS2Waves : 1;
   constexpr int HY = HASY ? 2 : 0;  // halo rows per side
-  __shared__ T ubuf[HASY ? 2 * NW * 64 * V : 1];
+  __shared__ T ubuf[HASY && !ZERO ? 2 * NW * 64 * V : 1];
   __shared__ T ybuf[HASY ? 2 * NW * 64 * V : 1];
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
@@ -255,9 +259,16 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
       }
     }
   };
-  load_vec<T, V, true>(u + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+  if constexpr (ZERO) {
 #pragma unroll
-  for (int k = 0; k <= D; ++k) load_vec<T, V, true>(u + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int i = 0; i < V; ++i) uo[k][i] = T(0);
+  } else {
+    load_vec<T, V, true>(u + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+#pragma unroll
+    for (int k = 0; k <= D; ++k) load_vec<T, V, true>(u + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+  }
 #pragma unroll
   for (int k = 0; k < D; ++k) load_vec<T, V, true>(rhs + wrapz(p0 + k) * sz + c_off, V, bb[k]);
   T cnew = T(0);  // the coarse value this wave fetched, on its way to the LDS ring
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
   for (int i = 0; i < V; ++i) y1[R - 2][i] = y1[R - 1][i] = bb[R - 1][i] = T(0);
   const int slot = (row * 64 + lane) * V;
   const int slot_m = ((row == 0 ? 0 : row - 1) * 64 + lane) * V, slot_p = ((row == NW - 1 ? NW - 1 : row + 1) * 64 + lane) * V;
-  if (HASY) {  // plane p0 of x for the first step's neighbours
+  if (HASY && !ZERO) {  // plane p0 of x for the first step's neighbours
     store_vec<T, V, true>(ubuf + slot, V, uo[0]);
     __syncthreads();
   }
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
       const int t = t0 + k;
       // (1) the loads of this step, consumed D steps later
       // (uniform plane pointer + 32-bit lane offset: the scalar-base form of the load, no 64-bit lane arithmetic)
-      load_vec<T, V, true>(u + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
+      if constexpr (!ZERO) load_vec<T, V, true>(u + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
       if (row_s1) load_vec<T, V, true>(rhs + pb * sz + c_off, V, bb[(k + D) % R]);
       if constexpr (SYNTH) {
         // fine plane s = z0 + t (parity of k: z0 and t0 are even) reads the coarse planes js - 1, js (even) or js, js + 1
@@ -312,13 +323,16 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
           synth(s, ((k >> 1) + 2) % 3, (k >> 1) % 3, uo[(k + 1) % R]);
       }
       // (2) plane p + 1 of x for the next step's y neighbours
-      if (HASY) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
+      if (HASY && !ZERO) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
       if (row_s1) {
         // (3) first sweep on plane p
         {
           const T (&qc)[V] = uo[k];
           T nm[V], np[V];
-          if (HASY) {
+          if constexpr (ZERO) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) nm[i] = np[i] = T(0);
+          } else if (HASY) {
             const T* buf = ubuf + (k & 1) * (NW * 64 * V);
             load_vec<T, V, true>(buf + slot_m, V, nm);
             load_vec<T, V, true>(buf + slot_p, V, np);
@@ -617,7 +631,7 @@ static int poisson_jacobi2(const T* u, const T* rhs, T* uout, const int64_t* sha
   Smooth2Args a;
   T h[3];
   if (int e = smooth2_args<T>(a, shape, ndim, h2, h, zc_hint, V, 1, "poisson_jacobi2")) return e;
-  if (!u || !rhs || !uout || u == uout) {
+  if (!rhs || !uout || u == uout) {  // (u == NULL: the sweeps start from the zero vector)
     set_error("poisson_jacobi2: null pointer, or the sweeps in place (x_out must differ from x)");
     return ODIL_E_INVAL;
   }
@@ -625,9 +639,15 @@ static int poisson_jacobi2(const T* u, const T* rhs, T* uout, const int64_t* sha
   const H2<T> hh = make_h2<T>(h);
   const bool mul = hh.mul_ok[0] && hh.mul_ok[1] && hh.mul_ok[2];
   const T* none = nullptr;
-#define ODIL_LAUNCH_J2(HASY, MUL, THREADS)                                                                          \
-  hipLaunchKernelGGL((k_poisson_jacobi2<T, V, HASY, MUL, false>), dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, u, \
-                     rhs, uout, none, a, hh, omega1, omega2)
+#define ODIL_LAUNCH_J2(HASY, MUL, THREADS)                                                                              \
+  do {                                                                                                                  \
+    if (u)                                                                                                              \
+      hipLaunchKernelGGL((k_poisson_jacobi2<T, V, HASY, MUL, false>), dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, \
+                         u, rhs, uout, none, a, hh, omega1, omega2);                                                    \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_poisson_jacobi2<T, V, HASY, MUL, false, kS2Ahead, true>), dim3(grid), dim3(THREADS), 0,      \
+                         (hipStream_t)stream, u, rhs, uout, none, a, hh, omega1, omega2);                               \
+  } while (0)
   if (a.active[1]) {
     if (mul)
       ODIL_LAUNCH_J2(true, true, 64 * kS2Waves);

@@ -103,14 +103,14 @@ class PoissonGMG:
         ops.poisson_residual(x, b, self.h2s[lvl], fu=out, loss=self.loss)
         return out
 
-    def smooth(self, lvl, x, b, n, chebyshev=True):
+    def smooth(self, lvl, x, b, n, chebyshev=True, zero=False):
         """n Jacobi sweeps, each ONE kernel (odil_poisson_jacobi: x' = x - omega_k (A x - b) / diag); the
         iterate ping-pongs between `x` and the level's spare buffer.  Returns the tensor holding it.
         The weights omega_k are those of the degree-n Chebyshev polynomial on [1/d, 2], the part of the
         spectrum of D^-1 A that the coarse grid cannot see (eigenvalues (1/d) sum_i (1 - cos theta_i) with
         some |theta_i| >= pi/2): two sweeps damp it by 0.34 (d = 3) where omega = 6/7 gives 0.51, three by
-        0.15 instead of 0.36."""
-        return self.sweeps(lvl, x, b, self.weights(n, chebyshev))
+        0.15 instead of 0.36.  zero: the iterate is the zero vector and `x` only a buffer -- its content is not read."""
+        return self.sweeps(lvl, x, b, self.weights(n, chebyshev), zero=zero)
 
     def weights(self, n, chebyshev=True):
         if not chebyshev:
@@ -119,27 +119,34 @@ class PoissonGMG:
         mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
         return [1.0 / (mid - half * math.cos(math.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
 
-    def sweeps(self, lvl, x, b, weights):
+    def sweeps(self, lvl, x, b, weights, zero=False):
         """Sweeps with the given weights, in PAIRS through the one-pass kernel (odil_poisson_jacobi2: the intermediate
         iterate stays on the CU, 3 words per cell and pair instead of 6; bit-identical to two single sweeps) on levels
-        large enough to be bandwidth-bound."""
+        large enough to be bandwidth-bound.  zero: the iterate is the zero vector (every coarse level of a cycle starts
+        there): the first launch does not read `x` -- the same bits as from an array of zeros, which nobody has to write."""
         weights = list(weights)
+        if zero and (not weights or not self.zero_start):
+            x.zero_()
+            zero = False
         # (float64 only: with four floats per lane the pair is bound by the vector ALU, 0.85 against 0.70 ms at 512^3)
         pair = (self.dtype == torch.float64 and ops.jacobi2_supported(self.shapes[lvl], self.dtype)
                 and math.prod(self.shapes[lvl]) >= self.pair_min_cells)
         while weights:
             y = self.spare[lvl]
+            src = None if zero else x
+            zero = False
             if pair and len(weights) >= 2:
-                ops.poisson_jacobi2(x, b, self.h2s[lvl], weights[0], weights[1], out=y)
+                ops.poisson_jacobi2(src, b, self.h2s[lvl], weights[0], weights[1], out=y)
                 weights = weights[2:]
             else:
-                ops.poisson_jacobi(x, b, self.h2s[lvl], weights[0], out=y)
+                ops.poisson_jacobi(src, b, self.h2s[lvl], weights[0], out=y)
                 weights = weights[1:]
             self.spare[lvl] = x
             x = y
         return x
 
     post_pair = True
+    zero_start = True  # (False: the zero iterate of a coarse level is written and read back -- the tests compare both, bit for bit)
     pair_min_cells = 128**3  # below: the levels are launch-bound and the single-sweep kernels' smaller workgroups fill the chip better (measured: 128^3 / 64^3 / 32^3 as the threshold -> 25.0 / 25.7 / 26.6 ms for the 256^3 diffusion step)
 
     # ---- the coarse tail in one launch --------------------------------------------------------------------------------
@@ -190,7 +197,8 @@ class PoissonGMG:
         residual is never stored); residual, restriction and sign as three launches otherwise."""
         bc = self.b[lvl + 1]
         if self.locs[lvl] == self.loc and ops.residual_restrict_supported(self.shapes[lvl], self.dtype):
-            ops.poisson_residual_restrict(x, b, self.h2s[lvl], -1.0 / 2**self.ndim, bc, self.loss)
+            # (the norm is the SOLVE's measure on the finest level; a coarser level's is nobody's: no reduction launch)
+            ops.poisson_residual_restrict(x, b, self.h2s[lvl], -1.0 / 2**self.ndim, bc, self.loss if lvl == 0 else None)
         else:
             r = self.residual(lvl, x, b, self.r(lvl))
             self.restrict(lvl, r, -1.0, out=bc)
@@ -234,9 +242,9 @@ class PoissonGMG:
         t = self.tail()
         if t is not None and lvl + 1 == t[0]:
             return self.tail_cycle(lvl + 1, None, self.b[lvl + 1])  # (the zero start is not even stored)
-        xc.zero_()
+        # (not zeroed: a cycle from the zero start does not read its iterate's buffer)
         xc_new = self.vcycle(lvl + 1, xc, self.b[lvl + 1], zero=True)
-        if xc_new is not xc:  # keep the zeroed-per-cycle buffer distinct from the level's spare
+        if xc_new is not xc:  # keep the per-cycle buffer distinct from the level's spare
             self.x[lvl + 1] = xc_new
         return xc_new
 
@@ -299,9 +307,9 @@ class PoissonGMG:
                 self.spare[lvl] = x
                 return out
             if self.continuation() is not None:  # an odd extent: the cycle goes on below on the padded grid
-                return self.continued_cycle(x, b)
-            return self.smooth(lvl, x, b, 40, chebyshev=False)  # cannot coarsen further: by iteration
-        x = self.smooth(lvl, x, b, self.nu1)
+                return self.continued_cycle(x.zero_() if zero else x, b)
+            return self.smooth(lvl, x, b, 40, chebyshev=False, zero=zero)  # cannot coarsen further: by iteration
+        x = self.smooth(lvl, x, b, self.nu1, zero=zero)
         self.coarse_rhs(lvl, x, b)
         return self.finish_cycle(lvl, x, b, post=post)
 
@@ -354,7 +362,7 @@ class PoissonGMG:
         while it < maxiter and res > tol * max(bn, 1e-300) and res == res:
             if have == m:  # restart: the stored directions are dropped
                 have = 0
-            e = self.vcycle(0, torch.zeros_like(b) if e is None else e.zero_(), r)   # M^-1 r
+            e = self.vcycle(0, torch.empty_like(b) if e is None else e, r, zero=True)   # M^-1 r (from the zero start)
             z, q = Z[have].view(b.shape), Q[have].view(b.shape)
             z.copy_(e)
             self.residual(0, z, zero_b, q)          # sign * A z
@@ -375,10 +383,11 @@ class PoissonGMG:
             res = float(ops.dots(r.view(1, -1), r.view(-1))[0]) ** 0.5
         return x, res, it
 
-    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True, fmg=True, krylov="auto"):
+    def solve(self, b, tol=1e-12, maxiter=60, status=None, x0=None, copy=True, fmg=True, krylov="auto", b_meansq=None):
         """Solves A x = b to ||A x - b|| <= tol * ||b||.  The residual that is tested is the one every cycle
         forms anyway (after its pre-smoothing sweeps, on its way to the coarse grid): the iterate returned
-        is that pre-smoothed one, so convergence costs no pass of its own."""
+        is that pre-smoothed one, so convergence costs no pass of its own.  b_meansq: 0-d device tensor holding mean(b^2)
+        when the caller has it (the evaluation that produced b reduced it already): no pass over b for its norm."""
         n = b.numel()
         # a relative residual below ~50 ulp of the working precision cannot be reached: asking float32 for 1e-12 would
         # burn every cycle of `maxiter` and report nothing
@@ -389,7 +398,10 @@ class PoissonGMG:
             x = self.full_multigrid(b, post=False)
         else:
             x = torch.zeros_like(b)
-        bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
+        if b_meansq is not None:
+            bn = math.sqrt(max(float(b_meansq), 0.0) * n)
+        else:
+            bn = float(ops.dots(b.view(1, -1), b.view(-1))[0]) ** 0.5
         res, it = bn, 0
         method = "gmg-vcycle"
         stagnated = False
@@ -465,7 +477,7 @@ def solve_mixed(high, low, b, tol=1e-12, maxiter=60, status=None, fmg=True):
         if it == 0 and fmg and low.nlvl > 2:
             e = low.full_multigrid(rl)
         else:
-            e = low.vcycle(0, torch.zeros_like(rl) if e is None else e.zero_(), rl)
+            e = low.vcycle(0, torch.empty_like(rl) if e is None else e, rl, zero=True)
         ops.widen_axpy(x, e, a=1.0, msq=high.loss)
         it += 1
     converged = res <= tol * max(bn, 1e-300)
@@ -578,10 +590,13 @@ class StencilGMG(PoissonGMG):
         ops.mean_reduce(out.reshape(-1), square=True, out=self.loss)
         return out
 
-    def sweeps(self, lvl, x, b, weights):
+    def sweeps(self, lvl, x, b, weights, zero=False):
         """Sweeps in PAIRS through the one-pass kernel (odil_stencil_var_smooth2: the coefficient arrays -- 7 of a sweep's
-        10 words in 3-D -- read once for both sweeps; bit-identical to two single sweeps) on the bandwidth-bound levels."""
+        10 words in 3-D -- read once for both sweeps; bit-identical to two single sweeps) on the bandwidth-bound levels.
+        zero: the iterate is the zero vector and `x` only a buffer (these kernels read it: it is zeroed here)."""
         weights = list(weights)
+        if zero:
+            x.zero_()
         pair = ops.smooth2_supported(self.shapes[lvl]) and math.prod(self.shapes[lvl]) >= self.pair_min_cells
         while weights:
             y = self.spare[lvl]

@@ -443,9 +443,9 @@ def poisson_residual_restrict(u, rhs, h2, scale, out, loss, zrange=None, denom=0
     assert u.shape == rhs.shape and tuple(out.shape) == tuple(n // 2 for n in u.shape)
     assert residual_restrict_supported(tuple(u.shape), u.dtype) and out.is_contiguous()
     h2a, h2p = host_reals(h2, u.dtype)
-    if zrange is None:
+    if zrange is None:  # (loss = None: no reduction launch)
         call("poisson_residual_restrict", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p, float(scale),
-             ptr(reduce_workspace(u.device)), ptr(loss), stream_ptr())
+             ptr(reduce_workspace(u.device)), ptr(loss) if loss is not None else None, stream_ptr())
     else:
         call("poisson_residual_restrict_slab", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(3), h2p,
              float(scale), c_int64(int(zrange[0])), c_int64(int(zrange[1])), c_double(float(denom)),
@@ -454,11 +454,12 @@ def poisson_residual_restrict(u, rhs, h2, scale, out, loss, zrange=None, denom=0
 
 
 def poisson_jacobi(u, rhs, h2, omega, out):
-    """out = u - omega (A u - rhs) / diag(A): one damped-Jacobi sweep of the Poisson stencil (out is not u)."""
-    assert u.shape == rhs.shape == out.shape and out.data_ptr() != u.data_ptr()
-    h2a, h2p = host_reals(h2, u.dtype)
-    call("poisson_jacobi", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p, float(omega),
-         stream_ptr())
+    """out = u - omega (A u - rhs) / diag(A): one damped-Jacobi sweep of the Poisson stencil (out is not u).
+    u = None: the sweep starts from the zero vector (nothing is read for it, nothing need be zeroed)."""
+    assert rhs.shape == out.shape and (u is None or (u.shape == rhs.shape and out.data_ptr() != u.data_ptr()))
+    h2a, h2p = host_reals(h2, rhs.dtype)
+    call("poisson_jacobi", rhs.dtype, ptr(u) if u is not None else None, ptr(rhs), ptr(out), i64(rhs.shape),
+         c_int(rhs.dim()), h2p, float(omega), stream_ptr())
     return out
 
 
@@ -481,12 +482,13 @@ def jacobi2_supported(shape, dtype):
 
 def poisson_jacobi2(u, rhs, h2, omega1, omega2, out, zc_hint=0):
     """Two damped-Jacobi sweeps (weights omega1, then omega2) in ONE pass: bit-identical to two calls of
-    `poisson_jacobi`, 3 words per cell instead of 6 (out is not u)."""
-    assert u.shape == rhs.shape == out.shape and out.data_ptr() != u.data_ptr() and jacobi2_supported(tuple(u.shape), u.dtype)
-    assert u.is_contiguous() and rhs.is_contiguous() and out.is_contiguous()
-    h2a, h2p = host_reals(h2, u.dtype)
-    call("poisson_jacobi2", u.dtype, ptr(u), ptr(rhs), ptr(out), i64(u.shape), c_int(u.dim()), h2p, float(omega1),
-         float(omega2), c_int(zc_hint), stream_ptr())
+    `poisson_jacobi`, 3 words per cell instead of 6 (out is not u).  u = None: from the zero vector (2 words)."""
+    assert rhs.shape == out.shape and jacobi2_supported(tuple(rhs.shape), rhs.dtype)
+    assert u is None or (u.shape == rhs.shape and out.data_ptr() != u.data_ptr() and u.is_contiguous())
+    assert rhs.is_contiguous() and out.is_contiguous()
+    h2a, h2p = host_reals(h2, rhs.dtype)
+    call("poisson_jacobi2", rhs.dtype, ptr(u) if u is not None else None, ptr(rhs), ptr(out), i64(rhs.shape),
+         c_int(rhs.dim()), h2p, float(omega1), float(omega2), c_int(zc_hint), stream_ptr())
     return out
 
 

@@ -325,7 +325,9 @@ def _poisson_newton_step(problem, state, args, status):
         delta = gmg.solve_mixed(solver[0], solver[1], b, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status)
         return delta.reshape(-1)
     # A d = r is solved and u - d formed (the solver is linear: d = -delta) -- the residual need not be negated first
-    d = solver.solve(r, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False)
+    # (||r||: the evaluation above reduced mean(r^2) into ev.loss already)
+    d = solver.solve(r, tol=tol, maxiter=getattr(args, "linsolver_maxiter", None) or 60, status=status, copy=False,
+                     b_meansq=ev.loss)
     ops.axpy(u, d, -1.0)  # (d: a work buffer of the solver, consumed here)
     if u.data_ptr() != field.array.data_ptr():
         field.array.copy_(u)

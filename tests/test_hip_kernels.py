@@ -570,6 +570,14 @@ def test_two_jacobi_sweeps_in_one_pass_are_bit_identical(dev, dtype, shape):
         for zc in (0, 1, 3, 64):
             got = ops.poisson_jacobi2(x, b, h2, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
             assert torch.equal(got, want), (shape, zc)
+        # from the ZERO vector (u = NULL: nothing read for the iterate): the bits of the same calls on an array of zeros
+        zero = torch.zeros_like(x)
+        y1 = ops.poisson_jacobi(zero, b, h2, 0.9, torch.empty_like(x))
+        assert torch.equal(ops.poisson_jacobi(None, b, h2, 0.9, torch.full_like(x, float("nan"))), y1), shape
+        want = ops.poisson_jacobi(y1, b, h2, 0.6, torch.empty_like(x))
+        for zc in (0, 3):
+            got = ops.poisson_jacobi2(None, b, h2, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
+            assert torch.equal(got, want), (shape, zc, "zero start")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -528,3 +528,29 @@ def test_two_variable_coefficient_sweeps_in_one_pass_are_bit_identical(dev, shap
     for zc in (0, 1, 3, 64):
         got = ops.stencil_var_smooth2(ct, x, b, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
         assert torch.equal(got, want), (shape, zc, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 64), torch.float64), ((128, 128, 128), torch.float64), ((48, 32, 64), torch.float32),
+                                         ((256, 256), torch.float64), ((4096,), torch.float64)])
+def test_cycles_that_do_not_read_their_zero_iterates_give_the_same_bits(shape, dtype):
+    """Every coarse level of a V-cycle starts from the zero vector.  `PoissonGMG.zero_start` (default): the first sweep
+    launch there is told so and reads nothing for the iterate (u = NULL: odil_poisson_jacobi / odil_poisson_jacobi2), nobody
+    writes the zeros, coarse levels skip their norm's reduction launch.  The solve equals the one that writes and reads
+    the zero arrays BIT for bit, cycle count included."""
+    from odil_amd import gmg
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(23)
+    b = torch.randn(shape, generator=gen, dtype=torch.float64).to(dev, dtype)
+    h2 = [1.0 / n**2 for n in shape]
+    out = []
+    try:
+        for flag in (True, False):
+            gmg.PoissonGMG.zero_start = flag
+            solver = gmg.PoissonGMG(shape, h2, dtype, dev)
+            st = dict()
+            out.append((solver.solve(b, tol=1e-11, maxiter=40, status=st).clone(), st["niter"], st["residual"]))
+    finally:
+        gmg.PoissonGMG.zero_start = True
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert torch.equal(out[0][0], out[1][0])

@@ -53,6 +53,8 @@ VARIANTS = {
     "pairs >= 64^3, tail": dict(pair_min_cells=64**3, tail_max_cells=8192),
     "pairs >= 32^3, tail": dict(pair_min_cells=32**3, tail_max_cells=8192),
 }
+if len(sys.argv) > 3 and sys.argv[3] == "zero":
+    VARIANTS = {"zero iterates written and read": dict(zero_start=False), "zero start not read   ": dict(zero_start=True)}
 best = {k: (1e9, None) for k in VARIANTS}
 for rnd in range(4):
     for name, attrs in VARIANTS.items():

@@ -22,33 +22,6 @@ def tick(label, t0):
     print("%-28s %8.2f ms" % (label, (t1 - t0) * 1e3))
     return t1
 
-t = time.perf_counter()
-ev = problem._fused
-(field,) = state.fields.values()
-u = field.array.contiguous()
-r, _ = ops.poisson_residual(u, ev.rhs, ev.h2, fu=ev.fu, loss=ev.loss)
-t = tick("residual", t)
-solver = gmg.PoissonGMG(ev.cshape, ev.h2, ev.dtype, ev.device)
-t = tick("solver construct", t)
-solver.coarse_inverse()
-t = tick("coarse inverse", t)
-b = ops.scale(r, -1.0, out=r)
-t = tick("negate", t)
-status = {}
-delta = solver.solve(b, tol=1e-10, maxiter=60, status=status, copy=False)
-t = tick("solve (%d cycles)" % status["niter"], t)
-domain = problem.domain
-packed = domain.pack_state(state)
-t = tick("pack_state", t)
-domain.unpack_state(packed + delta.reshape(-1), state)
-t = tick("unpack_state(packed+delta)", t)
-loss = problem.eval_loss_grad_device(state)[0]
-t = tick("eval_loss_grad", t)
-print("loss", float(loss))
-t = time.perf_counter()
-delta = solver.solve(b, tol=1e-10, maxiter=60, status=status, copy=False)
-t = tick("solve again (%d cycles)" % status["niter"], t)
-
 # the same step through the public driver, on a fresh problem (first-use costs included)
 import cProfile, pstats
 problem2, state2 = poisson.make_problem(args)
@@ -63,4 +36,24 @@ odil.util.optimize(args, "newton", problem2, state2, None)
 torch.cuda.synchronize()
 pr.disable()
 t = tick("util.optimize(newton, 1 epoch)", t)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
+# host time from the call to the FIRST launch of the step (the GPU idles meanwhile) and between solve phases
+import odil_amd.util as U
+real = U._poisson_newton_step
+marks = []
+def timed(problem, state, args, status):
+    marks.append(("enter step", time.perf_counter()))
+    out = real(problem, state, args, status)
+    marks.append(("leave step (host)", time.perf_counter()))
+    return out
+U._poisson_newton_step = timed
+state2.fields[list(state2.fields)[0]].array.zero_()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+odil.util.optimize(args, "newton", problem2, state2, None)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+for name, t in marks:
+    print("%-24s +%.3f ms" % (name, 1e3 * (t - t0)))
+print("optimize returned (host)  +%.3f ms; GPU done +%.3f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t0)))
