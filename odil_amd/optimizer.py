@@ -235,7 +235,7 @@ class AdamNativeOptimizer(Optimizer):
         # initialisation, allocator warm-up), the third is captured with the step size read from
         # device memory (`alpha_dev` of the *_adam kernels), the rest are replays.
         graph = None
-        if epochs > 4 and _graph_wanted(xf.numel(), loss_grad, epochs):
+        if last - epoch + 1 > 4 and _graph_wanted(xf.numel(), loss_grad, epochs):  # (epochs that are LEFT: none after whole-epoch launches)
             while epoch < first + 2:
                 self.evals += 1
                 pinfo = step(step_size(epoch))

@@ -348,18 +348,20 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
             pair = w[k: k + 2]
             if not (zero and k == 0):
                 self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
+            # (native kernels do not read a zero iterate: u = None -- the bits of the same launch on an array of zeros)
+            src = None if (zero and k == 0 and self.native) else x
             if (self.native and len(pair) == 2 and self.dtype == torch.float64 and lv.size >= self.pair_min_cells
                     and self.ops.jacobi2_supported(tuple(x.shape), self.dtype)):
                 y = self.spare[l]
-                self.ops.poisson_jacobi2(x, b, self.mh2[l], pair[0], pair[1], out=y)  # (== the two sweeps below, bit for bit)
+                self.ops.poisson_jacobi2(src, b, self.mh2[l], pair[0], pair[1], out=y)  # (== the two sweeps below, bit for bit)
                 self.spare[l] = x
                 x = y
                 pair = []
             for wk in pair:
                 y = self.spare[l]
-                self.ops.poisson_jacobi(x, b, self.mh2[l], wk, out=y)
+                self.ops.poisson_jacobi(src, b, self.mh2[l], wk, out=y)
                 self.spare[l] = x
-                x = y
+                x, src = y, y
             k += 2
         return x
 
@@ -434,7 +436,8 @@ class SlabPoissonNewtonGMG(SlabPoissonNewtonCG):
             if r is not None:  # (else: `_restricted_residual` has written the owned planes of bc)
                 lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc")).mul_(-1.0)
             self._halo_planes(comm, bc, lc, 1)
-            xc.zero_()
+            if not self.native:
+                xc.zero_()
             xc = self._vcycle(comm, l + 1, xc, bc, zero=True)
             self.mx[l + 1] = xc
             self._halo_planes(comm, xc, lc, 1)
