@@ -476,6 +476,10 @@ int odil_stencil_vcycle_tail_f32(const float* coeffs, const int64_t* shapes, con
  * y64 += s x32 with s = a sqrt(*msq). */
 int odil_narrow_scale(const double* x, float* y, int64_t n, double a, const double* msq, void* stream);
 int odil_widen_axpy(double* y, const float* x, int64_t n, double a, const double* msq, void* stream);
+/* out[r] = max |a[r n .. (r + 1) n)| for the nrows <= 64 rows of one array, two launches in all (the multigrid set-up reads
+ * the largest coupling of every direction on every level: the 2 d coefficient arrays of a level are rows of one buffer). */
+int odil_max_abs_rows_f64(const double* a, int nrows, int64_t n, double* partials, double* out, void* stream);
+int odil_max_abs_rows_f32(const float* a, int nrows, int64_t n, double* partials, float* out, void* stream);
 /* out[0] = max |a - b|, out[1] = max |b| over n entries in one pass (NaN differences propagate): the comparison by which
  * a linearised operator's coefficient arrays are recognised as a known stencil (gmg.recognise_poisson) -- no reference
  * counterpart.  `partials`: odil_reduce_workspace_bytes(). */

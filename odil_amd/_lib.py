@@ -71,6 +71,7 @@ _SIGNATURES = {
     "stencil_var_coarsen_axes": [_P, _P, _I64P, c_int, _P, _P],
     "stencil_vcycle_tail": [_P, _I64P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int, _P, c_int, _P, c_int, c_int, _P],
     "max_abs_diff": [_P, _P, c_int64, _P, _P, _P],
+    "max_abs_rows": [_P, c_int, c_int64, _P, _P, _P],
     "csr_assemble": [_P, _I64P, c_int, _I64P, c_int, c_int64, _P, _P, _P, _P],
     "dense_block_xty": [_P, _P, c_int64, c_int, c_int, c_int64, c_int64, _P, _P, _P],
     "dense_block_gram": [_P, c_int64, c_int, c_int64, _P, _P, _P],

@@ -432,6 +432,60 @@ static int max_abs_diff(const T* a, const T* b, int64_t n, double* partials, T* 
   return check_launch("k_max_abs_final");
 }
 
+// out[r] = max |a[r n .. (r + 1) n)| for the rows of one array in TWO launches (the set-up of the multigrid hierarchy asks for
+// the largest coupling of every direction on every level: 2 d arrays per level, one read-back)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_max_abs_rows(const T* __restrict__ a, int64_t n, double* __restrict__ partials) {
+  const T* row = a + (int64_t)blockIdx.y * n;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double m = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const double v = fabs((double)row[i]);
+    m = v > m || v != v ? v : m;  // (a NaN stays visible)
+  }
+  __shared__ double sm[kBlock];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double o = sm[threadIdx.x + off];
+      if (o > sm[threadIdx.x] || o != o) sm[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_max_abs_rows_final(const double* __restrict__ partials, int count, T* __restrict__ out) {
+  const double* p = partials + (int64_t)blockIdx.x * count;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < count; i += 64) {
+    const double v = p[i];
+    m = v > m || v != v ? v : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(m, off, 64);
+    m = o > m || o != o ? o : m;
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (T)m;
+}
+
+template <typename T>
+static int max_abs_rows(const T* a, int nrows, int64_t n, double* partials, T* out, void* stream) {
+  if (!a || !partials || !out || n < 1 || nrows < 1 || nrows > 64) {
+    set_error("max_abs_rows: null pointer, n < 1 or nrows outside 1 .. 64");
+    return ODIL_E_INVAL;
+  }
+  int grid = grid_for(n, kBlock * 8);
+  if (grid > kMaxPartials / nrows) grid = kMaxPartials / nrows;
+  hipLaunchKernelGGL((k_max_abs_rows<T>), dim3(grid, nrows), dim3(kBlock), 0, (hipStream_t)stream, a, n, partials);
+  if (int e = check_launch("k_max_abs_rows")) return e;
+  hipLaunchKernelGGL((k_max_abs_rows_final<T>), dim3(nrows), dim3(64), 0, (hipStream_t)stream, partials, grid, out);
+  return check_launch("k_max_abs_rows_final");
+}
+
 static int svar_fill(SvarArgs& a, const int64_t* shape, int ndim, const char* what) {
   if (ndim < 1 || ndim > 3 || !shape) {
     set_error("%s: ndim %d (1..3 supported)", what, ndim);
@@ -571,6 +625,12 @@ int odil_stencil_var_residual_restrict_slab_f32(const float* coeffs, const float
                                                 const int64_t* shape, int ndim, float scale, int64_t z0, int64_t z1,
                                                 double denom, double* partials, float* loss, void* stream) {
   return svar_residual_restrict<float>(coeffs, x, b, coarse, shape, ndim, scale, partials, loss, stream, z0, z1, denom);
+}
+int odil_max_abs_rows_f64(const double* a, int nrows, int64_t n, double* partials, double* out, void* stream) {
+  return max_abs_rows<double>(a, nrows, n, partials, out, stream);
+}
+int odil_max_abs_rows_f32(const float* a, int nrows, int64_t n, double* partials, float* out, void* stream) {
+  return max_abs_rows<float>(a, nrows, n, partials, out, stream);
 }
 int odil_max_abs_diff_f64(const double* a, const double* b, int64_t n, double* partials, double* out, void* stream) {
   return max_abs_diff<double>(a, b, n, partials, out, stream);

@@ -530,8 +530,7 @@ class StencilGMG(PoissonGMG):
             if self.ndim == 1:
                 halve = [True]
             else:
-                size = torch.stack([ops.max_abs_diff(cur[1 + k].reshape(-1), cur[1 + k].reshape(-1))[1]
-                                    for k in range(2 * self.ndim)]).cpu().numpy()
+                size = ops.max_abs_rows(cur[1:]).cpu().numpy()  # (2 d arrays: two launches, one read-back)
                 # (the smaller of the two directions: an upwind convection term inflates ONE of them, and it grows
                 # relative to the diffusion on every coarser level -- that is not an anisotropy of the smoothing problem)
                 strength = [min(float(size[2 * a]), float(size[2 * a + 1])) for a in range(self.ndim)]

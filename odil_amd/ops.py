@@ -225,6 +225,16 @@ def max_abs_diff(a, b):
     return out
 
 
+def max_abs_rows(a):
+    """max |row| of every row of a 2-D view (<= 64 rows) as a device tensor: two launches for all rows."""
+    a2 = a.reshape(a.shape[0], -1)
+    assert a2.is_contiguous() and 1 <= a2.shape[0] <= 64
+    out = torch.empty(a2.shape[0], dtype=a.dtype, device=a.device)
+    call("max_abs_rows", a.dtype, ptr(a2), c_int(a2.shape[0]), c_int64(a2.shape[1]), ptr(reduce_workspace(a.device)), ptr(out),
+         stream_ptr())
+    return out
+
+
 def stencil_var_coarsen(coeffs, halve=None):
     """Coefficient arrays of the coarse-grid operator [(2 d + 1), *(shape / 2)] (csrc/stencil_mg.hip).  halve: per axis,
     whether two cells are merged along it (default: every axis); the others keep their extent (semi-coarsening)."""

@@ -554,3 +554,20 @@ def test_cycles_that_do_not_read_their_zero_iterates_give_the_same_bits(shape, d
         gmg.PoissonGMG.zero_start = True
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert torch.equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("rows,n", [(1, 1), (6, 1000), (4, 70001), (6, 64**3)])
+def test_row_maxima_in_two_launches(dtype, rows, n):
+    """odil_max_abs_rows: the largest |entry| of every row (the hierarchy's set-up asks for the largest coupling of each of
+    the 2 d directions on every level) == torch, NaN kept visible."""
+    from odil_amd import ops
+
+    dev = torch.device("cuda:0")
+    a = torch.randn((rows, n), generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(dev, dtype)
+    got = ops.max_abs_rows(a)
+    assert torch.equal(got, a.abs().max(dim=1).values)
+    if n > 10:
+        a[rows - 1, n // 2] = float("nan")
+        got = ops.max_abs_rows(a)
+        assert bool(torch.isnan(got[rows - 1])) and (rows == 1 or not bool(torch.isnan(got[0])))
