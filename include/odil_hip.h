@@ -382,10 +382,13 @@ int odil_stencil_march_f32(const float* coeffs, const int64_t* shifts, int nshif
  * core.py:1113-1217; the reference hands M^T M to SuperLU / pyamg, linsolver.py:17-26, 61-72).  `coeffs`: the 2 ndim + 1
  * arrays one after another in the order (0, -e_0, +e_0, -e_1, +e_1, ...), each of `shape`; neighbours wrap periodically
  * (core.py:962-963), a wall row carries a zero coefficient towards the wall.
- *   smooth, mode 0:  out = x - omega (A x - b) / c0   (one damped-Jacobi sweep; out != x)
+ *   smooth, mode 0:  out = x - omega (A x - b) / c0   (one damped-Jacobi sweep; out != x).  x == NULL (here and in
+ *           odil_stencil_var_smooth2): the sweeps start from the ZERO vector, x is not read -- for finite coefficients the
+ *           bits of the same call on an array of zeros
  *           mode 1:  out = b - A x
  *   residual_restrict: coarse = scale * sum over the 2^ndim children of (b - A x), loss = mean((A x - b)^2)
- *           (deterministic two-stage sum; `partials`: odil_reduce_workspace_bytes()); even extents
+ *           (deterministic two-stage sum; `partials`: odil_reduce_workspace_bytes(); loss == NULL: no reduction launch);
+ *           even extents
  *   coarsen: the coarse-grid operator as 2 ndim + 1 arrays of shape / 2: aggregates of 2^ndim cells, piecewise-constant
  *           Galerkin products of the second-order part (x 1/2), the matrix-antisymmetric part and the row sums
  *           (csrc/stencil_mg.hip). */

@@ -395,7 +395,8 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_poisson_jacobi2(c
 // Same mapping as k_poisson_jacobi2 (a wave per row of 64 packs, 16 rows per workgroup of which 12 are owned, lane shifts
 // along x, LDS along y, registers along z); every window carries a halo pack per side, whose addresses wrap
 // periodically like every index of this operator (wall rows carry zero coefficients instead).
-template <typename T, int V, bool HASY, int DC>
+// ZERO: the sweeps start from the zero vector -- x is not read (the ring holds zeros: the same products, the same bits).
+template <typename T, int V, bool HASY, int DC, bool ZERO = false>
 __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_svar_smooth2(const T* __restrict__ c,
                                                                             const T* __restrict__ x,
                                                                             const T* __restrict__ rhs,
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_svar_smooth2(cons
   constexpr int NW = HASY ? kS2Waves : 1;
   constexpr int HY = HASY ? 2 : 0;
   constexpr int R = kS2Ring, D = 1;  // x runs one step ahead of its use, the coefficient set DC steps
-  __shared__ T ubuf[HASY ? 2 * NW * 64 * V : 1];
+  __shared__ T ubuf[HASY && !ZERO ? 2 * NW * 64 * V : 1];
   __shared__ T ybuf[HASY ? 2 * NW * 64 * V : 1];
   const int64_t Z = a.n[0], Y = a.n[1], X = a.n[2];
   const int64_t sy = X, sz = Y * X;
@@ -453,16 +454,23 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_svar_smooth2(cons
     load_vec<T, V, true>(cx + a.size + off, V, s[6]);
     load_vec<T, V, true>(rhs + off, V, s[7]);
   };
-  load_vec<T, V, true>(x + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+  if constexpr (ZERO) {
 #pragma unroll
-  for (int k = 0; k <= D; ++k) load_vec<T, V, true>(x + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int i = 0; i < V; ++i) uo[k][i] = T(0);
+  } else {
+    load_vec<T, V, true>(x + wrapz(p0 - 1) * sz + c_off, V, uo[R - 1]);
+#pragma unroll
+    for (int k = 0; k <= D; ++k) load_vec<T, V, true>(x + wrapz(p0 + k) * sz + c_off, V, uo[k]);
+  }
 #pragma unroll
   for (int k = 0; k < DC; ++k) load_set(wrapz(p0 + k), cs[k % (DC + 1)]);
 #pragma unroll
   for (int i = 0; i < V; ++i) y1[R - 1][i] = hp[i] = hzp[i] = hb[i] = T(0), hc0[i] = T(1);
   const int slot = (row * 64 + lane) * V;
   const int slot_m = ((row == 0 ? 0 : row - 1) * 64 + lane) * V, slot_p = ((row == NW - 1 ? NW - 1 : row + 1) * 64 + lane) * V;
-  if (HASY) {
+  if (HASY && !ZERO) {
     store_vec<T, V, true>(ubuf + slot, V, uo[0]);
     __syncthreads();
   }
@@ -474,16 +482,19 @@ __global__ __launch_bounds__(HASY ? 64 * kS2Waves : 64) void k_svar_smooth2(cons
       const int t = t0 + k;
       T (&cc)[8][V] = cs[k % (DC + 1)];  // the coefficients of plane p
       // (1) loads: x of plane p + 2, the coefficient set of plane p + DC
-      load_vec<T, V, true>(x + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
+      if constexpr (!ZERO) load_vec<T, V, true>(x + pa * sz + c_off, V, uo[(k + 1 + D) % R]);
       if (row_s1) load_set(pw, cs[(k + DC) % (DC + 1)]);
       // (2) plane p + 1 of x for the next step's y neighbours
-      if (HASY) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
+      if (HASY && !ZERO) store_vec<T, V, true>(ubuf + ((k + 1) & 1) * (NW * 64 * V) + slot, V, uo[(k + 1) % R]);
       if (row_s1) {
         // (3) first sweep on plane p
         {
           const T (&qc)[V] = uo[k];
           T nm[V], np[V];
-          if (HASY) {
+          if constexpr (ZERO) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) nm[i] = np[i] = T(0);
+          } else if (HASY) {
             const T* buf = ubuf + (k & 1) * (NW * 64 * V);
             load_vec<T, V, true>(buf + slot_m, V, nm);
             load_vec<T, V, true>(buf + slot_p, V, np);
@@ -706,7 +717,7 @@ static int svar_smooth2(const T* coeffs, const T* x, const T* b, T* out, const i
   T h[3];
   const T ones[3] = {T(1), T(1), T(1)};
   if (int e = smooth2_args<T>(a, shape, ndim, ones, h, zc_hint, V, 1, "stencil_var_smooth2")) return e;
-  if (!coeffs || !x || !b || !out || x == out) {
+  if (!coeffs || !b || !out || x == out) {  // (x == NULL: the sweeps start from the zero vector)
     set_error("stencil_var_smooth2: null pointer or in-place sweeps");
     return ODIL_E_INVAL;
   }
@@ -739,12 +750,18 @@ static int svar_smooth2(const T* coeffs, const T* x, const T* b, T* out, const i
     for (int i = 0; i < ndim; ++i) a.slot[map3[ndim - 1][i]] = 1 + 2 * i;
   }
   const int grid = unit_grid(a.usched);
-  if (a.active[1])
+  if (a.active[1] && x)
     hipLaunchKernelGGL((k_svar_smooth2<T, V, true, S2_SVAR_DC>), dim3(grid), dim3(64 * kS2Waves), 0, (hipStream_t)stream,
                        coeffs, x, b, out, a, omega1, omega2);
-  else
+  else if (a.active[1])  // (x == NULL: from the zero vector)
+    hipLaunchKernelGGL((k_svar_smooth2<T, V, true, S2_SVAR_DC, true>), dim3(grid), dim3(64 * kS2Waves), 0,
+                       (hipStream_t)stream, coeffs, x, b, out, a, omega1, omega2);
+  else if (x)
     hipLaunchKernelGGL((k_svar_smooth2<T, V, false, S2_SVAR_DC>), dim3(grid), dim3(64), 0, (hipStream_t)stream, coeffs, x, b,
                        out, a, omega1, omega2);
+  else
+    hipLaunchKernelGGL((k_svar_smooth2<T, V, false, S2_SVAR_DC, true>), dim3(grid), dim3(64), 0, (hipStream_t)stream, coeffs,
+                       x, b, out, a, omega1, omega2);
   return check_launch("k_svar_smooth2");
 }
 

@@ -93,6 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_svar_smooth(const T* __restrict__ c,
   if (i >= a.size) return;
   int64_t id[3];
   svar_decode(i, a, id);
+  if (MODE == 2) {  // the sweep from the ZERO vector: x is not read (A 0 = 0; finite coefficients: the same bits)
+    out[i] = T(0) - omega * (T(0) - b[i]) / c[i];
+    return;
+  }
   const T ax = svar_apply<T>(c, x, a, i, id);
   if (MODE == 0) {
     out[i] = x[i] - omega * (ax - b[i]) / c[i];
@@ -529,12 +533,15 @@ static int svar_smooth(const T* coeffs, const T* x, const T* b, T* out, const in
                        int mode, void* stream) {
   SvarArgs a;
   if (int e = svar_fill(a, shape, ndim, "stencil_var_smooth")) return e;
-  if (!coeffs || !x || !b || !out || x == out) {
+  if (!coeffs || (!x && mode != 0) || !b || !out || x == out) {  // (x == NULL with mode 0: the sweep starts from zero)
     set_error("stencil_var_smooth: null pointer or in-place sweep");
     return ODIL_E_INVAL;
   }
   const int64_t nb = (a.size + kBlock - 1) / kBlock;
-  if (mode == 0)
+  if (!x)
+    hipLaunchKernelGGL((k_svar_smooth<T, 2>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, x, b, out,
+                       a, omega);
+  else if (mode == 0)
     hipLaunchKernelGGL((k_svar_smooth<T, 0>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, x, b, out,
                        a, omega);
   else
@@ -550,7 +557,7 @@ static int svar_residual_restrict(const T* coeffs, const T* x, const T* b, T* co
   SvarArgs a, ca;
   if (int e = svar_fill(a, shape, ndim, "stencil_var_residual_restrict")) return e;
   if (int e = svar_coarse(a, ca, "stencil_var_residual_restrict")) return e;
-  if (!coeffs || !x || !b || !coarse || !partials || !loss) {
+  if (!coeffs || !x || !b || !coarse || !partials) {  // (loss == NULL: no reduction launch)
     set_error("stencil_var_residual_restrict: null pointer");
     return ODIL_E_INVAL;
   }
@@ -561,6 +568,7 @@ static int svar_residual_restrict(const T* coeffs, const T* x, const T* b, T* co
   hipLaunchKernelGGL((k_svar_residual_restrict<T>), dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, coeffs, x,
                      b, coarse, a, ca, scale, partials, z0, z1);
   if (int e = check_launch("k_svar_residual_restrict")) return e;
+  if (!loss) return 0;
   return launch_final_reduce<T>(partials, (int)nb, 0, 1, denom, loss, (hipStream_t)stream);
 }
 

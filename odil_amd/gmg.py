@@ -592,18 +592,21 @@ class StencilGMG(PoissonGMG):
     def sweeps(self, lvl, x, b, weights, zero=False):
         """Sweeps in PAIRS through the one-pass kernel (odil_stencil_var_smooth2: the coefficient arrays -- 7 of a sweep's
         10 words in 3-D -- read once for both sweeps; bit-identical to two single sweeps) on the bandwidth-bound levels.
-        zero: the iterate is the zero vector and `x` only a buffer (these kernels read it: it is zeroed here)."""
+        zero: the iterate is the zero vector and `x` only a buffer: the first launch does not read it (x = NULL)."""
         weights = list(weights)
-        if zero:
+        if zero and (not weights or not self.zero_start):
             x.zero_()
+            zero = False
         pair = ops.smooth2_supported(self.shapes[lvl]) and math.prod(self.shapes[lvl]) >= self.pair_min_cells
         while weights:
             y = self.spare[lvl]
+            src = None if zero else x
+            zero = False
             if pair and len(weights) >= 2:
-                ops.stencil_var_smooth2(self.coeffs[lvl], x, b, weights[0], weights[1], out=y)
+                ops.stencil_var_smooth2(self.coeffs[lvl], src, b, weights[0], weights[1], out=y)
                 weights = weights[2:]
             else:
-                ops.stencil_var_smooth(self.coeffs[lvl], x, b, weights[0], out=y)
+                ops.stencil_var_smooth(self.coeffs[lvl], src, b, weights[0], out=y)
                 weights = weights[1:]
             self.spare[lvl] = x
             x = y
@@ -612,7 +615,7 @@ class StencilGMG(PoissonGMG):
     def coarse_rhs(self, lvl, x, b):
         bc = self.b[lvl + 1]
         if self.locs[lvl] == self.loc:
-            ops.stencil_var_residual_restrict(self.coeffs[lvl], x, b, 1.0 / 2**self.ndim, bc, self.loss)
+            ops.stencil_var_residual_restrict(self.coeffs[lvl], x, b, 1.0 / 2**self.ndim, bc, self.loss if lvl == 0 else None)
         else:  # some axes only: the residual (its norm on the way), then the mean of the children
             self.restrict(lvl, self.residual(lvl, x, b, self.r(lvl)), 1.0, out=bc)
         return bc

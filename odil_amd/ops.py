@@ -153,9 +153,9 @@ def conv_valid(x, w, strides, transposed=False, out_shape=None):
 
 def stencil_var_smooth(coeffs, x, b, omega, out):
     """out = x - omega (A x - b) / c0 for the (2 d + 1)-point operator with coefficient arrays `coeffs` [(2 d + 1), *shape]
-    (include/odil_hip.h: odil_stencil_var_smooth, mode 0)."""
-    assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape) and out is not x
-    call("stencil_var_smooth", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()), float(omega),
+    (include/odil_hip.h: odil_stencil_var_smooth, mode 0).  x = None: from the zero vector (x' = omega b / c0: two words)."""
+    assert coeffs.shape[0] == 2 * b.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(b.shape) == tuple(out.shape) and out is not x
+    call("stencil_var_smooth", b.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(b.shape), c_int(b.dim()), float(omega),
          c_int(0), stream_ptr())
     return out
 
@@ -166,10 +166,11 @@ def smooth2_supported(shape):
 
 def stencil_var_smooth2(coeffs, x, b, omega1, omega2, out, zc_hint=0):
     """Two sweeps of `stencil_var_smooth` (weights omega1, then omega2) in ONE pass over the coefficient arrays;
-    bit-identical to two calls (out is not x)."""
-    assert coeffs.shape[0] == 2 * x.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(x.shape) and out.data_ptr() != x.data_ptr()
-    assert smooth2_supported(tuple(x.shape)) and coeffs.is_contiguous() and x.is_contiguous() and b.is_contiguous()
-    call("stencil_var_smooth2", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()), float(omega1),
+    bit-identical to two calls (out is not x).  x = None: from the zero vector (x is not read)."""
+    assert coeffs.shape[0] == 2 * b.dim() + 1 and tuple(coeffs.shape[1:]) == tuple(b.shape) == tuple(out.shape)
+    assert x is None or (x.shape == b.shape and out.data_ptr() != x.data_ptr() and x.is_contiguous())
+    assert smooth2_supported(tuple(b.shape)) and coeffs.is_contiguous() and b.is_contiguous()
+    call("stencil_var_smooth2", b.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(b.shape), c_int(b.dim()), float(omega1),
          float(omega2), c_int(zc_hint), stream_ptr())
     return out
 
@@ -187,7 +188,7 @@ def stencil_var_residual_restrict(coeffs, x, b, scale, out, loss, zrange=None, d
     """out = scale * (sum over the 2^d children of b - A x), loss <- mean((A x - b)^2), one pass.  zrange = (z0, z1): the
     slab form -- loss = sum over those planes of (A x - b)^2 / denom."""
     assert tuple(out.shape) == tuple(s // 2 for s in x.shape) and out.is_contiguous()
-    if zrange is None:
+    if zrange is None:  # (loss = None: no reduction launch)
         call("stencil_var_residual_restrict", x.dtype, ptr(coeffs), ptr(x), ptr(b), ptr(out), i64(x.shape), c_int(x.dim()),
              float(scale), ptr(reduce_workspace(x.device)), ptr(loss), stream_ptr())
     else:

@@ -528,6 +528,14 @@ def test_two_variable_coefficient_sweeps_in_one_pass_are_bit_identical(dev, shap
     for zc in (0, 1, 3, 64):
         got = ops.stencil_var_smooth2(ct, x, b, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
         assert torch.equal(got, want), (shape, zc, int((got != want).sum()))
+    # from the ZERO vector (x = NULL: nothing read for the iterate): the bits of the same calls on an array of zeros
+    zero = torch.zeros_like(x)
+    y1 = ops.stencil_var_smooth(ct, zero, b, 0.9, out=torch.empty_like(x))
+    assert torch.equal(ops.stencil_var_smooth(ct, None, b, 0.9, out=torch.full_like(x, float("nan"))), y1)
+    want = ops.stencil_var_smooth(ct, y1, b, 0.6, out=torch.empty_like(x))
+    for zc in (0, 3):
+        got = ops.stencil_var_smooth2(ct, None, b, 0.9, 0.6, torch.full_like(x, float("nan")), zc_hint=zc)
+        assert torch.equal(got, want), (shape, zc, "zero start", int((got != want).sum()))
 
 
 @pytest.mark.parametrize("shape,dtype", [((64, 64, 64), torch.float64), ((128, 128, 128), torch.float64), ((48, 32, 64), torch.float32),
@@ -571,3 +579,25 @@ def test_row_maxima_in_two_launches(dtype, rows, n):
         a[rows - 1, n // 2] = float("nan")
         got = ops.max_abs_rows(a)
         assert bool(torch.isnan(got[rows - 1])) and (rows == 1 or not bool(torch.isnan(got[0])))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 128, 128), (96, 64), (2048,)])
+def test_variable_coefficient_cycles_that_do_not_read_their_zero_iterates_give_the_same_bits(shape):
+    """The same for `StencilGMG` (odil_stencil_var_smooth / _smooth2 with x = NULL, no norm reduction on coarse levels)."""
+    from odil_amd import gmg
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    coeffs = torch.as_tensor(np.stack(diffusion_coeffs(shape, rng))).to(dev)
+    b = torch.as_tensor(rng.standard_normal(shape)).to(dev)
+    out = []
+    try:
+        for flag in (True, False):
+            gmg.PoissonGMG.zero_start = flag
+            solver = gmg.StencilGMG(coeffs)
+            st = dict()
+            out.append((solver.solve(b, tol=1e-10, maxiter=40, status=st).clone(), st["niter"], st["residual"]))
+    finally:
+        gmg.PoissonGMG.zero_start = True
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert torch.equal(out[0][0], out[1][0])
