@@ -188,9 +188,12 @@ class PoissonGMG:
         # (two result buffers in turn: a result may be the start iterate of the next call -- the second cycle on the first
         # coarse level of the variable-coefficient hierarchy -- and is otherwise consumed before the call after the next)
         out = outs[0] if x is None or x.data_ptr() != outs[0].data_ptr() else outs[1]
-        ops.stencil_vcycle_tail(flat, self.shapes[first:], [[c == "c" for c in loc] for loc in self.locs[first:]], x, b, out, work,
-                                self.coarse_inverse(), self.weights(self.nu1), self.weights(self.nu2), fmg=fmg)
-        return out
+        launch = self.__dict__.get("_tail_launch")
+        if launch is None or launch.keep[0] is not flat:  # (the launch's constant arguments, prepared once)
+            launch = self._tail_launch = ops.stencil_vcycle_tail_plan(
+                flat, self.shapes[first:], [[c == "c" for c in loc] for loc in self.locs[first:]], work, self.coarse_inverse(),
+                self.weights(self.nu1), self.weights(self.nu2))
+        return launch(x, b, out, fmg)
 
     def coarse_rhs(self, lvl, x, b):
         """b_{lvl+1} = R (b - A x), and mean((A x - b)^2) in self.loss.  One fused pass in 3-D (the fine
