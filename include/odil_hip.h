@@ -294,6 +294,15 @@ int odil_poisson_adjoint_adam_f32(const float* fu, float* gu, float* x, float* m
  * [centre, (-1 axis 0), (+1 axis 0), (-1 axis 1), ...]. */
 int odil_poisson_jac_coeffs_f64(double* coeffs, const int64_t* shape, int ndim, const double* h2, void* stream);
 int odil_poisson_jac_coeffs_f32(float* coeffs, const int64_t* shape, int ndim, const float* h2, void* stream);
+/* Are 2 ndim + 1 coefficient arrays (a HOST array of device pointers, the order above) that Jacobian?  One pass over
+ * them against the values odil_poisson_jac_coeffs would write, no reference arrays: out[2 k] = max |a_k - e_k|,
+ * out[2 k + 1] = max |e_k| (device, 2 (2 ndim + 1) numbers; a NaN stays visible).  The recognition step of the general
+ * Newton route (odil_amd/gmg.py: recognise_poisson; the reference has no counterpart: it factorises whatever it is given,
+ * linsolver.py:17-26). */
+int odil_poisson_jac_match_f64(const double* const* arrays, const int64_t* shape, int ndim, const double* h2,
+                               double* partials, double* out, void* stream);
+int odil_poisson_jac_match_f32(const float* const* arrays, const int64_t* shape, int ndim, const float* h2, double* partials,
+                               float* out, void* stream);
 
 /* ---- optimizers (reference optimizer.py:256-341) ------------------------------ */
 /* AdamNativeOptimizer._step (optimizer.py:311-319) on a flat vector:

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "poisson_adjoint_transpose_adam": [_P, _P, _P, _I64P, _P, _R, _P, _P, _P, _P, _P, _P, _R, _R, _R, _R, _P, c_int,
                                        c_int, _P],
     "poisson_jac_coeffs": [_P, _I64P, c_int, _P, _P],
+    "poisson_jac_match": [_P, _I64P, c_int, _P, _P, _P, _P],
     "adam_step": [_P, _P, _P, _P, c_int64, _R, _R, _R, _R, _P, _P],
     "adam_step_pieces": [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _R, _R, _R, _R, _P, _P],
     "planes_copy": [_P, _P, _P, c_int, c_int64, c_int, c_int, _P],

@@ -740,11 +740,10 @@ def recognise_poisson(op):
         return None
     npdt = np.float64 if op.dtype == torch.float64 else np.float32
     h2 = [npdt(op.domain.step_by_dim(i)) ** 2 for i in range(ndim)]
-    ref = ops.poisson_jac_coeffs(shape, h2, op.dtype, op.device)
     rtol = 1e-11 if op.dtype == torch.float64 else 1e-4
-    # one pass per coefficient array (odil_max_abs_diff), one read-back for all of them
-    pairs = torch.stack([ops.max_abs_diff(blocks[shift].reshape(-1).contiguous(), ref[slot].reshape(-1)) for slot, shift in enumerate(want)])
-    pairs = pairs.cpu().numpy()
+    # ONE pass over the coefficient arrays against the values the Poisson Jacobian has there (formed on the fly: no
+    # reference arrays), one read-back
+    pairs = ops.poisson_jac_match([blocks[shift] for shift in want], shape, h2).cpu().numpy()
     if not np.all(pairs[:, 0] <= rtol * pairs[:, 1]):  # (NaN compares false)
         return None
     return shape, h2

@@ -624,6 +624,22 @@ def poisson_adjoint_transpose(fu, h2, scale, g1, g0=None, adam0=None, adam1=None
     return g1
 
 
+def poisson_jac_match(arrays, shape, h2):
+    """[(2 d + 1), 2] device tensor: per coefficient array (centre, -e_0, +e_0, ...) max |a_k - e_k| and max |e_k| against the
+    Poisson Jacobian's values, formed on the fly in ONE pass (include/odil_hip.h: odil_poisson_jac_match)."""
+    from ._lib import ptr_array
+
+    ndim = len(shape)
+    assert len(arrays) == 2 * ndim + 1 and all(a.numel() == math.prod(shape) for a in arrays)
+    arrays = [a.reshape(-1) if a.is_contiguous() else a.reshape(-1).contiguous() for a in arrays]
+    dtype = arrays[0].dtype
+    h2a, h2p = host_reals(h2, dtype)
+    out = torch.empty((2 * ndim + 1, 2), dtype=dtype, device=arrays[0].device)
+    call("poisson_jac_match", dtype, ptr_array(arrays), i64(shape), c_int(ndim), h2p, ptr(reduce_workspace(out.device)), ptr(out),
+         stream_ptr())
+    return out
+
+
 def poisson_jac_coeffs(shape, h2, dtype, device):
     """(2*ndim+1, *shape) coefficient arrays [centre, -1 ax0, +1 ax0, ...] (reference core.py:1313-1361)."""
     ndim = len(shape)
