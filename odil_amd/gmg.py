@@ -444,6 +444,7 @@ class PoissonGMG:
                 res / max(bn, 1e-300), it, tol))
         if status is not None:
             status["residual"] = res
+            status["bnorm"] = bn  # (|b|: the caller that judges the residual against it need not reduce b again)
             status["niter"] = it
             status["method"] = method
             status["converged"] = converged

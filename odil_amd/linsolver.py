@@ -404,9 +404,10 @@ def dense_normal(op, rhs, damp=0.0, dampdiag=0.0, status=None):
     return x
 
 
-def solve(matr, rhs, args, status=None, linsolver="direct"):
+def solve(matr, rhs, args, status=None, linsolver="direct", consume=False):
     """Reference signature (linsolver.py:4).  `matr` is a `core.LinearizedOperator`; returns the
-    solution as a device vector."""
+    solution as a device vector.  consume=True (the Newton driver): the result may be a work buffer of the solver, valid
+    until the next solve -- no copy of it is made."""
     from .core import LinearizedOperator
 
     if status is None:
@@ -456,10 +457,10 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                 if solver is None:
                     cache.clear()
                     solver = cache[key] = gmg.PoissonGMG(shape, h2, matr.dtype, matr.device)
-                x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+                x = solver.solve(rhs.reshape(shape).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub, copy=not consume)
             # cells far from cubes (point smoothing with full coarsening loses its rate) can leave the cycles short of the
             # tolerance: the iterate is then handed to the normal-equation CG below as its starting point, not returned
-            bnorm = float(_dot(rhs, rhs)) ** 0.5
+            bnorm = sub["bnorm"] if "bnorm" in sub else float(_dot(rhs, rhs)) ** 0.5
             if sub.get("converged", True) or sub.get("residual", 0.0) <= 1e-6 * bnorm or (
                     sub.get("stagnated") and sub.get("residual", 0.0) <= 1e-3 * bnorm):
                 status.update(sub)
@@ -483,10 +484,12 @@ def solve(matr, rhs, args, status=None, linsolver="direct"):
                                     tol=gtol, maxiter=maxiter or 60, status=sub)
             else:
                 solver = gmg.StencilGMG(coeffs)
-                x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub)
+                x = solver.solve(rhs.reshape(tuple(coeffs.shape[1:])).contiguous(), tol=gtol, maxiter=maxiter or 60, status=sub,
+                                 copy=not consume)
             # (a residual below the tolerance, or cycles that stopped at the rounding floor of the working precision
             # well below the right-hand side: the iterate is finite)
-            if sub.get("converged") or (sub.get("stagnated") and sub.get("residual", 0.0) <= 1e-3 * float(_dot(rhs, rhs)) ** 0.5):
+            if sub.get("converged") or (sub.get("stagnated") and sub.get("residual", 0.0) <= 1e-3 * (
+                    sub["bnorm"] if "bnorm" in sub else float(_dot(rhs, rhs)) ** 0.5)):
                 sub["method"] = "gmg-vcycle (variable coefficients, {} levels{})".format(
                     solver.nlvl, "; float32 cycles, float64 residual" if mixed else "")
                 status.update(sub)

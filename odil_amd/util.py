@@ -353,11 +353,14 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         linstatus = dict()
         delta = _poisson_newton_step(problem, state, args, linstatus)
         applied = delta is True  # (the recognised-Poisson step updates the state itself)
+        negative = False  # (True: `delta` is d of M d = r and the update is x - d)
         if delta is None:
             vector, matrix = problem.linearize_device(state)
-            from . import ops as _ops
-
-            delta = solve(matrix, _ops.scale(vector.contiguous(), -1.0), args, linstatus, getattr(args, "linsolver", "direct"))
+            # M d = r is solved and x - d formed: every route is a linear solve, whose result for -r is exactly -d (IEEE
+            # arithmetic is symmetric in sign) -- the pass that negated r first is not needed; the result is consumed
+            # before the next solve (no copy out of the solver's work buffers)
+            delta = solve(matrix, vector.contiguous(), args, linstatus, getattr(args, "linsolver", "direct"), consume=True)
+            negative = True
         if getattr(args, "linsolver_verbose", 0):
             printlog(linstatus)
         from . import ops
@@ -369,10 +372,10 @@ def optimize_newton(args, problem, state, callback=None, **kwargs):
         elif len(fields) == 1 and type(fields[0]) is Field and torch.is_tensor(fields[0].array) \
                 and fields[0].array.is_contiguous() and fields[0].array.numel() == delta.numel():
 
-            ops.axpy(fields[0].array, delta.to(fields[0].array.dtype), 1.0)  # x += delta in place (util.py:176-178)
+            ops.axpy(fields[0].array, delta.to(fields[0].array.dtype), -1.0 if negative else 1.0)  # x += delta in place (util.py:176-178)
         else:
             packed = domain.pack_state(state)
-            domain.unpack_state(packed + delta, state)
+            domain.unpack_state(packed - delta if negative else packed + delta, state)
         if callback:  # one extra evaluation per step, for the report only (reference util.py:180)
             report = eval_pinfo(state)
             report["linsolver"] = linstatus
