@@ -137,14 +137,18 @@ def suffix_of(dtype):
 def call(name, dtype, *args, unserved_ok=False):
     """Calls odil_<name>_<f32|f64>(*args); raises OdilHipError on a non-zero status.  unserved_ok: the entry point may
     return 1 = "layout not served, nothing launched" (odil_interp_add_ld / _adj_ld); returns whether it served."""
-    lib = load()
-    fn = getattr(lib, "odil_{}_{}".format(name, suffix_of(dtype)))
+    fn = _entry.get((name, dtype))
+    if fn is None:
+        fn = _entry[(name, dtype)] = getattr(load(), "odil_{}_{}".format(name, suffix_of(dtype)))
     status = fn(*args)
     if status == 1 and unserved_ok:
         return False
     if status != 0:
-        raise OdilHipError("odil_{}: {} (status {})".format(name, lib.odil_last_error().decode(), status))
+        raise OdilHipError("odil_{}: {} (status {})".format(name, load().odil_last_error().decode(), status))
     return True
+
+
+_entry = dict()  # (name, dtype) -> the bound entry point (a launch is a few microseconds of host time: no lookups per call)
 
 
 def ptr(t):
@@ -182,7 +186,17 @@ def host_reals(values, dtype):
 
 
 def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as a pointer argument.  (torch.cuda.current_stream() builds a Stream
+    object through several Python layers, ~8 us per call -- more than the launch it precedes costs; the raw handle is one
+    C call.)"""
+    return c_void_p(_raw_stream(_current_device()))
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_device = getattr(torch._C, "_cuda_getDevice", None)
+if _raw_stream is None or _current_device is None:  # (another torch build: the documented route)
+    def stream_ptr():  # noqa: F811
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def reduce_workspace_elems():
