@@ -18,7 +18,6 @@ supported set -- flatten / reshape / contiguous / clone / casts, concatenation o
 with each other and with scalars -- raise `Unsupported`; the torch replay stays as the fallback for those.
 """
 
-import torch
 
 from .param_tape import OffGrid, ParamTensor, _Ref
 

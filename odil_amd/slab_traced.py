@@ -43,7 +43,6 @@ and with all ranks emulated in one process on one GPU (slab.run_lockstep, tests/
 import ctypes
 import contextlib
 import math
-import os
 
 import numpy as np
 import torch

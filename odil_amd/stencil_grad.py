@@ -18,7 +18,7 @@ offset, index leaves wrap, constant arrays are indexed with an offset).  Common 
 copies merge in the tracer's table.  The generated gather is then a plain pointwise kernel over that expression.
 """
 
-from .stencil_trace import _B, _I, _R, TraceUnsupported
+from .stencil_trace import _B, _R, TraceUnsupported
 
 _TRANSCENDENTAL = {"exp", "log", "tanh", "sqrt", "sin", "cos", "pow", "atan2", "div"}
 

@@ -20,7 +20,7 @@ import hashlib
 
 import torch
 
-from .stencil_trace import _B, _CMP, _I, _R
+from .stencil_trace import _B, _CMP, _I
 
 _COMMUTATIVE = {"add", "mul", "min", "max", "and", "or", "eq", "ne"}
 
