@@ -539,6 +539,7 @@ class SlabStencilGMG:
         the agglomerated box (0: slab levels down to two planes per rank)."""
         assert coeffs.dim() == 4 and coeffs.shape[0] == 7 and coeffs.is_contiguous()
         self.ops = ops or hip_ops
+        self._native = getattr(self.ops, "__name__", "") == "odil_amd.ops"  # (the library's kernels, not a stand-in)
         self.rank, self.world, self.nu, self.pair_min_cells = rank, world, nu, pair_min_cells
         self.dtype, self.device = coeffs.dtype, coeffs.device
         nz, ny, nx = (int(v) for v in coeffs.shape[1:])
@@ -620,17 +621,20 @@ class SlabStencilGMG:
             c[0, lv.g_lo + lv.nz:].fill_(1.0)
 
     # ---- pieces -------------------------------------------------------------------------------------------------------
-    def _sweeps(self, l, x, b, weights):
+    def _sweeps(self, l, x, b, weights, zero=False):
+        """zero (the library's own kernels only): the iterate is the zero vector -- the first launch does not read x."""
         c, size = self.mc[l], self.mlv[l].size
         weights = list(weights)
         pair = hasattr(self.ops, "stencil_var_smooth2") and size >= self.pair_min_cells and x.shape[-1] % 2 == 0
         while weights:
             y = self.spare[l]
+            src = None if zero else x
+            zero = False
             if pair and len(weights) >= 2:
-                self.ops.stencil_var_smooth2(c, x, b, weights[0], weights[1], out=y)
+                self.ops.stencil_var_smooth2(c, src, b, weights[0], weights[1], out=y)
                 weights = weights[2:]
             else:
-                self.ops.stencil_var_smooth(c, x, b, weights[0], out=y)
+                self.ops.stencil_var_smooth(c, src, b, weights[0], out=y)
                 weights = weights[1:]
             self.spare[l] = x
             x = y
@@ -643,7 +647,7 @@ class SlabStencilGMG:
             pair = w[k: k + 2]
             if not (zero and k == 0):  # (a zero iterate has the right ghost planes on every rank)
                 self._halo_planes(comm, x, lv, min(2, lv.nz) if len(pair) == 2 else 1)
-            x = self._sweeps(l, x, b, pair)
+            x = self._sweeps(l, x, b, pair, zero=zero and k == 0 and self._native)
             k += 2
         return x
 
@@ -688,7 +692,8 @@ class SlabStencilGMG:
             if r is not None:  # (else: the fused pass has written the owned planes of bc)
                 lc.owned(bc).copy_(self.ops.restrict_to_coarser(lv.owned(r).contiguous(), "ccc"))
             self._halo_planes(comm, bc, lc, 1)
-            xc.zero_()
+            if not self._native:
+                xc.zero_()
             xc = self._vcycle(comm, l + 1, xc, bc, zero=True)
             if l == 0 and len(self.mlv) + (len(self.agg) if self.agg else 0) > 2:
                 # TWO cycles on the first coarse level, as gmg.StencilGMG.finish_cycle: the aggregation-built coarse
